@@ -1,0 +1,186 @@
+// BLS12-381 prime fields Fp (381 bit, 12 x u32) and Fr (255 bit, 8 x u32), Montgomery form.
+//
+// Shared by the HIP kernels (device) and the host-side driver (final exponentiation,
+// Fiat-Shamir scalars).  Limbs are little-endian 32-bit words, so the in-memory image is
+// identical to the 6 x u64 / 4 x u64 little-endian Montgomery limbs that arkworks' Fp384 /
+// Fp256 hold (ark-ff 0.4 `BigInt<N>([u64; N])`) and that the C ABI (include/ripp_hip.h) uses.
+//
+// gfx950 notes: 32 x 32 -> 64 multiply-add is `v_mad_u64_u32` (the only wide integer multiply on
+// the VALU); everything here is written so that hipcc emits exactly one of those per limb product
+// and add-with-carry chains (`v_add_co_u32` / `v_addc_co_u32`) for the rest.
+#pragma once
+#include <stdint.h>
+#include "params.hpp"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define RIPP_HD __host__ __device__ __forceinline__
+#define RIPP_HD_NOINLINE __host__ __device__ __noinline__
+#else
+#define RIPP_HD inline __attribute__((always_inline))
+#define RIPP_HD_NOINLINE __attribute__((noinline))
+#endif
+
+namespace ripp {
+
+// ---------------------------------------------------------------- limb helpers
+RIPP_HD uint32_t addc32(uint32_t a, uint32_t b, uint32_t& carry) {
+    uint32_t co;
+    uint32_t r = __builtin_addc(a, b, carry, &co);
+    carry = co;
+    return r;
+}
+RIPP_HD uint32_t subb32(uint32_t a, uint32_t b, uint32_t& borrow) {
+    uint32_t bo;
+    uint32_t r = __builtin_subc(a, b, borrow, &bo);
+    borrow = bo;
+    return r;
+}
+// (carry, lo) = a*b + t + c   -- never overflows 64 bits
+RIPP_HD uint32_t mac32(uint32_t a, uint32_t b, uint32_t t, uint32_t& c) {
+    uint64_t s = (uint64_t)a * b + t + c;
+    c = (uint32_t)(s >> 32);
+    return (uint32_t)s;
+}
+
+// ---------------------------------------------------------------- field parameter packs
+struct FpParams {
+    static constexpr int N = 12;
+    static constexpr uint32_t INV = RIPP_FP_INV;
+    RIPP_HD static constexpr uint32_t mod(int i)  { constexpr uint32_t v[12] = RIPP_FP_P;  return v[i]; }
+    RIPP_HD static constexpr uint32_t one(int i)  { constexpr uint32_t v[12] = RIPP_FP_R1; return v[i]; }
+    RIPP_HD static constexpr uint32_t r2(int i)   { constexpr uint32_t v[12] = RIPP_FP_R2; return v[i]; }
+    RIPP_HD static constexpr uint32_t pm2(int i)  { constexpr uint32_t v[12] = RIPP_FP_P_MINUS_2; return v[i]; }
+    static constexpr int BITS = 381;
+};
+struct FrParams {
+    static constexpr int N = 8;
+    static constexpr uint32_t INV = RIPP_FR_INV;
+    RIPP_HD static constexpr uint32_t mod(int i)  { constexpr uint32_t v[8] = RIPP_FR_R;  return v[i]; }
+    RIPP_HD static constexpr uint32_t one(int i)  { constexpr uint32_t v[8] = RIPP_FR_R1; return v[i]; }
+    RIPP_HD static constexpr uint32_t r2(int i)   { constexpr uint32_t v[8] = RIPP_FR_R2; return v[i]; }
+    RIPP_HD static constexpr uint32_t pm2(int i)  { constexpr uint32_t v[8] = RIPP_FR_R_MINUS_2; return v[i]; }
+    static constexpr int BITS = 255;
+};
+
+// ---------------------------------------------------------------- generic Montgomery field
+template <class P>
+struct Mont {
+    static constexpr int N = P::N;
+    uint32_t l[N];
+
+    RIPP_HD static Mont zero() { Mont r; for (int i = 0; i < N; ++i) r.l[i] = 0; return r; }
+    RIPP_HD static Mont one()  { Mont r; for (int i = 0; i < N; ++i) r.l[i] = P::one(i); return r; }
+    RIPP_HD bool is_zero() const { uint32_t o = 0; for (int i = 0; i < N; ++i) o |= l[i]; return o == 0; }
+    RIPP_HD bool operator==(const Mont& b) const { uint32_t o = 0; for (int i = 0; i < N; ++i) o |= l[i] ^ b.l[i]; return o == 0; }
+    RIPP_HD bool operator!=(const Mont& b) const { return !(*this == b); }
+};
+
+// r = (a >= p) ? a - p : a        (a < 2p)
+template <class P>
+RIPP_HD void reduce_once(Mont<P>& a) {
+    constexpr int N = P::N;
+    uint32_t d[N], bo = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) d[i] = subb32(a.l[i], P::mod(i), bo);
+#pragma unroll
+    for (int i = 0; i < N; ++i) a.l[i] = bo ? a.l[i] : d[i];
+}
+
+template <class P>
+RIPP_HD Mont<P> add(const Mont<P>& a, const Mont<P>& b) {
+    constexpr int N = P::N;
+    Mont<P> r; uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.l[i] = addc32(a.l[i], b.l[i], c);
+    reduce_once(r);   // 2p < 2^(32N): no carry out of the top limb for both fields
+    return r;
+}
+template <class P>
+RIPP_HD Mont<P> sub(const Mont<P>& a, const Mont<P>& b) {
+    constexpr int N = P::N;
+    Mont<P> r; uint32_t bo = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.l[i] = subb32(a.l[i], b.l[i], bo);
+    uint32_t mask = 0u - bo, c = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.l[i] = addc32(r.l[i], P::mod(i) & mask, c);
+    return r;
+}
+template <class P>
+RIPP_HD Mont<P> neg(const Mont<P>& a) {
+    constexpr int N = P::N;
+    Mont<P> r; uint32_t bo = 0, nz = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { r.l[i] = subb32(P::mod(i), a.l[i], bo); nz |= a.l[i]; }
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.l[i] = nz ? r.l[i] : 0u;
+    return r;
+}
+template <class P>
+RIPP_HD Mont<P> dbl(const Mont<P>& a) { return add(a, a); }
+
+// Montgomery product, coarsely-integrated operand scanning (CIOS).  Inputs < p, output < p.
+// 2*N*N v_mad_u64_u32 per call.
+template <class P>
+RIPP_HD Mont<P> mul(const Mont<P>& a, const Mont<P>& b) {
+    constexpr int N = P::N;
+    uint32_t t[N + 1];
+#pragma unroll
+    for (int i = 0; i <= N; ++i) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        uint32_t c = 0;
+        const uint32_t bi = b.l[i];
+#pragma unroll
+        for (int j = 0; j < N; ++j) t[j] = mac32(a.l[j], bi, t[j], c);
+        t[N] += c;                           // running value < 2^33 * p < 2^(32(N+1)): no overflow
+        const uint32_t m = t[0] * P::INV;
+        uint32_t cc = 0;
+        (void)mac32(m, P::mod(0), t[0], cc);
+#pragma unroll
+        for (int j = 1; j < N; ++j) t[j - 1] = mac32(m, P::mod(j), t[j], cc);
+        t[N - 1] = t[N] + cc;                // shifted value < 2p < 2^(32N): fits N limbs
+        t[N] = 0;
+    }
+    Mont<P> r;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.l[i] = t[i];
+    reduce_once(r);                            // p < 2^(32N-2) for both fields => t < 2p, t[N] == 0
+    return r;
+}
+
+template <class P>
+RIPP_HD Mont<P> sqr(const Mont<P>& a) { return mul(a, a); }
+
+// a^e for a plain-integer exponent given as little-endian limbs (square-and-multiply, MSB first)
+template <class P, int EN>
+RIPP_HD Mont<P> pow_limbs(const Mont<P>& a, const uint32_t (&e)[EN]) {
+    Mont<P> r = Mont<P>::one();
+    bool started = false;
+    for (int i = EN * 32 - 1; i >= 0; --i) {
+        if (started) r = sqr(r);
+        if ((e[i >> 5] >> (i & 31)) & 1u) { r = started ? mul(r, a) : a; started = true; }
+    }
+    return r;
+}
+// Fermat inversion a^(p-2); returns 0 for a == 0 (callers check).
+template <class P>
+RIPP_HD_NOINLINE Mont<P> inv(const Mont<P>& a) {
+    uint32_t e[P::N];
+    for (int i = 0; i < P::N; ++i) e[i] = P::pm2(i);
+    return pow_limbs<P, P::N>(a, e);
+}
+
+// to / from Montgomery form
+template <class P>
+RIPP_HD Mont<P> to_mont(const Mont<P>& a) { Mont<P> r2; for (int i = 0; i < P::N; ++i) r2.l[i] = P::r2(i); return mul(a, r2); }
+template <class P>
+RIPP_HD Mont<P> from_mont(const Mont<P>& a) { Mont<P> o = Mont<P>::zero(); o.l[0] = 1; return mul(a, o); }
+
+using Fp = Mont<FpParams>;
+using Fr = Mont<FrParams>;
+
+RIPP_HD Fp fp_const(const uint32_t (&v)[12]) { Fp r; for (int i = 0; i < 12; ++i) r.l[i] = v[i]; return r; }
+
+}  // namespace ripp
