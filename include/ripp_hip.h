@@ -1,0 +1,136 @@
+/* ripp_hip.h -- C ABI of the MI355X-native inner-pairing-product engine (libripp_hip.so).
+ *
+ * Drop-in boundary for the data-parallel hot path of arkworks-rs/ripp on BLS12-381.  Each entry point names the
+ * reference interface it replaces (paths relative to the reference repository).  A Rust maintainer binds these
+ * with `extern "C"` and implements the `InnerProduct` / `DoublyHomomorphicCommitment` traits on top -- see
+ * INTEGRATION.md.
+ *
+ * Data layout (all plain-old-data, no torch / HIP types in any signature):
+ *   little-endian u64 limbs in MONTGOMERY form, R = 2^384 (Fp) / 2^256 (Fr) -- the limbs ark-ff 0.4 holds in
+ *   `Fp384.0.0` / `Fp256.0.0`, so the shim copies limbs without arithmetic.
+ *   affine infinity == (0, 0); Jacobian infinity == Z = 0.
+ *
+ * Status codes: 0 ok, 1 message length mismatch (InnerProductError::MessageLengthInvalid,
+ * inner_products/src/lib.rs:65-70), 2 length not a power of two (the asserts at sipp/src/lib.rs:48-53),
+ * 3 HIP runtime / no device, 4 bad argument.  Nothing throws or aborts.  There is NO CPU fallback: every compute
+ * entry point returns 3 when no gfx950 device is usable.
+ */
+#ifndef RIPP_HIP_H
+#define RIPP_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { uint64_t l[6]; } ripp_fp;
+typedef struct { uint64_t l[4]; } ripp_fr;
+typedef struct { ripp_fp c0, c1; } ripp_fp2;
+typedef struct { ripp_fp2 c[6]; } ripp_gt;            /* c0.c0, c0.c1, c0.c2, c1.c0, c1.c1, c1.c2 (Fp12 = Fp6[w], Fp6 = Fp2[v]) */
+typedef struct { ripp_fp x, y; } ripp_g1a;
+typedef struct { ripp_fp x, y, z; } ripp_g1j;
+typedef struct { ripp_fp2 x, y; } ripp_g2a;
+typedef struct { ripp_fp2 x, y, z; } ripp_g2j;
+
+enum { RIPP_OK = 0, RIPP_ERR_LENGTH = 1, RIPP_ERR_POW2 = 2, RIPP_ERR_DEVICE = 3, RIPP_ERR_ARG = 4 };
+
+/* per-call phase timings (milliseconds, HIP events on the engine's stream) -- counterpart of the reference's
+ * `start_timer!/end_timer!` scopes (ip_proofs/src/gipa.rs:197-291) */
+typedef struct {
+    double total_ms, upload_ms, scale_ms, miller_lines_ms, miller_products_ms, fold_ms, normalize_ms, host_ms, hash_ms;
+    double kernel_miller_lines_ms_sum, kernel_line_products_ms_sum;   /* summed launch durations of the two dominant kernels */
+    uint64_t kernel_miller_lines_launches, kernel_line_products_launches;
+    uint64_t pairs_lines, pairs_products;                             /* units processed by those launches */
+} ripp_stats;
+
+/* ---- lifecycle.  The traits are static (inner_products/src/lib.rs:40-49: no &self), so the engine is a
+ * process-global, lazily created context bound to ONE device (one process per GPU). */
+int32_t ripp_init(int32_t device_ordinal);
+void    ripp_shutdown(void);
+int32_t ripp_device_count(void);
+const char* ripp_last_error(void);
+
+/* ---- L1 trait surface on host slices ------------------------------------------------------------------ */
+/* PairingInnerProduct::inner_product(left: &[G1], right: &[G2])  -- inner_products/src/lib.rs:61-73 (cfg_multi_pairing :77-116) */
+int32_t ripp_pairing_product_j(const ripp_g1j* left, size_t n_left, const ripp_g2j* right, size_t n_right, ripp_gt* out);
+/* sipp::product_of_pairings(a: &[G1Affine], b: &[G2Affine])  -- sipp/src/lib.rs:219-224 */
+int32_t ripp_pairing_product_a(const ripp_g1a* a, const ripp_g2a* b, size_t n, ripp_gt* out);
+/* sipp::product_of_pairings_with_coeffs(a, b, r)  -- sipp/src/lib.rs:184-217 */
+int32_t ripp_pairing_product_coeffs_a(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr* r, size_t n, ripp_gt* out);
+/* MultiexponentiationInnerProduct::<G1|G2>::inner_product(left: &[G], right: &[Fr])  -- inner_products/src/lib.rs:128-141 */
+int32_t ripp_msm_g1_j(const ripp_g1j* bases, size_t n_left, const ripp_fr* scalars, size_t n_right, ripp_g1j* out);
+int32_t ripp_msm_g2_j(const ripp_g2j* bases, size_t n_left, const ripp_fr* scalars, size_t n_right, ripp_g2j* out);
+/* VariableBaseMSM::msm on affine bases (sipp/src/lib.rs:174-175) */
+int32_t ripp_msm_g1_a(const ripp_g1a* bases, const ripp_fr* scalars, size_t n, ripp_g1j* out);
+int32_t ripp_msm_g2_a(const ripp_g2a* bases, const ripp_fr* scalars, size_t n, ripp_g2j* out);
+
+/* ---- halving-round fold  out[i] = s * hi[i] + lo[i],  i < half ------------------------------------------ */
+/* SIPP form: affine in, batch-normalised affine out  -- sipp/src/lib.rs:87-92 (G1) and :95-100 (G2) */
+int32_t ripp_fold_g1_a(const ripp_g1a* hi, const ripp_g1a* lo, size_t half, const ripp_fr* s, ripp_g1a* out);
+int32_t ripp_fold_g2_a(const ripp_g2a* hi, const ripp_g2a* lo, size_t half, const ripp_fr* s, ripp_g2a* out);
+/* GIPA form: projective in/out through `mul_helper`  -- ip_proofs/src/gipa.rs:262-290, ip_proofs/src/lib.rs:15-19 */
+int32_t ripp_fold_g1_j(const ripp_g1j* hi, const ripp_g1j* lo, size_t half, const ripp_fr* s, ripp_g1j* out);
+int32_t ripp_fold_g2_j(const ripp_g2j* hi, const ripp_g2j* lo, size_t half, const ripp_fr* s, ripp_g2j* out);
+/* a_i <- r_i * a_i with per-element scalars, normalised  -- sipp/src/lib.rs:61-66 */
+int32_t ripp_scale_g1_a(const ripp_g1a* a, const ripp_fr* r, size_t n, ripp_g1a* out);
+/* CurveGroup::normalize_batch  -- inner_products/src/lib.rs:80-81,140; sipp/src/lib.rs:66,92,100 */
+int32_t ripp_normalize_g1(const ripp_g1j* in, size_t n, ripp_g1a* out);
+int32_t ripp_normalize_g2(const ripp_g2j* in, size_t n, ripp_g2a* out);
+
+/* ---- SIPP prover  -- SIPP::<Bls12_381, Blake2s>::prove, sipp/src/lib.rs:42-106 ---------------------------- */
+/* proof: 2*log2(n) GT elements, (z_l, z_r) per round in round order (Proof::gt_elems, sipp/src/lib.rs:32-34).
+ * challenges (optional, may be NULL): log2(n) Fr values x of sipp/src/lib.rs:85. */
+int32_t ripp_sipp_prove(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr* r, size_t n, const ripp_gt* value,
+                        ripp_gt* proof, ripp_fr* challenges, ripp_stats* stats);
+/* SIPP::verify, sipp/src/lib.rs:109-180.  *accept = 1/0. */
+int32_t ripp_sipp_verify(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr* r, size_t n, const ripp_gt* claimed,
+                         const ripp_gt* proof, size_t proof_rounds, int32_t* accept);
+
+/* Device-resident statement for repeated / timed proving (inputs stay in HBM between calls).
+ * Sharded proving (one process per GPU): rank `rank` of `world` holds the elements with index = rank (mod world);
+ * a[], b[], r[] passed here are that shard in local order (local j <-> global j*world + rank).  Partner elements
+ * of every halving round (i, i + len/2) then live on the same GPU for the whole proof. */
+typedef struct ripp_sipp_job ripp_sipp_job;
+int32_t ripp_sipp_job_create(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr* r, size_t n_local,
+                             int32_t rank, int32_t world, ripp_sipp_job** job);
+void    ripp_sipp_job_destroy(ripp_sipp_job* job);
+/* whole proof on one GPU (world == 1) from the resident statement */
+int32_t ripp_sipp_job_prove(ripp_sipp_job* job, const ripp_gt* value, ripp_gt* proof, ripp_fr* challenges, ripp_stats* stats);
+/* staged interface for world > 1 (the caller all-gathers the 2 x 68 x 576 B partial step-products over RCCL):
+ *   begin: re-arm the job from the resident statement, start hashing this rank's statement bytes (rank 0 hashes)
+ *   round_partials: this shard's 2 x 68 per-step line products (Fp12, Montgomery) of the current round
+ *   round_finish: given the world's combined per-step products, finish z_l, z_r (combine + final exp), derive x,
+ *                 fold the local halves.  seed_digest: Blake2s digest of the statement (needed in round 0 only). */
+int32_t ripp_sipp_job_begin(ripp_sipp_job* job);
+size_t  ripp_sipp_job_rounds_left(const ripp_sipp_job* job);
+int32_t ripp_sipp_job_round_partials(ripp_sipp_job* job, ripp_gt* partials /* [2][68] */);
+int32_t ripp_sipp_job_round_finish(ripp_sipp_job* job, const ripp_gt* combined /* [2][68] */, const uint8_t seed_digest[32],
+                                   ripp_gt* z_l, ripp_gt* z_r, ripp_fr* x);
+int32_t ripp_sipp_job_stats(const ripp_sipp_job* job, ripp_stats* stats);
+/* Blake2s digest of (a, b, r, value).serialize_uncompressed for a FULL statement held on the host (sipp/src/lib.rs:56-59) */
+int32_t ripp_sipp_seed_digest(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr* r, size_t n, const ripp_gt* value, uint8_t digest[32]);
+
+/* ---- host-side helpers (no device needed): what the host code around the kernels computes ---------------- */
+int32_t ripp_final_exp(const ripp_gt* miller_value, ripp_gt* out);                 /* Pairing::final_exponentiation */
+int32_t ripp_miller_combine(const ripp_gt* step_products /* [68] */, ripp_gt* out); /* stage (3) of pairing.hpp */
+int32_t ripp_gt_mul(const ripp_gt* a, const ripp_gt* b, ripp_gt* out);
+int32_t ripp_gt_pow(const ripp_gt* a, const ripp_fr* k, ripp_gt* out);
+int32_t ripp_fr_inverse(const ripp_fr* a, ripp_fr* out);
+/* ark-serialize 0.4 `serialize_uncompressed` byte images (what Fiat-Shamir hashes): */
+size_t  ripp_ser_gt(const ripp_gt* f, uint8_t out[576]);
+size_t  ripp_ser_g1(const ripp_g1a* p, uint8_t out[96]);
+size_t  ripp_ser_g2(const ripp_g2a* p, uint8_t out[192]);
+size_t  ripp_ser_fr(const ripp_fr* s, uint8_t out[32]);
+/* FiatShamirRng<Blake2s> step of sipp/src/lib.rs:80-85: absorb (z_l, z_r) into `seed` (in/out), draw x */
+int32_t ripp_sipp_challenge(uint8_t seed[32], const ripp_gt* z_l, const ripp_gt* z_r, ripp_fr* x);
+
+/* ---- synthetic inputs for benchmarks: generated ON THE DEVICE ---------------------- */
+/* out[i] = (start + first + i*stride) * G  (affine); scalars from SplitMix64(seed) skipping to element first + i*stride */
+int32_t ripp_synth_g1(uint64_t start, size_t first, size_t stride, size_t n, ripp_g1a* out);
+int32_t ripp_synth_g2(uint64_t start, size_t first, size_t stride, size_t n, ripp_g2a* out);
+int32_t ripp_synth_fr(uint64_t seed, size_t first, size_t stride, size_t n, ripp_fr* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

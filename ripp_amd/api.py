@@ -1,0 +1,336 @@
+"""Host-side mirror of the reference interface for the hot path, over the C ABI (include/ripp_hip.h).
+
+Names, argument order and error behaviour follow the reference so that parity tests read like its own:
+  inner_products/src/lib.rs:40-142   InnerProduct, PairingInnerProduct, MultiexponentiationInnerProduct, InnerProductError
+  dh_commitments/src/afgho16/mod.rs  AFGHOCommitmentG1 / AFGHOCommitmentG2
+  dh_commitments/src/pedersen/mod.rs PedersenCommitment
+  sipp/src/lib.rs:42-224             SIPP.prove / SIPP.verify, product_of_pairings(_with_coeffs)
+
+Values are numpy uint64 arrays in the flat C-ABI layouts (little-endian Montgomery limbs):
+  Fr (n,4)  G1Affine (n,12)  G1 projective/Jacobian (n,18)  G2Affine (n,24)  G2 projective (n,36)  GT (72,)
+"""
+import ctypes
+import numpy as np
+from ._lib import lib, last_error, RippStats, RIPP_OK, RIPP_ERR_LENGTH, RIPP_ERR_POW2, RIPP_ERR_DEVICE
+
+__all__ = ["InnerProductError", "DeviceError", "PairingInnerProduct", "MultiexponentiationInnerProductG1",
+           "MultiexponentiationInnerProductG2", "AFGHOCommitmentG1", "AFGHOCommitmentG2", "PedersenCommitmentG1",
+           "PedersenCommitmentG2", "SIPP", "SippJob", "product_of_pairings", "product_of_pairings_with_coeffs",
+           "normalize_batch_g1", "normalize_batch_g2", "fold_g1_affine", "fold_g2_affine", "fold_g1", "fold_g2",
+           "scale_g1_affine", "synth_g1", "synth_g2", "synth_fr", "init", "device_count", "final_exponentiation",
+           "ser_gt", "ser_g1", "ser_g2", "ser_fr", "sipp_seed_digest", "gt_mul"]
+
+
+class InnerProductError(Exception):
+    """InnerProductError::MessageLengthInvalid(left, right) -- inner_products/src/lib.rs:18-38."""
+
+    def __init__(self, left, right):
+        self.left, self.right = left, right
+        super().__init__(f"left length, right length: {left}, {right}")
+
+
+class DeviceError(RuntimeError):
+    pass
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _c(a, cols):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    if a.ndim == 1 and cols and a.size == cols:
+        a = a.reshape(1, cols)
+    if cols and (a.ndim != 2 or a.shape[1] != cols):
+        if a.size == 0:
+            return a.reshape(0, cols)
+        raise ValueError(f"expected shape (n, {cols}), got {a.shape}")
+    return a
+
+
+def _check(rc, left=None, right=None):
+    if rc == RIPP_OK:
+        return
+    if rc == RIPP_ERR_LENGTH:
+        raise InnerProductError(left, right)
+    if rc == RIPP_ERR_POW2:
+        raise AssertionError("vector length must be a power of two (sipp/src/lib.rs:48-53)")
+    if rc == RIPP_ERR_DEVICE:
+        raise DeviceError("HIP engine unavailable: " + last_error())
+    raise ValueError(f"libripp_hip status {rc}: {last_error()}")
+
+
+def init(device=0):
+    _check(lib().ripp_init(ctypes.c_int32(device)))
+
+
+def device_count():
+    return int(lib().ripp_device_count())
+
+
+# ------------------------------------------------------------------ InnerProduct implementations
+class PairingInnerProduct:
+    """inner_products/src/lib.rs:52-75.  left: G1 projective (n,18); right: G2 projective (n,36) -> GT (72,)."""
+
+    @staticmethod
+    def inner_product(left, right):
+        l, r = _c(left, 18), _c(right, 36)
+        out = np.zeros(72, dtype=np.uint64)
+        _check(lib().ripp_pairing_product_j(_p(l), ctypes.c_size_t(len(l)), _p(r), ctypes.c_size_t(len(r)), _p(out)), len(l), len(r))
+        return out
+
+
+class MultiexponentiationInnerProductG1:
+    """inner_products/src/lib.rs:119-142 with G = G1.  left: bases (n,18); right: scalars (n,4) -> G1 projective (18,)."""
+
+    @staticmethod
+    def inner_product(left, right):
+        l, r = _c(left, 18), _c(right, 4)
+        out = np.zeros(18, dtype=np.uint64)
+        _check(lib().ripp_msm_g1_j(_p(l), ctypes.c_size_t(len(l)), _p(r), ctypes.c_size_t(len(r)), _p(out)), len(l), len(r))
+        return out
+
+
+class MultiexponentiationInnerProductG2:
+    @staticmethod
+    def inner_product(left, right):
+        l, r = _c(left, 36), _c(right, 4)
+        out = np.zeros(36, dtype=np.uint64)
+        _check(lib().ripp_msm_g2_j(_p(l), ctypes.c_size_t(len(l)), _p(r), ctypes.c_size_t(len(r)), _p(out)), len(l), len(r))
+        return out
+
+
+# ------------------------------------------------------------------ DoublyHomomorphicCommitment implementations
+class _Commitment:
+    @classmethod
+    def verify(cls, k, m, com):
+        """Default `verify` of the trait: commit(k, m)? == *com  (dh_commitments/src/lib.rs:52-54)."""
+        return bool(np.array_equal(cls._canon(cls.commit(k, m)), cls._canon(com)))
+
+    @staticmethod
+    def _canon(x):
+        return x
+
+
+class AFGHOCommitmentG1(_Commitment):
+    """Message G1, Key G2: commit(k, m) = PairingInnerProduct(m, k)  (afgho16/mod.rs:20-32)."""
+
+    @staticmethod
+    def commit(k, m):
+        return PairingInnerProduct.inner_product(m, k)
+
+
+class AFGHOCommitmentG2(_Commitment):
+    """Message G2, Key G1: commit(k, m) = PairingInnerProduct(k, m)  (afgho16/mod.rs:35-47)."""
+
+    @staticmethod
+    def commit(k, m):
+        return PairingInnerProduct.inner_product(k, m)
+
+
+class PedersenCommitmentG1(_Commitment):
+    """commit(k, m) = MultiexponentiationInnerProduct(k, m)  (pedersen/mod.rs:14-26); output compared as a group element."""
+
+    @staticmethod
+    def commit(k, m):
+        return MultiexponentiationInnerProductG1.inner_product(k, m)
+
+    @staticmethod
+    def _canon(x):
+        return normalize_batch_g1(np.asarray(x, dtype=np.uint64).reshape(1, 18))
+
+
+class PedersenCommitmentG2(_Commitment):
+    @staticmethod
+    def commit(k, m):
+        return MultiexponentiationInnerProductG2.inner_product(k, m)
+
+    @staticmethod
+    def _canon(x):
+        return normalize_batch_g2(np.asarray(x, dtype=np.uint64).reshape(1, 36))
+
+
+# ------------------------------------------------------------------ sipp crate free functions
+def product_of_pairings(a, b):
+    """sipp/src/lib.rs:219-224 (affine inputs)."""
+    a, b = _c(a, 12), _c(b, 24)
+    if len(a) != len(b):
+        raise InnerProductError(len(a), len(b))
+    out = np.zeros(72, dtype=np.uint64)
+    _check(lib().ripp_pairing_product_a(_p(a), _p(b), ctypes.c_size_t(len(a)), _p(out)))
+    return out
+
+
+def product_of_pairings_with_coeffs(a, b, r):
+    """sipp/src/lib.rs:184-217."""
+    a, b, r = _c(a, 12), _c(b, 24), _c(r, 4)
+    assert len(a) == len(b) == len(r)
+    out = np.zeros(72, dtype=np.uint64)
+    _check(lib().ripp_pairing_product_coeffs_a(_p(a), _p(b), _p(r), ctypes.c_size_t(len(a)), _p(out)))
+    return out
+
+
+def normalize_batch_g1(pj):
+    pj = _c(pj, 18); out = np.zeros((len(pj), 12), dtype=np.uint64)
+    _check(lib().ripp_normalize_g1(_p(pj), ctypes.c_size_t(len(pj)), _p(out))); return out
+
+
+def normalize_batch_g2(pj):
+    pj = _c(pj, 36); out = np.zeros((len(pj), 24), dtype=np.uint64)
+    _check(lib().ripp_normalize_g2(_p(pj), ctypes.c_size_t(len(pj)), _p(out))); return out
+
+
+def _fold(fn, hi, lo, s, cin, cout):
+    hi, lo, s = _c(hi, cin), _c(lo, cin), np.ascontiguousarray(s, dtype=np.uint64).reshape(4)
+    assert len(hi) == len(lo)
+    out = np.zeros((len(hi), cout), dtype=np.uint64)
+    _check(fn(_p(hi), _p(lo), ctypes.c_size_t(len(hi)), _p(s), _p(out))); return out
+
+
+def fold_g1_affine(hi, lo, s):
+    """out[i] = s*hi[i] + lo[i], normalised (sipp/src/lib.rs:87-92)."""
+    return _fold(lib().ripp_fold_g1_a, hi, lo, s, 12, 12)
+
+
+def fold_g2_affine(hi, lo, s):
+    return _fold(lib().ripp_fold_g2_a, hi, lo, s, 24, 24)
+
+
+def fold_g1(hi, lo, s):
+    """projective in / out (ip_proofs/src/gipa.rs:262-290)."""
+    return _fold(lib().ripp_fold_g1_j, hi, lo, s, 18, 18)
+
+
+def fold_g2(hi, lo, s):
+    return _fold(lib().ripp_fold_g2_j, hi, lo, s, 36, 36)
+
+
+def scale_g1_affine(a, r):
+    a, r = _c(a, 12), _c(r, 4); out = np.zeros((len(a), 12), dtype=np.uint64)
+    _check(lib().ripp_scale_g1_a(_p(a), _p(r), ctypes.c_size_t(len(a)), _p(out))); return out
+
+
+# ------------------------------------------------------------------ SIPP
+class SippJob:
+    """Device-resident SIPP statement (shard).  world == 1: `prove`.  world > 1: staged rounds (ripp_amd/sharded.py)."""
+
+    def __init__(self, a, b, r, rank=0, world=1):
+        a, b, r = _c(a, 12), _c(b, 24), _c(r, 4)
+        assert len(a) == len(b) == len(r)
+        self.n_local, self.rank, self.world = len(a), rank, world
+        self._h = ctypes.c_void_p()
+        _check(lib().ripp_sipp_job_create(_p(a), _p(b), _p(r), ctypes.c_size_t(len(a)), ctypes.c_int32(rank), ctypes.c_int32(world), ctypes.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().ripp_sipp_job_destroy(self._h); self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def prove(self, value):
+        n = self.n_local; lg = n.bit_length() - 1
+        value = np.ascontiguousarray(value, dtype=np.uint64).reshape(72)
+        proof = np.zeros((2 * lg, 72), dtype=np.uint64); ch = np.zeros((lg, 4), dtype=np.uint64); st = RippStats()
+        _check(lib().ripp_sipp_job_prove(self._h, _p(value), _p(proof), _p(ch), ctypes.byref(st)))
+        return proof, ch, st.as_dict()
+
+    # staged interface
+    def begin(self):
+        _check(lib().ripp_sipp_job_begin(self._h))
+
+    def rounds_left(self):
+        return int(lib().ripp_sipp_job_rounds_left(self._h))
+
+    def round_partials(self):
+        out = np.zeros((2 * 68, 72), dtype=np.uint64)
+        _check(lib().ripp_sipp_job_round_partials(self._h, _p(out))); return out
+
+    def round_finish(self, combined, seed_digest):
+        combined = np.ascontiguousarray(combined, dtype=np.uint64)
+        zl = np.zeros(72, dtype=np.uint64); zr = np.zeros(72, dtype=np.uint64); x = np.zeros(4, dtype=np.uint64)
+        d = (ctypes.c_uint8 * 32).from_buffer_copy(seed_digest) if seed_digest is not None else None
+        _check(lib().ripp_sipp_job_round_finish(self._h, _p(combined), d, _p(zl), _p(zr), _p(x)))
+        return zl, zr, x
+
+    def stats(self):
+        st = RippStats(); _check(lib().ripp_sipp_job_stats(self._h, ctypes.byref(st))); return st.as_dict()
+
+
+class SIPP:
+    """SIPP::<Bls12_381, Blake2s> (sipp/src/lib.rs:25-181)."""
+
+    @staticmethod
+    def prove(a, b, r, value):
+        a, b, r = _c(a, 12), _c(b, 24), _c(r, 4)
+        assert len(a) == len(b), "assert_eq!(a.len(), b.len())"
+        n = len(a)
+        if n == 0 or n & (n - 1):
+            raise AssertionError("vector length must be a power of two (sipp/src/lib.rs:48-53)")
+        lg = n.bit_length() - 1
+        value = np.ascontiguousarray(value, dtype=np.uint64).reshape(72)
+        proof = np.zeros((2 * lg, 72), dtype=np.uint64); ch = np.zeros((lg, 4), dtype=np.uint64); st = RippStats()
+        _check(lib().ripp_sipp_prove(_p(a), _p(b), _p(r), ctypes.c_size_t(n), _p(value), _p(proof), _p(ch), ctypes.byref(st)))
+        return proof
+
+    @staticmethod
+    def prove_with_stats(a, b, r, value):
+        job = SippJob(a, b, r)
+        try:
+            return job.prove(value)
+        finally:
+            job.close()
+
+    @staticmethod
+    def verify(a, b, r, claimed_value, proof):
+        a, b, r = _c(a, 12), _c(b, 24), _c(r, 4)
+        proof = np.ascontiguousarray(proof, dtype=np.uint64).reshape(-1, 72)
+        claimed_value = np.ascontiguousarray(claimed_value, dtype=np.uint64).reshape(72)
+        acc = ctypes.c_int32(0)
+        _check(lib().ripp_sipp_verify(_p(a), _p(b), _p(r), ctypes.c_size_t(len(a)), _p(claimed_value), _p(proof), ctypes.c_size_t(len(proof) // 2), ctypes.byref(acc)))
+        return bool(acc.value)
+
+
+# ------------------------------------------------------------------ host helpers / synthetic inputs
+def final_exponentiation(f):
+    f = np.ascontiguousarray(f, dtype=np.uint64).reshape(72); out = np.zeros(72, dtype=np.uint64)
+    _check(lib().ripp_final_exp(_p(f), _p(out))); return out
+
+
+def gt_mul(a, b):
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(72); b = np.ascontiguousarray(b, dtype=np.uint64).reshape(72)
+    out = np.zeros(72, dtype=np.uint64); _check(lib().ripp_gt_mul(_p(a), _p(b), _p(out))); return out
+
+
+def _ser(fn, x, nbytes):
+    x = np.ascontiguousarray(x, dtype=np.uint64); out = np.zeros(nbytes, dtype=np.uint8); fn(_p(x), _p(out)); return bytes(out)
+
+
+def ser_gt(f): return _ser(lib().ripp_ser_gt, f, 576)
+def ser_g1(p): return _ser(lib().ripp_ser_g1, p, 96)
+def ser_g2(p): return _ser(lib().ripp_ser_g2, p, 192)
+def ser_fr(s): return _ser(lib().ripp_ser_fr, s, 32)
+
+
+def sipp_seed_digest(a, b, r, value):
+    a, b, r = _c(a, 12), _c(b, 24), _c(r, 4); value = np.ascontiguousarray(value, dtype=np.uint64).reshape(72)
+    out = np.zeros(32, dtype=np.uint8)
+    _check(lib().ripp_sipp_seed_digest(_p(a), _p(b), _p(r), ctypes.c_size_t(len(a)), _p(value), _p(out))); return bytes(out)
+
+
+def synth_g1(start, n, first=0, stride=1):
+    out = np.zeros((n, 12), dtype=np.uint64)
+    _check(lib().ripp_synth_g1(ctypes.c_uint64(start), ctypes.c_size_t(first), ctypes.c_size_t(stride), ctypes.c_size_t(n), _p(out))); return out
+
+
+def synth_g2(start, n, first=0, stride=1):
+    out = np.zeros((n, 24), dtype=np.uint64)
+    _check(lib().ripp_synth_g2(ctypes.c_uint64(start), ctypes.c_size_t(first), ctypes.c_size_t(stride), ctypes.c_size_t(n), _p(out))); return out
+
+
+def synth_fr(seed, n, first=0, stride=1):
+    out = np.zeros((n, 4), dtype=np.uint64)
+    _check(lib().ripp_synth_fr(ctypes.c_uint64(seed), ctypes.c_size_t(first), ctypes.c_size_t(stride), ctypes.c_size_t(n), _p(out))); return out

@@ -15,10 +15,22 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define RIPP_HD __host__ __device__ __forceinline__
-#define RIPP_HD_NOINLINE __host__ __device__ __noinline__
+// Heavy primitives (Fp2 multiply/square, Fp inversion, ...) are REAL functions on host and device: a 12x12-limb
+// Montgomery product is ~600 VALU instructions, so inlining the tower makes kernels of 10^5 instructions that
+// neither fit the instruction cache nor compile in reasonable time.  Everything above them inlines into
+// sequences of calls + carry-chain adds.
+#define RIPP_FN __host__ __device__ inline __attribute__((noinline))
+// Mid-level compositions (Fp6/Fp12 products, group law): inlined into kernels on the device so operands stay in
+// VGPRs, but ordinary out-of-line functions in the host pass (keeps host compile time and code size sane).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RIPP_MID __host__ __device__ __forceinline__
+#else
+#define RIPP_MID __host__ __device__ inline __attribute__((noinline))
+#endif
 #else
 #define RIPP_HD inline __attribute__((always_inline))
-#define RIPP_HD_NOINLINE __attribute__((noinline))
+#define RIPP_FN inline __attribute__((noinline))
+#define RIPP_MID inline __attribute__((noinline))
 #endif
 
 namespace ripp {
@@ -65,7 +77,7 @@ struct FrParams {
 
 // ---------------------------------------------------------------- generic Montgomery field
 template <class P>
-struct Mont {
+struct alignas(16) Mont {   // 16-byte aligned so device loads/stores are dwordx4
     static constexpr int N = P::N;
     uint32_t l[N];
 
@@ -121,9 +133,9 @@ template <class P>
 RIPP_HD Mont<P> dbl(const Mont<P>& a) { return add(a, a); }
 
 // Montgomery product, coarsely-integrated operand scanning (CIOS).  Inputs < p, output < p.
-// 2*N*N v_mad_u64_u32 per call.
+// Portable form (host, and the reference the device form is tested against).
 template <class P>
-RIPP_HD Mont<P> mul(const Mont<P>& a, const Mont<P>& b) {
+RIPP_HD Mont<P> mul_cios(const Mont<P>& a, const Mont<P>& b) {
     constexpr int N = P::N;
     uint32_t t[N + 1];
 #pragma unroll
@@ -146,16 +158,62 @@ RIPP_HD Mont<P> mul(const Mont<P>& a, const Mont<P>& b) {
     Mont<P> r;
 #pragma unroll
     for (int i = 0; i < N; ++i) r.l[i] = t[i];
-    reduce_once(r);                            // p < 2^(32N-2) for both fields => t < 2p, t[N] == 0
+    reduce_once(r);                            // p < 2^(32N-2) for both fields => t < 2p
     return r;
 }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// gfx950 form: finely-integrated product scanning.  Measured on MI355X (profiles/r01_ubench_valu_rates.txt):
+// v_mad_u64_u32 3.85 cyc/wave, v_addc_co_u32 3.85, v_lshl_add_u64 3.6, v_mov/v_add_u32 2.  hipcc's CIOS spends
+// 2/3 of its cycles zero-extending limbs into 64-bit pairs (v_mov + v_lshl_add_u64).  Here every limb product is
+// ONE v_mad_u64_u32 accumulating into a 96-bit column accumulator {c2:acc}, with the MAD's carry-out (VCC)
+// captured by ONE v_addc_co_u32 -- 2 VALU ops per limb product, no zero-extension.
+RIPP_HD void madc96(uint64_t& acc, uint32_t& c2, uint32_t x, uint32_t y) {
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc), "+v"(c2) : "v"(x), "v"(y) : "vcc");
+}
+RIPP_HD void madc96_s(uint64_t& acc, uint32_t& c2, uint32_t x, uint32_t y_const) {   // y in an SGPR (modulus limb)
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc), "+v"(c2) : "v"(x), "s"(y_const) : "vcc");
+}
+template <class P>
+RIPP_HD Mont<P> mul(const Mont<P>& a, const Mont<P>& b) {
+    constexpr int N = P::N;
+    uint32_t m[N];
+    Mont<P> r;
+    uint64_t acc = 0; uint32_t c2 = 0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+#pragma unroll
+        for (int i = 0; i <= k; ++i) madc96(acc, c2, a.l[i], b.l[k - i]);
+#pragma unroll
+        for (int i = 0; i < k; ++i) madc96_s(acc, c2, m[i], P::mod(k - i));
+        m[k] = (uint32_t)acc * P::INV;
+        madc96_s(acc, c2, m[k], P::mod(0));                 // low word becomes 0
+        acc = (acc >> 32) | ((uint64_t)c2 << 32); c2 = 0;
+    }
+#pragma unroll
+    for (int k = N; k < 2 * N - 1; ++k) {
+#pragma unroll
+        for (int i = k - N + 1; i < N; ++i) madc96(acc, c2, a.l[i], b.l[k - i]);
+#pragma unroll
+        for (int i = k - N + 1; i < N; ++i) madc96_s(acc, c2, m[i], P::mod(k - i));
+        r.l[k - N] = (uint32_t)acc;
+        acc = (acc >> 32) | ((uint64_t)c2 << 32); c2 = 0;
+    }
+    r.l[N - 1] = (uint32_t)acc;                             // result < 2p < 2^(32N): acc >> 32 == 0
+    reduce_once(r);
+    return r;
+}
+#else
+template <class P>
+RIPP_HD Mont<P> mul(const Mont<P>& a, const Mont<P>& b) { return mul_cios(a, b); }
+#endif
 
 template <class P>
 RIPP_HD Mont<P> sqr(const Mont<P>& a) { return mul(a, a); }
 
 // a^e for a plain-integer exponent given as little-endian limbs (square-and-multiply, MSB first)
 template <class P, int EN>
-RIPP_HD Mont<P> pow_limbs(const Mont<P>& a, const uint32_t (&e)[EN]) {
+RIPP_FN Mont<P> pow_limbs(const Mont<P>& a, const uint32_t (&e)[EN]) {
     Mont<P> r = Mont<P>::one();
     bool started = false;
     for (int i = EN * 32 - 1; i >= 0; --i) {
@@ -166,7 +224,7 @@ RIPP_HD Mont<P> pow_limbs(const Mont<P>& a, const uint32_t (&e)[EN]) {
 }
 // Fermat inversion a^(p-2); returns 0 for a == 0 (callers check).
 template <class P>
-RIPP_HD_NOINLINE Mont<P> inv(const Mont<P>& a) {
+RIPP_FN Mont<P> inv(const Mont<P>& a) {
     uint32_t e[P::N];
     for (int i = 0; i < P::N; ++i) e[i] = P::pm2(i);
     return pow_limbs<P, P::N>(a, e);
@@ -180,6 +238,35 @@ RIPP_HD Mont<P> from_mont(const Mont<P>& a) { Mont<P> o = Mont<P>::zero(); o.l[0
 
 using Fp = Mont<FpParams>;
 using Fr = Mont<FrParams>;
+
+// Out-of-line Fp multiply / square: THE call boundary of the device code.  hipcc passes aggregates of more than
+// 16 dwords through scratch memory, so the device entry takes the two operands as six 4-dword vectors (24 VGPRs
+// in, 12 VGPRs out, nothing on the stack); everything above (Fp2/Fp6/Fp12, group law) inlines into call sequences.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef uint32_t ripp_v4u __attribute__((ext_vector_type(4)));
+struct FpRegs { ripp_v4u v0, v1, v2; };
+static_assert(sizeof(FpRegs) == sizeof(Fp), "layout");
+__device__ __noinline__ inline FpRegs fp_mul_call(ripp_v4u a0, ripp_v4u a1, ripp_v4u a2, ripp_v4u b0, ripp_v4u b1, ripp_v4u b2) {
+    Fp a, b;
+    ripp_v4u* pa = reinterpret_cast<ripp_v4u*>(a.l); pa[0] = a0; pa[1] = a1; pa[2] = a2;
+    ripp_v4u* pb = reinterpret_cast<ripp_v4u*>(b.l); pb[0] = b0; pb[1] = b1; pb[2] = b2;
+    const Fp r = mul(a, b);
+    const ripp_v4u* pr = reinterpret_cast<const ripp_v4u*>(r.l);
+    return {pr[0], pr[1], pr[2]};
+}
+RIPP_HD Fp fmul(const Fp& a, const Fp& b) {
+    const ripp_v4u* pa = reinterpret_cast<const ripp_v4u*>(a.l);
+    const ripp_v4u* pb = reinterpret_cast<const ripp_v4u*>(b.l);
+    const FpRegs r = fp_mul_call(pa[0], pa[1], pa[2], pb[0], pb[1], pb[2]);
+    Fp o; ripp_v4u* po = reinterpret_cast<ripp_v4u*>(o.l); po[0] = r.v0; po[1] = r.v1; po[2] = r.v2;
+    return o;
+}
+RIPP_HD Fp fsqr(const Fp& a) { return fmul(a, a); }
+#else
+RIPP_FN Fp fmul(const Fp& a, const Fp& b) { return mul(a, b); }
+RIPP_FN Fp fsqr(const Fp& a) { return mul(a, a); }
+#endif
+RIPP_FN Fr fmul(const Fr& a, const Fr& b) { return mul(a, b); }
 
 RIPP_HD Fp fp_const(const uint32_t (&v)[12]) { Fp r; for (int i = 0; i < 12; ++i) r.l[i] = v[i]; return r; }
 

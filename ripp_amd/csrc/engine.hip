@@ -1,0 +1,591 @@
+// libripp_hip.so -- engine + C ABI (include/ripp_hip.h).  One process drives ONE MI355X (one process per GPU);
+// multi-GPU proofs are sharded by index residue and combined by the caller over RCCL (ripp_amd/sharded.py).
+//
+// There is no CPU compute fallback in this file: every data-parallel step is a HIP kernel from kernels.hpp.  The
+// host does only what the reference's host code does between its parallel sections -- Fiat-Shamir hashing, the
+// per-round final exponentiation of ONE Fp12 value, scalar inversion -- exactly the serial glue of
+// sipp/src/lib.rs:56-60,80-85,94.
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+#include "../../include/ripp_hip.h"
+#include "kernels.hpp"
+#include "host_fs.hpp"
+
+using namespace ripp;
+
+static_assert(sizeof(ripp_fp) == sizeof(Fp) && sizeof(ripp_fr) == sizeof(Fr), "limb layout");
+static_assert(sizeof(ripp_gt) == sizeof(Fp12) && sizeof(ripp_g1a) == sizeof(G1A) && sizeof(ripp_g2a) == sizeof(G2A), "layout");
+static_assert(sizeof(ripp_g1j) == sizeof(G1J) && sizeof(ripp_g2j) == sizeof(G2J), "layout");
+
+namespace {
+
+std::mutex g_mu;
+std::string g_err;
+struct Engine;
+Engine* g_engine = nullptr;
+
+#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_err(std::string(#expr) + ": " + hipGetErrorString(e_)); return RIPP_ERR_DEVICE; } } while (0)
+void set_err(const std::string& s) { g_err = s; }
+
+inline unsigned nblk(size_t n, unsigned b) { return (unsigned)((n + b - 1) / b); }
+inline uint32_t pow2_floor(uint32_t v) { uint32_t p = 1; while ((p << 1) <= v && (p << 1) != 0) p <<= 1; return p; }
+
+// A grow-only device buffer
+struct DevBuf {
+    void* p = nullptr; size_t cap = 0;
+    int32_t reserve(size_t bytes) {
+        if (bytes <= cap) return RIPP_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        HIPCHK(hipMalloc(&p, bytes)); cap = bytes; return RIPP_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() { return reinterpret_cast<T*>(p); }
+};
+
+struct Timer {   // HIP-event stopwatch on the engine stream
+    hipEvent_t a{}, b{};
+    int32_t init() { HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); return RIPP_OK; }
+    void destroy() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); a = b = nullptr; }
+};
+
+struct Engine {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    // scratch
+    DevBuf lines, partA, partB, jacG1, jacG2, tmpA, tmpB, tmpR, affG1, affG2;
+    Fp12* pinned_rows = nullptr;          // pinned host landing zone for per-step products
+    size_t pinned_rows_cap = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_lines, ev_prod;   // per-launch event pairs of the two dominant kernels
+    size_t max_pairs_per_batch = (size_t)1 << 19;                        // lines buffer cap: 2^19 pairs * 19.6 KB = 10.3 GB
+    ripp_stats stats{};
+
+    int32_t init(int dev) {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_err("no HIP device available (libripp_hip has no CPU fallback)"); return RIPP_ERR_DEVICE; }
+        if (dev < 0 || dev >= n) { set_err("device ordinal out of range"); return RIPP_ERR_ARG; }
+        HIPCHK(hipSetDevice(dev));
+        HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        device = dev;
+        return RIPP_OK;
+    }
+    void destroy() {
+        for (DevBuf* b : {&lines, &partA, &partB, &jacG1, &jacG2, &tmpA, &tmpB, &tmpR, &affG1, &affG2}) b->release();
+        if (pinned_rows) (void)hipHostFree(pinned_rows);
+        for (auto& e : ev_lines) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+        for (auto& e : ev_prod) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+    int32_t ensure_pinned_rows(size_t rows) {
+        if (rows <= pinned_rows_cap) return RIPP_OK;
+        if (pinned_rows) (void)hipHostFree(pinned_rows);
+        HIPCHK(hipHostMalloc((void**)&pinned_rows, rows * sizeof(Fp12), hipHostMallocDefault));
+        pinned_rows_cap = rows; return RIPP_OK;
+    }
+    int32_t sync() { HIPCHK(hipStreamSynchronize(stream)); return RIPP_OK; }
+
+    // ---- event bookkeeping for the roofline figures -----------------------------------------------------
+    int32_t mark(std::vector<std::pair<hipEvent_t, hipEvent_t>>& v, bool begin) {
+        if (begin) { hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); v.emplace_back(a, b); HIPCHK(hipEventRecord(a, stream)); }
+        else HIPCHK(hipEventRecord(v.back().second, stream));
+        return RIPP_OK;
+    }
+    void collect_kernel_stats() {   // call after a stream sync
+        auto drain = [](std::vector<std::pair<hipEvent_t, hipEvent_t>>& v, double& sum, uint64_t& cnt) {
+            for (auto& e : v) { float ms = 0; if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) { sum += ms; ++cnt; } (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+            v.clear(); };
+        drain(ev_lines, stats.kernel_miller_lines_ms_sum, stats.kernel_miller_lines_launches);
+        drain(ev_prod, stats.kernel_line_products_ms_sum, stats.kernel_line_products_launches);
+    }
+
+    // ---- normalisation (device in, device out) ------------------------------------------------------------
+    template <class F> int32_t normalize_dev(const Jac<F>* in, size_t n, Affine<F>* out) {
+        if (n == 0) return RIPP_OK;
+        // one inversion (~600 Fp products) per lane: amortise over up to 16 points but keep >= ~64K lanes busy
+        uint32_t K = (uint32_t)std::min<size_t>(16, std::max<size_t>(1, n / 65536));
+        uint32_t T = (uint32_t)((n + K - 1) / K);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_normalize<F>), dim3(nblk(T, 256)), dim3(256), 0, stream, in, (uint32_t)n, out, T);
+        HIPCHK(hipGetLastError());
+        return RIPP_OK;
+    }
+
+    // ---- pairing product: per-step products of `nprod` products of M pairs each ---------------------------
+    // a[p], b[p]: device pointers to M affine pairs for product p.  rows_out: host, [nprod][68] Fp12 (Montgomery).
+    int32_t step_products(const G1A* const* a, const G2A* const* b, int nprod, size_t M, Fp12* rows_out) {
+        const size_t nrows = (size_t)nprod * N_LINES;
+        for (size_t r = 0; r < nrows; ++r) rows_out[r] = Fp12::one();
+        if (M == 0) return RIPP_OK;
+        int32_t rc;
+        if ((rc = ensure_pinned_rows(nrows)) != RIPP_OK) return rc;
+        const size_t batch = std::min(M, std::max<size_t>(1, max_pairs_per_batch / nprod));
+        for (size_t off = 0; off < M; off += batch) {
+            const size_t m = std::min(batch, M - off);
+            const size_t stride = (m + 63) & ~(size_t)63;
+            if ((rc = lines.reserve(nrows * LINE_CHUNKS * stride * sizeof(uint4))) != RIPP_OK) return rc;
+            // stage 1
+            for (int p = 0; p < nprod; ++p) {
+                if ((rc = mark(ev_lines, true)) != RIPP_OK) return rc;
+                hipLaunchKernelGGL(k_miller_lines, dim3(nblk(m, 256)), dim3(256), 0, stream, a[p] + off, b[p] + off, (uint32_t)m,
+                                   lines.as<uint4>(), (size_t)p * N_LINES, stride, (size_t)0);
+                HIPCHK(hipGetLastError());
+                if ((rc = mark(ev_lines, false)) != RIPP_OK) return rc;
+                stats.pairs_lines += m;
+            }
+            // stage 2a: T lanes per row
+            uint32_t T = std::min<uint32_t>(pow2_floor((uint32_t)m), 1024);
+            if ((rc = partA.reserve(nrows * FP12_CHUNKS * (size_t)T * sizeof(uint4))) != RIPP_OK) return rc;
+            if ((rc = partB.reserve(nrows * FP12_CHUNKS * (size_t)((T + 3) / 4) * sizeof(uint4))) != RIPP_OK) return rc;
+            if ((rc = mark(ev_prod, true)) != RIPP_OK) return rc;
+            hipLaunchKernelGGL(k_line_products, dim3(nblk(T, 64), (unsigned)nrows), dim3(64), 0, stream, lines.as<uint4>(), stride, (uint32_t)m, partA.as<uint4>(), T);
+            HIPCHK(hipGetLastError());
+            if ((rc = mark(ev_prod, false)) != RIPP_OK) return rc;
+            stats.pairs_products += m * nprod;
+            // stage 2b: dense tree, radix 4
+            uint4* cur = partA.as<uint4>(); uint4* nxt = partB.as<uint4>();
+            while (T > 1) {
+                const uint32_t Tout = (T + 3) / 4;
+                hipLaunchKernelGGL(k_fp12_tree, dim3(nblk(Tout, 64), (unsigned)nrows), dim3(64), 0, stream, cur, T, nxt, Tout, 4);
+                HIPCHK(hipGetLastError());
+                std::swap(cur, nxt); T = Tout;
+            }
+            // rows are now [nrows][36][1] == nrows contiguous Fp12
+            HIPCHK(hipMemcpyAsync(pinned_rows, cur, nrows * sizeof(Fp12), hipMemcpyDeviceToHost, stream));
+            if ((rc = sync()) != RIPP_OK) return rc;
+            for (size_t r = 0; r < nrows; ++r) rows_out[r] = (off == 0) ? pinned_rows[r] : mul(rows_out[r], pinned_rows[r]);
+        }
+        return RIPP_OK;
+    }
+};
+
+int32_t get_engine(Engine** out) {
+    if (!g_engine) {
+        Engine* e = new Engine();
+        int32_t rc = e->init(0);
+        if (rc != RIPP_OK) { delete e; return rc; }
+        g_engine = e;
+    }
+    if (hipSetDevice(g_engine->device) != hipSuccess) { set_err("hipSetDevice failed"); return RIPP_ERR_DEVICE; }
+    *out = g_engine; return RIPP_OK;
+}
+
+ScalarBits scalar_bits(const Fr& s_mont) {
+    const Fr c = from_mont(s_mont);
+    ScalarBits sb; int top = -1;
+    for (int i = 0; i < 8; ++i) { sb.w[i] = c.l[i]; }
+    for (int i = 255; i >= 0; --i) if ((c.l[i >> 5] >> (i & 31)) & 1u) { top = i; break; }
+    sb.nbits = top + 1; return sb;
+}
+
+template <class T> int32_t upload(Engine* e, DevBuf& buf, const void* host, size_t n, T** dev) {
+    int32_t rc = buf.reserve(std::max<size_t>(n, 1) * sizeof(T)); if (rc != RIPP_OK) return rc;
+    if (n) HIPCHK(hipMemcpyAsync(buf.p, host, n * sizeof(T), hipMemcpyHostToDevice, e->stream));
+    *dev = buf.as<T>(); return RIPP_OK;
+}
+
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// Blake2s of (a, b, r, value).serialize_uncompressed (sipp/src/lib.rs:56-59).  Serialisation (Montgomery -> canonical
+// big-endian) is spread over worker threads in blocks; the hash itself is inherently sequential.
+void statement_digest(const G1A* a, const G2A* b, const Fr* r, size_t n, const Fp12& value, uint8_t digest[32]) {
+    fs::Blake2s h;
+    const uint64_t len = (uint64_t)n;
+    const size_t BLK = 1 << 14;
+    unsigned nthreads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<uint8_t> buf[2] = {std::vector<uint8_t>(BLK * 192), std::vector<uint8_t>(BLK * 192)};
+    auto ser_block = [&](int which, size_t s, size_t e, int kind) {
+        uint8_t* out = buf[which].data();
+        auto work = [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; ++i) {
+                if (kind == 0) fs::ser_g1(a[i], out + (i - s) * 96);
+                else if (kind == 1) fs::ser_g2(b[i], out + (i - s) * 192);
+                else fs::ser_fr(r[i], out + (i - s) * 32);
+            } };
+        const size_t cnt = e - s;
+        if (cnt < 256 || nthreads == 1) { work(s, e); return; }
+        std::vector<std::thread> th; const size_t per = (cnt + nthreads - 1) / nthreads;
+        for (unsigned t = 0; t < nthreads; ++t) { size_t lo = s + t * per, hi = std::min(e, lo + per); if (lo < hi) th.emplace_back(work, lo, hi); }
+        for (auto& t : th) t.join();
+    };
+    const size_t item[3] = {96, 192, 32};
+    for (int kind = 0; kind < 3; ++kind) {
+        h.update(reinterpret_cast<const uint8_t*>(&len), 8);
+        // double-buffered: serialise block k+1 on workers while block k is being hashed on this thread
+        size_t nblocks = (n + BLK - 1) / BLK;
+        if (nblocks == 0) continue;
+        ser_block(0, 0, std::min(BLK, n), kind);
+        for (size_t k = 0; k < nblocks; ++k) {
+            const size_t s = k * BLK, e = std::min(n, s + BLK);
+            std::thread next;
+            if (k + 1 < nblocks) next = std::thread(ser_block, (int)((k + 1) & 1), e, std::min(n, e + BLK), kind);
+            h.update(buf[k & 1].data(), (e - s) * item[kind]);
+            if (next.joinable()) next.join();
+        }
+    }
+    uint8_t gt[576]; fs::ser_gt(value, gt); h.update(gt, 576);
+    h.finish(digest);
+}
+
+}  // namespace
+
+// =============================================================================================== SIPP job
+struct ripp_sipp_job {
+    size_t n_local = 0, len = 0;          // statement shard size; current vector length of this shard
+    int rank = 0, world = 1;
+    DevBuf a0, b0, r0;                    // resident statement shard
+    DevBuf a, b, a_next, b_next, jac1, jac2;   // working vectors
+    std::vector<G1A> ha; std::vector<G2A> hb; std::vector<Fr> hr;   // host copy of the statement (rank 0 hashes it)
+    fs::FiatShamirRng rng; bool seeded = false;
+    std::thread hash_thread; uint8_t digest[32]; std::atomic<bool> digest_ready{false};
+    double t_begin = 0;
+};
+
+namespace {
+
+int32_t job_begin(Engine* e, ripp_sipp_job* j) {
+    const size_t n = j->n_local;
+    int32_t rc;
+    if ((rc = j->a.reserve(n * sizeof(G1A))) != RIPP_OK) return rc;
+    if ((rc = j->b.reserve(n * sizeof(G2A))) != RIPP_OK) return rc;
+    if ((rc = j->a_next.reserve(std::max<size_t>(n / 2, 1) * sizeof(G1A))) != RIPP_OK) return rc;
+    if ((rc = j->b_next.reserve(std::max<size_t>(n / 2, 1) * sizeof(G2A))) != RIPP_OK) return rc;
+    if ((rc = j->jac1.reserve(n * sizeof(G1J))) != RIPP_OK) return rc;
+    if ((rc = j->jac2.reserve(std::max<size_t>(n / 2, 1) * sizeof(G2J))) != RIPP_OK) return rc;
+    e->stats = ripp_stats{};
+    j->t_begin = now_ms();
+    // a_i <- r_i * a_i, normalised (sipp/src/lib.rs:61-66); b copied (:67)
+    hipEvent_t t0, t1; HIPCHK(hipEventCreate(&t0)); HIPCHK(hipEventCreate(&t1));
+    HIPCHK(hipEventRecord(t0, e->stream));
+    hipLaunchKernelGGL(k_scale_g1, dim3(nblk(n, 256)), dim3(256), 0, e->stream, j->a0.as<G1A>(), j->r0.as<Fr>(), (uint32_t)n, j->jac1.as<G1J>());
+    HIPCHK(hipGetLastError());
+    if ((rc = e->normalize_dev<Fp>(j->jac1.as<G1J>(), n, j->a.as<G1A>())) != RIPP_OK) return rc;
+    HIPCHK(hipMemcpyAsync(j->b.p, j->b0.p, n * sizeof(G2A), hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipEventRecord(t1, e->stream));
+    if ((rc = e->sync()) != RIPP_OK) return rc;
+    float ms = 0; (void)hipEventElapsedTime(&ms, t0, t1); e->stats.scale_ms += ms;
+    (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+    j->len = n; j->seeded = false;
+    return RIPP_OK;
+}
+
+// this shard's per-step products for z_l = prod e(a_r, b_l), z_r = prod e(a_l, b_r)   (sipp/src/lib.rs:70-78)
+int32_t job_round_partials(Engine* e, ripp_sipp_job* j, Fp12* rows /* [2][68] */) {
+    const size_t half = j->len / 2;
+    const G1A* a = j->a.as<G1A>(); const G2A* b = j->b.as<G2A>();
+    const G1A* as[2] = {a + half, a};       // z_l pairs a_r with b_l; z_r pairs a_l with b_r
+    const G2A* bs[2] = {b, b + half};
+    const double t0 = now_ms();
+    int32_t rc = e->step_products(as, bs, 2, half, rows);
+    e->stats.miller_products_ms += now_ms() - t0;
+    return rc;
+}
+
+int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x) {
+    const size_t half = j->len / 2;
+    int32_t rc;
+    const Fr x_inv = inv(x);                                                        // sipp/src/lib.rs:94
+    hipEvent_t t0, t1; HIPCHK(hipEventCreate(&t0)); HIPCHK(hipEventCreate(&t1));
+    HIPCHK(hipEventRecord(t0, e->stream));
+    G1A* a = j->a.as<G1A>(); G2A* b = j->b.as<G2A>();
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_affine<Fp>), dim3(nblk(half, 256)), dim3(256), 0, e->stream, a + half, a, (uint32_t)half, scalar_bits(x), j->jac1.as<G1J>());
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_affine<Fp2>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, b + half, b, (uint32_t)half, scalar_bits(x_inv), j->jac2.as<G2J>());
+    HIPCHK(hipGetLastError());
+    if ((rc = e->normalize_dev<Fp>(j->jac1.as<G1J>(), half, j->a_next.as<G1A>())) != RIPP_OK) return rc;
+    if ((rc = e->normalize_dev<Fp2>(j->jac2.as<G2J>(), half, j->b_next.as<G2A>())) != RIPP_OK) return rc;
+    HIPCHK(hipEventRecord(t1, e->stream));
+    if ((rc = e->sync()) != RIPP_OK) return rc;
+    float ms = 0; (void)hipEventElapsedTime(&ms, t0, t1); e->stats.fold_ms += ms;
+    (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+    std::swap(j->a, j->a_next); std::swap(j->b, j->b_next);
+    j->len = half;
+    return RIPP_OK;
+}
+
+void job_start_hash(ripp_sipp_job* j, const Fp12& value) {
+    if (j->hash_thread.joinable()) j->hash_thread.join();
+    j->digest_ready = false;
+    j->hash_thread = std::thread([j, value]() {
+        statement_digest(j->ha.data(), j->hb.data(), j->hr.data(), j->ha.size(), value, j->digest);
+        j->digest_ready = true; });
+}
+
+}  // namespace
+
+// =============================================================================================== C ABI
+extern "C" {
+
+#define API __attribute__((visibility("default")))
+#define LOCK std::lock_guard<std::mutex> lk_(g_mu)
+#define ENGINE Engine* e; { int32_t rc_ = get_engine(&e); if (rc_ != RIPP_OK) return rc_; }
+
+API const char* ripp_last_error(void) { return g_err.c_str(); }
+API int32_t ripp_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+API int32_t ripp_init(int32_t dev) {
+    LOCK;
+    if (g_engine) { if (g_engine->device == dev) return RIPP_OK; g_engine->destroy(); delete g_engine; g_engine = nullptr; }
+    Engine* e = new Engine(); int32_t rc = e->init(dev);
+    if (rc != RIPP_OK) { delete e; return rc; }
+    g_engine = e; return RIPP_OK;
+}
+API void ripp_shutdown(void) { LOCK; if (g_engine) { g_engine->destroy(); delete g_engine; g_engine = nullptr; } }
+
+// ---- normalisation / scaling / folds on host slices ---------------------------------------------------------
+API int32_t ripp_normalize_g1(const ripp_g1j* in, size_t n, ripp_g1a* out) {
+    LOCK; ENGINE; if (n == 0) return RIPP_OK; if (!in || !out) return RIPP_ERR_ARG;
+    G1J* d; int32_t rc = upload<G1J>(e, e->jacG1, in, n, &d); if (rc) return rc;
+    if ((rc = e->affG1.reserve(n * sizeof(G1A)))) return rc;
+    if ((rc = e->normalize_dev<Fp>(d, n, e->affG1.as<G1A>()))) return rc;
+    HIPCHK(hipMemcpyAsync(out, e->affG1.p, n * sizeof(G1A), hipMemcpyDeviceToHost, e->stream));
+    return e->sync();
+}
+API int32_t ripp_normalize_g2(const ripp_g2j* in, size_t n, ripp_g2a* out) {
+    LOCK; ENGINE; if (n == 0) return RIPP_OK; if (!in || !out) return RIPP_ERR_ARG;
+    G2J* d; int32_t rc = upload<G2J>(e, e->jacG2, in, n, &d); if (rc) return rc;
+    if ((rc = e->affG2.reserve(n * sizeof(G2A)))) return rc;
+    if ((rc = e->normalize_dev<Fp2>(d, n, e->affG2.as<G2A>()))) return rc;
+    HIPCHK(hipMemcpyAsync(out, e->affG2.p, n * sizeof(G2A), hipMemcpyDeviceToHost, e->stream));
+    return e->sync();
+}
+API int32_t ripp_scale_g1_a(const ripp_g1a* a, const ripp_fr* r, size_t n, ripp_g1a* out) {
+    LOCK; ENGINE; if (n == 0) return RIPP_OK; if (!a || !r || !out) return RIPP_ERR_ARG;
+    G1A* da; Fr* dr; int32_t rc;
+    if ((rc = upload<G1A>(e, e->tmpA, a, n, &da))) return rc;
+    if ((rc = upload<Fr>(e, e->tmpR, r, n, &dr))) return rc;
+    if ((rc = e->jacG1.reserve(n * sizeof(G1J)))) return rc;
+    if ((rc = e->affG1.reserve(n * sizeof(G1A)))) return rc;
+    hipLaunchKernelGGL(k_scale_g1, dim3(nblk(n, 256)), dim3(256), 0, e->stream, da, dr, (uint32_t)n, e->jacG1.as<G1J>());
+    HIPCHK(hipGetLastError());
+    if ((rc = e->normalize_dev<Fp>(e->jacG1.as<G1J>(), n, e->affG1.as<G1A>()))) return rc;
+    HIPCHK(hipMemcpyAsync(out, e->affG1.p, n * sizeof(G1A), hipMemcpyDeviceToHost, e->stream));
+    return e->sync();
+}
+
+extern "C++" {
+template <class F, bool JAC_IN, bool AFF_OUT, class IN, class OUT>
+static int32_t fold_impl(const IN* hi, const IN* lo, size_t half, const ripp_fr* s, OUT* out) {
+    LOCK; ENGINE; if (half == 0) return RIPP_OK; if (!hi || !lo || !s || !out) return RIPP_ERR_ARG;
+    Fr sm; std::memcpy(&sm, s, sizeof(Fr));
+    const ScalarBits sb = scalar_bits(sm);
+    int32_t rc;
+    DevBuf& jac = std::is_same<F, Fp>::value ? e->jacG1 : e->jacG2;
+    DevBuf& aff = std::is_same<F, Fp>::value ? e->affG1 : e->affG2;
+    if ((rc = jac.reserve(half * sizeof(Jac<F>)))) return rc;
+    if (JAC_IN) {
+        Jac<F>*dh, *dl;
+        if ((rc = upload<Jac<F>>(e, e->tmpA, hi, half, &dh))) return rc;
+        if ((rc = upload<Jac<F>>(e, e->tmpB, lo, half, &dl))) return rc;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_jac<F>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, dh, dl, (uint32_t)half, sb, jac.as<Jac<F>>());
+    } else {
+        Affine<F>*dh, *dl;
+        if ((rc = upload<Affine<F>>(e, e->tmpA, hi, half, &dh))) return rc;
+        if ((rc = upload<Affine<F>>(e, e->tmpB, lo, half, &dl))) return rc;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_affine<F>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, dh, dl, (uint32_t)half, sb, jac.as<Jac<F>>());
+    }
+    HIPCHK(hipGetLastError());
+    if (AFF_OUT) {
+        if ((rc = aff.reserve(half * sizeof(Affine<F>)))) return rc;
+        if ((rc = e->normalize_dev<F>(jac.as<Jac<F>>(), half, aff.as<Affine<F>>()))) return rc;
+        HIPCHK(hipMemcpyAsync(out, aff.p, half * sizeof(Affine<F>), hipMemcpyDeviceToHost, e->stream));
+    } else {
+        HIPCHK(hipMemcpyAsync(out, jac.p, half * sizeof(Jac<F>), hipMemcpyDeviceToHost, e->stream));
+    }
+    return e->sync();
+}
+}  // extern "C++"
+API int32_t ripp_fold_g1_a(const ripp_g1a* hi, const ripp_g1a* lo, size_t half, const ripp_fr* s, ripp_g1a* out) { return fold_impl<Fp, false, true>(hi, lo, half, s, out); }
+API int32_t ripp_fold_g2_a(const ripp_g2a* hi, const ripp_g2a* lo, size_t half, const ripp_fr* s, ripp_g2a* out) { return fold_impl<Fp2, false, true>(hi, lo, half, s, out); }
+API int32_t ripp_fold_g1_j(const ripp_g1j* hi, const ripp_g1j* lo, size_t half, const ripp_fr* s, ripp_g1j* out) { return fold_impl<Fp, true, false>(hi, lo, half, s, out); }
+API int32_t ripp_fold_g2_j(const ripp_g2j* hi, const ripp_g2j* lo, size_t half, const ripp_fr* s, ripp_g2j* out) { return fold_impl<Fp2, true, false>(hi, lo, half, s, out); }
+
+// ---- pairing products ------------------------------------------------------------------------------------------
+static int32_t pairing_product_dev(Engine* e, const G1A* da, const G2A* db, size_t n, ripp_gt* out) {
+    Fp12 rows[N_LINES];
+    const G1A* as[1] = {da}; const G2A* bs[1] = {db};
+    int32_t rc = e->step_products(as, bs, 1, n, rows); if (rc) return rc;
+    const Fp12 z = final_exponentiation(miller_combine(rows));
+    std::memcpy(out, &z, sizeof(Fp12));
+    e->collect_kernel_stats();
+    return RIPP_OK;
+}
+API int32_t ripp_pairing_product_a(const ripp_g1a* a, const ripp_g2a* b, size_t n, ripp_gt* out) {
+    LOCK; ENGINE; if (!out || (n && (!a || !b))) return RIPP_ERR_ARG;
+    G1A* da; G2A* db; int32_t rc;
+    if ((rc = upload<G1A>(e, e->tmpA, a, n, &da))) return rc;
+    if ((rc = upload<G2A>(e, e->tmpB, b, n, &db))) return rc;
+    return pairing_product_dev(e, da, db, n, out);
+}
+API int32_t ripp_pairing_product_j(const ripp_g1j* l, size_t nl, const ripp_g2j* r, size_t nr, ripp_gt* out) {
+    if (nl != nr) { set_err("left length, right length: " + std::to_string(nl) + ", " + std::to_string(nr)); return RIPP_ERR_LENGTH; }
+    LOCK; ENGINE; if (!out || (nl && (!l || !r))) return RIPP_ERR_ARG;
+    G1J* dl; G2J* dr; int32_t rc;
+    if ((rc = upload<G1J>(e, e->jacG1, l, nl, &dl))) return rc;
+    if ((rc = upload<G2J>(e, e->jacG2, r, nr, &dr))) return rc;
+    if ((rc = e->affG1.reserve(std::max<size_t>(nl, 1) * sizeof(G1A)))) return rc;
+    if ((rc = e->affG2.reserve(std::max<size_t>(nl, 1) * sizeof(G2A)))) return rc;
+    if ((rc = e->normalize_dev<Fp>(dl, nl, e->affG1.as<G1A>()))) return rc;       // inner_products/src/lib.rs:80-81
+    if ((rc = e->normalize_dev<Fp2>(dr, nr, e->affG2.as<G2A>()))) return rc;
+    return pairing_product_dev(e, e->affG1.as<G1A>(), e->affG2.as<G2A>(), nl, out);
+}
+API int32_t ripp_pairing_product_coeffs_a(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr* r, size_t n, ripp_gt* out) {
+    LOCK; ENGINE; if (!out || (n && (!a || !b || !r))) return RIPP_ERR_ARG;
+    G1A* da; G2A* db; Fr* dr; int32_t rc;
+    if ((rc = upload<G1A>(e, e->tmpA, a, n, &da))) return rc;
+    if ((rc = upload<G2A>(e, e->tmpB, b, n, &db))) return rc;
+    if ((rc = upload<Fr>(e, e->tmpR, r, n, &dr))) return rc;
+    if ((rc = e->jacG1.reserve(std::max<size_t>(n, 1) * sizeof(G1J)))) return rc;
+    if ((rc = e->affG1.reserve(std::max<size_t>(n, 1) * sizeof(G1A)))) return rc;
+    if (n) {
+        hipLaunchKernelGGL(k_scale_g1, dim3(nblk(n, 256)), dim3(256), 0, e->stream, da, dr, (uint32_t)n, e->jacG1.as<G1J>());
+        HIPCHK(hipGetLastError());
+        if ((rc = e->normalize_dev<Fp>(e->jacG1.as<G1J>(), n, e->affG1.as<G1A>()))) return rc;
+    }
+    return pairing_product_dev(e, e->affG1.as<G1A>(), db, n, out);
+}
+
+// ---- SIPP ----------------------------------------------------------------------------------------------------------
+API int32_t ripp_sipp_job_create(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr* r, size_t n_local, int32_t rank, int32_t world, ripp_sipp_job** job) {
+    LOCK; ENGINE; if (!a || !b || !r || !job || n_local == 0 || world < 1 || rank < 0 || rank >= world) return RIPP_ERR_ARG;
+    if (n_local & (n_local - 1)) return RIPP_ERR_POW2;
+    ripp_sipp_job* j = new ripp_sipp_job();
+    j->n_local = n_local; j->rank = rank; j->world = world;
+    int32_t rc;
+    if ((rc = j->a0.reserve(n_local * sizeof(G1A))) || (rc = j->b0.reserve(n_local * sizeof(G2A))) || (rc = j->r0.reserve(n_local * sizeof(Fr)))) { delete j; return rc; }
+    HIPCHK(hipMemcpyAsync(j->a0.p, a, n_local * sizeof(G1A), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(j->b0.p, b, n_local * sizeof(G2A), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(j->r0.p, r, n_local * sizeof(Fr), hipMemcpyHostToDevice, e->stream));
+    if (world == 1) {   // single-GPU jobs hash their own statement; keep the host image
+        j->ha.resize(n_local); j->hb.resize(n_local); j->hr.resize(n_local);
+        std::memcpy(j->ha.data(), a, n_local * sizeof(G1A)); std::memcpy(j->hb.data(), b, n_local * sizeof(G2A)); std::memcpy(j->hr.data(), r, n_local * sizeof(Fr));
+    }
+    if ((rc = e->sync())) { delete j; return rc; }
+    *job = j; return RIPP_OK;
+}
+API void ripp_sipp_job_destroy(ripp_sipp_job* j) {
+    if (!j) return; LOCK;
+    if (j->hash_thread.joinable()) j->hash_thread.join();
+    for (DevBuf* b : {&j->a0, &j->b0, &j->r0, &j->a, &j->b, &j->a_next, &j->b_next, &j->jac1, &j->jac2}) b->release();
+    delete j;
+}
+API int32_t ripp_sipp_job_begin(ripp_sipp_job* j) { LOCK; ENGINE; if (!j) return RIPP_ERR_ARG; return job_begin(e, j); }
+API size_t ripp_sipp_job_rounds_left(const ripp_sipp_job* j) { if (!j) return 0; size_t total = j->len * (size_t)j->world, r = 0; while (total > 1) { total >>= 1; ++r; } return r; }
+API int32_t ripp_sipp_job_round_partials(ripp_sipp_job* j, ripp_gt* partials) {
+    LOCK; ENGINE; if (!j || !partials) return RIPP_ERR_ARG;
+    if (j->len < 2) { set_err("shard exhausted: gather the remaining elements onto one rank"); return RIPP_ERR_ARG; }
+    return job_round_partials(e, j, reinterpret_cast<Fp12*>(partials));
+}
+API int32_t ripp_sipp_job_round_finish(ripp_sipp_job* j, const ripp_gt* combined, const uint8_t seed_digest[32], ripp_gt* z_l, ripp_gt* z_r, ripp_fr* x) {
+    LOCK; ENGINE; if (!j || !combined || !z_l || !z_r || !x) return RIPP_ERR_ARG;
+    const double t0 = now_ms();
+    const Fp12* rows = reinterpret_cast<const Fp12*>(combined);
+    const Fp12 zl = final_exponentiation(miller_combine(rows)), zr = final_exponentiation(miller_combine(rows + N_LINES));
+    if (!j->seeded) { if (!seed_digest) return RIPP_ERR_ARG; j->rng.from_digest(seed_digest); j->seeded = true; }
+    const Fr xc = fs::sipp_challenge(j->rng, zl, zr);
+    e->stats.host_ms += now_ms() - t0;
+    std::memcpy(z_l, &zl, sizeof(Fp12)); std::memcpy(z_r, &zr, sizeof(Fp12)); std::memcpy(x, &xc, sizeof(Fr));
+    return job_fold(e, j, xc);
+}
+API int32_t ripp_sipp_job_stats(const ripp_sipp_job* j, ripp_stats* st) { LOCK; ENGINE; if (!j || !st) return RIPP_ERR_ARG; e->collect_kernel_stats(); *st = e->stats; return RIPP_OK; }
+
+API int32_t ripp_sipp_job_prove(ripp_sipp_job* j, const ripp_gt* value, ripp_gt* proof, ripp_fr* challenges, ripp_stats* st) {
+    LOCK; ENGINE; if (!j || !value || !proof || j->world != 1) return RIPP_ERR_ARG;
+    Fp12 val; std::memcpy(&val, value, sizeof(Fp12));
+    const double t_start = now_ms();
+    job_start_hash(j, val);                                  // overlaps with the scaling + round-1 kernels
+    int32_t rc = job_begin(e, j); if (rc) return rc;
+    size_t round = 0;
+    while (j->len > 1) {
+        Fp12 rows[2 * N_LINES];
+        if ((rc = job_round_partials(e, j, rows))) return rc;
+        const double t0 = now_ms();
+        const Fp12 zl = final_exponentiation(miller_combine(rows)), zr = final_exponentiation(miller_combine(rows + N_LINES));
+        if (!j->seeded) {
+            const double th = now_ms();
+            if (j->hash_thread.joinable()) j->hash_thread.join();
+            e->stats.hash_ms += now_ms() - th;               // time the prover actually WAITED for the statement hash
+            j->rng.from_digest(j->digest); j->seeded = true;
+        }
+        const Fr x = fs::sipp_challenge(j->rng, zl, zr);
+        e->stats.host_ms += now_ms() - t0;
+        std::memcpy(&proof[2 * round], &zl, sizeof(Fp12)); std::memcpy(&proof[2 * round + 1], &zr, sizeof(Fp12));
+        if (challenges) std::memcpy(&challenges[round], &x, sizeof(Fr));
+        if ((rc = job_fold(e, j, x))) return rc;
+        ++round;
+    }
+    if (j->hash_thread.joinable()) j->hash_thread.join();     // n == 1: no rounds
+    e->collect_kernel_stats();
+    e->stats.total_ms = now_ms() - t_start;
+    if (st) *st = e->stats;
+    return RIPP_OK;
+}
+
+API int32_t ripp_sipp_prove(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr* r, size_t n, const ripp_gt* value, ripp_gt* proof, ripp_fr* challenges, ripp_stats* st) {
+    if (n == 0 || (n & (n - 1))) return RIPP_ERR_POW2;
+    ripp_sipp_job* j = nullptr;
+    int32_t rc = ripp_sipp_job_create(a, b, r, n, 0, 1, &j); if (rc) return rc;
+    rc = ripp_sipp_job_prove(j, value, proof, challenges, st);
+    ripp_sipp_job_destroy(j);
+    return rc;
+}
+
+API int32_t ripp_sipp_seed_digest(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr* r, size_t n, const ripp_gt* value, uint8_t digest[32]) {
+    if (!value || !digest || (n && (!a || !b || !r))) return RIPP_ERR_ARG;
+    std::vector<G1A> ha(n); std::vector<G2A> hb(n); std::vector<Fr> hr(n); Fp12 v;
+    if (n) { std::memcpy(ha.data(), a, n * sizeof(G1A)); std::memcpy(hb.data(), b, n * sizeof(G2A)); std::memcpy(hr.data(), r, n * sizeof(Fr)); }
+    std::memcpy(&v, value, sizeof(Fp12));
+    statement_digest(ha.data(), hb.data(), hr.data(), n, v, digest);
+    return RIPP_OK;
+}
+
+// ---- host helpers ----------------------------------------------------------------------------------------------------
+API int32_t ripp_final_exp(const ripp_gt* f, ripp_gt* out) { if (!f || !out) return RIPP_ERR_ARG; Fp12 x; std::memcpy(&x, f, sizeof x); const Fp12 r = final_exponentiation(x); std::memcpy(out, &r, sizeof r); return RIPP_OK; }
+API int32_t ripp_miller_combine(const ripp_gt* rows, ripp_gt* out) { if (!rows || !out) return RIPP_ERR_ARG; std::vector<Fp12> L(N_LINES); std::memcpy(L.data(), rows, N_LINES * sizeof(Fp12)); const Fp12 r = miller_combine(L.data()); std::memcpy(out, &r, sizeof r); return RIPP_OK; }
+API int32_t ripp_gt_mul(const ripp_gt* a, const ripp_gt* b, ripp_gt* out) { if (!a || !b || !out) return RIPP_ERR_ARG; Fp12 x, y; std::memcpy(&x, a, sizeof x); std::memcpy(&y, b, sizeof y); const Fp12 r = mul(x, y); std::memcpy(out, &r, sizeof r); return RIPP_OK; }
+API int32_t ripp_gt_pow(const ripp_gt* a, const ripp_fr* k, ripp_gt* out) {
+    if (!a || !k || !out) return RIPP_ERR_ARG; Fp12 x; Fr km; std::memcpy(&x, a, sizeof x); std::memcpy(&km, k, sizeof km);
+    const Fr c = from_mont(km); Fp12 acc = Fp12::one();
+    for (int i = 255; i >= 0; --i) { acc = sqr(acc); if ((c.l[i >> 5] >> (i & 31)) & 1u) acc = mul(acc, x); }
+    std::memcpy(out, &acc, sizeof acc); return RIPP_OK;
+}
+API int32_t ripp_fr_inverse(const ripp_fr* a, ripp_fr* out) { if (!a || !out) return RIPP_ERR_ARG; Fr x; std::memcpy(&x, a, sizeof x); const Fr r = inv(x); std::memcpy(out, &r, sizeof r); return RIPP_OK; }
+API size_t ripp_ser_gt(const ripp_gt* f, uint8_t out[576]) { Fp12 x; std::memcpy(&x, f, sizeof x); fs::ser_gt(x, out); return 576; }
+API size_t ripp_ser_g1(const ripp_g1a* p, uint8_t out[96]) { G1A x; std::memcpy(&x, p, sizeof x); fs::ser_g1(x, out); return 96; }
+API size_t ripp_ser_g2(const ripp_g2a* p, uint8_t out[192]) { G2A x; std::memcpy(&x, p, sizeof x); fs::ser_g2(x, out); return 192; }
+API size_t ripp_ser_fr(const ripp_fr* s, uint8_t out[32]) { Fr x; std::memcpy(&x, s, sizeof x); fs::ser_fr(x, out); return 32; }
+API int32_t ripp_sipp_challenge(uint8_t seed[32], const ripp_gt* z_l, const ripp_gt* z_r, ripp_fr* x) {
+    if (!seed || !z_l || !z_r || !x) return RIPP_ERR_ARG;
+    fs::FiatShamirRng rng; rng.from_digest(seed); Fp12 a, b; std::memcpy(&a, z_l, sizeof a); std::memcpy(&b, z_r, sizeof b);
+    const Fr c = fs::sipp_challenge(rng, a, b); std::memcpy(seed, rng.seed, 32); std::memcpy(x, &c, sizeof c); return RIPP_OK;
+}
+
+// ---- synthetic inputs ---------------------------------------------------------------------------------------------------
+extern "C++" {
+template <class F> static int32_t synth_points(const Affine<F>& g, uint64_t start, size_t first, size_t stride, size_t n, void* out) {
+    LOCK; ENGINE; if (n == 0) return RIPP_OK; if (!out) return RIPP_ERR_ARG;
+    DevBuf& jac = std::is_same<F, Fp>::value ? e->jacG1 : e->jacG2;
+    DevBuf& aff = std::is_same<F, Fp>::value ? e->affG1 : e->affG2;
+    int32_t rc; if ((rc = jac.reserve(n * sizeof(Jac<F>))) || (rc = aff.reserve(n * sizeof(Affine<F>)))) return rc;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_synth_points<F>), dim3(nblk(n, 64)), dim3(64), 0, e->stream, g, start, (uint64_t)first, (uint64_t)stride, (uint32_t)n, jac.as<Jac<F>>());
+    HIPCHK(hipGetLastError());
+    if ((rc = e->normalize_dev<F>(jac.as<Jac<F>>(), n, aff.as<Affine<F>>()))) return rc;
+    HIPCHK(hipMemcpyAsync(out, aff.p, n * sizeof(Affine<F>), hipMemcpyDeviceToHost, e->stream));
+    return e->sync();
+}
+}  // extern "C++"
+API int32_t ripp_synth_g1(uint64_t start, size_t first, size_t stride, size_t n, ripp_g1a* out) { return synth_points<Fp>(g1_generator(), start, first, stride, n, out); }
+API int32_t ripp_synth_g2(uint64_t start, size_t first, size_t stride, size_t n, ripp_g2a* out) { return synth_points<Fp2>(g2_generator(), start, first, stride, n, out); }
+API int32_t ripp_synth_fr(uint64_t seed, size_t first, size_t stride, size_t n, ripp_fr* out) {
+    LOCK; ENGINE; if (n == 0) return RIPP_OK; if (!out) return RIPP_ERR_ARG;
+    int32_t rc; if ((rc = e->tmpR.reserve(n * sizeof(Fr)))) return rc;
+    hipLaunchKernelGGL(k_synth_fr, dim3(nblk(n, 256)), dim3(256), 0, e->stream, seed, (uint64_t)first, (uint64_t)stride, (uint32_t)n, e->tmpR.as<Fr>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, e->tmpR.p, n * sizeof(Fr), hipMemcpyDeviceToHost, e->stream));
+    return e->sync();
+}
+
+}  // extern "C"

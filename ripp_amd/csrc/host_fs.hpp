@@ -1,0 +1,111 @@
+// Host-side Fiat-Shamir plumbing of the SIPP prover (product code; NOT the oracle):
+//   * ark-serialize 0.4 `serialize_uncompressed` byte images of Fr / G1Affine / G2Affine / Fq12
+//     (ark-bls12-381 0.4 uses the zcash big-endian point layout), as hashed at sipp/src/lib.rs:56-59,80-84
+//   * BLAKE2s-256 (RFC 7693) = `blake2::Blake2s` of sipp/src/lib.rs:230
+//   * ChaCha20 keystream = `rand_chacha::ChaChaRng`, and `FiatShamirRng` of sipp/src/rng.rs:47-72
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <cstddef>
+#include "bls12_381/pairing.hpp"
+
+namespace ripp { namespace fs {
+
+// ------------------------------------------------------------------ BLAKE2s
+struct Blake2s {
+    uint32_t h[8]; uint64_t t = 0; uint8_t buf[64]; size_t buflen = 0;
+    static constexpr uint32_t IV[8] = {0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au, 0x510E527Fu, 0x9B05688Cu, 0x1F83D9ABu, 0x5BE0CD19u};
+    Blake2s() { for (int i = 0; i < 8; ++i) h[i] = IV[i]; h[0] ^= 0x01010000u ^ 32u; }
+    static inline uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+    void compress(const uint8_t* blk, bool last) {
+        static const uint8_t S[10][16] = {
+            {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+            {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+            {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+            {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+            {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0}};
+        uint32_t m[16], v[16];
+        std::memcpy(m, blk, 64);
+        for (int i = 0; i < 8; ++i) { v[i] = h[i]; v[i + 8] = IV[i]; }
+        v[12] ^= (uint32_t)t; v[13] ^= (uint32_t)(t >> 32); if (last) v[14] = ~v[14];
+        auto G = [&](int a, int b, int c, int d, uint32_t x, uint32_t y) {
+            v[a] += v[b] + x; v[d] = rotr(v[d] ^ v[a], 16); v[c] += v[d]; v[b] = rotr(v[b] ^ v[c], 12);
+            v[a] += v[b] + y; v[d] = rotr(v[d] ^ v[a], 8); v[c] += v[d]; v[b] = rotr(v[b] ^ v[c], 7); };
+        for (int r = 0; r < 10; ++r) {
+            const uint8_t* s = S[r];
+            G(0, 4, 8, 12, m[s[0]], m[s[1]]); G(1, 5, 9, 13, m[s[2]], m[s[3]]); G(2, 6, 10, 14, m[s[4]], m[s[5]]); G(3, 7, 11, 15, m[s[6]], m[s[7]]);
+            G(0, 5, 10, 15, m[s[8]], m[s[9]]); G(1, 6, 11, 12, m[s[10]], m[s[11]]); G(2, 7, 8, 13, m[s[12]], m[s[13]]); G(3, 4, 9, 14, m[s[14]], m[s[15]]);
+        }
+        for (int i = 0; i < 8; ++i) h[i] ^= v[i] ^ v[i + 8];
+    }
+    void update(const uint8_t* in, size_t n) {
+        while (n) {
+            if (buflen == 64) { t += 64; compress(buf, false); buflen = 0; }
+            if (buflen == 0 && n > 64) {   // bulk path: compress straight from the input
+                while (n > 64) { t += 64; compress(in, false); in += 64; n -= 64; }
+                continue;
+            }
+            size_t k = 64 - buflen; if (k > n) k = n;
+            std::memcpy(buf + buflen, in, k); buflen += k; in += k; n -= k;
+        }
+    }
+    void finish(uint8_t out[32]) { t += buflen; std::memset(buf + buflen, 0, 64 - buflen); compress(buf, true); std::memcpy(out, h, 32); }
+};
+
+// ------------------------------------------------------------------ ChaCha20 (64-bit counter, stream id 0)
+inline void chacha20_block(const uint8_t key[32], uint64_t counter, uint8_t out[64]) {
+    auto rotl = [](uint32_t x, int n) { return (x << n) | (x >> (32 - n)); };
+    uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u}, w[16];
+    std::memcpy(&s[4], key, 32);
+    s[12] = (uint32_t)counter; s[13] = (uint32_t)(counter >> 32); s[14] = 0; s[15] = 0;
+    std::memcpy(w, s, 64);
+    auto QR = [&](int a, int b, int c, int d) {
+        w[a] += w[b]; w[d] = rotl(w[d] ^ w[a], 16); w[c] += w[d]; w[b] = rotl(w[b] ^ w[c], 12);
+        w[a] += w[b]; w[d] = rotl(w[d] ^ w[a], 8); w[c] += w[d]; w[b] = rotl(w[b] ^ w[c], 7); };
+    for (int i = 0; i < 10; ++i) { QR(0, 4, 8, 12); QR(1, 5, 9, 13); QR(2, 6, 10, 14); QR(3, 7, 11, 15); QR(0, 5, 10, 15); QR(1, 6, 11, 12); QR(2, 7, 8, 13); QR(3, 4, 9, 14); }
+    for (int i = 0; i < 16; ++i) w[i] += s[i];
+    std::memcpy(out, w, 64);
+}
+
+// ------------------------------------------------------------------ serialisation
+inline void ser_fp_le(const Fp& a, uint8_t* out) { const Fp c = from_mont(a); std::memcpy(out, c.l, 48); }
+inline void ser_fp_be(const Fp& a, uint8_t* out) {
+    const Fp c = from_mont(a);
+    for (int i = 0; i < 12; ++i) { const uint32_t w = c.l[i]; out[47 - 4 * i] = (uint8_t)w; out[46 - 4 * i] = (uint8_t)(w >> 8); out[45 - 4 * i] = (uint8_t)(w >> 16); out[44 - 4 * i] = (uint8_t)(w >> 24); }
+}
+inline void ser_fr(const Fr& a, uint8_t* out) { const Fr c = from_mont(a); std::memcpy(out, c.l, 32); }
+inline void ser_g1(const G1A& p, uint8_t* out) {
+    if (is_inf(p)) { std::memset(out, 0, 96); out[0] = 0x40; return; }
+    ser_fp_be(p.x, out); ser_fp_be(p.y, out + 48);
+}
+inline void ser_g2(const G2A& p, uint8_t* out) {
+    if (is_inf(p)) { std::memset(out, 0, 192); out[0] = 0x40; return; }
+    ser_fp_be(p.x.c1, out); ser_fp_be(p.x.c0, out + 48); ser_fp_be(p.y.c1, out + 96); ser_fp_be(p.y.c0, out + 144);
+}
+inline void ser_gt(const Fp12& f, uint8_t* out) {
+    const Fp2* c[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
+    for (int i = 0; i < 6; ++i) { ser_fp_le(c[i]->c0, out + 96 * i); ser_fp_le(c[i]->c1, out + 96 * i + 48); }
+}
+
+// ------------------------------------------------------------------ FiatShamirRng<Blake2s>
+struct FiatShamirRng {
+    uint8_t seed[32];
+    void from_digest(const uint8_t d[32]) { std::memcpy(seed, d, 32); }
+    // seed <- H(new || seed); the ChaCha stream restarts (sipp/src/rng.rs:67-72)
+    void absorb(const uint8_t* bytes, size_t n) { Blake2s h; h.update(bytes, n); h.update(seed, 32); h.finish(seed); }
+    // first `u128::rand` after a reseed: rand 0.8 Standard = two next_u64, low half first = 16 LE keystream bytes
+    void next_u128(uint64_t& lo, uint64_t& hi) const { uint8_t blk[64]; chacha20_block(seed, 0, blk); std::memcpy(&lo, blk, 8); std::memcpy(&hi, blk + 8, 8); }
+};
+inline Fr fr_from_u128(uint64_t lo, uint64_t hi) {
+    Fr t = Fr::zero(); t.l[0] = (uint32_t)lo; t.l[1] = (uint32_t)(lo >> 32); t.l[2] = (uint32_t)hi; t.l[3] = (uint32_t)(hi >> 32);
+    return to_mont(t);
+}
+// sipp/src/lib.rs:80-85
+inline Fr sipp_challenge(FiatShamirRng& rng, const Fp12& z_l, const Fp12& z_r) {
+    uint8_t buf[1152]; ser_gt(z_l, buf); ser_gt(z_r, buf + 576);
+    rng.absorb(buf, 1152);
+    uint64_t lo, hi; rng.next_u128(lo, hi);
+    return fr_from_u128(lo, hi);
+}
+
+}}  // namespace ripp::fs

@@ -1,0 +1,207 @@
+// HIP kernels of the inner-pairing-product engine (gfx950 / MI355X).  Included once, by engine.hip.
+//
+// Work decomposition (see bls12_381/pairing.hpp for the algebra):
+//   k_miller_lines    one LANE per (P,Q) pair; 68 sequential steps; writes the sparse line element of every step
+//   k_line_products   grid.y = step-rows; each lane multiplies a strided subset of one row's lines (mul_by_014)
+//   k_fp12_tree       dense Fp12 product tree over the per-lane partials
+//   k_scale / k_fold  per-lane scalar multiplication (+ add) for the SIPP scaling and halving-round folds
+//   k_normalize       Jacobian -> affine with one inversion per lane-batch (Montgomery's trick)
+// No MFMA anywhere: this is 381-bit modular integer arithmetic on the VALU (v_mad_u64_u32).
+//
+// HBM layout of the line / partial buffers: 16-byte chunks, chunk-major then lane:  buf[(row*Q + q)*stride + i]
+// (Q = 18 chunks per sparse line, 36 per dense Fp12), so that the 64 lanes of a wave read/write 1 KiB contiguous
+// per instruction (global_load/store_dwordx4, fully coalesced).  Points are read as AoS structs (96/192 B).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "bls12_381/pairing.hpp"
+
+namespace ripp {
+
+constexpr int LINE_CHUNKS = 18;    // 3 Fp2 = 72 dwords
+constexpr int FP12_CHUNKS = 36;    // 144 dwords
+
+struct ScalarBits { uint32_t w[8]; int nbits; };   // canonical little-endian scalar shared by all lanes of a launch
+
+// ---- chunked SoA accessors -------------------------------------------------------------------------------
+template <int NCH, class T>
+__device__ __forceinline__ void store_chunks(uint4* buf, size_t row, size_t stride, size_t i, const T& v) {
+    static_assert(sizeof(T) == NCH * 16, "size");
+    const uint4* src = reinterpret_cast<const uint4*>(&v);
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) buf[(row * NCH + q) * stride + i] = src[q];
+}
+template <int NCH, class T>
+__device__ __forceinline__ T load_chunks(const uint4* buf, size_t row, size_t stride, size_t i) {
+    static_assert(sizeof(T) == NCH * 16, "size");
+    T v;
+    uint4* dst = reinterpret_cast<uint4*>(&v);
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) dst[q] = buf[(row * NCH + q) * stride + i];
+    return v;
+}
+
+// ---- stage 1: line elements --------------------------------------------------------------------------------
+// a, b: M pairs (affine).  lines: [nrows = 68][18][stride].  Pairs with a point at infinity emit the unit line.
+__global__ void __launch_bounds__(256) k_miller_lines(const G1A* __restrict__ a, const G2A* __restrict__ b, uint32_t M,
+                                                       uint4* __restrict__ lines, size_t row0, size_t stride, size_t col0) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const G1A P = a[i];
+    Fp2 X, Y, Z = Fp2::one();
+    { const G2A Q = b[i]; X = Q.x; Y = Q.y; }
+    const bool skip = is_inf(P) || (X.is_zero() && Y.is_zero());
+    const LineCoeffs unit = {Fp2::one(), Fp2::zero(), Fp2::zero()};
+    size_t s = row0;
+#pragma unroll 1
+    for (int bit = 62; bit >= 0; --bit) {
+        LineCoeffs l = line_double(X, Y, Z, P.x, P.y);
+        store_chunks<LINE_CHUNKS>(lines, s, stride, col0 + i, skip ? unit : l);
+        ++s;
+        if ((BLS_X_ABS >> bit) & 1ull) {
+            const G2A Q = b[i];
+            l = line_add(X, Y, Z, Q.x, Q.y, P.x, P.y);
+            store_chunks<LINE_CHUNKS>(lines, s, stride, col0 + i, skip ? unit : l);
+            ++s;
+        }
+    }
+}
+
+// ---- stage 2a: sparse accumulation -------------------------------------------------------------------------
+// grid = (T / block, rows).  Lane t of row r multiplies lines r[t], r[t+T], ... (< M) and writes one dense partial.
+__global__ void __launch_bounds__(256) k_line_products(const uint4* __restrict__ lines, size_t stride, uint32_t M,
+                                                        uint4* __restrict__ partials, uint32_t T) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const size_t row = blockIdx.y;
+    Fp12 acc = Fp12::one();
+    if (t < M) {
+        const LineCoeffs l0 = load_chunks<LINE_CHUNKS, LineCoeffs>(lines, row, stride, t);
+        acc.c0.c0 = l0.c0; acc.c0.c1 = l0.c1; acc.c1.c1 = l0.c2;       // 1 * line, without the multiplication
+#pragma unroll 1
+        for (uint32_t i = t + T; i < M; i += T) {
+            const LineCoeffs l = load_chunks<LINE_CHUNKS, LineCoeffs>(lines, row, stride, i);
+            acc = mul_by_014(acc, l.c0, l.c1, l.c2);
+        }
+    }
+    store_chunks<FP12_CHUNKS>(partials, row, T, t, acc);
+}
+
+// ---- stage 2b: dense product tree --------------------------------------------------------------------------
+// in: [rows][36][Tin] -> out: [rows][36][Tout];  out[j] = prod_{k<R} in[j + k*Tout]
+__global__ void __launch_bounds__(64) k_fp12_tree(const uint4* __restrict__ in, uint32_t Tin, uint4* __restrict__ out, uint32_t Tout, int R) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Tout) return;
+    const size_t row = blockIdx.y;
+    Fp12 acc = load_chunks<FP12_CHUNKS, Fp12>(in, row, Tin, j);
+#pragma unroll 1
+    for (int k = 1; k < R; ++k) {
+        const uint32_t idx = j + k * Tout;
+        if (idx < Tin) acc = mul(acc, load_chunks<FP12_CHUNKS, Fp12>(in, row, Tin, idx));
+    }
+    store_chunks<FP12_CHUNKS>(out, row, Tout, j, acc);
+}
+
+// ---- scalar multiplication kernels -------------------------------------------------------------------------
+// out[i] = r[i] * a[i]  (per-element 255-bit scalars, Montgomery form in memory)   -- sipp/src/lib.rs:61-65
+__global__ void __launch_bounds__(256) k_scale_g1(const G1A* __restrict__ a, const Fr* __restrict__ r, uint32_t n, G1J* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Fr k = from_mont(r[i]);
+    const G1A p = a[i];
+    G1J acc = jac_inf<Fp>();
+#pragma unroll 1
+    for (int bit = 254; bit >= 0; --bit) {
+        acc = dbl(acc);
+        if ((k.l[bit >> 5] >> (bit & 31)) & 1u) acc = add_mixed(acc, p);
+    }
+    out[i] = acc;
+}
+
+// out[i] = s * hi[i] + lo[i]  with ONE scalar for the whole launch (uniform control flow)
+//   -- sipp/src/lib.rs:87-91, 95-99 (affine operands); ip_proofs/src/gipa.rs:262-290 (projective operands)
+template <class F>
+__global__ void __launch_bounds__(256) k_fold_affine(const Affine<F>* __restrict__ hi, const Affine<F>* __restrict__ lo, uint32_t half,
+                                                      ScalarBits s, Jac<F>* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= half) return;
+    const Affine<F> p = hi[i];
+    Jac<F> acc = jac_inf<F>();
+#pragma unroll 1
+    for (int bit = s.nbits - 1; bit >= 0; --bit) {
+        acc = dbl(acc);
+        if ((s.w[bit >> 5] >> (bit & 31)) & 1u) acc = add_mixed(acc, p);
+    }
+    out[i] = add_mixed(acc, lo[i]);
+}
+template <class F>
+__global__ void __launch_bounds__(256) k_fold_jac(const Jac<F>* __restrict__ hi, const Jac<F>* __restrict__ lo, uint32_t half,
+                                                   ScalarBits s, Jac<F>* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= half) return;
+    const Jac<F> p = hi[i];
+    Jac<F> acc = jac_inf<F>();
+#pragma unroll 1
+    for (int bit = s.nbits - 1; bit >= 0; --bit) {
+        acc = dbl(acc);
+        if ((s.w[bit >> 5] >> (bit & 31)) & 1u) acc = add(acc, p);
+    }
+    out[i] = add(acc, lo[i]);
+}
+
+// ---- batch normalisation (CurveGroup::normalize_batch) ------------------------------------------------------
+// Lane t handles points t, t+T, ..., one inversion per lane (Montgomery's trick over its K points).  The running
+// prefix products are parked in out[i].x, so `in` and `out` must not alias.
+template <class F>
+__global__ void __launch_bounds__(256) k_normalize(const Jac<F>* __restrict__ in, uint32_t n, Affine<F>* __restrict__ out, uint32_t T) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    F acc = F::one();
+#pragma unroll 1
+    for (uint32_t i = t; i < n; i += T) {
+        const F z = in[i].z;
+        if (!z.is_zero()) { out[i].x = acc; acc = fmul(acc, z); }
+    }
+    F ainv = inv(acc);
+    uint32_t last = t + ((n - 1 - t) / T) * T;       // largest index of this lane (t < n guaranteed by T <= n)
+#pragma unroll 1
+    for (uint32_t i = last;; i -= T) {
+        const Jac<F> p = in[i];
+        if (p.z.is_zero()) { out[i] = aff_inf<F>(); }
+        else {
+            const F zi = fmul(ainv, out[i].x);
+            ainv = fmul(ainv, p.z);
+            const F zi2 = fsqr(zi);
+            Affine<F> o; o.x = fmul(p.x, zi2); o.y = fmul(p.y, fmul(zi2, zi));
+            out[i] = o;
+        }
+        if (i == t) break;
+    }
+}
+
+// ---- synthetic inputs (bench harness) ---------------------------------------------------
+template <class F>
+__global__ void __launch_bounds__(256) k_synth_points(Affine<F> g, uint64_t start, uint64_t first, uint64_t stride_, uint32_t n, Jac<F>* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = start + first + (uint64_t)i * stride_;
+    Jac<F> acc = jac_inf<F>();
+#pragma unroll 1
+    for (int bit = 63; bit >= 0; --bit) { acc = dbl(acc); if ((k >> bit) & 1ull) acc = add_mixed(acc, g); }
+    out[i] = acc;
+}
+__device__ __forceinline__ uint64_t splitmix_at(uint64_t seed, uint64_t draw /* 1-based */) {
+    uint64_t z = seed + draw * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31);
+}
+__global__ void __launch_bounds__(256) k_synth_fr(uint64_t seed, uint64_t first, uint64_t stride_, uint32_t n, Fr* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t e = first + (uint64_t)i * stride_;
+    Fr v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const uint64_t d = splitmix_at(seed, 4 * e + j + 1); v.l[2 * j] = (uint32_t)d; v.l[2 * j + 1] = (uint32_t)(d >> 32); }
+    v.l[7] &= 0x3fffffffu;                      // 254-bit canonical integer, always < r
+    out[i] = to_mont(v);
+}
+
+}  // namespace ripp

@@ -26,6 +26,30 @@ __global__ void __launch_bounds__(256) k_mul_chain(const Fp* in, Fp* out, int it
     out[tid] = acc;
 }
 
+template <int CHAINS>
+__global__ void __launch_bounds__(256) k_mulcios_chain(const Fp* in, Fp* out, int iters) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    Fp x[CHAINS];
+    Fp y = in[(tid + 1) & 1023];
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c) x[c] = in[(tid + 7 * c) & 1023];
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int c = 0; c < CHAINS; ++c) x[c] = mul_cios(x[c], y);
+    }
+    Fp acc = x[0];
+#pragma unroll
+    for (int c = 1; c < CHAINS; ++c) acc = add(acc, x[c]);
+    out[tid] = acc;
+}
+__device__ __noinline__ Fp mul_noinline(const Fp& a, const Fp& b) { return mul(a, b); }
+__global__ void __launch_bounds__(256) k_mulni_chain(const Fp* in, Fp* out, int iters) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    Fp x = in[tid & 1023], y = in[(tid + 1) & 1023];
+    for (int i = 0; i < iters; ++i) x = mul_noinline(x, y);
+    out[tid] = x;
+}
+
 __global__ void __launch_bounds__(256) k_add_chain(const Fp* in, Fp* out, int iters) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     Fp x = in[tid & 1023], y = in[(tid + 1) & 1023];
@@ -97,6 +121,8 @@ int main() {
         return 0;
     };
     run("fp_mul x1 chain", k_mul_chain<1>, 1, 1);
+    run("fp_mul CIOS(compiler) x1", k_mulcios_chain<1>, 1, 1);
+    run("fp_mul noinline call x1", k_mulni_chain, 1, 1);
     run("fp_mul x2 chains", k_mul_chain<2>, 2, 2);
     run("fp_mul x4 chains", k_mul_chain<4>, 4, 4);
     run("fp_add+fp_sub", k_add_chain, 1, 2);
