@@ -16,6 +16,7 @@
 #include <vector>
 #include "../../include/ripp_hip.h"
 #include "kernels.hpp"
+#include "msm.hpp"
 #include "host_fs.hpp"
 
 using namespace ripp;
@@ -60,6 +61,7 @@ struct Engine {
     hipStream_t stream = nullptr;
     // scratch
     DevBuf lines, partA, partB, jacG1, jacG2, tmpA, tmpB, tmpR, affG1, affG2;
+    DevBuf m_digits, m_hist, m_offs, m_cursor, m_slotoffs, m_spw, m_sorted, m_slots, m_buckets, m_seg, m_win, m_out;   // MSM scratch
     Fp12* pinned_rows = nullptr;          // pinned host landing zone for per-step products
     size_t pinned_rows_cap = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_lines, ev_prod;   // per-launch event pairs of the two dominant kernels
@@ -76,7 +78,7 @@ struct Engine {
         return RIPP_OK;
     }
     void destroy() {
-        for (DevBuf* b : {&lines, &partA, &partB, &jacG1, &jacG2, &tmpA, &tmpB, &tmpR, &affG1, &affG2}) b->release();
+        for (DevBuf* b : {&lines, &partA, &partB, &jacG1, &jacG2, &tmpA, &tmpB, &tmpR, &affG1, &affG2, &m_digits, &m_hist, &m_offs, &m_cursor, &m_slotoffs, &m_spw, &m_sorted, &m_slots, &m_buckets, &m_seg, &m_win, &m_out}) b->release();
         if (pinned_rows) (void)hipHostFree(pinned_rows);
         for (auto& e : ev_lines) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         for (auto& e : ev_prod) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -113,6 +115,35 @@ struct Engine {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_normalize<F>), dim3(nblk(T, 256)), dim3(256), 0, stream, in, (uint32_t)n, out, T);
         HIPCHK(hipGetLastError());
         return RIPP_OK;
+    }
+
+
+    // ---- Pippenger MSM over device-resident affine bases and Montgomery scalars; result (Jacobian) to host --------
+    template <class F> int32_t msm_dev(const Affine<F>* bases, const Fr* scalars, size_t n, Jac<F>* out_host) {
+        if (n == 0) { *out_host = jac_inf<F>(); return RIPP_OK; }
+        const MsmPlan p = msm_plan(n);
+        const size_t nwb = (size_t)p.nwin * p.nb;
+        const uint32_t max_slots = (uint32_t)(n / MSM_CH + std::min<size_t>(p.nb, n) + 1);
+        const uint32_t nseg = (p.nb + MSM_SEG - 1) / MSM_SEG;
+        int32_t rc;
+        if ((rc = m_digits.reserve((size_t)p.nwin * n * sizeof(uint16_t))) || (rc = m_hist.reserve(nwb * 4)) || (rc = m_offs.reserve(nwb * 4)) ||
+            (rc = m_cursor.reserve(nwb * 4)) || (rc = m_slotoffs.reserve(nwb * 4)) || (rc = m_spw.reserve(p.nwin * 4)) ||
+            (rc = m_sorted.reserve((size_t)p.nwin * n * 4)) || (rc = m_slots.reserve((size_t)p.nwin * max_slots * sizeof(Jac<F>))) ||
+            (rc = m_buckets.reserve(nwb * sizeof(Jac<F>))) || (rc = m_seg.reserve((size_t)p.nwin * nseg * sizeof(Jac<F>))) ||
+            (rc = m_win.reserve(64 * sizeof(Jac<F>))) || (rc = m_out.reserve(sizeof(Jac<F>)))) return rc;
+        HIPCHK(hipMemsetAsync(m_hist.p, 0, nwb * 4, stream));
+        hipLaunchKernelGGL(k_msm_digits, dim3(nblk(n, 256)), dim3(256), 0, stream, scalars, p, m_digits.as<uint16_t>(), m_hist.as<uint32_t>());
+        hipLaunchKernelGGL(k_msm_scan, dim3(p.nwin), dim3(1024), 0, stream, m_hist.as<uint32_t>(), p, m_offs.as<uint32_t>(), m_cursor.as<uint32_t>(), m_slotoffs.as<uint32_t>(), m_spw.as<uint32_t>());
+        hipLaunchKernelGGL(k_msm_scatter, dim3(nblk(n, 256)), dim3(256), 0, stream, m_digits.as<uint16_t>(), p, m_cursor.as<uint32_t>(), m_sorted.as<uint32_t>());
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_slot_sum<F>), dim3(nblk(max_slots, 64), p.nwin), dim3(64), 0, stream, bases, p, m_hist.as<uint32_t>(), m_offs.as<uint32_t>(),
+                           m_slotoffs.as<uint32_t>(), m_spw.as<uint32_t>(), m_sorted.as<uint32_t>(), m_slots.as<Jac<F>>(), max_slots);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_bucket_merge<F>), dim3(nblk(p.nb, 64), p.nwin), dim3(64), 0, stream, p, m_hist.as<uint32_t>(), m_slotoffs.as<uint32_t>(),
+                           m_slots.as<Jac<F>>(), max_slots, m_buckets.as<Jac<F>>());
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_segments<F>), dim3(nblk(nseg, 64), p.nwin), dim3(64), 0, stream, p, m_buckets.as<Jac<F>>(), m_seg.as<Jac<F>>(), nseg);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_finish<F>), dim3(1), dim3(64), 0, stream, p, m_seg.as<Jac<F>>(), nseg, m_win.as<Jac<F>>(), m_out.as<Jac<F>>());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(out_host, m_out.p, sizeof(Jac<F>), hipMemcpyDeviceToHost, stream));
+        return sync();
     }
 
     // ---- pairing product: per-step products of `nprod` products of M pairs each ---------------------------
@@ -446,6 +477,67 @@ API int32_t ripp_pairing_product_coeffs_a(const ripp_g1a* a, const ripp_g2a* b, 
         if ((rc = e->normalize_dev<Fp>(e->jacG1.as<G1J>(), n, e->affG1.as<G1A>()))) return rc;
     }
     return pairing_product_dev(e, e->affG1.as<G1A>(), db, n, out);
+}
+
+
+// ---- MSM -----------------------------------------------------------------------------------------------------------
+extern "C++" {
+template <class F, bool JAC> static int32_t msm_impl(const void* bases, size_t nl, const ripp_fr* scalars, size_t nr, void* out) {
+    if (nl != nr) { set_err("left length, right length: " + std::to_string(nl) + ", " + std::to_string(nr)); return RIPP_ERR_LENGTH; }
+    LOCK; ENGINE; if (!out || (nl && (!bases || !scalars))) return RIPP_ERR_ARG;
+    Jac<F> res = jac_inf<F>();
+    if (nl) {
+        int32_t rc; Fr* ds; Affine<F>* db;
+        if ((rc = upload<Fr>(e, e->tmpR, scalars, nl, &ds))) return rc;
+        DevBuf& jac = std::is_same<F, Fp>::value ? e->jacG1 : e->jacG2;
+        DevBuf& aff = std::is_same<F, Fp>::value ? e->affG1 : e->affG2;
+        if (JAC) {
+            Jac<F>* dj; if ((rc = upload<Jac<F>>(e, jac, bases, nl, &dj))) return rc;
+            if ((rc = aff.reserve(nl * sizeof(Affine<F>)))) return rc;
+            if ((rc = e->normalize_dev<F>(dj, nl, aff.as<Affine<F>>()))) return rc;      // inner_products/src/lib.rs:140
+            db = aff.as<Affine<F>>();
+        } else { if ((rc = upload<Affine<F>>(e, aff, bases, nl, &db))) return rc; }
+        if ((rc = e->msm_dev<F>(db, ds, nl, &res))) return rc;
+    }
+    std::memcpy(out, &res, sizeof(Jac<F>));
+    return RIPP_OK;
+}
+}  // extern "C++"
+API int32_t ripp_msm_g1_j(const ripp_g1j* b, size_t nl, const ripp_fr* s, size_t nr, ripp_g1j* out) { return msm_impl<Fp, true>(b, nl, s, nr, out); }
+API int32_t ripp_msm_g2_j(const ripp_g2j* b, size_t nl, const ripp_fr* s, size_t nr, ripp_g2j* out) { return msm_impl<Fp2, true>(b, nl, s, nr, out); }
+API int32_t ripp_msm_g1_a(const ripp_g1a* b, const ripp_fr* s, size_t n, ripp_g1j* out) { return msm_impl<Fp, false>(b, n, s, n, out); }
+API int32_t ripp_msm_g2_a(const ripp_g2a* b, const ripp_fr* s, size_t n, ripp_g2j* out) { return msm_impl<Fp2, false>(b, n, s, n, out); }
+
+// ---- SIPP verifier (sipp/src/lib.rs:109-180) ----------------------------------------------------------------------------
+API int32_t ripp_sipp_verify(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr* r, size_t n, const ripp_gt* claimed, const ripp_gt* proof, size_t proof_rounds, int32_t* accept) {
+    if (!a || !b || !r || !claimed || !proof || !accept) return RIPP_ERR_ARG;
+    if (n < 2 || (n & (n - 1))) return RIPP_ERR_POW2;                     // asserts at :118-119
+    size_t lg = 0; while (((size_t)1 << lg) < n) ++lg;
+    if (proof_rounds != lg) return RIPP_ERR_ARG;                          // :122-123
+    uint8_t digest[32];
+    int32_t rc = ripp_sipp_seed_digest(a, b, r, n, claimed, digest); if (rc) return rc;      // :126-132
+    fs::FiatShamirRng rng; rng.from_digest(digest);
+    const Fp12* pr = reinterpret_cast<const Fp12*>(proof);
+    std::vector<Fp12> P(2 * lg); std::memcpy(P.data(), pr, 2 * lg * sizeof(Fp12));
+    std::vector<Fr> xs(lg), xinv(lg);
+    for (size_t j = 0; j < lg; ++j) { xs[j] = fs::sipp_challenge(rng, P[2 * j], P[2 * j + 1]); xinv[j] = inv(xs[j]); }   // :134-149
+    Fp12 zp; std::memcpy(&zp, claimed, sizeof zp);
+    auto gt_pow = [](const Fp12& x, const Fr& k) { const Fr c = from_mont(k); Fp12 acc = Fp12::one(); bool st = false;
+        for (int i = 255; i >= 0; --i) { if (st) acc = sqr(acc); if ((c.l[i >> 5] >> (i & 31)) & 1u) { acc = st ? mul(acc, x) : x; st = true; } } return acc; };
+    for (size_t j = 0; j < lg; ++j) zp = mul(zp, mul(gt_pow(P[2 * j], xs[j]), gt_pow(P[2 * j + 1], xinv[j])));           // :151-158
+    // s_i = r_i * prod_{j : bit (lg-1-j) of i set} x_j ;  s_inv likewise (:160-172), built by doubling
+    std::vector<Fr> s(n), si(n); s[0] = Fr::one(); si[0] = Fr::one();
+    for (size_t j = lg; j-- > 0;) { const size_t bit = (size_t)1 << (lg - 1 - j); for (size_t i = 0; i < bit; ++i) { s[i + bit] = mul(s[i], xs[j]); si[i + bit] = mul(si[i], xinv[j]); } }
+    std::vector<Fr> rr(n); std::memcpy(rr.data(), r, n * sizeof(Fr));
+    for (size_t i = 0; i < n; ++i) s[i] = mul(s[i], rr[i]);
+    ripp_g1j ap; ripp_g2j bp;
+    if ((rc = ripp_msm_g1_a(a, reinterpret_cast<const ripp_fr*>(s.data()), n, &ap))) return rc;                           // :174
+    if ((rc = ripp_msm_g2_a(b, reinterpret_cast<const ripp_fr*>(si.data()), n, &bp))) return rc;                          // :175
+    ripp_gt e12;
+    if ((rc = ripp_pairing_product_j(&ap, 1, &bp, 1, &e12))) return rc;                                                    // :177
+    Fp12 ev; std::memcpy(&ev, &e12, sizeof ev);
+    *accept = (ev == zp) ? 1 : 0;
+    return RIPP_OK;
 }
 
 // ---- SIPP ----------------------------------------------------------------------------------------------------------

@@ -245,6 +245,10 @@ def gt_pow(f, k):
     out = u64(72); lib().orc_gt_pow(_p(f), _p(k), _p(out)); return out
 
 
+def gt_one():
+    out = u64(72); lib().orc_fp12_one(_p(out)); return out
+
+
 def gt_mul(f, g):
     out = u64(72); lib().orc_gt_mul(_p(f), _p(g), _p(out)); return out
 

@@ -1,0 +1,180 @@
+"""GPU parity tests (-m gpu): the HIP engine, called through the C ABI, against the CPU oracle on identical seeded
+inputs (bit-exact: integer arithmetic), against the committed golden vectors, and -- at BASELINE.json's full sizes --
+through size-independent properties.  Mirrors the reference's own tests where they exist
+(dh_commitments/src/afgho16/mod.rs:61-94, pedersen/mod.rs:39-55, sipp/src/lib.rs:232-254)."""
+import numpy as np
+import pytest
+
+from helpers import g1arr, g2arr, frarr, gt_from_bytes, g1pt, g2pt
+
+pytestmark = pytest.mark.gpu
+
+
+def test_library_is_the_hip_engine(engine):
+    from ripp_amd._lib import lib
+    assert lib().ripp_device_count() >= 1
+
+
+def test_synthetic_inputs_match_oracle(engine, orc):
+    n = 257
+    assert np.array_equal(engine.synth_g1(1000, n), orc.gen_g1(1000, n))
+    assert np.array_equal(engine.synth_g2(2000, n), orc.gen_g2(2000, n))
+    assert np.array_equal(engine.synth_fr(3, n), orc.gen_scalars(3, n))
+    # strided shard == every world-th element
+    assert np.array_equal(engine.synth_g1(1000, 64, first=1, stride=4), orc.gen_g1(1000, 256)[1::4])
+    assert np.array_equal(engine.synth_fr(3, 64, first=3, stride=4), orc.gen_scalars(3, 256)[3::4])
+
+
+def test_golden_pairing_vectors(engine, vectors):
+    g = vectors["generators"]
+    e = engine.product_of_pairings(g1arr([g["g1"]]), g2arr([g["g2"]]))
+    assert engine.ser_gt(e).hex() == vectors["pairing_generators"]["gt"]
+    v = vectors["product8"]
+    assert engine.ser_gt(engine.product_of_pairings(g1arr(v["a"]), g2arr(v["b"]))).hex() == v["gt"]
+    assert engine.ser_g1(g1arr([g["g1"]])[0]).hex() == g["ser_g1"] and engine.ser_g2(g2arr([g["g2"]])[0]).hex() == g["ser_g2"]
+
+
+def test_golden_sipp_vector(engine, vectors):
+    v = vectors["sipp4"]
+    a, b, r = g1arr(v["a"]), g2arr(v["b"]), frarr(v["r"])
+    value = engine.product_of_pairings_with_coeffs(a, b, r)
+    assert engine.ser_gt(value).hex() == v["value"]
+    assert engine.sipp_seed_digest(a, b, r, value).hex() == v["seed_digest"]
+    proof = engine.SIPP.prove(a, b, r, value)
+    assert [[engine.ser_gt(proof[2 * j]).hex(), engine.ser_gt(proof[2 * j + 1]).hex()] for j in range(2)] == v["proof"]
+    assert engine.SIPP.verify(a, b, r, value, proof)
+
+
+def test_golden_msm_and_fold(engine, orc, vectors):
+    v = vectors["msm8"]; sc = frarr(v["scalars"])
+    r1 = engine.MultiexponentiationInnerProductG1.inner_product(orc.blind_g1(g1arr(v["g1_bases"]), 5), sc)
+    r2 = engine.MultiexponentiationInnerProductG2.inner_product(orc.blind_g2(g2arr(v["g2_bases"]), 6), sc)
+    assert orc.g1_from_row(engine.normalize_batch_g1(r1)[0]) == g1pt(v["g1"])
+    assert orc.g2_from_row(engine.normalize_batch_g2(r2)[0]) == g2pt(v["g2"])
+    f = vectors["fold"]; s = frarr([f["s"]])[0]
+    assert orc.g1_from_row(engine.fold_g1_affine(g1arr([f["g1_hi"]]), g1arr([f["g1_lo"]]), s)[0]) == g1pt(f["g1"])
+    assert orc.g2_from_row(engine.fold_g2_affine(g2arr([f["g2_hi"]]), g2arr([f["g2_lo"]]), s)[0]) == g2pt(f["g2"])
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 31, 32, 33, 64, 1000])
+def test_pairing_inner_product_vs_oracle(engine, orc, n):
+    """PairingInnerProduct::inner_product on projective inputs with random Z and points at infinity (config 2 shape)."""
+    a, b = orc.gen_g1(11, n), orc.gen_g2(17, n)
+    aj, bj = orc.blind_g1(a, 1), orc.blind_g2(b, 2)
+    if n > 4:
+        aj[1] = 0; bj[3] = 0                      # infinity on either side contributes 1
+    rc, exp = orc.pairing_product_j(aj, bj)
+    assert rc == 0 and np.array_equal(engine.PairingInnerProduct.inner_product(aj, bj), exp)
+
+
+def test_pairing_inner_product_length_error(engine, orc):
+    aj, bj = orc.blind_g1(orc.gen_g1(1, 5), 1), orc.blind_g2(orc.gen_g2(1, 4), 2)
+    with pytest.raises(engine.InnerProductError) as ei:
+        engine.PairingInnerProduct.inner_product(aj, bj)
+    assert str(ei.value) == "left length, right length: 5, 4"       # Display impl, inner_products/src/lib.rs:29-38
+
+
+def test_afgho_commitments(engine, orc):
+    n = 8
+    for C, keys, mk in ((engine.AFGHOCommitmentG1, orc.blind_g2(orc.gen_g2(10, n), 1), lambda s, m: orc.blind_g1(orc.gen_g1(s, m), 2)),
+                        (engine.AFGHOCommitmentG2, orc.blind_g1(orc.gen_g1(10, n), 1), lambda s, m: orc.blind_g2(orc.gen_g2(s, m), 2))):
+        msg, wrong = mk(20, n), mk(30, n)
+        com = C.commit(keys, msg)
+        assert C.verify(keys, msg, com) and not C.verify(keys, wrong, com)
+        with pytest.raises(engine.InnerProductError):
+            C.verify(keys, mk(20, n + 1), com)
+    # AFGHO-G1 commit(k, m) = e-product(m, k): same value as the oracle's PairingInnerProduct(m, k)
+    keys, msg = orc.blind_g2(orc.gen_g2(10, n), 1), orc.blind_g1(orc.gen_g1(20, n), 2)
+    assert np.array_equal(engine.AFGHOCommitmentG1.commit(keys, msg), orc.pairing_product_j(msg, keys)[1])
+
+
+def test_pedersen_commitment(engine, orc):
+    n = 8
+    keys, msg, wrong = orc.blind_g1(orc.gen_g1(40, n), 4), orc.gen_scalars(5, n), orc.gen_scalars(6, n)
+    C = engine.PedersenCommitmentG1
+    com = C.commit(keys, msg)
+    assert C.verify(keys, msg, com) and not C.verify(keys, wrong, com)
+    with pytest.raises(engine.InnerProductError):
+        C.verify(keys, orc.gen_scalars(5, n + 1), com)
+
+
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 1 << 10, (1 << 12) + 5])
+def test_msm_vs_oracle(engine, orc, n):
+    s = orc.gen_scalars(21, n)
+    b1, b2 = orc.gen_g1(5, n), orc.gen_g2(6, n)
+    assert np.array_equal(engine.normalize_batch_g1(engine.MultiexponentiationInnerProductG1.inner_product(orc.blind_g1(b1, 9), s)), orc.g1_to_affine(orc.msm_g1_a(b1, s)).reshape(1, 12))
+    if n <= 1 << 10:
+        assert np.array_equal(engine.normalize_batch_g2(engine.MultiexponentiationInnerProductG2.inner_product(orc.blind_g2(b2, 9), s)), orc.g2_to_affine(orc.msm_g2_a(b2, s)).reshape(1, 24))
+
+
+def test_msm_adversarial_scalars(engine, orc):
+    """all-zero, all-one, all-(r-1), few distinct values (bucket skew) -- SURVEY.md section 8d config 3."""
+    n = 1 << 11
+    b1 = orc.gen_g1(5, n)
+    for vals in ([0] * n, [1] * n, [orc.R - 1] * n, [(i % 7) * 0x1234567890ABCDEF1234567 + 3 for i in range(n)]):
+        s = orc.fr_array(vals)
+        got = engine.normalize_batch_g1(engine.MultiexponentiationInnerProductG1.inner_product(orc.blind_g1(b1, 3), s))
+        assert np.array_equal(got, orc.g1_to_affine(orc.msm_g1_a(b1, s)).reshape(1, 12))
+
+
+def test_folds_and_normalise_vs_oracle(engine, orc):
+    n = 300; half = n // 2
+    a, b = orc.gen_g1(31, n), orc.gen_g2(37, n)
+    aj, bj = orc.blind_g1(a, 4), orc.blind_g2(b, 5); aj[7] = 0; bj[9] = 0
+    assert np.array_equal(engine.normalize_batch_g1(aj), orc.normalize_g1(aj))
+    assert np.array_equal(engine.normalize_batch_g2(bj), orc.normalize_g2(bj))
+    for s in (orc.gen_scalars(8, 1)[0], orc.fr_array([2**128 - 1])[0], orc.fr_array([1])[0], orc.fr_array([0])[0]):
+        assert np.array_equal(engine.fold_g1_affine(a[half:], a[:half], s), orc.fold_g1_a(a[half:], a[:half], s))
+        assert np.array_equal(engine.fold_g2_affine(b[half:], b[:half], s), orc.fold_g2_a(b[half:], b[:half], s))
+    s = orc.gen_scalars(8, 1)[0]
+    assert np.array_equal(engine.normalize_batch_g1(engine.fold_g1(aj[half:], aj[:half], s)), orc.normalize_g1(orc.fold_g1_j(aj[half:], aj[:half], s)))
+    assert np.array_equal(engine.normalize_batch_g2(engine.fold_g2(bj[half:], bj[:half], s)), orc.normalize_g2(orc.fold_g2_j(bj[half:], bj[:half], s)))
+    r = orc.gen_scalars(9, n)
+    assert np.array_equal(engine.scale_g1_affine(a, r), orc.scale_g1_a(a, r))
+
+
+@pytest.mark.parametrize("n", [1, 2, 32, 1 << 10])
+def test_sipp_prove_vs_oracle(engine, orc, n):
+    """Whole proof byte-identical to the CPU path; n = 32 is the reference's own test size, 2^10 is config 1."""
+    a, b, r = orc.gen_g1(123, n), orc.gen_g2(456, n), orc.gen_scalars(7, n)
+    value = orc.product_of_pairings_with_coeffs(a, b, r)
+    assert np.array_equal(engine.product_of_pairings_with_coeffs(a, b, r), value)
+    proof, ch, _ = engine.SIPP.prove_with_stats(a, b, r, value)
+    rc, eproof, ech = orc.sipp_prove(a, b, r, value)
+    assert rc == 0 and np.array_equal(proof, eproof) and np.array_equal(ch, ech)
+    if n >= 2:
+        assert engine.SIPP.verify(a, b, r, value, proof)
+        bad = proof.copy(); bad[1] = proof[0]
+        assert not engine.SIPP.verify(a, b, r, value, bad)
+
+
+def test_sipp_rejects_non_power_of_two(engine, orc):
+    a, b, r = orc.gen_g1(1, 24), orc.gen_g2(1, 24), orc.gen_scalars(1, 24)
+    with pytest.raises(AssertionError):
+        engine.SIPP.prove(a, b, r, np.zeros(72, dtype=np.uint64))
+
+
+def test_pairing_product_config2_size(engine, orc):
+    """Config 2: PairingInnerProduct at n = 2^16, checked (a) bit-exact against the oracle on a 2^12 slice,
+    (b) by multiplicativity over a split of the full vector, (c) by bilinearity e(2A, B) = e(A, B)^2 on the full size."""
+    n = 1 << 16
+    a, b = engine.synth_g1(1000, n), engine.synth_g2(2000, n)
+    full = engine.product_of_pairings(a, b)
+    lo, hi = engine.product_of_pairings(a[: n // 2], b[: n // 2]), engine.product_of_pairings(a[n // 2:], b[n // 2:])
+    assert np.array_equal(engine.gt_mul(lo, hi), full)
+    m = 1 << 12
+    assert np.array_equal(engine.product_of_pairings(a[:m], b[:m]), orc.pairing_product_a(a[:m], b[:m]))
+    two = orc.fr_array([2])[0]
+    a2 = engine.fold_g1_affine(a, np.zeros_like(a), two)                        # 2*A_i + infinity
+    assert np.array_equal(engine.product_of_pairings(a2, b), engine.gt_mul(full, full))
+
+
+def test_sipp_full_size_round_trip(engine):
+    """Config 4 shape on one GPU at 2^16: prove -> verify accepts, tampered proof rejected (size-independent property)."""
+    n = 1 << 16
+    a, b, r = engine.synth_g1(1000, n), engine.synth_g2(2000, n), engine.synth_fr(0, n)
+    value = engine.product_of_pairings_with_coeffs(a, b, r)
+    proof = engine.SIPP.prove(a, b, r, value)
+    assert engine.SIPP.verify(a, b, r, value, proof)
+    bad = proof.copy(); bad[5] = proof[4]
+    assert not engine.SIPP.verify(a, b, r, value, bad)
