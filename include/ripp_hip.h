@@ -107,6 +107,15 @@ int32_t ripp_sipp_job_round_partials(ripp_sipp_job* job, ripp_gt* partials /* [2
 int32_t ripp_sipp_job_round_finish(ripp_sipp_job* job, const ripp_gt* combined /* [2][68] */, const uint8_t seed_digest[32],
                                    ripp_gt* z_l, ripp_gt* z_r, ripp_fr* x);
 int32_t ripp_sipp_job_stats(const ripp_sipp_job* job, ripp_stats* stats);
+/* tail of a sharded proof: once every rank holds ONE element (global length == world) the ranks all-gather the
+ * exported elements and each imports the whole remaining vector (global order = rank order); from then on the
+ * job behaves as world == 1 (partials are complete products) while keeping its Fiat-Shamir state. */
+size_t  ripp_sipp_job_local_len(const ripp_sipp_job* job);
+int32_t ripp_sipp_job_export(ripp_sipp_job* job, ripp_g1a* a_out, ripp_g2a* b_out);
+int32_t ripp_sipp_job_import(ripp_sipp_job* job, const ripp_g1a* a, const ripp_g2a* b, size_t len);
+/* element-wise product over `world` ranks of their [count] partial step-products (what replaces a custom RCCL
+ * reduction op: all-gather + local multiply) */
+int32_t ripp_combine_partials(const ripp_gt* gathered /* [world][count] */, int32_t world, size_t count, ripp_gt* out /* [count] */);
 /* Blake2s digest of (a, b, r, value).serialize_uncompressed for a FULL statement held on the host (sipp/src/lib.rs:56-59) */
 int32_t ripp_sipp_seed_digest(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr* r, size_t n, const ripp_gt* value, uint8_t digest[32]);
 

@@ -35,7 +35,7 @@ def lib():
                 "(hipcc --offload-arch=gfx950).  ripp_amd has no CPU fallback.")
         L = ctypes.CDLL(LIB_PATH)
         L.ripp_last_error.restype = ctypes.c_char_p
-        for name in ("ripp_ser_gt", "ripp_ser_g1", "ripp_ser_g2", "ripp_ser_fr", "ripp_sipp_job_rounds_left"):
+        for name in ("ripp_ser_gt", "ripp_ser_g1", "ripp_ser_g2", "ripp_ser_fr", "ripp_sipp_job_rounds_left", "ripp_sipp_job_local_len"):
             getattr(L, name).restype = ctypes.c_size_t
         _lib = L
     return _lib

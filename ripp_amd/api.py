@@ -256,6 +256,24 @@ class SippJob:
         _check(lib().ripp_sipp_job_round_finish(self._h, _p(combined), d, _p(zl), _p(zr), _p(x)))
         return zl, zr, x
 
+    def local_len(self):
+        return int(lib().ripp_sipp_job_local_len(self._h))
+
+    def export(self):
+        n = self.local_len(); a = np.zeros((n, 12), dtype=np.uint64); b = np.zeros((n, 24), dtype=np.uint64)
+        _check(lib().ripp_sipp_job_export(self._h, _p(a), _p(b))); return a, b
+
+    def import_(self, a, b):
+        a, b = _c(a, 12), _c(b, 24)
+        _check(lib().ripp_sipp_job_import(self._h, _p(a), _p(b), ctypes.c_size_t(len(a))))
+
+    @staticmethod
+    def combine(gathered):
+        """element-wise GT product over ranks of their (count,72) partial arrays."""
+        g = np.ascontiguousarray(np.stack(gathered), dtype=np.uint64); world, count = g.shape[0], g.shape[1]
+        out = np.zeros((count, 72), dtype=np.uint64)
+        _check(lib().ripp_combine_partials(_p(g), ctypes.c_int32(world), ctypes.c_size_t(count), _p(out))); return out
+
     def stats(self):
         st = RippStats(); _check(lib().ripp_sipp_job_stats(self._h, ctypes.byref(st))); return st.as_dict()
 

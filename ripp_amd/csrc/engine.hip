@@ -267,7 +267,7 @@ void statement_digest(const G1A* a, const G2A* b, const Fr* r, size_t n, const F
 // =============================================================================================== SIPP job
 struct ripp_sipp_job {
     size_t n_local = 0, len = 0;          // statement shard size; current vector length of this shard
-    int rank = 0, world = 1;
+    int rank = 0, world = 1, world0 = 1;  // world0: sharding of the resident statement; world drops to 1 after the tail import
     DevBuf a0, b0, r0;                    // resident statement shard
     DevBuf a, b, a_next, b_next, jac1, jac2;   // working vectors
     std::vector<G1A> ha; std::vector<G2A> hb; std::vector<Fr> hr;   // host copy of the statement (rank 0 hashes it)
@@ -300,7 +300,7 @@ int32_t job_begin(Engine* e, ripp_sipp_job* j) {
     if ((rc = e->sync()) != RIPP_OK) return rc;
     float ms = 0; (void)hipEventElapsedTime(&ms, t0, t1); e->stats.scale_ms += ms;
     (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
-    j->len = n; j->seeded = false;
+    j->len = n; j->seeded = false; j->world = j->world0;
     return RIPP_OK;
 }
 
@@ -545,7 +545,7 @@ API int32_t ripp_sipp_job_create(const ripp_g1a* a, const ripp_g2a* b, const rip
     LOCK; ENGINE; if (!a || !b || !r || !job || n_local == 0 || world < 1 || rank < 0 || rank >= world) return RIPP_ERR_ARG;
     if (n_local & (n_local - 1)) return RIPP_ERR_POW2;
     ripp_sipp_job* j = new ripp_sipp_job();
-    j->n_local = n_local; j->rank = rank; j->world = world;
+    j->n_local = n_local; j->rank = rank; j->world = world; j->world0 = world;
     int32_t rc;
     if ((rc = j->a0.reserve(n_local * sizeof(G1A))) || (rc = j->b0.reserve(n_local * sizeof(G2A))) || (rc = j->r0.reserve(n_local * sizeof(Fr)))) { delete j; return rc; }
     HIPCHK(hipMemcpyAsync(j->a0.p, a, n_local * sizeof(G1A), hipMemcpyHostToDevice, e->stream));
@@ -582,10 +582,38 @@ API int32_t ripp_sipp_job_round_finish(ripp_sipp_job* j, const ripp_gt* combined
     std::memcpy(z_l, &zl, sizeof(Fp12)); std::memcpy(z_r, &zr, sizeof(Fp12)); std::memcpy(x, &xc, sizeof(Fr));
     return job_fold(e, j, xc);
 }
+API size_t ripp_sipp_job_local_len(const ripp_sipp_job* j) { return j ? j->len : 0; }
+API int32_t ripp_sipp_job_export(ripp_sipp_job* j, ripp_g1a* a_out, ripp_g2a* b_out) {
+    LOCK; ENGINE; if (!j || !a_out || !b_out) return RIPP_ERR_ARG;
+    HIPCHK(hipMemcpyAsync(a_out, j->a.p, j->len * sizeof(G1A), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(b_out, j->b.p, j->len * sizeof(G2A), hipMemcpyDeviceToHost, e->stream));
+    return e->sync();
+}
+API int32_t ripp_sipp_job_import(ripp_sipp_job* j, const ripp_g1a* a, const ripp_g2a* b, size_t len) {
+    LOCK; ENGINE; if (!j || !a || !b || len == 0 || (len & (len - 1))) return RIPP_ERR_ARG;
+    int32_t rc;
+    if ((rc = j->a.reserve(len * sizeof(G1A))) || (rc = j->b.reserve(len * sizeof(G2A))) || (rc = j->a_next.reserve(len * sizeof(G1A))) ||
+        (rc = j->b_next.reserve(len * sizeof(G2A))) || (rc = j->jac1.reserve(len * sizeof(G1J))) || (rc = j->jac2.reserve(len * sizeof(G2J)))) return rc;
+    HIPCHK(hipMemcpyAsync(j->a.p, a, len * sizeof(G1A), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(j->b.p, b, len * sizeof(G2A), hipMemcpyHostToDevice, e->stream));
+    if ((rc = e->sync())) return rc;
+    j->len = len; j->world = 1;
+    return RIPP_OK;
+}
+API int32_t ripp_combine_partials(const ripp_gt* gathered, int32_t world, size_t count, ripp_gt* out) {
+    if (!gathered || !out || world < 1) return RIPP_ERR_ARG;
+    const Fp12* g = reinterpret_cast<const Fp12*>(gathered);
+    for (size_t k = 0; k < count; ++k) {
+        Fp12 acc; std::memcpy(&acc, &g[k], sizeof acc);
+        for (int w = 1; w < world; ++w) { Fp12 t; std::memcpy(&t, &g[(size_t)w * count + k], sizeof t); acc = mul(acc, t); }
+        std::memcpy(&out[k], &acc, sizeof acc);
+    }
+    return RIPP_OK;
+}
 API int32_t ripp_sipp_job_stats(const ripp_sipp_job* j, ripp_stats* st) { LOCK; ENGINE; if (!j || !st) return RIPP_ERR_ARG; e->collect_kernel_stats(); *st = e->stats; return RIPP_OK; }
 
 API int32_t ripp_sipp_job_prove(ripp_sipp_job* j, const ripp_gt* value, ripp_gt* proof, ripp_fr* challenges, ripp_stats* st) {
-    LOCK; ENGINE; if (!j || !value || !proof || j->world != 1) return RIPP_ERR_ARG;
+    LOCK; ENGINE; if (!j || !value || !proof || j->world0 != 1) return RIPP_ERR_ARG;
     Fp12 val; std::memcpy(&val, value, sizeof(Fp12));
     const double t_start = now_ms();
     job_start_hash(j, val);                                  // overlaps with the scaling + round-1 kernels
