@@ -61,6 +61,7 @@ struct Engine {
     hipStream_t stream = nullptr;
     // scratch
     DevBuf lines, partA, partB, jacG1, jacG2, tmpA, tmpB, tmpR, affG1, affG2;
+    DevBuf qtab;                          // [u^j]Q table of the GLS G2 fold
     DevBuf m_digits, m_hist, m_offs, m_cursor, m_slotoffs, m_spw, m_sorted, m_slots, m_buckets, m_seg, m_win, m_out;   // MSM scratch
     Fp12* pinned_rows = nullptr;          // pinned host landing zone for per-step products
     size_t pinned_rows_cap = 0;
@@ -78,7 +79,7 @@ struct Engine {
         return RIPP_OK;
     }
     void destroy() {
-        for (DevBuf* b : {&lines, &partA, &partB, &jacG1, &jacG2, &tmpA, &tmpB, &tmpR, &affG1, &affG2, &m_digits, &m_hist, &m_offs, &m_cursor, &m_slotoffs, &m_spw, &m_sorted, &m_slots, &m_buckets, &m_seg, &m_win, &m_out}) b->release();
+        for (DevBuf* b : {&lines, &partA, &partB, &jacG1, &jacG2, &tmpA, &tmpB, &tmpR, &affG1, &affG2, &qtab, &m_digits, &m_hist, &m_offs, &m_cursor, &m_slotoffs, &m_spw, &m_sorted, &m_slots, &m_buckets, &m_seg, &m_win, &m_out}) b->release();
         if (pinned_rows) (void)hipHostFree(pinned_rows);
         for (auto& e : ev_lines) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         for (auto& e : ev_prod) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -213,6 +214,50 @@ ScalarBits scalar_bits(const Fr& s_mont) {
     sb.nbits = top + 1; return sb;
 }
 
+// non-adjacent form of a little-endian multi-word integer; returns the digit count (digits[0] = least significant)
+int naf_recode(const uint32_t* words, int nwords, int8_t* digits, int maxd) {
+    uint32_t w[10] = {0};
+    for (int i = 0; i < nwords; ++i) w[i] = words[i];
+    auto is_zero = [&]() { for (int i = 0; i <= nwords; ++i) if (w[i]) return false; return true; };
+    int n = 0;
+    while (!is_zero() && n < maxd) {
+        int8_t d = 0;
+        if (w[0] & 1u) {
+            d = (int8_t)(2 - (int)(w[0] & 3u));                // +1 if w = 1 mod 4, -1 if w = 3 mod 4
+            if (d > 0) { w[0] &= ~1u; }
+            else { for (int i = 0; i <= nwords; ++i) { if (++w[i] != 0) break; } }   // w += 1
+        }
+        digits[n++] = d;
+        for (int i = 0; i < nwords; ++i) w[i] = (w[i] >> 1) | (w[i + 1] << 31);       // w >>= 1
+        w[nwords] >>= 1;
+    }
+    return n;
+}
+NafDigits naf_digits(const Fr& s_mont) {
+    const Fr c = from_mont(s_mont);
+    NafDigits nd; std::memset(&nd, 0, sizeof nd);
+    nd.len = naf_recode(c.l, 8, nd.d, 258);
+    return nd;
+}
+// s = d0 + d1 u + d2 u^2 + d3 u^3 with u = |x| = 0xd201000000010000, each digit NAF-recoded
+GlsDigits gls_digits(const Fr& s_mont) {
+    const Fr c = from_mont(s_mont);
+    uint64_t v[4] = {(uint64_t)c.l[0] | ((uint64_t)c.l[1] << 32), (uint64_t)c.l[2] | ((uint64_t)c.l[3] << 32),
+                     (uint64_t)c.l[4] | ((uint64_t)c.l[5] << 32), (uint64_t)c.l[6] | ((uint64_t)c.l[7] << 32)};
+    GlsDigits g; std::memset(&g, 0, sizeof g);
+    int maxlen = 0;
+    for (int j = 0; j < 4; ++j) {
+        unsigned __int128 rem = 0;                             // v <- v / u, digit = v mod u
+        for (int i = 3; i >= 0; --i) { const unsigned __int128 cur = (rem << 64) | v[i]; v[i] = (uint64_t)(cur / BLS_X_ABS); rem = cur % BLS_X_ABS; }
+        const uint64_t dj = (uint64_t)rem;
+        const uint32_t words[2] = {(uint32_t)dj, (uint32_t)(dj >> 32)};
+        const int len = naf_recode(words, 2, g.d[j], 66);
+        if (len > maxlen) maxlen = len;
+    }
+    g.len = maxlen;
+    return g;
+}
+
 template <class T> int32_t upload(Engine* e, DevBuf& buf, const void* host, size_t n, T** dev) {
     int32_t rc = buf.reserve(std::max<size_t>(n, 1) * sizeof(T)); if (rc != RIPP_OK) return rc;
     if (n) HIPCHK(hipMemcpyAsync(buf.p, host, n * sizeof(T), hipMemcpyHostToDevice, e->stream));
@@ -323,9 +368,11 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x) {
     hipEvent_t t0, t1; HIPCHK(hipEventCreate(&t0)); HIPCHK(hipEventCreate(&t1));
     HIPCHK(hipEventRecord(t0, e->stream));
     G1A* a = j->a.as<G1A>(); G2A* b = j->b.as<G2A>();
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_affine<Fp>), dim3(nblk(half, 256)), dim3(256), 0, e->stream, a + half, a, (uint32_t)half, scalar_bits(x), j->jac1.as<G1J>());
+    const size_t qstride = (half + 63) & ~(size_t)63;
+    if ((rc = e->qtab.reserve(4 * G2A_CHUNKS * qstride * sizeof(uint4))) != RIPP_OK) return rc;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_affine_naf<Fp>), dim3(nblk(half, 256)), dim3(256), 0, e->stream, a + half, a, (uint32_t)half, naf_digits(x), j->jac1.as<G1J>());
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_affine<Fp2>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, b + half, b, (uint32_t)half, scalar_bits(x_inv), j->jac2.as<G2J>());
+    hipLaunchKernelGGL(k_fold_g2_gls, dim3(nblk(half, 64)), dim3(64), 0, e->stream, b + half, b, (uint32_t)half, gls_digits(x_inv), e->qtab.as<uint4>(), qstride, j->jac2.as<G2J>());
     HIPCHK(hipGetLastError());
     if ((rc = e->normalize_dev<Fp>(j->jac1.as<G1J>(), half, j->a_next.as<G1A>())) != RIPP_OK) return rc;
     if ((rc = e->normalize_dev<Fp2>(j->jac2.as<G2J>(), half, j->b_next.as<G2A>())) != RIPP_OK) return rc;
@@ -416,7 +463,14 @@ static int32_t fold_impl(const IN* hi, const IN* lo, size_t half, const ripp_fr*
         Affine<F>*dh, *dl;
         if ((rc = upload<Affine<F>>(e, e->tmpA, hi, half, &dh))) return rc;
         if ((rc = upload<Affine<F>>(e, e->tmpB, lo, half, &dl))) return rc;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_affine<F>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, dh, dl, (uint32_t)half, sb, jac.as<Jac<F>>());
+        if (std::is_same<F, Fp2>::value) {
+            const size_t qstride = (half + 63) & ~(size_t)63;
+            if ((rc = e->qtab.reserve(4 * G2A_CHUNKS * qstride * sizeof(uint4)))) return rc;
+            hipLaunchKernelGGL(k_fold_g2_gls, dim3(nblk(half, 64)), dim3(64), 0, e->stream, reinterpret_cast<const G2A*>(dh), reinterpret_cast<const G2A*>(dl), (uint32_t)half,
+                               gls_digits(sm), e->qtab.as<uint4>(), qstride, reinterpret_cast<G2J*>(jac.p));
+        } else {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_affine_naf<F>), dim3(nblk(half, 256)), dim3(256), 0, e->stream, dh, dl, (uint32_t)half, naf_digits(sm), jac.as<Jac<F>>());
+        }
     }
     HIPCHK(hipGetLastError());
     if (AFF_OUT) {

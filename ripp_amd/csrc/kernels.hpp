@@ -148,6 +148,70 @@ __global__ void __launch_bounds__(256) k_fold_jac(const Jac<F>* __restrict__ hi,
     out[i] = add(acc, lo[i]);
 }
 
+// ---- G2 fold with the GLS endomorphism --------------------------------------------------------------------
+// psi = twist o Frobenius o untwist acts on G2 as multiplication by x (p = x mod r), so with u = |x| (64 bit)
+//   [u^j] Q = (conj^j(x_Q) * PSIj_CX, conj^j(y_Q) * PSIj_CY)          (constants from tools/gen_params.py)
+// costs two Fp2 multiplications.  The shared 255-bit scalar s is written in base u on the host,
+// s = d0 + d1 u + d2 u^2 + d3 u^3 (0 <= d_j < u), each d_j NAF-recoded, and every lane runs the SAME joint
+// double-and-add over <= 65 digit positions: 65 doublings + ~87 mixed additions instead of 255 + ~128.
+// The four affine points [u^j]Q of a lane are parked in HBM (chunked SoA, L2-resident) so only T stays in VGPRs.
+struct GlsDigits { int8_t d[4][68]; int len; };
+constexpr int G2A_CHUNKS = 12;     // 192 B
+
+RIPP_HD G2A gls_image(const G2A& q, int j) {
+    if (j == 0) return q;
+    Fp2 cx, cy;
+    if (j == 1) { cx = {fp_const(RIPP_PSI1_CX0), fp_const(RIPP_PSI1_CX1)}; cy = {fp_const(RIPP_PSI1_CY0), fp_const(RIPP_PSI1_CY1)}; }
+    else if (j == 2) { cx = {fp_const(RIPP_PSI2_CX0), fp_const(RIPP_PSI2_CX1)}; cy = {fp_const(RIPP_PSI2_CY0), fp_const(RIPP_PSI2_CY1)}; }
+    else { cx = {fp_const(RIPP_PSI3_CX0), fp_const(RIPP_PSI3_CX1)}; cy = {fp_const(RIPP_PSI3_CY0), fp_const(RIPP_PSI3_CY1)}; }
+    const bool odd = (j & 1) != 0;
+    return {mul(odd ? conj(q.x) : q.x, cx), mul(odd ? conj(q.y) : q.y, cy)};
+}
+
+__global__ void __launch_bounds__(64) k_fold_g2_gls(const G2A* __restrict__ hi, const G2A* __restrict__ lo, uint32_t half, GlsDigits dg,
+                                                     uint4* __restrict__ qtab, size_t stride, G2J* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= half) return;
+    {
+        const G2A q = hi[i];
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j) store_chunks<G2A_CHUNKS>(qtab, j, stride, i, gls_image(q, j));
+    }
+    G2J acc = jac_inf<Fp2>();
+#pragma unroll 1
+    for (int pos = dg.len - 1; pos >= 0; --pos) {
+        acc = dbl(acc);
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j) {
+            const int d = dg.d[j][pos];
+            if (d != 0) {
+                G2A q = load_chunks<G2A_CHUNKS, G2A>(qtab, j, stride, i);
+                if (d < 0) q.y = neg(q.y);
+                acc = add_mixed(acc, q);
+            }
+        }
+    }
+    out[i] = add_mixed(acc, lo[i]);
+}
+
+// Single-scalar NAF fold (G1 with the 128-bit SIPP challenge): out[i] = s*hi[i] + lo[i]
+struct NafDigits { int8_t d[260]; int len; };
+template <class F>
+__global__ void __launch_bounds__(256) k_fold_affine_naf(const Affine<F>* __restrict__ hi, const Affine<F>* __restrict__ lo, uint32_t half,
+                                                          NafDigits dg, Jac<F>* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= half) return;
+    const Affine<F> p = hi[i];
+    Jac<F> acc = jac_inf<F>();
+#pragma unroll 1
+    for (int pos = dg.len - 1; pos >= 0; --pos) {
+        acc = dbl(acc);
+        const int d = dg.d[pos];
+        if (d != 0) { Affine<F> q = p; if (d < 0) q.y = neg(q.y); acc = add_mixed(acc, q); }
+    }
+    out[i] = add_mixed(acc, lo[i]);
+}
+
 // ---- batch normalisation (CurveGroup::normalize_batch) ------------------------------------------------------
 // Lane t handles points t, t+T, ..., one inversion per lane (Montgomery's trick over its K points).  The running
 // prefix products are parked in out[i].x, so `in` and `out` must not alias.
