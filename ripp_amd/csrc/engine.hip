@@ -7,6 +7,7 @@
 // sipp/src/lib.rs:56-60,80-85,94.
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <future>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -58,7 +59,9 @@ struct Timer {   // HIP-event stopwatch on the engine stream
 
 struct Engine {
     int device = -1;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: the G1 half of a fold runs beside the G2 half
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int n_simd = 1024;
     // scratch
     DevBuf lines, partA, partB, jacG1, jacG2, tmpA, tmpB, tmpR, affG1, affG2;
     DevBuf qtab;                          // [u^j]Q table of the GLS G2 fold
@@ -75,6 +78,9 @@ struct Engine {
         if (dev < 0 || dev >= n) { set_err("device ordinal out of range"); return RIPP_ERR_ARG; }
         HIPCHK(hipSetDevice(dev));
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n_simd = pr.multiProcessorCount * 4; }
         device = dev;
         return RIPP_OK;
     }
@@ -84,6 +90,8 @@ struct Engine {
         for (auto& e : ev_lines) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         for (auto& e : ev_prod) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         if (stream) (void)hipStreamDestroy(stream);
+        if (stream2) (void)hipStreamDestroy(stream2);
+        if (ev_fork) (void)hipEventDestroy(ev_fork); if (ev_join) (void)hipEventDestroy(ev_join);
     }
     int32_t ensure_pinned_rows(size_t rows) {
         if (rows <= pinned_rows_cap) return RIPP_OK;
@@ -108,12 +116,13 @@ struct Engine {
     }
 
     // ---- normalisation (device in, device out) ------------------------------------------------------------
-    template <class F> int32_t normalize_dev(const Jac<F>* in, size_t n, Affine<F>* out) {
+    template <class F> int32_t normalize_dev(const Jac<F>* in, size_t n, Affine<F>* out, hipStream_t st = nullptr) {
         if (n == 0) return RIPP_OK;
+        if (!st) st = stream;
         // one inversion (~600 Fp products) per lane: amortise over up to 16 points but keep >= ~64K lanes busy
         uint32_t K = (uint32_t)std::min<size_t>(16, std::max<size_t>(1, n / 65536));
         uint32_t T = (uint32_t)((n + K - 1) / K);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_normalize<F>), dim3(nblk(T, 256)), dim3(256), 0, stream, in, (uint32_t)n, out, T);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_normalize<F>), dim3(nblk(T, 256)), dim3(256), 0, st, in, (uint32_t)n, out, T);
         HIPCHK(hipGetLastError());
         return RIPP_OK;
     }
@@ -155,22 +164,25 @@ struct Engine {
         if (M == 0) return RIPP_OK;
         int32_t rc;
         if ((rc = ensure_pinned_rows(nrows)) != RIPP_OK) return rc;
+        if (nprod > 2) return RIPP_ERR_ARG;
         const size_t batch = std::min(M, std::max<size_t>(1, max_pairs_per_batch / nprod));
         for (size_t off = 0; off < M; off += batch) {
             const size_t m = std::min(batch, M - off);
             const size_t stride = (m + 63) & ~(size_t)63;
             if ((rc = lines.reserve(nrows * LINE_CHUNKS * stride * sizeof(uint4))) != RIPP_OK) return rc;
-            // stage 1
-            for (int p = 0; p < nprod; ++p) {
+            // stage 1: one launch, grid.y = product
+            {
+                PairSets ps{}; for (int p = 0; p < nprod; ++p) { ps.a[p] = a[p] + off; ps.b[p] = b[p] + off; }
                 if ((rc = mark(ev_lines, true)) != RIPP_OK) return rc;
-                hipLaunchKernelGGL(k_miller_lines, dim3(nblk(m, 256)), dim3(256), 0, stream, a[p] + off, b[p] + off, (uint32_t)m,
-                                   lines.as<uint4>(), (size_t)p * N_LINES, stride, (size_t)0);
+                hipLaunchKernelGGL(k_miller_lines, dim3(nblk(m, 256), nprod), dim3(256), 0, stream, ps, (uint32_t)m, lines.as<uint4>(), stride);
                 HIPCHK(hipGetLastError());
                 if ((rc = mark(ev_lines, false)) != RIPP_OK) return rc;
-                stats.pairs_lines += m;
+                stats.pairs_lines += m * nprod;
             }
             // stage 2a: T lanes per row
-            uint32_t T = std::min<uint32_t>(pow2_floor((uint32_t)m), 1024);
+            // one resident batch: rows * T / 64 waves <= SIMDs * RIPP_OCC, so no partially filled second batch
+            uint32_t T = (uint32_t)std::max<size_t>(64, ((size_t)n_simd * RIPP_OCC / nrows) * 64);
+            if (T > m) T = (uint32_t)m;
             if ((rc = partA.reserve(nrows * FP12_CHUNKS * (size_t)T * sizeof(uint4))) != RIPP_OK) return rc;
             if ((rc = partB.reserve(nrows * FP12_CHUNKS * (size_t)((T + 3) / 4) * sizeof(uint4))) != RIPP_OK) return rc;
             if ((rc = mark(ev_prod, true)) != RIPP_OK) return rc;
@@ -370,12 +382,17 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x) {
     G1A* a = j->a.as<G1A>(); G2A* b = j->b.as<G2A>();
     const size_t qstride = (half + 63) & ~(size_t)63;
     if ((rc = e->qtab.reserve(4 * G2A_CHUNKS * qstride * sizeof(uint4))) != RIPP_OK) return rc;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_affine_naf<Fp>), dim3(nblk(half, 256)), dim3(256), 0, e->stream, a + half, a, (uint32_t)half, naf_digits(x), j->jac1.as<G1J>());
+    // G1 half on stream2, G2 half on the main stream (small rounds leave most of the chip idle otherwise)
+    HIPCHK(hipEventRecord(e->ev_fork, e->stream));
+    HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_affine_naf<Fp>), dim3(nblk(half, 256)), dim3(256), 0, e->stream2, a + half, a, (uint32_t)half, naf_digits(x), j->jac1.as<G1J>());
     HIPCHK(hipGetLastError());
+    if ((rc = e->normalize_dev<Fp>(j->jac1.as<G1J>(), half, j->a_next.as<G1A>(), e->stream2)) != RIPP_OK) return rc;
+    HIPCHK(hipEventRecord(e->ev_join, e->stream2));
     hipLaunchKernelGGL(k_fold_g2_gls, dim3(nblk(half, 64)), dim3(64), 0, e->stream, b + half, b, (uint32_t)half, gls_digits(x_inv), e->qtab.as<uint4>(), qstride, j->jac2.as<G2J>());
     HIPCHK(hipGetLastError());
-    if ((rc = e->normalize_dev<Fp>(j->jac1.as<G1J>(), half, j->a_next.as<G1A>())) != RIPP_OK) return rc;
     if ((rc = e->normalize_dev<Fp2>(j->jac2.as<G2J>(), half, j->b_next.as<G2A>())) != RIPP_OK) return rc;
+    HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
     HIPCHK(hipEventRecord(t1, e->stream));
     if ((rc = e->sync()) != RIPP_OK) return rc;
     float ms = 0; (void)hipEventElapsedTime(&ms, t0, t1); e->stats.fold_ms += ms;
@@ -629,7 +646,9 @@ API int32_t ripp_sipp_job_round_finish(ripp_sipp_job* j, const ripp_gt* combined
     LOCK; ENGINE; if (!j || !combined || !z_l || !z_r || !x) return RIPP_ERR_ARG;
     const double t0 = now_ms();
     const Fp12* rows = reinterpret_cast<const Fp12*>(combined);
-    const Fp12 zl = final_exponentiation(miller_combine(rows)), zr = final_exponentiation(miller_combine(rows + N_LINES));
+    auto fut = std::async(std::launch::async, [rows]() { return final_exponentiation(miller_combine(rows + N_LINES)); });
+    const Fp12 zl = final_exponentiation(miller_combine(rows));
+    const Fp12 zr = fut.get();
     if (!j->seeded) { if (!seed_digest) return RIPP_ERR_ARG; j->rng.from_digest(seed_digest); j->seeded = true; }
     const Fr xc = fs::sipp_challenge(j->rng, zl, zr);
     e->stats.host_ms += now_ms() - t0;
@@ -677,7 +696,9 @@ API int32_t ripp_sipp_job_prove(ripp_sipp_job* j, const ripp_gt* value, ripp_gt*
         Fp12 rows[2 * N_LINES];
         if ((rc = job_round_partials(e, j, rows))) return rc;
         const double t0 = now_ms();
-        const Fp12 zl = final_exponentiation(miller_combine(rows)), zr = final_exponentiation(miller_combine(rows + N_LINES));
+        auto fut = std::async(std::launch::async, [&rows]() { return final_exponentiation(miller_combine(rows + N_LINES)); });
+        const Fp12 zl = final_exponentiation(miller_combine(rows));
+        const Fp12 zr = fut.get();
         if (!j->seeded) {
             const double th = now_ms();
             if (j->hash_thread.joinable()) j->hash_thread.join();

@@ -17,6 +17,9 @@
 
 namespace ripp {
 
+#ifndef RIPP_OCC
+#define RIPP_OCC 2      // min waves per SIMD requested for the register-heavy kernels (caps them at 256 VGPR+AGPR)
+#endif
 constexpr int LINE_CHUNKS = 18;    // 3 Fp2 = 72 dwords
 constexpr int FP12_CHUNKS = 36;    // 144 dwords
 
@@ -41,26 +44,29 @@ __device__ __forceinline__ T load_chunks(const uint4* buf, size_t row, size_t st
 }
 
 // ---- stage 1: line elements --------------------------------------------------------------------------------
-// a, b: M pairs (affine).  lines: [nrows = 68][18][stride].  Pairs with a point at infinity emit the unit line.
-__global__ void __launch_bounds__(256) k_miller_lines(const G1A* __restrict__ a, const G2A* __restrict__ b, uint32_t M,
-                                                       uint4* __restrict__ lines, size_t row0, size_t stride, size_t col0) {
+// grid.y = product index p: pairs (a[p][i], b[p][i]), i < M, rows p*68 .. p*68+67 of lines[rows][18][stride].
+// Pairs with a point at infinity emit the unit line.  Both pairing products of a SIPP round go in ONE launch.
+struct PairSets { const G1A* a[2]; const G2A* b[2]; };
+__global__ void __launch_bounds__(256, RIPP_OCC) k_miller_lines(PairSets ps, uint32_t M, uint4* __restrict__ lines, size_t stride) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
+    const G1A* __restrict__ a = ps.a[blockIdx.y];
+    const G2A* __restrict__ b = ps.b[blockIdx.y];
     const G1A P = a[i];
     Fp2 X, Y, Z = Fp2::one();
     { const G2A Q = b[i]; X = Q.x; Y = Q.y; }
     const bool skip = is_inf(P) || (X.is_zero() && Y.is_zero());
     const LineCoeffs unit = {Fp2::one(), Fp2::zero(), Fp2::zero()};
-    size_t s = row0;
+    size_t s = (size_t)blockIdx.y * N_LINES;
 #pragma unroll 1
     for (int bit = 62; bit >= 0; --bit) {
         LineCoeffs l = line_double(X, Y, Z, P.x, P.y);
-        store_chunks<LINE_CHUNKS>(lines, s, stride, col0 + i, skip ? unit : l);
+        store_chunks<LINE_CHUNKS>(lines, s, stride, i, skip ? unit : l);
         ++s;
         if ((BLS_X_ABS >> bit) & 1ull) {
             const G2A Q = b[i];
             l = line_add(X, Y, Z, Q.x, Q.y, P.x, P.y);
-            store_chunks<LINE_CHUNKS>(lines, s, stride, col0 + i, skip ? unit : l);
+            store_chunks<LINE_CHUNKS>(lines, s, stride, i, skip ? unit : l);
             ++s;
         }
     }
@@ -68,7 +74,7 @@ __global__ void __launch_bounds__(256) k_miller_lines(const G1A* __restrict__ a,
 
 // ---- stage 2a: sparse accumulation -------------------------------------------------------------------------
 // grid = (T / block, rows).  Lane t of row r multiplies lines r[t], r[t+T], ... (< M) and writes one dense partial.
-__global__ void __launch_bounds__(256) k_line_products(const uint4* __restrict__ lines, size_t stride, uint32_t M,
+__global__ void __launch_bounds__(64, RIPP_OCC) k_line_products(const uint4* __restrict__ lines, size_t stride, uint32_t M,
                                                         uint4* __restrict__ partials, uint32_t T) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
@@ -88,7 +94,7 @@ __global__ void __launch_bounds__(256) k_line_products(const uint4* __restrict__
 
 // ---- stage 2b: dense product tree --------------------------------------------------------------------------
 // in: [rows][36][Tin] -> out: [rows][36][Tout];  out[j] = prod_{k<R} in[j + k*Tout]
-__global__ void __launch_bounds__(64) k_fp12_tree(const uint4* __restrict__ in, uint32_t Tin, uint4* __restrict__ out, uint32_t Tout, int R) {
+__global__ void __launch_bounds__(64, RIPP_OCC) k_fp12_tree(const uint4* __restrict__ in, uint32_t Tin, uint4* __restrict__ out, uint32_t Tout, int R) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= Tout) return;
     const size_t row = blockIdx.y;
@@ -168,7 +174,7 @@ RIPP_HD G2A gls_image(const G2A& q, int j) {
     return {mul(odd ? conj(q.x) : q.x, cx), mul(odd ? conj(q.y) : q.y, cy)};
 }
 
-__global__ void __launch_bounds__(64) k_fold_g2_gls(const G2A* __restrict__ hi, const G2A* __restrict__ lo, uint32_t half, GlsDigits dg,
+__global__ void __launch_bounds__(64, RIPP_OCC) k_fold_g2_gls(const G2A* __restrict__ hi, const G2A* __restrict__ lo, uint32_t half, GlsDigits dg,
                                                      uint4* __restrict__ qtab, size_t stride, G2J* __restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= half) return;
