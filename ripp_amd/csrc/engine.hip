@@ -35,6 +35,7 @@ Engine* g_engine = nullptr;
 
 #define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_err(std::string(#expr) + ": " + hipGetErrorString(e_)); return RIPP_ERR_DEVICE; } } while (0)
 void set_err(const std::string& s) { g_err = s; }
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 inline unsigned nblk(size_t n, unsigned b) { return (unsigned)((n + b - 1) / b); }
 inline uint32_t pow2_floor(uint32_t v) { uint32_t p = 1; while ((p << 1) <= v && (p << 1) != 0) p <<= 1; return p; }
@@ -276,12 +277,13 @@ template <class T> int32_t upload(Engine* e, DevBuf& buf, const void* host, size
     *dev = buf.as<T>(); return RIPP_OK;
 }
 
-double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // Blake2s of (a, b, r, value).serialize_uncompressed (sipp/src/lib.rs:56-59).  Serialisation (Montgomery -> canonical
 // big-endian) is spread over worker threads in blocks; the hash itself is inherently sequential.
+double g_digest_hash_ms = 0, g_digest_wait_ms = 0;
 void statement_digest(const G1A* a, const G2A* b, const Fr* r, size_t n, const Fp12& value, uint8_t digest[32]) {
     fs::Blake2s h;
+    g_digest_hash_ms = g_digest_wait_ms = 0;
     const uint64_t len = (uint64_t)n;
     const size_t BLK = 1 << 14;
     unsigned nthreads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
@@ -311,8 +313,11 @@ void statement_digest(const G1A* a, const G2A* b, const Fr* r, size_t n, const F
             const size_t s = k * BLK, e = std::min(n, s + BLK);
             std::thread next;
             if (k + 1 < nblocks) next = std::thread(ser_block, (int)((k + 1) & 1), e, std::min(n, e + BLK), kind);
+            double t0 = now_ms();
             h.update(buf[k & 1].data(), (e - s) * item[kind]);
+            double t1 = now_ms();
             if (next.joinable()) next.join();
+            g_digest_hash_ms += t1 - t0; g_digest_wait_ms += now_ms() - t1;
         }
     }
     uint8_t gt[576]; fs::ser_gt(value, gt); h.update(gt, 576);
@@ -420,6 +425,7 @@ extern "C" {
 #define ENGINE Engine* e; { int32_t rc_ = get_engine(&e); if (rc_ != RIPP_OK) return rc_; }
 
 API const char* ripp_last_error(void) { return g_err.c_str(); }
+API void ripp_debug_digest_times(double* hash_ms, double* wait_ms) { *hash_ms = g_digest_hash_ms; *wait_ms = g_digest_wait_ms; }
 API int32_t ripp_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 API int32_t ripp_init(int32_t dev) {
     LOCK;
