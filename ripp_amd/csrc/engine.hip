@@ -11,6 +11,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -70,6 +71,7 @@ struct Engine {
     Fp12* pinned_rows = nullptr;          // pinned host landing zone for per-step products
     size_t pinned_rows_cap = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_lines, ev_prod;   // per-launch event pairs of the two dominant kernels
+    size_t gls_split_max = (size_t)1 << 14;                               // rounds with <= this many outputs use the 4-lane GLS fold
     size_t max_pairs_per_batch = (size_t)1 << 19;                        // lines buffer cap: 2^19 pairs * 19.6 KB = 10.3 GB
     ripp_stats stats{};
 
@@ -185,7 +187,7 @@ struct Engine {
             uint32_t T = (uint32_t)std::max<size_t>(64, ((size_t)n_simd * RIPP_OCC / nrows) * 64);
             if (T > m) T = (uint32_t)m;
             if ((rc = partA.reserve(nrows * FP12_CHUNKS * (size_t)T * sizeof(uint4))) != RIPP_OK) return rc;
-            if ((rc = partB.reserve(nrows * FP12_CHUNKS * (size_t)((T + 3) / 4) * sizeof(uint4))) != RIPP_OK) return rc;
+            if ((rc = partB.reserve(nrows * FP12_CHUNKS * (size_t)((T + 1) / 2) * sizeof(uint4))) != RIPP_OK) return rc;
             if ((rc = mark(ev_prod, true)) != RIPP_OK) return rc;
             hipLaunchKernelGGL(k_line_products, dim3(nblk(T, 64), (unsigned)nrows), dim3(64), 0, stream, lines.as<uint4>(), stride, (uint32_t)m, partA.as<uint4>(), T);
             HIPCHK(hipGetLastError());
@@ -194,8 +196,10 @@ struct Engine {
             // stage 2b: dense tree, radix 4
             uint4* cur = partA.as<uint4>(); uint4* nxt = partB.as<uint4>();
             while (T > 1) {
-                const uint32_t Tout = (T + 3) / 4;
-                hipLaunchKernelGGL(k_fp12_tree, dim3(nblk(Tout, 64), (unsigned)nrows), dim3(64), 0, stream, cur, T, nxt, Tout, 4);
+                // radix 4 while the level still fills the chip, radix 2 (one dependent Fp12 product per level) once it is latency-bound
+                const int R = ((size_t)T * nrows > (size_t)n_simd * 64) ? 4 : 2;
+                const uint32_t Tout = (T + R - 1) / R;
+                hipLaunchKernelGGL(k_fp12_tree, dim3(nblk(Tout, 64), (unsigned)nrows), dim3(64), 0, stream, cur, T, nxt, Tout, R);
                 HIPCHK(hipGetLastError());
                 std::swap(cur, nxt); T = Tout;
             }
@@ -218,6 +222,8 @@ int32_t get_engine(Engine** out) {
     if (hipSetDevice(g_engine->device) != hipSuccess) { set_err("hipSetDevice failed"); return RIPP_ERR_DEVICE; }
     *out = g_engine; return RIPP_OK;
 }
+
+bool trace_on() { static const bool on = std::getenv("RIPP_TRACE") != nullptr; return on; }
 
 ScalarBits scalar_bits(const Fr& s_mont) {
     const Fr c = from_mont(s_mont);
@@ -394,7 +400,13 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x) {
     HIPCHK(hipGetLastError());
     if ((rc = e->normalize_dev<Fp>(j->jac1.as<G1J>(), half, j->a_next.as<G1A>(), e->stream2)) != RIPP_OK) return rc;
     HIPCHK(hipEventRecord(e->ev_join, e->stream2));
-    hipLaunchKernelGGL(k_fold_g2_gls, dim3(nblk(half, 64)), dim3(64), 0, e->stream, b + half, b, (uint32_t)half, gls_digits(x_inv), e->qtab.as<uint4>(), qstride, j->jac2.as<G2J>());
+    if (half <= e->gls_split_max) {     // latency-bound round: 4 lanes per element
+        if ((rc = e->qtab.reserve(std::max<size_t>(4 * G2A_CHUNKS * qstride * sizeof(uint4), 4 * half * sizeof(G2J)))) != RIPP_OK) return rc;
+        hipLaunchKernelGGL(k_fold_g2_gls_split, dim3(nblk(half, 64), 4), dim3(64), 0, e->stream, b + half, (uint32_t)half, gls_digits(x_inv), e->qtab.as<G2J>());
+        hipLaunchKernelGGL(k_fold_g2_combine, dim3(nblk(half, 64)), dim3(64), 0, e->stream, e->qtab.as<G2J>(), b, (uint32_t)half, j->jac2.as<G2J>());
+    } else {
+        hipLaunchKernelGGL(k_fold_g2_gls, dim3(nblk(half, 64)), dim3(64), 0, e->stream, b + half, b, (uint32_t)half, gls_digits(x_inv), e->qtab.as<uint4>(), qstride, j->jac2.as<G2J>());
+    }
     HIPCHK(hipGetLastError());
     if ((rc = e->normalize_dev<Fp2>(j->jac2.as<G2J>(), half, j->b_next.as<G2A>())) != RIPP_OK) return rc;
     HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
@@ -697,9 +709,11 @@ API int32_t ripp_sipp_job_prove(ripp_sipp_job* j, const ripp_gt* value, ripp_gt*
     const double t_start = now_ms();
     job_start_hash(j, val);                                  // overlaps with the scaling + round-1 kernels
     int32_t rc = job_begin(e, j); if (rc) return rc;
+    if (trace_on()) fprintf(stderr, "[ripp] scale+normalize done at t=%.1f ms\n", now_ms() - t_start);
     size_t round = 0;
     while (j->len > 1) {
         Fp12 rows[2 * N_LINES];
+        const double tr0 = now_ms();
         if ((rc = job_round_partials(e, j, rows))) return rc;
         const double t0 = now_ms();
         auto fut = std::async(std::launch::async, [&rows]() { return final_exponentiation(miller_combine(rows + N_LINES)); });
@@ -715,7 +729,9 @@ API int32_t ripp_sipp_job_prove(ripp_sipp_job* j, const ripp_gt* value, ripp_gt*
         e->stats.host_ms += now_ms() - t0;
         std::memcpy(&proof[2 * round], &zl, sizeof(Fp12)); std::memcpy(&proof[2 * round + 1], &zr, sizeof(Fp12));
         if (challenges) std::memcpy(&challenges[round], &x, sizeof(Fr));
+        const double tf0 = now_ms();
         if ((rc = job_fold(e, j, x))) return rc;
+        if (trace_on()) fprintf(stderr, "[ripp] round %2zu len %8zu: products %.2f ms, host %.2f ms, fold %.2f ms (t=%.1f)\n", round, j->len * 2, t0 - tr0, tf0 - t0, now_ms() - tf0, now_ms() - t_start);
         ++round;
     }
     if (j->hash_thread.joinable()) j->hash_thread.join();     // n == 1: no rounds

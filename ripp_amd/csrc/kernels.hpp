@@ -200,6 +200,32 @@ __global__ void __launch_bounds__(64, RIPP_OCC) k_fold_g2_gls(const G2A* __restr
     out[i] = add_mixed(acc, lo[i]);
 }
 
+// Latency form of the GLS fold for SMALL rounds (the chip is mostly idle, a lone lane needs ~2.4 us per dependent
+// Fp product): the four sub-scalar multiplications d_j * [u^j]Q run on four different lanes.  blockIdx.y = j, so
+// every wave still has uniform control flow (one digit string per wave); 65 dbl + ~22 adds per lane instead of
+// 65 + ~87.  k_fold_g2_combine then sums the four partial points and adds lo.  1.9x the total work of the
+// single-lane form, so the engine uses it only below a size threshold.
+__global__ void __launch_bounds__(64) k_fold_g2_gls_split(const G2A* __restrict__ hi, uint32_t half, GlsDigits dg, G2J* __restrict__ parts /* [4][half] */) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= half) return;
+    const int j = blockIdx.y;
+    const G2A q = gls_image(hi[i], j);
+    G2J acc = jac_inf<Fp2>();
+#pragma unroll 1
+    for (int pos = dg.len - 1; pos >= 0; --pos) {
+        acc = dbl(acc);
+        const int d = dg.d[j][pos];
+        if (d != 0) { G2A t = q; if (d < 0) t.y = neg(t.y); acc = add_mixed(acc, t); }
+    }
+    parts[(size_t)j * half + i] = acc;
+}
+__global__ void __launch_bounds__(64) k_fold_g2_combine(const G2J* __restrict__ parts, const G2A* __restrict__ lo, uint32_t half, G2J* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= half) return;
+    G2J acc = add(add(parts[i], parts[(size_t)half + i]), add(parts[2 * (size_t)half + i], parts[3 * (size_t)half + i]));
+    out[i] = add_mixed(acc, lo[i]);
+}
+
 // Single-scalar NAF fold (G1 with the 128-bit SIPP challenge): out[i] = s*hi[i] + lo[i]
 struct NafDigits { int8_t d[260]; int len; };
 template <class F>
