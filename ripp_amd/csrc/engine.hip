@@ -19,6 +19,7 @@
 #include "../../include/ripp_hip.h"
 #include "kernels.hpp"
 #include "msm.hpp"
+#include "vm.hpp"
 #include "host_fs.hpp"
 
 using namespace ripp;
@@ -71,6 +72,7 @@ struct Engine {
     Fp12* pinned_rows = nullptr;          // pinned host landing zone for per-step products
     size_t pinned_rows_cap = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_lines, ev_prod;   // per-launch event pairs of the two dominant kernels
+    size_t vm_lines_max = (size_t)1 << 13;                                // launches with <= this many pairs use the 16-lanes-per-pair VM line kernel
     size_t gls_split_max = (size_t)1 << 14;                               // rounds with <= this many outputs use the 4-lane GLS fold
     size_t max_pairs_per_batch = (size_t)1 << 19;                        // lines buffer cap: 2^19 pairs * 19.6 KB = 10.3 GB
     ripp_stats stats{};
@@ -177,7 +179,10 @@ struct Engine {
             {
                 PairSets ps{}; for (int p = 0; p < nprod; ++p) { ps.a[p] = a[p] + off; ps.b[p] = b[p] + off; }
                 if ((rc = mark(ev_lines, true)) != RIPP_OK) return rc;
-                hipLaunchKernelGGL(k_miller_lines, dim3(nblk(m, 256), nprod), dim3(256), 0, stream, ps, (uint32_t)m, lines.as<uint4>(), stride);
+                if (m * nprod <= vm_lines_max && !std::getenv("RIPP_NO_VM"))
+                    hipLaunchKernelGGL(k_vm_miller_lines, dim3(nblk(m, 4 * VM_EPW), nprod), dim3(256), 4 * VM_EPW * VM_LINES_SLOTS * sizeof(Fp), stream, ps, (uint32_t)m, lines.as<uint4>(), stride);
+                else
+                    hipLaunchKernelGGL(k_miller_lines, dim3(nblk(m, 256), nprod), dim3(256), 0, stream, ps, (uint32_t)m, lines.as<uint4>(), stride);
                 HIPCHK(hipGetLastError());
                 if ((rc = mark(ev_lines, false)) != RIPP_OK) return rc;
                 stats.pairs_lines += m * nprod;

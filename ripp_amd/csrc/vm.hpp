@@ -1,0 +1,123 @@
+// Lane-parallel field VM: G lanes of a wave cooperate on ONE element; every Fp value of the element lives in a
+// per-element LDS workspace; a program is a list of homogeneous LAYERS (tables generated and verified offline by
+// tools/vmgen.py) in which each lane performs one
+//     MUL  ws[dst] = (+-ws[a0] +-ws[a1]) * (+-ws[a2] +-ws[a3])
+//     LIN  ws[dst] = ((+-ws[a0] +-ws[a1] +-ws[a2] +-ws[a3]) << sh) [/ 2]
+// Why: the scalar kernels (one lane per element) keep ~400 dwords of live state per lane, so they run one wave per
+// SIMD and, in the small late rounds of a proof, one lone lane pays ~2.4 us per DEPENDENT Fp product.  Here the
+// state sits in LDS (160 KB/CU), each lane needs ~60 VGPRs, the multiplier is inlined once (no calls), and the
+// 25-54 independent products of a step run side by side: a Miller doubling step is 2 product layers instead of 25
+// dependent products.  Used for the latency-bound part of the pipeline; the scalar kernels remain the throughput
+// path (and the fallback if an exceptional group-law case is flagged).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "bls12_381/pairing.hpp"
+#include "kernels.hpp"
+
+namespace ripp {
+
+struct VmOp { unsigned char dst, a0, a1, a2, a3, flags; };
+}  // namespace ripp
+#include "vm_programs.inc"
+namespace ripp {
+
+constexpr int VM_G = 16;                 // lanes per element
+constexpr int VM_EPW = 64 / VM_G;        // elements per wave
+
+__device__ __forceinline__ Fp vm_cneg(const Fp& x, bool f) {
+    const Fp n = neg(x);
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) r.l[i] = f ? n.l[i] : x.l[i];
+    return r;
+}
+
+// Run one program on this lane's element.  `ws` = LDS workspace of the element, `lg` = lane index within the group.
+__device__ __forceinline__ void vm_run(Fp* ws, const unsigned char* __restrict__ kind, const VmOp* __restrict__ ops, int nlayers, int lg) {
+#pragma unroll 1
+    for (int l = 0; l < nlayers; ++l) {
+        const VmOp op = ops[l * VM_G + lg];
+        const Fp x0 = ws[op.a0], x1 = ws[op.a1], x2 = ws[op.a2], x3 = ws[op.a3];
+        const unsigned f = op.flags;
+        Fp r;
+        if (kind[l] == 0) {                                    // MUL layer (uniform over the wave)
+            const Fp A = add(vm_cneg(x0, f & 1u), vm_cneg(x1, f & 2u));
+            const Fp B = add(vm_cneg(x2, f & 4u), vm_cneg(x3, f & 8u));
+            r = mul(A, B);
+        } else {                                                // LIN layer
+            r = add(add(vm_cneg(x0, f & 1u), vm_cneg(x1, f & 2u)), add(vm_cneg(x2, f & 4u), vm_cneg(x3, f & 8u)));
+            const unsigned sh = (f >> 5) & 3u;
+            if (__any(sh != 0u)) {
+#pragma unroll 1
+                for (unsigned k = 0; k < 3; ++k) { const Fp d = dbl(r); const bool t = k < sh;
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) r.l[i] = t ? d.l[i] : r.l[i]; }
+            }
+            if (__any((f & 16u) != 0u)) { const Fp h = half(r); const bool t = (f & 16u) != 0u;
+#pragma unroll
+                for (int i = 0; i < 12; ++i) r.l[i] = t ? h.l[i] : r.l[i]; }
+        }
+        ws[op.dst] = r;     // all lanes of the wave have issued their reads of this layer before any write (lockstep, in-order LDS)
+    }
+}
+
+// ---- stage 1 of the pairing product in latency form: VM_G lanes per (P,Q) pair ---------------------------------
+// grid.x covers ceil(M / (4 * VM_EPW)) blocks of 256 threads, grid.y = product; same line buffer layout as k_miller_lines.
+constexpr int VM_LINES_SLOTS = (vmprog::line_double_g16_nslots > vmprog::line_add_g16_nslots) ? vmprog::line_double_g16_nslots : vmprog::line_add_g16_nslots;
+__global__ void __launch_bounds__(256) k_vm_miller_lines(PairSets ps, uint32_t M, uint4* __restrict__ lines, size_t stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char vm_smem[];
+    Fp* const lds = reinterpret_cast<Fp*>(vm_smem);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lg = lane & (VM_G - 1), grp = lane / VM_G;
+    const uint32_t i = (blockIdx.x * 4 + wave) * VM_EPW + grp;       // pair index handled by this group
+    Fp* const ws = lds + (size_t)(wave * VM_EPW + grp) * VM_LINES_SLOTS;
+    const bool active = i < M;
+    const G1A* __restrict__ a = ps.a[blockIdx.y];
+    const G2A* __restrict__ b = ps.b[blockIdx.y];
+    namespace vp = vmprog;
+    bool skip = false;
+    if (active) {
+        // lanes 0..7 of the group load the 8 input Fp's; everyone learns whether the pair contributes the unit line
+        const G1A P = a[i]; const G2A Q = b[i];
+        skip = is_inf(P) || is_inf(Q);
+        if (lg == 0) { ws[0] = Fp::zero(); ws[vp::line_double_g16_in_X0] = Q.x.c0; ws[vp::line_double_g16_in_X1] = Q.x.c1; }
+        if (lg == 1) { ws[vp::line_double_g16_in_Y0] = Q.y.c0; ws[vp::line_double_g16_in_Y1] = Q.y.c1; }
+        if (lg == 2) { ws[vp::line_double_g16_in_Z0] = Fp::one(); ws[vp::line_double_g16_in_Z1] = Fp::zero(); }
+        if (lg == 3) { ws[vp::line_double_g16_in_xP] = P.x; ws[vp::line_double_g16_in_yP] = P.y; }
+    }
+    const size_t row0 = (size_t)blockIdx.y * N_LINES;
+    int s = 0;
+#pragma unroll 1
+    for (int bit = 62; bit >= 0; --bit) {
+        vm_run(ws, vp::line_double_g16_kind, vp::line_double_g16_ops, vp::line_double_g16_nlayers, lg);
+        if (active && lg < 6) {
+            constexpr int OUT[6] = {vp::line_double_g16_out_L00, vp::line_double_g16_out_L01, vp::line_double_g16_out_L10, vp::line_double_g16_out_L11, vp::line_double_g16_out_L20, vp::line_double_g16_out_L21};
+            int src = OUT[0];
+#pragma unroll
+            for (int k = 1; k < 6; ++k) src = (lg == k) ? OUT[k] : src;
+            Fp v = ws[src];
+            if (skip) v = (lg == 0) ? Fp::one() : Fp::zero();
+            const uint4* pv = reinterpret_cast<const uint4*>(&v);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) lines[((row0 + s) * LINE_CHUNKS + 3 * lg + c) * stride + i] = pv[c];
+        }
+        ++s;
+        if ((BLS_X_ABS >> bit) & 1ull) {
+            if (active && lg == 4) { const G2A Q = b[i]; ws[vp::line_add_g16_in_qx0] = Q.x.c0; ws[vp::line_add_g16_in_qx1] = Q.x.c1; ws[vp::line_add_g16_in_qy0] = Q.y.c0; ws[vp::line_add_g16_in_qy1] = Q.y.c1; }
+            vm_run(ws, vp::line_add_g16_kind, vp::line_add_g16_ops, vp::line_add_g16_nlayers, lg);
+            if (active && lg < 6) {
+                constexpr int OUT[6] = {vp::line_add_g16_out_L00, vp::line_add_g16_out_L01, vp::line_add_g16_out_L10, vp::line_add_g16_out_L11, vp::line_add_g16_out_L20, vp::line_add_g16_out_L21};
+                int src = OUT[0];
+#pragma unroll
+                for (int k = 1; k < 6; ++k) src = (lg == k) ? OUT[k] : src;
+                Fp v = ws[src];
+                if (skip) v = (lg == 0) ? Fp::one() : Fp::zero();
+                const uint4* pv = reinterpret_cast<const uint4*>(&v);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) lines[((row0 + s) * LINE_CHUNKS + 3 * lg + c) * stride + i] = pv[c];
+            }
+            ++s;
+        }
+    }
+}
+
+}  // namespace ripp
