@@ -72,6 +72,9 @@ struct Engine {
     Fp12* pinned_rows = nullptr;          // pinned host landing zone for per-step products
     size_t pinned_rows_cap = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_lines, ev_prod;   // per-launch event pairs of the two dominant kernels
+    size_t vm_tree_max = (size_t)1 << 14;                                 // tree levels with <= this many products use the VM Fp12 multiplier
+    size_t vm_fold_max = (size_t)1 << 11;                                 // folds with <= this many outputs use the VM scalar multiplications
+    DevBuf vm_flag;
     size_t vm_lines_max = (size_t)1 << 13;                                // launches with <= this many pairs use the 16-lanes-per-pair VM line kernel
     size_t gls_split_max = (size_t)1 << 14;                               // rounds with <= this many outputs use the 4-lane GLS fold
     size_t max_pairs_per_batch = (size_t)1 << 19;                        // lines buffer cap: 2^19 pairs * 19.6 KB = 10.3 GB
@@ -90,7 +93,7 @@ struct Engine {
         return RIPP_OK;
     }
     void destroy() {
-        for (DevBuf* b : {&lines, &partA, &partB, &jacG1, &jacG2, &tmpA, &tmpB, &tmpR, &affG1, &affG2, &qtab, &m_digits, &m_hist, &m_offs, &m_cursor, &m_slotoffs, &m_spw, &m_sorted, &m_slots, &m_buckets, &m_seg, &m_win, &m_out}) b->release();
+        for (DevBuf* b : {&lines, &partA, &partB, &jacG1, &jacG2, &tmpA, &tmpB, &tmpR, &affG1, &affG2, &qtab, &vm_flag, &m_digits, &m_hist, &m_offs, &m_cursor, &m_slotoffs, &m_spw, &m_sorted, &m_slots, &m_buckets, &m_seg, &m_win, &m_out}) b->release();
         if (pinned_rows) (void)hipHostFree(pinned_rows);
         for (auto& e : ev_lines) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         for (auto& e : ev_prod) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -204,6 +207,9 @@ struct Engine {
                 // radix 4 while the level still fills the chip, radix 2 (one dependent Fp12 product per level) once it is latency-bound
                 const int R = ((size_t)T * nrows > (size_t)n_simd * 64) ? 4 : 2;
                 const uint32_t Tout = (T + R - 1) / R;
+                if (R == 2 && (size_t)Tout * nrows <= vm_tree_max && !std::getenv("RIPP_NO_VM"))
+                    hipLaunchKernelGGL(k_vm_fp12_tree, dim3(nblk(Tout, 2 * VM_EPW), (unsigned)nrows), dim3(128), 2 * VM_EPW * VM_F12_SLOTS * sizeof(Fp), stream, cur, T, nxt, Tout);
+                else
                 hipLaunchKernelGGL(k_fp12_tree, dim3(nblk(Tout, 64), (unsigned)nrows), dim3(64), 0, stream, cur, T, nxt, Tout, R);
                 HIPCHK(hipGetLastError());
                 std::swap(cur, nxt); T = Tout;
@@ -389,7 +395,7 @@ int32_t job_round_partials(Engine* e, ripp_sipp_job* j, Fp12* rows /* [2][68] */
     return rc;
 }
 
-int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x) {
+int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true) {
     const size_t half = j->len / 2;
     int32_t rc;
     const Fr x_inv = inv(x);                                                        // sipp/src/lib.rs:94
@@ -399,12 +405,22 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x) {
     const size_t qstride = (half + 63) & ~(size_t)63;
     if ((rc = e->qtab.reserve(4 * G2A_CHUNKS * qstride * sizeof(uint4))) != RIPP_OK) return rc;
     // G1 half on stream2, G2 half on the main stream (small rounds leave most of the chip idle otherwise)
+    const bool use_vm = allow_vm && half <= e->vm_fold_max && !std::getenv("RIPP_NO_VM");
+    if (use_vm) { if ((rc = e->vm_flag.reserve(sizeof(uint32_t))) != RIPP_OK) return rc; HIPCHK(hipMemsetAsync(e->vm_flag.p, 0, sizeof(uint32_t), e->stream)); }
     HIPCHK(hipEventRecord(e->ev_fork, e->stream));
     HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_affine_naf<Fp>), dim3(nblk(half, 256)), dim3(256), 0, e->stream2, a + half, a, (uint32_t)half, naf_digits(x), j->jac1.as<G1J>());
+    if (use_vm)
+        hipLaunchKernelGGL(k_vm_fold_g1, dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VM_G1_SLOTS * sizeof(Fp), e->stream2, a + half, a, (uint32_t)half, naf_digits(x), j->jac1.as<G1J>(), e->vm_flag.as<uint32_t>());
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_affine_naf<Fp>), dim3(nblk(half, 256)), dim3(256), 0, e->stream2, a + half, a, (uint32_t)half, naf_digits(x), j->jac1.as<G1J>());
     HIPCHK(hipGetLastError());
     if ((rc = e->normalize_dev<Fp>(j->jac1.as<G1J>(), half, j->a_next.as<G1A>(), e->stream2)) != RIPP_OK) return rc;
     HIPCHK(hipEventRecord(e->ev_join, e->stream2));
+    if (use_vm) {
+        if ((rc = e->qtab.reserve(std::max<size_t>(4 * G2A_CHUNKS * qstride * sizeof(uint4), 4 * half * sizeof(G2J)))) != RIPP_OK) return rc;
+        hipLaunchKernelGGL(k_vm_fold_g2_split, dim3(nblk(half, 4 * VM_EPW), 4), dim3(256), 4 * VM_EPW * VM_G2_SLOTS * sizeof(Fp), e->stream, b + half, (uint32_t)half, gls_digits(x_inv), e->qtab.as<G2J>(), e->vm_flag.as<uint32_t>());
+        hipLaunchKernelGGL(k_fold_g2_combine, dim3(nblk(half, 64)), dim3(64), 0, e->stream, e->qtab.as<G2J>(), b, (uint32_t)half, j->jac2.as<G2J>());
+    } else
     if (half <= e->gls_split_max) {     // latency-bound round: 4 lanes per element
         if ((rc = e->qtab.reserve(std::max<size_t>(4 * G2A_CHUNKS * qstride * sizeof(uint4), 4 * half * sizeof(G2J)))) != RIPP_OK) return rc;
         hipLaunchKernelGGL(k_fold_g2_gls_split, dim3(nblk(half, 64), 4), dim3(64), 0, e->stream, b + half, (uint32_t)half, gls_digits(x_inv), e->qtab.as<G2J>());
@@ -419,6 +435,10 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x) {
     if ((rc = e->sync()) != RIPP_OK) return rc;
     float ms = 0; (void)hipEventElapsedTime(&ms, t0, t1); e->stats.fold_ms += ms;
     (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+    if (use_vm) {   // an addition met T = +-Q (lambda == 0): the VM formulas do not cover it -> redo with the scalar kernels
+        uint32_t flag = 0; HIPCHK(hipMemcpy(&flag, e->vm_flag.p, sizeof flag, hipMemcpyDeviceToHost));
+        if (flag) return job_fold(e, j, x, false);
+    }
     std::swap(j->a, j->a_next); std::swap(j->b, j->b_next);
     j->len = half;
     return RIPP_OK;

@@ -178,3 +178,39 @@ def test_sipp_full_size_round_trip(engine):
     assert engine.SIPP.verify(a, b, r, value, proof)
     bad = proof.copy(); bad[5] = proof[4]
     assert not engine.SIPP.verify(a, b, r, value, bad)
+
+
+def test_scalar_kernels_without_vm(engine, orc):
+    """The latency-form (lane-parallel VM) kernels serve small launches; RIPP_NO_VM=1 forces the scalar kernels so
+    both implementations of the same path stay pinned to the oracle."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import numpy as np, orclib as o, ripp_amd as R
+        R.init(0)
+        n = 128
+        a, b, r = o.gen_g1(123, n), o.gen_g2(456, n), o.gen_scalars(7, n)
+        v = o.product_of_pairings_with_coeffs(a, b, r)
+        proof = R.SIPP.prove(a, b, r, v)
+        rc, eproof, _ = o.sipp_prove(a, b, r, v)
+        assert rc == 0 and np.array_equal(proof, eproof)
+        print("ok")
+    """) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RIPP_NO_VM="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_exceptional_group_law_cases_fall_back(engine, orc):
+    """(0, 2) is a point of order 3 on y^2 = x^3 + 4 (outside G1).  Multiplying it by any scalar walks through
+    T = +-Q and T = infinity, which the VM's incomplete addition formulas flag; the engine must then redo the fold with
+    the complete scalar kernels and still match the oracle bit for bit (the reference's group law is complete)."""
+    n = 8
+    a, b, r = orc.gen_g1(123, n), orc.gen_g2(456, n), orc.gen_scalars(7, n)
+    a[5, :6] = orc.fp_to_limbs(0); a[5, 6:] = orc.fp_to_limbs(2)
+    a[2] = 0                                                      # and a point at infinity
+    value = orc.product_of_pairings_with_coeffs(a, b, r)
+    assert np.array_equal(engine.product_of_pairings_with_coeffs(a, b, r), value)
+    proof = engine.SIPP.prove(a, b, r, value)
+    rc, eproof, _ = orc.sipp_prove(a, b, r, value)
+    assert rc == 0 and np.array_equal(proof, eproof)

@@ -135,6 +135,21 @@ class F2:
     def mat(self): return F2(self.p, self.p.materialise(self.c0), self.p.materialise(self.c1))
 
 
+class F1:
+    """Fp itself behind the F2 interface (for the G1 programs)."""
+
+    def __init__(self, p, c0): self.p, self.c0 = p, Lin.of(c0)
+    def __add__(self, o): return F1(self.p, self.c0 + o.c0)
+    def __sub__(self, o): return F1(self.p, self.c0 - o.c0)
+    def __neg__(self): return F1(self.p, -self.c0)
+    def scale(self, c): return F1(self.p, self.c0 * c)
+    def mul_xi(self): return self                               # G1: b = 4, no twist factor
+    def mul(self, o): return F1(self.p, self.p.mul(self.c0, o.c0))
+    def sqr(self): return F1(self.p, self.p.mul(self.c0, self.c0))
+    def half(self): return F1(self.p, self.p.half(self.c0))
+    def mat(self): return F1(self.p, self.p.materialise(self.c0))
+
+
 # ------------------------------------------------------------------------------------------------ scheduling
 def schedule(prog, G):
     """List-schedule prog.nodes into homogeneous layers of <= G ops.  Returns list of (kind, [Val])."""
@@ -304,6 +319,43 @@ def prog_line_add():
     return p
 
 
+def fin(p, name, deg): return f2in(p, name) if deg == 2 else F1(p, p.inp(name + "0"))
+def fout(p, name, v, into=None):
+    if isinstance(v, F2): f2out(p, name, v, into)
+    else: p.out(name + "0", v.c0, into=(into + "0") if into else None)
+
+
+def prog_hom_double(deg):
+    """T <- 2T on y^2 = x^3 + b (b = 4 on G1, 4(1+u) on G2), homogeneous projective (x = X/Z, y = Y/Z): the
+    doubling of bls12_381/pairing.hpp line_double without the line -- product depth 2."""
+    p = Prog("g%d_hdbl" % deg)
+    X, Y, Z = fin(p, "X", deg), fin(p, "Y", deg), fin(p, "Z", deg)
+    fin(p, "qx", deg); fin(p, "qy", deg)                       # resident affine addend: slots reserved, not used here
+    a = X.mul(Y).half()
+    b, c = Y.sqr().mat(), Z.sqr().mat()
+    e = c.mul_xi().scale(12).mat()
+    f = e.scale(3).mat()
+    g = (b + f).half()
+    h = ((Y + Z).sqr() - (b + c)).mat()
+    e2 = e.sqr()
+    fout(p, "X", a.mul((b - f).mat()), into="X"); fout(p, "Y", g.sqr() - e2.scale(3), into="Y"); fout(p, "Z", b.mul(h), into="Z")
+    return p
+
+
+def prog_hom_add(deg):
+    """T <- T + Q, Q affine; lambda (= 0 iff T = +-Q, the exceptional case) is exported so the kernel can flag it."""
+    p = Prog("g%d_hadd" % deg)
+    X, Y, Z = fin(p, "X", deg), fin(p, "Y", deg), fin(p, "Z", deg)
+    qx, qy = fin(p, "qx", deg), fin(p, "qy", deg)
+    theta = (Y - qy.mul(Z)).mat(); lam = (X - qx.mul(Z)).mat()
+    c, d = theta.sqr(), lam.sqr().mat()
+    e, f, g = lam.mul(d).mat(), Z.mul(c.mat()), X.mul(d).mat()
+    h = (e + f - g.scale(2)).mat()
+    fout(p, "X", lam.mul(h), into="X"); fout(p, "Y", theta.mul((g - h).mat()) - e.mul(Y), into="Y"); fout(p, "Z", Z.mul(e), into="Z")
+    fout(p, "lam", lam)
+    return p
+
+
 class F6:
     def __init__(s, c0, c1, c2): s.c0, s.c1, s.c2 = c0, c1, c2
     def __add__(s, o): return F6(s.c0 + o.c0, s.c1 + o.c1, s.c2 + o.c2)
@@ -418,6 +470,52 @@ def validate():
         out = run_compiled(c, inp)
         ref = f12m(f, g)
         for n, v in zip(F12_NAMES, ref): assert (out["f" + n + "0"], out["f" + n + "1"]) == v, ("fp12_mul", G, n)
+        # group-law programs: compare X/Z, Y/Z with the affine chord-tangent law
+        for deg in (1, 2):
+            if deg == 1:
+                fm = lambda a, b: a * b % P; fi = lambda a: pow(a, -1, P); fs = lambda a, b: (a - b) % P; fk = lambda a, k: a * k % P
+                bcoef = 4
+            else:
+                fm, fs, fk = f2m, f2s, f2k
+                fi = lambda a: (lambda d: (a[0] * d % P, (-a[1]) * d % P))(pow(a[0] * a[0] + a[1] * a[1], -1, P))
+                bcoef = (4, 4)
+            fa = (lambda a, b: (a + b) % P) if deg == 1 else f2a
+            def rnd_pt():
+                while True:   # random affine point on the curve
+                    x = rf() if deg == 1 else rf2()
+                    y2 = fa(fm(fm(x, x), x), bcoef)
+                    if deg == 1:
+                        y = pow(y2, (P + 1) // 4, P)
+                        if y * y % P == y2: return x, y
+                    else:     # sqrt in Fp2 via the norm method (p = 3 mod 4)
+                        a0, a1 = y2
+                        n = (a0 * a0 + a1 * a1) % P; sn = pow(n, (P + 1) // 4, P)
+                        if sn * sn % P != n: continue
+                        for sgn in (1, -1):
+                            t = (a0 + sgn * sn) * pow(2, -1, P) % P; x0 = pow(t, (P + 1) // 4, P)
+                            if x0 * x0 % P == t and x0:
+                                x1 = a1 * pow(2 * x0, -1, P) % P
+                                if f2m((x0, x1), (x0, x1)) == y2: return x, (x0, x1)
+            def aff_add(p1, p2):
+                (x1, y1), (x2, y2) = p1, p2
+                lam = fm(fk(fm(x1, x1), 3), fi(fk(y1, 2))) if p1 == p2 else fm(fs(y2, y1), fi(fs(x2, x1)))
+                x3 = fs(fs(fm(lam, lam), x1), x2); return x3, fs(fm(lam, fs(x1, x3)), y1)
+            T, Q = rnd_pt(), rnd_pt()
+            z = rf() if deg == 1 else rf2()
+            Th = (fm(T[0], z), fm(T[1], z), z)                # homogeneous representative of T
+            def pack(names, vals):
+                d = {}
+                for nm, v in zip(names, vals):
+                    if deg == 1: d[nm + "0"] = v
+                    else: d[nm + "0"], d[nm + "1"] = v
+                return d
+            def unpack(out, nm): return out[nm + "0"] if deg == 1 else (out[nm + "0"], out[nm + "1"])
+            c = compile_prog(prog_hom_double(deg), G); progs[("g%d_hdbl" % deg, G)] = c
+            out = run_compiled(c, pack(["X", "Y", "Z", "qx", "qy"], Th + Q))
+            zi = fi(unpack(out, "Z")); assert (fm(unpack(out, "X"), zi), fm(unpack(out, "Y"), zi)) == aff_add(T, T), ("hdbl", deg, G)
+            c = compile_prog(prog_hom_add(deg), G); progs[("g%d_hadd" % deg, G)] = c
+            out = run_compiled(c, pack(["X", "Y", "Z", "qx", "qy"], Th + Q))
+            zi = fi(unpack(out, "Z")); assert (fm(unpack(out, "X"), zi), fm(unpack(out, "Y"), zi)) == aff_add(T, Q), ("hadd", deg, G)
     return progs
 
 
@@ -435,6 +533,8 @@ def emit(progs, path):
         for _, row in c["layers"]:
             for op in row: rows.append("{%d,%d,%d,%d,%d,%d}" % (op["dst"], op["a"][0], op["a"][1], op["a"][2], op["a"][3], op["neg"] | (op["half"] << 4) | (op["sh"] << 5)))
         w.append(f"__device__ const VmOp {tag}_ops[{len(rows)}] = {{" + ",".join(rows) + "};")
+        w.append(f"__device__ const unsigned char {tag}_in[{len(c['ins'])}] = {{" + ", ".join(str(x) for x in c["ins"].values()) + "};   // declaration order")
+        w.append(f"__device__ const unsigned char {tag}_out[{len(c['outs'])}] = {{" + ", ".join(str(x) for x in c["outs"].values()) + "};")
         for nm, s in c["ins"].items(): w.append(f"constexpr int {tag}_in_{nm} = {s};")
         for nm, s in c["outs"].items(): w.append(f"constexpr int {tag}_out_{nm} = {s};")
     w.append("} }")
