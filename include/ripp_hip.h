@@ -119,6 +119,16 @@ int32_t ripp_combine_partials(const ripp_gt* gathered /* [world][count] */, int3
 /* Blake2s digest of (a, b, r, value).serialize_uncompressed for a FULL statement held on the host (sipp/src/lib.rs:56-59) */
 int32_t ripp_sipp_seed_digest(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr* r, size_t n, const ripp_gt* value, uint8_t digest[32]);
 
+/* ---- GIPA prover, TIPP instantiation  -- GIPA::prove_with_aux / _prove, ip_proofs/src/gipa.rs:162-312 ------------
+ * GIPA<PairingInnerProduct, AFGHOCommitmentG1, AFGHOCommitmentG2, IdentityCommitment<GT, Fr>, Blake2b> (the instantiation
+ * of the reference's tests, gipa.rs:470-497, and of TIPA).  m_a, ck_b: G1 projective; m_b, ck_a: G2 projective.
+ * Outputs in ROUND order (the reference reverses both vectors at gipa.rs:298-299):
+ *   com_steps[round][6] = (com_1.0, com_1.1, com_1.2[0], com_2.0, com_2.1, com_2.2[0]),  transcript[round] = c,
+ *   base = (m_a[0], m_b[0]) = proof.r_base,  ck_base = (ck_a[0], ck_b[0]) = aux.ck_base  (any projective representative). */
+int32_t ripp_gipa_tipp_prove(const ripp_g1j* m_a, const ripp_g2j* m_b, const ripp_g2j* ck_a, const ripp_g1j* ck_b, size_t n,
+                             ripp_gt* com_steps, ripp_fr* transcript, ripp_g1j* base_a, ripp_g2j* base_b,
+                             ripp_g2j* ck_base_a, ripp_g1j* ck_base_b, ripp_stats* stats);
+
 /* ---- host-side helpers (no device needed): what the host code around the kernels computes ---------------- */
 int32_t ripp_final_exp(const ripp_gt* miller_value, ripp_gt* out);                 /* Pairing::final_exponentiation */
 int32_t ripp_miller_combine(const ripp_gt* step_products /* [68] */, ripp_gt* out); /* stage (3) of pairing.hpp */

@@ -383,3 +383,97 @@ ORC_API void orc_jacobian_blind_g2(const g2a_t *in, size_t n, uint64_t seed, g2j
         fp2_mul(&out[i].x, &in[i].x, &z2); fp2_mul(&out[i].y, &in[i].y, &z3); out[i].z = z;
     }
 }
+
+/* ================================================================== GIPA, TIPP instantiation
+ * GIPA<PairingInnerProduct, AFGHOCommitmentG1, AFGHOCommitmentG2, IdentityCommitment<GT, Fr>, Blake2b>
+ * as in the reference's own test (ip_proofs/src/gipa.rs:470-497).  Vectors stay projective between rounds
+ * (gipa.rs:262-290), every commitment re-normalises its inputs (inner_products/src/lib.rs:80-81). */
+static fr_t gipa_challenge(const fr_t *prev /* NULL = Default */, const fp12_t com[6], fr_t *c_inv_out) {
+    /* gipa.rs:235-258: nonce (usize, big-endian 8 B) || transcript || com_1.{0,1,2} || com_2.{0,1,2}; IdentityOutput(Vec<GT>) carries a u64 length */
+    uint64_t nonce = 0;
+    for (;;) {
+        uint8_t buf[8 + 32 + 6 * 576 + 16], *p = buf;
+        for (int i = 0; i < 8; ++i) *p++ = (uint8_t)(nonce >> (56 - 8 * i));
+        fr_t zero = fr_zero(); orc_ser_fr(prev ? prev : &zero, p); p += 32;
+        for (int k = 0; k < 6; ++k) {
+            if (k == 2 || k == 5) { uint64_t one = 1; memcpy(p, &one, 8); p += 8; }
+            orc_ser_gt(&com[k], p); p += 576;
+        }
+        uint8_t dig[64]; blake2b(buf, (size_t)(p - buf), dig);
+        uint64_t hi = 0, lo = 0;                                   /* u128::from_be_bytes(digest[0..16]) */
+        for (int i = 0; i < 8; ++i) { hi = (hi << 8) | dig[i]; lo = (lo << 8) | dig[8 + i]; }
+        fr_t c128 = fr_from_u128(lo, hi);
+        if (!fr_is_zero(&c128)) { fr_t inv; fr_inv(&inv, &c128); *c_inv_out = c128; return inv; }   /* (c, c_inv) := (c128^-1, c128): names swapped, gipa.rs:252-256 */
+        ++nonce;
+    }
+}
+
+/* GIPA::_prove (gipa.rs:181-312).  Outputs in ROUND order (the proof stores them reversed, gipa.rs:298-299):
+ * com_steps[round][6] = (com_1.0, com_1.1, com_1.2[0], com_2.0, com_2.1, com_2.2[0]); transcript[round] = c. */
+ORC_API int orc_gipa_tipp_prove(const g1j_t *m_a_in, const g2j_t *m_b_in, const g2j_t *ck_a_in, const g1j_t *ck_b_in, size_t n,
+                                fp12_t *com_steps, fr_t *transcript, g1j_t *base_a, g2j_t *base_b, g2j_t *ck_base_a, g1j_t *ck_base_b) {
+    if (n == 0 || (n & (n - 1))) return 2;
+    g1j_t *m_a = (g1j_t *)malloc(n * sizeof(g1j_t)), *ck_b = (g1j_t *)malloc(n * sizeof(g1j_t));
+    g2j_t *m_b = (g2j_t *)malloc(n * sizeof(g2j_t)), *ck_a = (g2j_t *)malloc(n * sizeof(g2j_t));
+    memcpy(m_a, m_a_in, n * sizeof(g1j_t)); memcpy(m_b, m_b_in, n * sizeof(g2j_t)); memcpy(ck_a, ck_a_in, n * sizeof(g2j_t)); memcpy(ck_b, ck_b_in, n * sizeof(g1j_t));
+    size_t len = n, round = 0;
+    while (len > 1) {
+        size_t split = len / 2;
+        const g1j_t *m_a_1 = m_a + split, *m_a_2 = m_a, *ck_b_1 = ck_b + split, *ck_b_2 = ck_b;
+        const g2j_t *ck_a_1 = ck_a, *ck_a_2 = ck_a + split, *m_b_1 = m_b, *m_b_2 = m_b + split;
+        fp12_t *com = com_steps + 6 * round;
+        orc_pairing_product_j(m_a_1, split, ck_a_1, split, &com[0]);      /* LMC::commit(ck_a_1, m_a_1) = IP(m, k)   afgho16/mod.rs:31 */
+        orc_pairing_product_j(ck_b_1, split, m_b_1, split, &com[1]);      /* RMC::commit(ck_b_1, m_b_1) = IP(k, m)   afgho16/mod.rs:46 */
+        orc_pairing_product_j(m_a_1, split, m_b_1, split, &com[2]);       /* IP::inner_product(m_a_1, m_b_1) */
+        orc_pairing_product_j(m_a_2, split, ck_a_2, split, &com[3]);
+        orc_pairing_product_j(ck_b_2, split, m_b_2, split, &com[4]);
+        orc_pairing_product_j(m_a_2, split, m_b_2, split, &com[5]);
+        fr_t c_inv, c = gipa_challenge(round ? &transcript[round - 1] : NULL, com, &c_inv);
+        g1j_t *na = (g1j_t *)malloc(split * sizeof(g1j_t)), *nkb = (g1j_t *)malloc(split * sizeof(g1j_t));
+        g2j_t *nb = (g2j_t *)malloc(split * sizeof(g2j_t)), *nka = (g2j_t *)malloc(split * sizeof(g2j_t));
+        orc_fold_g1_j(m_a_1, m_a_2, split, &c, na);                        /* gipa.rs:262-266 */
+        orc_fold_g2_j(m_b_2, m_b_1, split, &c_inv, nb);                    /* :270-274 */
+        orc_fold_g2_j(ck_a_2, ck_a_1, split, &c_inv, nka);                 /* :278-282 */
+        orc_fold_g1_j(ck_b_1, ck_b_2, split, &c, nkb);                     /* :286-290 */
+        memcpy(m_a, na, split * sizeof(g1j_t)); memcpy(m_b, nb, split * sizeof(g2j_t)); memcpy(ck_a, nka, split * sizeof(g2j_t)); memcpy(ck_b, nkb, split * sizeof(g1j_t));
+        free(na); free(nb); free(nka); free(nkb);
+        transcript[round] = c; ++round; len = split;
+    }
+    *base_a = m_a[0]; *base_b = m_b[0]; *ck_base_a = ck_a[0]; *ck_base_b = ck_b[0];
+    free(m_a); free(m_b); free(ck_a); free(ck_b);
+    return 0;
+}
+
+/* GIPA::verify (gipa.rs:135-160, 322-415) for the same instantiation; inputs in ROUND order as produced above.
+ * com = (com_a, com_b, com_t[0]).  returns 1 accept / 0 reject. */
+ORC_API int orc_gipa_tipp_verify(const g2j_t *ck_a, const g1j_t *ck_b, size_t n, const fp12_t com[3], const fp12_t *com_steps, size_t rounds,
+                                 const g1j_t *base_a, const g2j_t *base_b) {
+    if (n == 0 || (n & (n - 1)) || ((size_t)1 << rounds) != n) return -2;
+    fp12_t ca = com[0], cb = com[1], ct = com[2];
+    fr_t *tr = (fr_t *)malloc((rounds ? rounds : 1) * sizeof(fr_t));
+    for (size_t k = 0; k < rounds; ++k) {                                   /* proof.r_commitment_steps.iter().rev() == round order */
+        const fp12_t *s = com_steps + 6 * k;
+        fr_t c_inv, c = gipa_challenge(k ? &tr[k - 1] : NULL, s, &c_inv);
+        fp12_t t1, t2;
+        gt_pow(&t1, &s[0], &c); gt_pow(&t2, &s[3], &c_inv); fp12_mul(&ca, &ca, &t1); fp12_mul(&ca, &ca, &t2);   /* gipa.rs:358-360 */
+        gt_pow(&t1, &s[1], &c); gt_pow(&t2, &s[4], &c_inv); fp12_mul(&cb, &cb, &t1); fp12_mul(&cb, &cb, &t2);
+        gt_pow(&t1, &s[2], &c); gt_pow(&t2, &s[5], &c_inv); fp12_mul(&ct, &ct, &t1); fp12_mul(&ct, &ct, &t2);
+        tr[k] = c;
+    }
+    /* _compute_final_commitment_keys (gipa.rs:367-399) on the REVERSED transcript */
+    fr_t *ea = (fr_t *)malloc(n * sizeof(fr_t)), *eb = (fr_t *)malloc(n * sizeof(fr_t));
+    ea[0] = fr_one(); eb[0] = fr_one(); size_t cnt = 1;
+    for (size_t i = 0; i < rounds; ++i) {
+        const fr_t *c = &tr[rounds - 1 - i]; fr_t ci; fr_inv(&ci, c);
+        for (size_t j = 0; j < ((size_t)1 << i); ++j) { fr_mul(&ea[cnt + j], &ea[j], &ci); fr_mul(&eb[cnt + j], &eb[j], c); }
+        cnt += (size_t)1 << i;
+    }
+    g2j_t ka; g1j_t kb; orc_msm_g2_j(ck_a, n, ea, n, &ka); orc_msm_g1_j(ck_b, n, eb, n, &kb);
+    fp12_t e1, e2, e3;
+    orc_pairing_product_j(base_a, 1, &ka, 1, &e1);                          /* LMC::verify([ck_a_base], [a_base], com_a) */
+    orc_pairing_product_j(&kb, 1, base_b, 1, &e2);                          /* RMC::verify([ck_b_base], [b_base], com_b) */
+    orc_pairing_product_j(base_a, 1, base_b, 1, &e3);                       /* IPC: [IP(a_base, b_base)] == com_t */
+    int ok = fp12_eq(&e1, &ca) && fp12_eq(&e2, &cb) && fp12_eq(&e3, &ct);
+    free(tr); free(ea); free(eb);
+    return ok;
+}

@@ -15,7 +15,7 @@ from ._lib import lib, last_error, RippStats, RIPP_OK, RIPP_ERR_LENGTH, RIPP_ERR
 
 __all__ = ["InnerProductError", "DeviceError", "PairingInnerProduct", "MultiexponentiationInnerProductG1",
            "MultiexponentiationInnerProductG2", "AFGHOCommitmentG1", "AFGHOCommitmentG2", "PedersenCommitmentG1",
-           "PedersenCommitmentG2", "SIPP", "SippJob", "product_of_pairings", "product_of_pairings_with_coeffs",
+           "PedersenCommitmentG2", "SIPP", "SippJob", "GIPA_TIPP", "product_of_pairings", "product_of_pairings_with_coeffs",
            "normalize_batch_g1", "normalize_batch_g2", "fold_g1_affine", "fold_g2_affine", "fold_g1", "fold_g2",
            "scale_g1_affine", "synth_g1", "synth_g2", "synth_fr", "init", "device_count", "final_exponentiation",
            "ser_gt", "ser_g1", "ser_g2", "ser_fr", "sipp_seed_digest", "gt_mul"]
@@ -310,6 +310,29 @@ class SIPP:
         acc = ctypes.c_int32(0)
         _check(lib().ripp_sipp_verify(_p(a), _p(b), _p(r), ctypes.c_size_t(len(a)), _p(claimed_value), _p(proof), ctypes.c_size_t(len(proof) // 2), ctypes.byref(acc)))
         return bool(acc.value)
+
+
+class GIPA_TIPP:
+    """GIPA<PairingInnerProduct, AFGHOCommitmentG1, AFGHOCommitmentG2, IdentityCommitment<GT,Fr>, Blake2b>
+    (ip_proofs/src/gipa.rs:97-312).  prove_with_aux returns, in the reference's (reversed) order,
+    proof = {r_commitment_steps: [(com_1, com_2)], r_base: (m_a[0], m_b[0])}, aux = {r_transcript, ck_base}."""
+
+    @staticmethod
+    def prove_with_aux(m_a, m_b, ck_a, ck_b):
+        m_a, m_b, ck_a, ck_b = _c(m_a, 18), _c(m_b, 36), _c(ck_a, 36), _c(ck_b, 18)
+        n = len(m_a)
+        assert len(m_b) == len(ck_a) == len(ck_b) == n
+        if n == 0 or n & (n - 1):
+            raise AssertionError("assert!(m_a.len().is_power_of_two())  (ip_proofs/src/gipa.rs:195)")
+        rounds = n.bit_length() - 1
+        steps = np.zeros((max(rounds, 1) * 6, 72), dtype=np.uint64); tr = np.zeros((max(rounds, 1), 4), dtype=np.uint64)
+        ba = np.zeros(18, dtype=np.uint64); bb = np.zeros(36, dtype=np.uint64); ka = np.zeros(36, dtype=np.uint64); kb = np.zeros(18, dtype=np.uint64)
+        st = RippStats()
+        _check(lib().ripp_gipa_tipp_prove(_p(m_a), _p(m_b), _p(ck_a), _p(ck_b), ctypes.c_size_t(n), _p(steps), _p(tr), _p(ba), _p(bb), _p(ka), _p(kb), ctypes.byref(st)))
+        steps, tr = steps[: rounds * 6].reshape(rounds, 6, 72), tr[:rounds]
+        proof = {"r_commitment_steps": [((s[0], s[1], [s[2]]), (s[3], s[4], [s[5]])) for s in steps[::-1]], "r_base": (ba, bb)}
+        aux = {"r_transcript": tr[::-1].copy(), "ck_base": (ka, kb)}
+        return proof, aux, {"round_order_steps": steps.reshape(rounds * 6, 72), "round_order_transcript": tr, "stats": st.as_dict()}
 
 
 # ------------------------------------------------------------------ host helpers / synthetic inputs

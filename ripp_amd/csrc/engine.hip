@@ -89,6 +89,8 @@ struct Engine {
         HIPCHK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
         { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n_simd = pr.multiProcessorCount * 4; }
+        auto env_sz = [](const char* k, size_t& v) { if (const char* s = std::getenv(k)) v = (size_t)std::strtoull(s, nullptr, 10); };
+        env_sz("RIPP_VM_LINES_MAX", vm_lines_max); env_sz("RIPP_VM_FOLD_MAX", vm_fold_max); env_sz("RIPP_VM_TREE_MAX", vm_tree_max); env_sz("RIPP_GLS_SPLIT_MAX", gls_split_max);
         device = dev;
         return RIPP_OK;
     }
@@ -172,7 +174,7 @@ struct Engine {
         if (M == 0) return RIPP_OK;
         int32_t rc;
         if ((rc = ensure_pinned_rows(nrows)) != RIPP_OK) return rc;
-        if (nprod > 2) return RIPP_ERR_ARG;
+        if (nprod > MAX_PRODUCTS) return RIPP_ERR_ARG;
         const size_t batch = std::min(M, std::max<size_t>(1, max_pairs_per_batch / nprod));
         for (size_t off = 0; off < M; off += batch) {
             const size_t m = std::min(batch, M - off);
@@ -192,7 +194,7 @@ struct Engine {
             }
             // stage 2a: T lanes per row
             // one resident batch: rows * T / 64 waves <= SIMDs * RIPP_OCC, so no partially filled second batch
-            uint32_t T = (uint32_t)std::max<size_t>(64, ((size_t)n_simd * RIPP_OCC / nrows) * 64);
+            uint32_t T = (uint32_t)std::max<size_t>(64, ((size_t)n_simd * RIPP_OCC_PROD / nrows) * 64);
             if (T > m) T = (uint32_t)m;
             if ((rc = partA.reserve(nrows * FP12_CHUNKS * (size_t)T * sizeof(uint4))) != RIPP_OK) return rc;
             if ((rc = partB.reserve(nrows * FP12_CHUNKS * (size_t)((T + 1) / 2) * sizeof(uint4))) != RIPP_OK) return rc;
@@ -651,6 +653,102 @@ API int32_t ripp_sipp_verify(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr
     if ((rc = ripp_pairing_product_j(&ap, 1, &bp, 1, &e12))) return rc;                                                    // :177
     Fp12 ev; std::memcpy(&ev, &e12, sizeof ev);
     *accept = (ev == zp) ? 1 : 0;
+    return RIPP_OK;
+}
+
+
+// ---- GIPA / TIPP prover (ip_proofs/src/gipa.rs:181-312) ------------------------------------------------------------------
+// The four vectors are kept AFFINE on the device between rounds (each commitment of the reference re-normalises its
+// projective inputs anyway, inner_products/src/lib.rs:80-81; group elements are identical), the six commitments of a
+// round share ONE line launch, and the folds reuse the NAF / GLS kernels: G1 vectors take the full-width c, G2 vectors
+// the 128-bit c_inv -- exactly the reference's choice (gipa.rs:252-256).
+extern "C++" {
+template <class F> static int32_t fold_dev(Engine* e, hipStream_t st, const Affine<F>* hi, const Affine<F>* lo, size_t half, const Fr& s, DevBuf& jac, DevBuf& qt, Affine<F>* out);
+template <> int32_t fold_dev<Fp>(Engine* e, hipStream_t st, const G1A* hi, const G1A* lo, size_t half, const Fr& s, DevBuf& jac, DevBuf&, G1A* out) {
+    int32_t rc; if ((rc = jac.reserve(half * sizeof(G1J)))) return rc;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_affine_naf<Fp>), dim3(nblk(half, 256)), dim3(256), 0, st, hi, lo, (uint32_t)half, naf_digits(s), jac.as<G1J>());
+    HIPCHK(hipGetLastError());
+    return e->normalize_dev<Fp>(jac.as<G1J>(), half, out, st);
+}
+template <> int32_t fold_dev<Fp2>(Engine* e, hipStream_t st, const G2A* hi, const G2A* lo, size_t half, const Fr& s, DevBuf& jac, DevBuf& qt, G2A* out) {
+    int32_t rc; if ((rc = jac.reserve(half * sizeof(G2J)))) return rc;
+    const size_t qstride = (half + 63) & ~(size_t)63;
+    if ((rc = qt.reserve(std::max<size_t>(4 * G2A_CHUNKS * qstride * sizeof(uint4), 4 * half * sizeof(G2J))))) return rc;
+    if (half <= e->gls_split_max) {
+        hipLaunchKernelGGL(k_fold_g2_gls_split, dim3(nblk(half, 64), 4), dim3(64), 0, st, hi, (uint32_t)half, gls_digits(s), qt.as<G2J>());
+        hipLaunchKernelGGL(k_fold_g2_combine, dim3(nblk(half, 64)), dim3(64), 0, st, qt.as<G2J>(), lo, (uint32_t)half, jac.as<G2J>());
+    } else {
+        hipLaunchKernelGGL(k_fold_g2_gls, dim3(nblk(half, 64)), dim3(64), 0, st, hi, lo, (uint32_t)half, gls_digits(s), qt.as<uint4>(), qstride, jac.as<G2J>());
+    }
+    HIPCHK(hipGetLastError());
+    return e->normalize_dev<Fp2>(jac.as<G2J>(), half, out, st);
+}
+}  // extern "C++"
+
+API int32_t ripp_gipa_tipp_prove(const ripp_g1j* m_a, const ripp_g2j* m_b, const ripp_g2j* ck_a, const ripp_g1j* ck_b, size_t n,
+                                 ripp_gt* com_steps, ripp_fr* transcript, ripp_g1j* base_a, ripp_g2j* base_b,
+                                 ripp_g2j* ck_base_a, ripp_g1j* ck_base_b, ripp_stats* st) {
+    if (n == 0 || (n & (n - 1))) return RIPP_ERR_POW2;                       // assert!(m_a.len().is_power_of_two()), gipa.rs:195
+    LOCK; ENGINE;
+    if (!m_a || !m_b || !ck_a || !ck_b || !base_a || !base_b || !ck_base_a || !ck_base_b || (n > 1 && (!com_steps || !transcript))) return RIPP_ERR_ARG;
+    e->stats = ripp_stats{};
+    const double t_start = now_ms();
+    // device vectors: A = m_a, KB = ck_b (G1);  B = m_b, KA = ck_a (G2); ping-pong buffers for the folds
+    DevBuf dA, dA2, dKB, dKB2, dB, dB2, dKA, dKA2, jac1, jac1b, jac2, jac2b, qt2;
+    struct Cleanup { std::vector<DevBuf*> v; ~Cleanup() { for (auto* b : v) b->release(); } } cleanup{{&dA, &dA2, &dKB, &dKB2, &dB, &dB2, &dKA, &dKA2, &jac1, &jac1b, &jac2, &jac2b, &qt2}};
+    int32_t rc;
+    if ((rc = dA.reserve(n * sizeof(G1A))) || (rc = dKB.reserve(n * sizeof(G1A))) || (rc = dB.reserve(n * sizeof(G2A))) || (rc = dKA.reserve(n * sizeof(G2A))) ||
+        (rc = dA2.reserve(n * sizeof(G1A))) || (rc = dKB2.reserve(n * sizeof(G1A))) || (rc = dB2.reserve(n * sizeof(G2A))) || (rc = dKA2.reserve(n * sizeof(G2A))) ||
+        (rc = jac1.reserve(n * sizeof(G1J))) || (rc = jac2.reserve(n * sizeof(G2J)))) return rc;
+    // upload + normalise the four projective inputs
+    HIPCHK(hipMemcpyAsync(jac1.p, m_a, n * sizeof(G1J), hipMemcpyHostToDevice, e->stream)); if ((rc = e->normalize_dev<Fp>(jac1.as<G1J>(), n, dA.as<G1A>()))) return rc; if ((rc = e->sync())) return rc;
+    HIPCHK(hipMemcpyAsync(jac1.p, ck_b, n * sizeof(G1J), hipMemcpyHostToDevice, e->stream)); if ((rc = e->normalize_dev<Fp>(jac1.as<G1J>(), n, dKB.as<G1A>()))) return rc; if ((rc = e->sync())) return rc;
+    HIPCHK(hipMemcpyAsync(jac2.p, m_b, n * sizeof(G2J), hipMemcpyHostToDevice, e->stream)); if ((rc = e->normalize_dev<Fp2>(jac2.as<G2J>(), n, dB.as<G2A>()))) return rc; if ((rc = e->sync())) return rc;
+    HIPCHK(hipMemcpyAsync(jac2.p, ck_a, n * sizeof(G2J), hipMemcpyHostToDevice, e->stream)); if ((rc = e->normalize_dev<Fp2>(jac2.as<G2J>(), n, dKA.as<G2A>()))) return rc; if ((rc = e->sync())) return rc;
+    size_t len = n, round = 0;
+    Fr prev_c = Fr::zero();
+    std::vector<Fp12> rows(6 * N_LINES);
+    while (len > 1) {
+        const size_t split = len / 2;
+        const G1A *A = dA.as<G1A>(), *KB = dKB.as<G1A>(); const G2A *B = dB.as<G2A>(), *KA = dKA.as<G2A>();
+        //            com_1.0 (m_a_1,ck_a_1)  com_1.1 (ck_b_1,m_b_1)  com_1.2 (m_a_1,m_b_1)  com_2.0 (m_a_2,ck_a_2)  com_2.1 (ck_b_2,m_b_2)  com_2.2 (m_a_2,m_b_2)   gipa.rs:209-231
+        const G1A* as[6] = {A + split,             KB + split,            A + split,             A,                     KB,                    A};
+        const G2A* bs[6] = {KA,                    B,                     B,                     KA + split,            B + split,             B + split};
+        const double tp = now_ms();
+        if ((rc = e->step_products(as, bs, 6, split, rows.data()))) return rc;
+        e->stats.miller_products_ms += now_ms() - tp;
+        const double th = now_ms();
+        Fp12 com[6];
+        { std::vector<std::future<Fp12>> fut;
+          for (int k = 1; k < 6; ++k) fut.push_back(std::async(std::launch::async, [&rows, k]() { return final_exponentiation(miller_combine(rows.data() + k * N_LINES)); }));
+          com[0] = final_exponentiation(miller_combine(rows.data()));
+          for (int k = 1; k < 6; ++k) com[k] = fut[k - 1].get(); }
+        Fr c_inv; const Fr c = fs::gipa_tipp_challenge(round ? &prev_c : nullptr, com, c_inv);
+        e->stats.host_ms += now_ms() - th;
+        std::memcpy(&com_steps[6 * round], com, sizeof com); std::memcpy(&transcript[round], &c, sizeof c);
+        prev_c = c;
+        // folds (gipa.rs:262-290): hi = upper half, lo = lower half for all four vectors
+        const double tf = now_ms();
+        HIPCHK(hipEventRecord(e->ev_fork, e->stream)); HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
+        if ((rc = fold_dev<Fp>(e, e->stream2, A + split, A, split, c, jac1, qt2, dA2.as<G1A>()))) return rc;          // m_a  <- m_a_1 * c + m_a_2
+        if ((rc = fold_dev<Fp>(e, e->stream2, KB + split, KB, split, c, jac1b, qt2, dKB2.as<G1A>()))) return rc;       // ck_b <- ck_b_1 * c + ck_b_2
+        HIPCHK(hipEventRecord(e->ev_join, e->stream2));
+        if ((rc = fold_dev<Fp2>(e, e->stream, B + split, B, split, c_inv, jac2, e->qtab, dB2.as<G2A>()))) return rc;   // m_b  <- m_b_2 * c_inv + m_b_1
+        if ((rc = fold_dev<Fp2>(e, e->stream, KA + split, KA, split, c_inv, jac2b, e->qtab, dKA2.as<G2A>()))) return rc; // ck_a <- ck_a_2 * c_inv + ck_a_1
+        HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
+        if ((rc = e->sync())) return rc;
+        e->stats.fold_ms += now_ms() - tf;
+        std::swap(dA, dA2); std::swap(dKB, dKB2); std::swap(dB, dB2); std::swap(dKA, dKA2);
+        len = split; ++round;
+    }
+    G1A ha, hkb; G2A hb, hka;
+    HIPCHK(hipMemcpy(&ha, dA.p, sizeof ha, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(&hkb, dKB.p, sizeof hkb, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&hb, dB.p, sizeof hb, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(&hka, dKA.p, sizeof hka, hipMemcpyDeviceToHost));
+    const G1J ja = to_jac(ha), jkb = to_jac(hkb); const G2J jb = to_jac(hb), jka = to_jac(hka);
+    std::memcpy(base_a, &ja, sizeof ja); std::memcpy(base_b, &jb, sizeof jb); std::memcpy(ck_base_a, &jka, sizeof jka); std::memcpy(ck_base_b, &jkb, sizeof jkb);
+    e->collect_kernel_stats();
+    e->stats.total_ms = now_ms() - t_start;
+    if (st) *st = e->stats;
     return RIPP_OK;
 }
 

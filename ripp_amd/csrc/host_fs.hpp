@@ -102,6 +102,38 @@ struct Blake2s {
     void finish(uint8_t out[32]) { t += buflen; std::memset(buf + buflen, 0, 64 - buflen); compress(buf, true); std::memcpy(out, h, 32); }
 };
 
+// ------------------------------------------------------------------ BLAKE2b-512 (the digest of GIPA's challenges, ip_proofs/src/gipa.rs:248-251)
+struct Blake2b {
+    uint64_t h[8]; uint64_t t = 0; uint8_t buf[128]; size_t buflen = 0;
+    static constexpr uint64_t IV[8] = {0x6a09e667f3bcc908ull, 0xbb67ae8584caa73bull, 0x3c6ef372fe94f82bull, 0xa54ff53a5f1d36f1ull,
+                                       0x510e527fade682d1ull, 0x9b05688c2b3e6c1full, 0x1f83d9abfb41bd6bull, 0x5be0cd19137e2179ull};
+    Blake2b() { for (int i = 0; i < 8; ++i) h[i] = IV[i]; h[0] ^= 0x01010000ull ^ 64ull; }
+    static inline uint64_t rotr(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
+    void compress(const uint8_t* blk, bool last) {
+        uint64_t m[16], v[16];
+        std::memcpy(m, blk, 128);
+        for (int i = 0; i < 8; ++i) { v[i] = h[i]; v[i + 8] = IV[i]; }
+        v[12] ^= t; if (last) v[14] = ~v[14];
+        auto G = [&](int a, int b, int c, int d, uint64_t x, uint64_t y) {
+            v[a] += v[b] + x; v[d] = rotr(v[d] ^ v[a], 32); v[c] += v[d]; v[b] = rotr(v[b] ^ v[c], 24);
+            v[a] += v[b] + y; v[d] = rotr(v[d] ^ v[a], 16); v[c] += v[d]; v[b] = rotr(v[b] ^ v[c], 63); };
+        for (int r = 0; r < 12; ++r) {
+            const uint8_t* s = Blake2s::sigma(r % 10);
+            G(0, 4, 8, 12, m[s[0]], m[s[1]]); G(1, 5, 9, 13, m[s[2]], m[s[3]]); G(2, 6, 10, 14, m[s[4]], m[s[5]]); G(3, 7, 11, 15, m[s[6]], m[s[7]]);
+            G(0, 5, 10, 15, m[s[8]], m[s[9]]); G(1, 6, 11, 12, m[s[10]], m[s[11]]); G(2, 7, 8, 13, m[s[12]], m[s[13]]); G(3, 4, 9, 14, m[s[14]], m[s[15]]);
+        }
+        for (int i = 0; i < 8; ++i) h[i] ^= v[i] ^ v[i + 8];
+    }
+    void update(const uint8_t* in, size_t n) {
+        while (n) {
+            if (buflen == 128) { t += 128; compress(buf, false); buflen = 0; }
+            size_t k = 128 - buflen; if (k > n) k = n;
+            std::memcpy(buf + buflen, in, k); buflen += k; in += k; n -= k;
+        }
+    }
+    void finish(uint8_t out[64]) { t += buflen; std::memset(buf + buflen, 0, 128 - buflen); compress(buf, true); std::memcpy(out, h, 64); }
+};
+
 // ------------------------------------------------------------------ ChaCha20 (64-bit counter, stream id 0)
 inline void chacha20_block(const uint8_t key[32], uint64_t counter, uint8_t out[64]) {
     auto rotl = [](uint32_t x, int n) { return (x << n) | (x >> (32 - n)); };
@@ -156,6 +188,27 @@ inline Fr sipp_challenge(FiatShamirRng& rng, const Fp12& z_l, const Fp12& z_r) {
     rng.absorb(buf, 1152);
     uint64_t lo, hi; rng.next_u128(lo, hi);
     return fr_from_u128(lo, hi);
+}
+
+// GIPA challenge (ip_proofs/src/gipa.rs:235-258) for the TIPP instantiation: Blake2b over
+//   nonce (usize, big-endian 8 B) || previous challenge (Fr, 32 B LE; Default = 0) || com_1.{0,1,2} || com_2.{0,1,2}
+// where com_x.2 is IdentityOutput(Vec<GT>) => u64-LE length prefix (1) before the element.
+// Returns c = c128^-1 and c_inv = c128 (the reference swaps the names on purpose, :252-256).
+inline Fr gipa_tipp_challenge(const Fr* prev, const Fp12 com[6], Fr& c_inv) {
+    for (uint64_t nonce = 0;; ++nonce) {
+        uint8_t buf[8 + 32 + 6 * 576 + 16], *p = buf;
+        for (int i = 0; i < 8; ++i) *p++ = (uint8_t)(nonce >> (56 - 8 * i));
+        ser_fr(prev ? *prev : Fr::zero(), p); p += 32;
+        for (int k = 0; k < 6; ++k) {
+            if (k == 2 || k == 5) { const uint64_t one = 1; std::memcpy(p, &one, 8); p += 8; }
+            ser_gt(com[k], p); p += 576;
+        }
+        uint8_t dig[64]; Blake2b h; h.update(buf, (size_t)(p - buf)); h.finish(dig);
+        uint64_t hi = 0, lo = 0;
+        for (int i = 0; i < 8; ++i) { hi = (hi << 8) | dig[i]; lo = (lo << 8) | dig[8 + i]; }
+        const Fr c128 = fr_from_u128(lo, hi);
+        if (!c128.is_zero()) { c_inv = c128; return inv(c128); }
+    }
 }
 
 }}  // namespace ripp::fs

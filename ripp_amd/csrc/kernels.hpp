@@ -17,6 +17,9 @@
 
 namespace ripp {
 
+#ifndef RIPP_OCC_PROD
+#define RIPP_OCC_PROD 2
+#endif
 #ifndef RIPP_OCC
 #define RIPP_OCC 2      // min waves per SIMD requested for the register-heavy kernels (caps them at 256 VGPR+AGPR)
 #endif
@@ -46,7 +49,8 @@ __device__ __forceinline__ T load_chunks(const uint4* buf, size_t row, size_t st
 // ---- stage 1: line elements --------------------------------------------------------------------------------
 // grid.y = product index p: pairs (a[p][i], b[p][i]), i < M, rows p*68 .. p*68+67 of lines[rows][18][stride].
 // Pairs with a point at infinity emit the unit line.  Both pairing products of a SIPP round go in ONE launch.
-struct PairSets { const G1A* a[2]; const G2A* b[2]; };
+constexpr int MAX_PRODUCTS = 6;     // pairing products sharing one launch (2 per SIPP round, 6 per GIPA/TIPP round)
+struct PairSets { const G1A* a[MAX_PRODUCTS]; const G2A* b[MAX_PRODUCTS]; };
 __global__ void __launch_bounds__(256, RIPP_OCC) k_miller_lines(PairSets ps, uint32_t M, uint4* __restrict__ lines, size_t stride) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
@@ -74,7 +78,7 @@ __global__ void __launch_bounds__(256, RIPP_OCC) k_miller_lines(PairSets ps, uin
 
 // ---- stage 2a: sparse accumulation -------------------------------------------------------------------------
 // grid = (T / block, rows).  Lane t of row r multiplies lines r[t], r[t+T], ... (< M) and writes one dense partial.
-__global__ void __launch_bounds__(64, RIPP_OCC) k_line_products(const uint4* __restrict__ lines, size_t stride, uint32_t M,
+__global__ void __launch_bounds__(64, RIPP_OCC_PROD) k_line_products(const uint4* __restrict__ lines, size_t stride, uint32_t M,
                                                         uint4* __restrict__ partials, uint32_t T) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;

@@ -280,3 +280,15 @@ def blake2b(data):
 def chacha20_block(key, counter):
     k = np.frombuffer(bytes(key), dtype=np.uint8).copy(); out = np.zeros(64, dtype=np.uint8)
     lib().orc_chacha20_block(_p(k), ctypes.c_uint64(counter), _p(out)); return bytes(out)
+
+
+def gipa_tipp_prove(m_a, m_b, ck_a, ck_b):
+    n = len(m_a); rounds = n.bit_length() - 1
+    steps = u64((rounds * 6, 72)); tr = u64((rounds, 4)); ba = u64(18); bb = u64(36); ka = u64(36); kb = u64(18)
+    rc = lib().orc_gipa_tipp_prove(_p(m_a), _p(m_b), _p(ck_a), _p(ck_b), ctypes.c_size_t(n), _p(steps), _p(tr), _p(ba), _p(bb), _p(ka), _p(kb))
+    return rc, steps, tr, ba, bb, ka, kb
+
+
+def gipa_tipp_verify(ck_a, ck_b, com, steps, base_a, base_b):
+    com = np.ascontiguousarray(np.stack(com), dtype=np.uint64)
+    return lib().orc_gipa_tipp_verify(_p(ck_a), _p(ck_b), ctypes.c_size_t(len(ck_a)), _p(com), _p(steps), ctypes.c_size_t(len(steps) // 6), _p(base_a), _p(base_b))

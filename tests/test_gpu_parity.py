@@ -214,3 +214,25 @@ def test_exceptional_group_law_cases_fall_back(engine, orc):
     proof = engine.SIPP.prove(a, b, r, value)
     rc, eproof, _ = orc.sipp_prove(a, b, r, value)
     assert rc == 0 and np.array_equal(proof, eproof)
+
+
+@pytest.mark.parametrize("n", [1, 2, 8, 64, 1 << 10])
+def test_gipa_tipp_prove_vs_oracle(engine, orc, n):
+    """GIPA::_prove round body (ip_proofs/src/gipa.rs:196-297) for the TIPP instantiation; n = 8 is the reference's
+    TEST_SIZE (gipa.rs:468).  Commitments, challenges and the base case must equal the oracle's, and the oracle's
+    GIPA verifier (gipa.rs:135-160) must accept the GPU-made proof."""
+    m_a, m_b = orc.blind_g1(orc.gen_g1(11, n), 1), orc.blind_g2(orc.gen_g2(22, n), 2)
+    ck_a, ck_b = orc.blind_g2(orc.gen_g2(33, n), 3), orc.blind_g1(orc.gen_g1(44, n), 4)
+    proof, aux, raw = engine.GIPA_TIPP.prove_with_aux(m_a, m_b, ck_a, ck_b)
+    rc, steps, tr, ba, bb, ka, kb = orc.gipa_tipp_prove(m_a, m_b, ck_a, ck_b)
+    assert rc == 0
+    assert np.array_equal(raw["round_order_steps"], steps) and np.array_equal(raw["round_order_transcript"], tr)
+    assert np.array_equal(engine.normalize_batch_g1(proof["r_base"][0]), orc.g1_to_affine(ba).reshape(1, 12))
+    assert np.array_equal(engine.normalize_batch_g2(proof["r_base"][1]), orc.g2_to_affine(bb).reshape(1, 24))
+    assert np.array_equal(engine.normalize_batch_g2(aux["ck_base"][0]), orc.g2_to_affine(ka).reshape(1, 24))
+    assert np.array_equal(engine.normalize_batch_g1(aux["ck_base"][1]), orc.g1_to_affine(kb).reshape(1, 12))
+    if n >= 2:
+        com = [engine.AFGHOCommitmentG1.commit(ck_a, m_a), engine.AFGHOCommitmentG2.commit(ck_b, m_b), engine.PairingInnerProduct.inner_product(m_a, m_b)]
+        assert orc.gipa_tipp_verify(ck_a, ck_b, com, raw["round_order_steps"], proof["r_base"][0], proof["r_base"][1]) == 1
+        bad = raw["round_order_steps"].copy(); bad[0] = bad[1]
+        assert orc.gipa_tipp_verify(ck_a, ck_b, com, bad, proof["r_base"][0], proof["r_base"][1]) == 0
