@@ -666,7 +666,10 @@ extern "C++" {
 template <class F> static int32_t fold_dev(Engine* e, hipStream_t st, const Affine<F>* hi, const Affine<F>* lo, size_t half, const Fr& s, DevBuf& jac, DevBuf& qt, Affine<F>* out);
 template <> int32_t fold_dev<Fp>(Engine* e, hipStream_t st, const G1A* hi, const G1A* lo, size_t half, const Fr& s, DevBuf& jac, DevBuf&, G1A* out) {
     int32_t rc; if ((rc = jac.reserve(half * sizeof(G1J)))) return rc;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_affine_naf<Fp>), dim3(nblk(half, 256)), dim3(256), 0, st, hi, lo, (uint32_t)half, naf_digits(s), jac.as<G1J>());
+    if (half <= e->vm_fold_max && !std::getenv("RIPP_NO_VM"))     // latency form; e->vm_flag reports exceptional additions
+        hipLaunchKernelGGL(k_vm_fold_g1, dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VM_G1_SLOTS * sizeof(Fp), st, hi, lo, (uint32_t)half, naf_digits(s), jac.as<G1J>(), e->vm_flag.as<uint32_t>());
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_affine_naf<Fp>), dim3(nblk(half, 256)), dim3(256), 0, st, hi, lo, (uint32_t)half, naf_digits(s), jac.as<G1J>());
     HIPCHK(hipGetLastError());
     return e->normalize_dev<Fp>(jac.as<G1J>(), half, out, st);
 }
@@ -674,7 +677,10 @@ template <> int32_t fold_dev<Fp2>(Engine* e, hipStream_t st, const G2A* hi, cons
     int32_t rc; if ((rc = jac.reserve(half * sizeof(G2J)))) return rc;
     const size_t qstride = (half + 63) & ~(size_t)63;
     if ((rc = qt.reserve(std::max<size_t>(4 * G2A_CHUNKS * qstride * sizeof(uint4), 4 * half * sizeof(G2J))))) return rc;
-    if (half <= e->gls_split_max) {
+    if (half <= e->vm_fold_max && !std::getenv("RIPP_NO_VM")) {
+        hipLaunchKernelGGL(k_vm_fold_g2_split, dim3(nblk(half, 4 * VM_EPW), 4), dim3(256), 4 * VM_EPW * VM_G2_SLOTS * sizeof(Fp), st, hi, (uint32_t)half, gls_digits(s), qt.as<G2J>(), e->vm_flag.as<uint32_t>());
+        hipLaunchKernelGGL(k_fold_g2_combine, dim3(nblk(half, 64)), dim3(64), 0, st, qt.as<G2J>(), lo, (uint32_t)half, jac.as<G2J>());
+    } else if (half <= e->gls_split_max) {
         hipLaunchKernelGGL(k_fold_g2_gls_split, dim3(nblk(half, 64), 4), dim3(64), 0, st, hi, (uint32_t)half, gls_digits(s), qt.as<G2J>());
         hipLaunchKernelGGL(k_fold_g2_combine, dim3(nblk(half, 64)), dim3(64), 0, st, qt.as<G2J>(), lo, (uint32_t)half, jac.as<G2J>());
     } else {
@@ -729,6 +735,10 @@ API int32_t ripp_gipa_tipp_prove(const ripp_g1j* m_a, const ripp_g2j* m_b, const
         prev_c = c;
         // folds (gipa.rs:262-290): hi = upper half, lo = lower half for all four vectors
         const double tf = now_ms();
+        const size_t saved_vm_max = e->vm_fold_max;
+        if ((rc = e->vm_flag.reserve(sizeof(uint32_t)))) return rc;
+      redo_folds:
+        HIPCHK(hipMemsetAsync(e->vm_flag.p, 0, sizeof(uint32_t), e->stream));
         HIPCHK(hipEventRecord(e->ev_fork, e->stream)); HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
         if ((rc = fold_dev<Fp>(e, e->stream2, A + split, A, split, c, jac1, qt2, dA2.as<G1A>()))) return rc;          // m_a  <- m_a_1 * c + m_a_2
         if ((rc = fold_dev<Fp>(e, e->stream2, KB + split, KB, split, c, jac1b, qt2, dKB2.as<G1A>()))) return rc;       // ck_b <- ck_b_1 * c + ck_b_2
@@ -737,6 +747,11 @@ API int32_t ripp_gipa_tipp_prove(const ripp_g1j* m_a, const ripp_g2j* m_b, const
         if ((rc = fold_dev<Fp2>(e, e->stream, KA + split, KA, split, c_inv, jac2b, e->qtab, dKA2.as<G2A>()))) return rc; // ck_a <- ck_a_2 * c_inv + ck_a_1
         HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
         if ((rc = e->sync())) return rc;
+        if (e->vm_fold_max != 0 && split <= e->vm_fold_max) {          // exceptional addition met by a VM fold: redo with the complete scalar kernels
+            uint32_t flag = 0; HIPCHK(hipMemcpy(&flag, e->vm_flag.p, sizeof flag, hipMemcpyDeviceToHost));
+            if (flag) { e->vm_fold_max = 0; goto redo_folds; }
+        }
+        e->vm_fold_max = saved_vm_max;
         e->stats.fold_ms += now_ms() - tf;
         std::swap(dA, dA2); std::swap(dKB, dKB2); std::swap(dB, dB2); std::swap(dKA, dKA2);
         len = split; ++round;
