@@ -65,13 +65,17 @@ def main():
     import ripp_amd as R
     from ripp_amd.sharded import ShardedSippProver, TorchComm, SingleComm
 
+    # test hooks (used on 1-GPU boxes to exercise the N > 1 control flow): all ranks on device 0, gloo transport
+    if os.environ.get("RIPP_BENCH_SINGLE_DEVICE"):
+        local_rank = 0
+    backend = os.environ.get("RIPP_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     R.init(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)      # "nccl" IS RCCL on ROCm
-        comm = TorchComm(f"cuda:{local_rank}")
+        dist.init_process_group(backend, rank=rank, world_size=world)     # "nccl" IS RCCL on ROCm
+        comm = TorchComm(f"cuda:{local_rank}" if backend == "nccl" else "cpu")
     else:
         dist = None
         comm = SingleComm()
@@ -90,7 +94,8 @@ def main():
         if rank == 0:
             full = (R.synth_g1(1000, n), R.synth_g2(2000, n), R.synth_fr(0, n))
             value = R.product_of_pairings_with_coeffs(*full)
-        t = torch.from_numpy(value.view(np.int64).copy()).cuda(); dist.broadcast(t, src=0); value = t.cpu().numpy().view(np.uint64)
+        t = torch.from_numpy(value.view(np.int64).copy()); t = t.cuda() if backend == "nccl" else t
+        dist.broadcast(t, src=0); value = t.cpu().numpy().view(np.uint64)
 
     job = R.SippJob(a, b, r, rank=rank, world=world)      # statement (shard) now resident in HBM
     pool = ThreadPoolExecutor(max_workers=1)
@@ -121,7 +126,7 @@ def main():
         assert np.array_equal(proof, ref_proof), "non-deterministic proof"
     total = sum(times)
     if dist is not None:
-        tt = torch.tensor([total], dtype=torch.float64, device="cuda"); dist.all_reduce(tt, op=dist.ReduceOp.MAX); total = float(tt.item())
+        tt = torch.tensor([total], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu"); dist.all_reduce(tt, op=dist.ReduceOp.MAX); total = float(tt.item())
     ms_per_step = total / args.steps * 1e3
 
     if rank == 0:
