@@ -135,6 +135,15 @@ def main():
         k_prod = (stats["kernel_line_products_ms_sum"], stats["kernel_line_products_launches"], stats["pairs_products"], "k_line_products")
         dom = max(k_lines, k_prod, key=lambda k: k[0])
         achieved = (dom[2] * ALG_BYTES_PER_PAIR) / (dom[0] * 1e-3) / 1e9 if dom[0] > 0 else 0.0
+        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE,
+        # separate passes, same workload) -- see profiles/r01_hbm_traffic_pmc.csv.  None when the profile is absent / n differs.
+        traffic = None
+        try:
+            if args.log_n == 20 and world == 1:
+                tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"].get(dom[3])
+                traffic = tr["bytes_per_launch"] if tr else None
+        except Exception:
+            traffic = None
         out = {
             "metric": "SIPP prover pairing-products/sec at n=2^%d BLS12-381" % args.log_n,
             "value": n / (ms_per_step * 1e-3), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -143,7 +152,8 @@ def main():
             "config": {"workload": "sipp_prove (all log2 n rounds, Blake2s Fiat-Shamir)", "curve": "BLS12-381", "n": n,
                        "sharding": "index residue mod %d" % world, "inputs": "a_i=(1000+i)G1, b_i=(2000+i)G2, r_i=SplitMix64(0) 254-bit"},
             "roofline": {"bound": "hbm", "kernel": dom[3], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": dom[2] * ALG_BYTES_PER_PAIR / max(dom[1], 1),
                          "avg_launch_ms": dom[0] / max(dom[1], 1), "launches_per_step": dom[1], "pairs_per_step": dom[2],
                          "note": "integer-ALU bound (381-bit Montgomery arithmetic, ~5e3 Fp products per 288 input bytes); see DESIGN.md"},
             "phase_ms": {k: round(v, 3) for k, v in stats.items() if k.endswith("_ms")},
