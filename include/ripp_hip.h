@@ -96,15 +96,17 @@ int32_t ripp_sipp_job_create(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr
 void    ripp_sipp_job_destroy(ripp_sipp_job* job);
 /* whole proof on one GPU (world == 1) from the resident statement */
 int32_t ripp_sipp_job_prove(ripp_sipp_job* job, const ripp_gt* value, ripp_gt* proof, ripp_fr* challenges, ripp_stats* stats);
-/* staged interface for world > 1 (the caller all-gathers the 2 x 68 x 576 B partial step-products over RCCL):
- *   begin: re-arm the job from the resident statement, start hashing this rank's statement bytes (rank 0 hashes)
- *   round_partials: this shard's 2 x 68 per-step line products (Fp12, Montgomery) of the current round
- *   round_finish: given the world's combined per-step products, finish z_l, z_r (combine + final exp), derive x,
- *                 fold the local halves.  seed_digest: Blake2s digest of the statement (needed in round 0 only). */
+/* staged interface for world > 1 (the caller all-gathers 2 x 576 B per round over RCCL):
+ *   begin: re-arm the job from the resident statement (scaling a_i <- r_i a_i of this shard)
+ *   round_partials: this shard's two MILLER VALUES (before the final exponentiation) of the current round's
+ *                   z_l and z_r.  prod_ranks miller_combine(rows_rank) == miller_combine(prod_ranks rows_rank) because the
+ *                   f <- f^2 * L recurrence is multiplicative, so every rank folds its own 68 step products first.
+ *   round_finish: given the product over ranks of those values, final-exponentiate to z_l, z_r, derive x, fold the
+ *                 local halves.  seed_digest: Blake2s digest of the statement (needed in round 0 only). */
 int32_t ripp_sipp_job_begin(ripp_sipp_job* job);
 size_t  ripp_sipp_job_rounds_left(const ripp_sipp_job* job);
-int32_t ripp_sipp_job_round_partials(ripp_sipp_job* job, ripp_gt* partials /* [2][68] */);
-int32_t ripp_sipp_job_round_finish(ripp_sipp_job* job, const ripp_gt* combined /* [2][68] */, const uint8_t seed_digest[32],
+int32_t ripp_sipp_job_round_partials(ripp_sipp_job* job, ripp_gt* partials /* [2] */);
+int32_t ripp_sipp_job_round_finish(ripp_sipp_job* job, const ripp_gt* combined /* [2] */, const uint8_t seed_digest[32],
                                    ripp_gt* z_l, ripp_gt* z_r, ripp_fr* x);
 int32_t ripp_sipp_job_stats(const ripp_sipp_job* job, ripp_stats* stats);
 /* tail of a sharded proof: once every rank holds ONE element (global length == world) the ranks all-gather the

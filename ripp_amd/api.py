@@ -246,7 +246,7 @@ class SippJob:
         return int(lib().ripp_sipp_job_rounds_left(self._h))
 
     def round_partials(self):
-        out = np.zeros((2 * 68, 72), dtype=np.uint64)
+        out = np.zeros((2, 72), dtype=np.uint64)
         _check(lib().ripp_sipp_job_round_partials(self._h, _p(out))); return out
 
     def round_finish(self, combined, seed_digest):

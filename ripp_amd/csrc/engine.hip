@@ -796,14 +796,19 @@ API size_t ripp_sipp_job_rounds_left(const ripp_sipp_job* j) { if (!j) return 0;
 API int32_t ripp_sipp_job_round_partials(ripp_sipp_job* j, ripp_gt* partials) {
     LOCK; ENGINE; if (!j || !partials) return RIPP_ERR_ARG;
     if (j->len < 2) { set_err("shard exhausted: gather the remaining elements onto one rank"); return RIPP_ERR_ARG; }
-    return job_round_partials(e, j, reinterpret_cast<Fp12*>(partials));
+    Fp12 rows[2 * N_LINES];
+    int32_t rc = job_round_partials(e, j, rows); if (rc) return rc;
+    auto fut = std::async(std::launch::async, [&rows]() { return miller_combine(rows + N_LINES); });
+    const Fp12 ml = miller_combine(rows), mr = fut.get();
+    std::memcpy(&partials[0], &ml, sizeof ml); std::memcpy(&partials[1], &mr, sizeof mr);
+    return RIPP_OK;
 }
 API int32_t ripp_sipp_job_round_finish(ripp_sipp_job* j, const ripp_gt* combined, const uint8_t seed_digest[32], ripp_gt* z_l, ripp_gt* z_r, ripp_fr* x) {
     LOCK; ENGINE; if (!j || !combined || !z_l || !z_r || !x) return RIPP_ERR_ARG;
     const double t0 = now_ms();
-    const Fp12* rows = reinterpret_cast<const Fp12*>(combined);
-    auto fut = std::async(std::launch::async, [rows]() { return final_exponentiation(miller_combine(rows + N_LINES)); });
-    const Fp12 zl = final_exponentiation(miller_combine(rows));
+    Fp12 mv[2]; std::memcpy(mv, combined, sizeof mv);
+    auto fut = std::async(std::launch::async, [&mv]() { return final_exponentiation(mv[1]); });
+    const Fp12 zl = final_exponentiation(mv[0]);
     const Fp12 zr = fut.get();
     if (!j->seeded) { if (!seed_digest) return RIPP_ERR_ARG; j->rng.from_digest(seed_digest); j->seeded = true; }
     const Fr xc = fs::sipp_challenge(j->rng, zl, zr);

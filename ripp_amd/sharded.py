@@ -3,8 +3,9 @@ RCCL (torch.distributed backend "nccl" on ROCm) -- the host logic of SURVEY.md s
 
 Sharding: global element i lives on rank i mod G at local index i div G.  Every halving round pairs (i, i + L/2);
 while L/2 is a multiple of G both partners have the same residue, so the fold is 100% local and each rank simply
-halves its own shard with the common challenge.  The only exchange per round is the rank's partial step-products
-(2 x 68 x 576 B = 78 KB): all-gather + local multiply (RCCL has no Fq12-product reduction op).  When every rank is
+halves its own shard with the common challenge.  The only exchange per round is the rank's two partial Miller values
+(2 x 576 B): all-gather + local multiply (RCCL has no Fq12-product reduction op); each rank folds its own 68 per-step
+products first, which is valid because the f <- f^2 * L recurrence is multiplicative.  When every rank is
 down to ONE element (L == G) the G remaining elements are all-gathered and the last log2(G) rounds run replicated.
 
 The engine (device job) and the communicator are injected, so the N > 1 control flow is testable on CPU with gloo
