@@ -69,7 +69,7 @@ template <class F> RIPP_MID Jac<F> add(const Jac<F>& p, const Jac<F>& q) {
 
 template <class F> RIPP_FN Affine<F> to_affine(const Jac<F>& p) {
     if (is_inf(p)) return aff_inf<F>();
-    const F zi = inv(p.z), zi2 = fsqr(zi);
+    const F zi = finv(p.z), zi2 = fsqr(zi);
     return {fmul(p.x, zi2), fmul(p.y, fmul(zi2, zi))};
 }
 template <class F> RIPP_HD bool eq(const Jac<F>& a, const Jac<F>& b) {

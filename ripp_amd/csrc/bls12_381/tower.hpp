@@ -5,6 +5,7 @@
 // of ark-serialize's `serialize_uncompressed` for `PairingOutput` (sipp/src/lib.rs:80-84).
 #pragma once
 #include "fp.hpp"
+#include "fp_inv.hpp"
 
 namespace ripp {
 
@@ -33,10 +34,11 @@ RIPP_MID Fp2 sqr(const Fp2& a) {                          // (a0+a1)(a0-a1), 2 a
 RIPP_MID Fp2 mul_fp(const Fp2& a, const Fp& s) { return {fmul(a.c0, s), fmul(a.c1, s)}; }
 RIPP_HD Fp2 mul_xi(const Fp2& a) { return {sub(a.c0, a.c1), add(a.c0, a.c1)}; }     // * (1 + u)
 RIPP_MID Fp2 inv(const Fp2& a) {
-    const Fp n = inv(add(fsqr(a.c0), fsqr(a.c1)));
+    const Fp n = finv(add(fsqr(a.c0), fsqr(a.c1)));
     return {fmul(a.c0, n), neg(fmul(a.c1, n))};
 }
 
+RIPP_HD Fp2 finv(const Fp2& a) { return inv(a); }
 RIPP_HD Fp2 fmul(const Fp2& a, const Fp2& b) { return mul(a, b); }
 RIPP_HD Fp2 fsqr(const Fp2& a) { return sqr(a); }
 

@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(256) k_normalize(const Jac<F>* __restrict__ in
         const F z = in[i].z;
         if (!z.is_zero()) { out[i].x = acc; acc = fmul(acc, z); }
     }
-    F ainv = inv(acc);
+    F ainv = finv(acc);
     uint32_t last = t + ((n - 1 - t) / T) * T;       // largest index of this lane (t < n guaranteed by T <= n)
 #pragma unroll 1
     for (uint32_t i = last;; i -= T) {
