@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Counterpart of the reference's `sipp/examples/scaling-ipp.rs` (its only measurement harness for SIPP):
+for each log-size in [log_min, log_max] time the direct product, the prover and the verifier and write
+`ipp-<backend>.csv` with the reference's columns (scaling-ipp.rs:13-19) plus backend/threads.
+
+  python tools/scaling_ipp.py <log_min> <log_max> <out_dir> [--cpu-max LOG]   (CPU oracle rows only up to --cpu-max)
+
+Differences from the reference, on purpose: BLS12-381 instead of BLS12-377, and distinct
+points a_i = (1000+i)G1, b_i = (2000+i)G2, r_i = SplitMix64(0) instead of one repeated point/scalar."""
+import argparse, csv, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def timed(f, reps):
+    best = None
+    for _ in range(reps):
+        t = time.perf_counter(); r = f(); dt = time.perf_counter() - t
+        best = dt if best is None else min(best, dt)
+    return best, r
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("log_min", type=int); ap.add_argument("log_max", type=int); ap.add_argument("out_dir")
+    ap.add_argument("--cpu-max", type=int, default=14)
+    args = ap.parse_args()
+    import numpy as np, orclib as o, ripp_amd as R
+    R.init(0)
+    os.makedirs(args.out_dir, exist_ok=True)
+    rows_gpu, rows_cpu = [], []
+    for lg in range(args.log_min, args.log_max + 1):
+        n = 1 << lg
+        reps = 5 if lg <= 14 else (3 if lg <= 18 else 2)         # scaling-ipp.rs:57-62 scales repetitions with size too
+        a, b, r = R.synth_g1(1000, n), R.synth_g2(2000, n), R.synth_fr(0, n)
+        td, z = timed(lambda: R.product_of_pairings_with_coeffs(a, b, r), reps)
+        tp, proof = timed(lambda: R.SIPP.prove(a, b, r, z), reps)
+        tv, ok = timed(lambda: R.SIPP.verify(a, b, r, z, proof), reps)
+        assert ok
+        rows_gpu.append(dict(size=n, direct=td * 1e3, prover=tp * 1e3, verifier=tv * 1e3, backend="mi355x-hip", threads=1))
+        print(f"2^{lg}: gpu direct {td*1e3:.1f} ms, prover {tp*1e3:.1f} ms, verifier {tv*1e3:.1f} ms", flush=True)
+        if lg <= args.cpu_max:
+            cd, cz = timed(lambda: o.product_of_pairings_with_coeffs(a, b, r), 1)
+            cp, (rc, cproof, _) = timed(lambda: o.sipp_prove(a, b, r, cz), 1)
+            cv, cok = timed(lambda: o.sipp_verify(a, b, r, cz, cproof), 1)
+            assert rc == 0 and cok == 1 and np.array_equal(cproof, proof) and np.array_equal(cz, z)
+            rows_cpu.append(dict(size=n, direct=cd * 1e3, prover=cp * 1e3, verifier=cv * 1e3, backend="cpu-oracle", threads=o.lib().orc_num_threads()))
+            print(f"      cpu direct {cd*1e3:.1f} ms, prover {cp*1e3:.1f} ms, verifier {cv*1e3:.1f} ms  (proofs identical)", flush=True)
+    for name, rows in (("ipp-mi355x-hip.csv", rows_gpu), ("ipp-cpu-oracle.csv", rows_cpu)):
+        with open(os.path.join(args.out_dir, name), "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=["size", "direct", "prover", "verifier", "backend", "threads"]); w.writeheader(); w.writerows(rows)
+
+
+if __name__ == "__main__":
+    main()
