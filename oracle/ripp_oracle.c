@@ -477,3 +477,5 @@ ORC_API int orc_gipa_tipp_verify(const g2j_t *ck_a, const g1j_t *ck_b, size_t n,
     free(tr); free(ea); free(eb);
     return ok;
 }
+
+#include "tipa.h"

@@ -22,6 +22,47 @@ class RippStats(ctypes.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+def _u64(n):
+    return ctypes.c_uint64 * n
+
+
+class AggregateProofStruct(ctypes.Structure):
+    """`ripp_aggregate_proof` of include/ripp_hip.h (AggregateProof, groth16_aggregation.rs:59-69).  Step arrays are
+    caller-allocated and filled in ROUND order."""
+    _fields_ = [
+        ("com_a", _u64(72)), ("com_b", _u64(72)), ("com_c", _u64(72)), ("ip_ab", _u64(72)), ("agg_c", _u64(18)), ("r", _u64(4)),
+        ("ab_com_steps", ctypes.c_void_p), ("ab_transcript", ctypes.c_void_p),
+        ("ab_base_a", _u64(18)), ("ab_base_b", _u64(36)), ("ab_final_ck_a", _u64(36)), ("ab_final_ck_b", _u64(18)),
+        ("ab_opening_a", _u64(36)), ("ab_opening_b", _u64(18)), ("ab_kzg_c", _u64(4)),
+        ("c_com_gt", ctypes.c_void_p), ("c_com_g1", ctypes.c_void_p), ("c_transcript", ctypes.c_void_p),
+        ("c_base_a", _u64(18)), ("c_base_b", _u64(4)), ("c_final_ck_a", _u64(36)), ("c_opening_a", _u64(36)), ("c_kzg_c", _u64(4))]
+
+
+class AggregateProof:
+    """Owner of an AggregateProofStruct and of its step arrays (numpy); `field(name)` views a fixed-size member."""
+
+    def __init__(self, n):
+        import numpy as np
+        self.n, self.rounds = n, max(n.bit_length() - 1, 1)
+        r = self.rounds
+        self.ab_com_steps = np.zeros((r * 6, 72), dtype=np.uint64); self.ab_transcript = np.zeros((r, 4), dtype=np.uint64)
+        self.c_com_gt = np.zeros((r * 2, 72), dtype=np.uint64); self.c_com_g1 = np.zeros((r * 2, 18), dtype=np.uint64); self.c_transcript = np.zeros((r, 4), dtype=np.uint64)
+        self.s = AggregateProofStruct()
+        for name in ("ab_com_steps", "ab_transcript", "c_com_gt", "c_com_g1", "c_transcript"):
+            setattr(self.s, name, getattr(self, name).ctypes.data)
+
+    def field(self, name):
+        import numpy as np
+        return np.ctypeslib.as_array(getattr(self.s, name))
+
+    def ref(self):
+        return ctypes.byref(self.s)
+
+    FIXED = ("com_a", "com_b", "com_c", "ip_ab", "agg_c", "r", "ab_base_a", "ab_base_b", "ab_final_ck_a", "ab_final_ck_b", "ab_opening_a",
+             "ab_opening_b", "ab_kzg_c", "c_base_a", "c_base_b", "c_final_ck_a", "c_opening_a", "c_kzg_c")
+    STEPS = ("ab_com_steps", "ab_transcript", "c_com_gt", "c_com_g1", "c_transcript")
+
+
 _lib = None
 
 

@@ -17,3 +17,42 @@ def gt_from_bytes(hexstr):
     for i in range(12):
         out[6 * i:6 * i + 6] = o.fp_to_limbs(int.from_bytes(b[48 * i:48 * i + 48], "little"))
     return out
+
+
+# ---------------------------------------------------------------- TIPA SRS and synthetic Groth16 instances (oracle-side, test infrastructure)
+def make_srs(n, alpha, beta):
+    """SRS of TIPA::setup (tipa/mod.rs:150-165) for fixed trapdoors: (g_alpha_powers[2n-1], h_beta_powers[2n-1], g_beta, h_alpha), all Jacobian."""
+    fa, fb = o.fr_array([alpha]), o.fr_array([beta])
+    gap = o.srs_powers_g1(fa[0], 2 * n - 1); hbp = o.srs_powers_g2(fb[0], 2 * n - 1)
+    g_beta = o.to_jac_g1(o.g1_mul_a(o.g1_generator(), fb[0]))[0]; h_alpha = o.to_jac_g2(o.g2_mul_a(o.g2_generator(), fa[0]))[0]
+    return gap, hbp, g_beta, h_alpha
+
+
+def verifier_srs(srs):
+    gap, hbp, g_beta, h_alpha = srs
+    return gap[0].copy(), hbp[0].copy(), g_beta, h_alpha
+
+
+def commitment_keys(srs):
+    """SRS::get_commitment_keys (tipa/mod.rs:114-118): even powers."""
+    return np.ascontiguousarray(srs[1][::2]), np.ascontiguousarray(srs[0][::2])
+
+
+def fake_groth16(n, m, seed):
+    """n Groth16 (A, B, C) triples over m public inputs that SATISFY e(A,B) = e(alpha,beta) e(sum x_k abc_k, gamma) e(C, delta) for a
+    verifying key with known discrete logs (no circuit needed).  Returns vk = (alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1[m+1]),
+    public_inputs (n, m, 4), a (n,12), b (n,24), c (n,12)."""
+    import random
+    rng = random.Random(seed); R = o.R
+    rnd = lambda: rng.randrange(1, R)
+    al, be, ga, de = rnd(), rnd(), rnd(), rnd(); abc = [rnd() for _ in range(m + 1)]
+    g1, g2 = o.g1_generator(), o.g2_generator()
+    mul1 = lambda k: o.g1_mul_a(g1, o.fr_array([k])[0]); mul2 = lambda k: o.g2_mul_a(g2, o.fr_array([k])[0])
+    vk = (mul1(al), mul2(be), mul2(ga), mul2(de), np.stack([mul1(k) for k in abc]))
+    a = np.zeros((n, 12), dtype=np.uint64); b = np.zeros((n, 24), dtype=np.uint64); c = np.zeros((n, 12), dtype=np.uint64); pub = np.zeros((n, m, 4), dtype=np.uint64)
+    for i in range(n):
+        ai, bi = rnd(), rnd(); xs = [rnd() for _ in range(m)]
+        s = (abc[0] + sum(x * k for x, k in zip(xs, abc[1:]))) % R
+        ci = (ai * bi - al * be - ga * s) * pow(de, -1, R) % R
+        a[i], b[i], c[i] = mul1(ai), mul2(bi), mul1(ci); pub[i] = o.fr_array(xs)
+    return vk, pub, a, b, c

@@ -292,3 +292,92 @@ def gipa_tipp_prove(m_a, m_b, ck_a, ck_b):
 def gipa_tipp_verify(ck_a, ck_b, com, steps, base_a, base_b):
     com = np.ascontiguousarray(np.stack(com), dtype=np.uint64)
     return lib().orc_gipa_tipp_verify(_p(ck_a), _p(ck_b), ctypes.c_size_t(len(ck_a)), _p(com), _p(steps), ctypes.c_size_t(len(steps) // 6), _p(base_a), _p(base_b))
+
+
+# ---------------------------------------------------------------- TIPA / TIPAWithSSM / Groth16 aggregation (oracle/tipa.h)
+def fr_from_random_bytes(digest):
+    d = np.frombuffer(bytes(digest), dtype=np.uint8).copy(); out = u64(4)
+    ok = lib().orc_fr_from_random_bytes(_p(d), _p(out)); return (out if ok else None)
+
+
+def srs_powers_g1(s, num):
+    out = u64((num, 18)); lib().orc_srs_powers_g1(_p(s), ctypes.c_size_t(num), _p(out)); return out
+
+
+def srs_powers_g2(s, num):
+    out = u64((num, 36)); lib().orc_srs_powers_g2(_p(s), ctypes.c_size_t(num), _p(out)); return out
+
+
+def g1_mul_a(p, k):
+    out = u64(12); lib().orc_g1_mul_a(_p(p), _p(k), _p(out)); return out
+
+
+def g2_mul_a(p, k):
+    out = u64(24); lib().orc_g2_mul_a(_p(p), _p(k), _p(out)); return out
+
+
+def g1_generator():
+    out = u64(12); lib().orc_g1_generator(_p(out)); return out
+
+
+def g2_generator():
+    out = u64(24); lib().orc_g2_generator(_p(out)); return out
+
+
+def to_jac_g1(a):
+    """affine (n,12) -> Jacobian (n,18) with Z = 1 (infinity -> Z = 0)."""
+    a = np.atleast_2d(a); out = u64((len(a), 18)); out[:, :12] = a
+    one = np.array(fp_to_limbs(1), dtype=np.uint64); inf = ~a.any(axis=1)
+    out[:, 12:18] = one; out[inf, 0:6] = one; out[inf, 6:12] = one; out[inf, 12:18] = 0
+    return out
+
+
+def to_jac_g2(b):
+    b = np.atleast_2d(b); out = u64((len(b), 36)); out[:, :24] = b
+    one = np.array(fp_to_limbs(1), dtype=np.uint64); inf = ~b.any(axis=1)
+    out[:, 24:30] = one; out[inf, 0:6] = one; out[inf, 12:18] = one; out[inf, 24:30] = 0
+    return out
+
+
+def tipa_tipp_prove(g_alpha_powers, h_beta_powers, m_a, m_b, ck_a, ck_b, r_shift):
+    n = len(m_a); rounds = n.bit_length() - 1
+    o = dict(steps=u64((max(rounds, 1) * 6, 72)), tr=u64((max(rounds, 1), 4)), base_a=u64(18), base_b=u64(36), final_ck_a=u64(36), final_ck_b=u64(18),
+             opening_a=u64(36), opening_b=u64(18), kzg_c=u64(4))
+    rc = lib().orc_tipa_tipp_prove(_p(g_alpha_powers), _p(h_beta_powers), _p(m_a), _p(m_b), _p(ck_a), _p(ck_b), ctypes.c_size_t(n), _p(r_shift),
+                                   _p(o["steps"]), _p(o["tr"]), _p(o["base_a"]), _p(o["base_b"]), _p(o["final_ck_a"]), _p(o["final_ck_b"]),
+                                   _p(o["opening_a"]), _p(o["opening_b"]), _p(o["kzg_c"]))
+    return rc, o
+
+
+def tipa_tipp_verify(g, h, g_beta, h_alpha, com, o, r_shift):
+    com = np.ascontiguousarray(np.stack(com), dtype=np.uint64)
+    return lib().orc_tipa_tipp_verify(_p(g), _p(h), _p(g_beta), _p(h_alpha), _p(com), _p(o["steps"]), ctypes.c_size_t(len(o["steps"]) // 6),
+                                      _p(o["base_a"]), _p(o["base_b"]), _p(o["final_ck_a"]), _p(o["final_ck_b"]), _p(o["opening_a"]), _p(o["opening_b"]), _p(r_shift))
+
+
+def tipa_ssm_prove(h_beta_powers, m_a, m_b, ck_a):
+    n = len(m_a); rounds = n.bit_length() - 1
+    o = dict(com_gt=u64((max(rounds, 1) * 2, 72)), com_g1=u64((max(rounds, 1) * 2, 18)), tr=u64((max(rounds, 1), 4)), base_a=u64(18), base_b=u64(4),
+             final_ck_a=u64(36), opening_a=u64(36), kzg_c=u64(4))
+    rc = lib().orc_tipa_ssm_prove(_p(h_beta_powers), _p(m_a), _p(m_b), _p(ck_a), ctypes.c_size_t(n), _p(o["com_gt"]), _p(o["com_g1"]), _p(o["tr"]),
+                                  _p(o["base_a"]), _p(o["base_b"]), _p(o["final_ck_a"]), _p(o["opening_a"]), _p(o["kzg_c"]))
+    return rc, o
+
+
+def tipa_ssm_verify(g, h, g_beta, com_a, com_t, scalar_b, o):
+    return lib().orc_tipa_ssm_verify(_p(g), _p(h), _p(g_beta), _p(com_a), _p(com_t), _p(scalar_b), _p(o["com_gt"]), _p(o["com_g1"]),
+                                     ctypes.c_size_t(len(o["com_gt"]) // 2), _p(o["base_a"]), _p(o["final_ck_a"]), _p(o["opening_a"]))
+
+
+def aggregate_proofs(g_alpha_powers, h_beta_powers, a, b, c):
+    from ripp_amd._lib import AggregateProof
+    pf = AggregateProof(len(a))
+    rc = lib().orc_aggregate_proofs(_p(g_alpha_powers), _p(h_beta_powers), _p(a), _p(b), _p(c), ctypes.c_size_t(len(a)), pf.ref())
+    return rc, pf
+
+
+def verify_aggregate_proof(v_srs, vk, public_inputs, pf):
+    g, h, g_beta, h_alpha = v_srs; alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1 = vk
+    public_inputs = np.ascontiguousarray(public_inputs, dtype=np.uint64); n, m = public_inputs.shape[0], public_inputs.shape[1]
+    return lib().orc_verify_aggregate_proof(_p(g), _p(h), _p(g_beta), _p(h_alpha), _p(alpha_g1), _p(beta_g2), _p(gamma_g2), _p(delta_g2), _p(gamma_abc_g1),
+                                            _p(public_inputs), ctypes.c_size_t(n), ctypes.c_size_t(m), pf.ref())
