@@ -131,6 +131,61 @@ int32_t ripp_gipa_tipp_prove(const ripp_g1j* m_a, const ripp_g2j* m_b, const rip
                              ripp_gt* com_steps, ripp_fr* transcript, ripp_g1j* base_a, ripp_g2j* base_b,
                              ripp_g2j* ck_base_a, ripp_g1j* ck_base_b, ripp_stats* stats);
 
+/* ---- TIPA: GIPA + KZG openings of the final commitment keys -- ip_proofs/src/tipa/mod.rs ---------------------------
+ * The SRS (tipa/mod.rs:94-102: g_alpha_powers, h_beta_powers with 2n-1 entries each) is normalised ONCE and stays
+ * resident in HBM behind a handle; provers take commitment keys from it (even powers, get_commitment_keys :114-118)
+ * and run the two opening MSMs of size 2n-1 against it. */
+typedef struct ripp_srs ripp_srs;
+int32_t ripp_srs_create(const ripp_g1j* g_alpha_powers, const ripp_g2j* h_beta_powers, size_t num /* = 2n-1 */, ripp_srs** srs);
+void    ripp_srs_destroy(ripp_srs* srs);
+/* structured_generators_scalar_power (tipa/mod.rs:372-391): out[i] = s^i * generator, on the device */
+int32_t ripp_srs_powers_g1(const ripp_fr* s, size_t num, ripp_g1j* out);
+int32_t ripp_srs_powers_g2(const ripp_fr* s, size_t num, ripp_g2j* out);
+/* SRS::get_commitment_keys (tipa/mod.rs:114-118): ck_1 = even h_beta powers, ck_2 = even g_alpha powers (n each, Z = 1) */
+int32_t ripp_srs_commitment_keys(const ripp_srs* srs, ripp_g2j* ck_1, ripp_g1j* ck_2);
+
+/* TIPA::prove_with_srs_shift (tipa/mod.rs:176-231), TIPP instantiation (PairingInnerProductAB, groth16_aggregation.rs:24-31).
+ * Outputs: the GIPA proof as for ripp_gipa_tipp_prove (ROUND order), final_ck = aux.ck_base, final_ck_proof = the two
+ * KZG openings (prove_commitment_key_kzg_opening, :304-337), and the KZG challenge point for inspection.  n >= 2. */
+int32_t ripp_tipa_tipp_prove(const ripp_srs* srs, const ripp_g1j* m_a, const ripp_g2j* m_b, const ripp_g2j* ck_a, const ripp_g1j* ck_b, size_t n,
+                             const ripp_fr* r_shift, ripp_gt* com_steps, ripp_fr* transcript, ripp_g1j* base_a, ripp_g2j* base_b,
+                             ripp_g2j* final_ck_a, ripp_g1j* final_ck_b, ripp_g2j* opening_a, ripp_g1j* opening_b, ripp_fr* kzg_challenge,
+                             ripp_stats* stats);
+/* TIPAWithSSM::prove_with_structured_scalar_message (tipa/structured_scalar_message.rs:211-268), MultiExpInnerProductC
+ * instantiation (groth16_aggregation.rs:42-48): m_a in G1, m_b in Fr, ck_a in G2.
+ *   com_gt[round][2] = (com_1.0, com_2.0)   com_g1[round][2] = (com_1.2[0], com_2.2[0])   (com_x.1 is Fr::zero(), ssm.rs:44-46) */
+int32_t ripp_tipa_ssm_prove(const ripp_srs* srs, const ripp_g1j* m_a, const ripp_fr* m_b, const ripp_g2j* ck_a, size_t n,
+                            ripp_gt* com_gt, ripp_g1j* com_g1, ripp_fr* transcript, ripp_g1j* base_a, ripp_fr* base_b,
+                            ripp_g2j* final_ck_a, ripp_g2j* opening_a, ripp_fr* kzg_challenge, ripp_stats* stats);
+
+/* ---- Groth16 proof aggregation -- aggregate_proofs, ip_proofs/src/applications/groth16_aggregation.rs:77-160 --------
+ * AggregateProof (:59-69).  Step arrays are caller-allocated ([rounds = log2 n] entries as sized below) and filled in
+ * ROUND order; projective members are any representative of the group element. */
+typedef struct {
+    ripp_gt com_a, com_b, com_c, ip_ab;
+    ripp_g1j agg_c;
+    ripp_fr r;                                  /* the Fiat-Shamir combination scalar (:105-116) */
+    /* tipa_proof_ab */
+    ripp_gt* ab_com_steps;                      /* [rounds][6] */
+    ripp_fr* ab_transcript;                     /* [rounds] */
+    ripp_g1j ab_base_a; ripp_g2j ab_base_b;
+    ripp_g2j ab_final_ck_a; ripp_g1j ab_final_ck_b;
+    ripp_g2j ab_opening_a; ripp_g1j ab_opening_b;
+    ripp_fr ab_kzg_c;
+    /* tipa_proof_c */
+    ripp_gt* c_com_gt;                          /* [rounds][2] */
+    ripp_g1j* c_com_g1;                         /* [rounds][2] */
+    ripp_fr* c_transcript;                      /* [rounds] */
+    ripp_g1j c_base_a; ripp_fr c_base_b;
+    ripp_g2j c_final_ck_a; ripp_g2j c_opening_a;
+    ripp_fr c_kzg_c;
+} ripp_aggregate_proof;
+/* a, b, c: the (A, B, C) members of n Groth16 proofs (affine, as ark_groth16::Proof stores them); n a power of two >= 2 and
+ * srs built for the same n.  RIPP_ERR_ARG with ripp_last_error() = "commitment key shift check failed" mirrors the
+ * assert_eq! at :133-136. */
+int32_t ripp_aggregate_proofs(const ripp_srs* srs, const ripp_g1a* a, const ripp_g2a* b, const ripp_g1a* c, size_t n,
+                              ripp_aggregate_proof* out, ripp_stats* stats);
+
 /* ---- host-side helpers (no device needed): what the host code around the kernels computes ---------------- */
 int32_t ripp_final_exp(const ripp_gt* miller_value, ripp_gt* out);                 /* Pairing::final_exponentiation */
 int32_t ripp_miller_combine(const ripp_gt* step_products /* [68] */, ripp_gt* out); /* stage (3) of pairing.hpp */

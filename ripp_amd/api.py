@@ -11,11 +11,11 @@ Values are numpy uint64 arrays in the flat C-ABI layouts (little-endian Montgome
 """
 import ctypes
 import numpy as np
-from ._lib import lib, last_error, RippStats, RIPP_OK, RIPP_ERR_LENGTH, RIPP_ERR_POW2, RIPP_ERR_DEVICE
+from ._lib import lib, last_error, RippStats, AggregateProof, RIPP_OK, RIPP_ERR_LENGTH, RIPP_ERR_POW2, RIPP_ERR_DEVICE
 
 __all__ = ["InnerProductError", "DeviceError", "PairingInnerProduct", "MultiexponentiationInnerProductG1",
            "MultiexponentiationInnerProductG2", "AFGHOCommitmentG1", "AFGHOCommitmentG2", "PedersenCommitmentG1",
-           "PedersenCommitmentG2", "SIPP", "SippJob", "GIPA_TIPP", "product_of_pairings", "product_of_pairings_with_coeffs",
+           "PedersenCommitmentG2", "SIPP", "SippJob", "GIPA_TIPP", "SRS", "TIPA_TIPP", "TIPAWithSSM", "aggregate_proofs", "AggregateProof", "product_of_pairings", "product_of_pairings_with_coeffs",
            "normalize_batch_g1", "normalize_batch_g2", "fold_g1_affine", "fold_g2_affine", "fold_g1", "fold_g2",
            "scale_g1_affine", "synth_g1", "synth_g2", "synth_fr", "init", "device_count", "final_exponentiation",
            "ser_gt", "ser_g1", "ser_g2", "ser_fr", "sipp_seed_digest", "gt_mul"]
@@ -333,6 +333,108 @@ class GIPA_TIPP:
         proof = {"r_commitment_steps": [((s[0], s[1], [s[2]]), (s[3], s[4], [s[5]])) for s in steps[::-1]], "r_base": (ba, bb)}
         aux = {"r_transcript": tr[::-1].copy(), "ck_base": (ka, kb)}
         return proof, aux, {"round_order_steps": steps.reshape(rounds * 6, 72), "round_order_transcript": tr, "stats": st.as_dict()}
+
+
+# ------------------------------------------------------------------ TIPA, TIPAWithSSM, Groth16 aggregation
+FR_ONE = np.array([0x00000001fffffffe, 0x5884b7fa00034802, 0x998c4fefecbc4ff5, 0x1824b159acc5056f], dtype=np.uint64)   # Fr::one(), Montgomery form
+
+
+class SRS:
+    """SRS<Bls12_381> (ip_proofs/src/tipa/mod.rs:94-128): g_alpha_powers (2n-1,18), h_beta_powers (2n-1,36), normalised once and
+    kept resident in HBM; g_beta / h_alpha are carried for `get_verifier_key`."""
+
+    def __init__(self, g_alpha_powers, h_beta_powers, g_beta=None, h_alpha=None):
+        gap, hbp = _c(g_alpha_powers, 18), _c(h_beta_powers, 36)
+        assert len(gap) == len(hbp)
+        self.g_alpha_powers, self.h_beta_powers, self.g_beta, self.h_alpha = gap, hbp, g_beta, h_alpha
+        self.size = (len(gap) + 1) // 2
+        self._h = ctypes.c_void_p()
+        _check(lib().ripp_srs_create(_p(gap), _p(hbp), ctypes.c_size_t(len(gap)), ctypes.byref(self._h)))
+
+    @staticmethod
+    def from_trapdoors(alpha, beta, size):
+        """TIPA::setup with the two field elements given instead of drawn (tipa/mod.rs:150-165): powers computed on the device."""
+        alpha = np.ascontiguousarray(alpha, dtype=np.uint64).reshape(4); beta = np.ascontiguousarray(beta, dtype=np.uint64).reshape(4)
+        num = 2 * size - 1
+        gap = np.zeros((num, 18), dtype=np.uint64); hbp = np.zeros((num, 36), dtype=np.uint64)
+        _check(lib().ripp_srs_powers_g1(_p(alpha), ctypes.c_size_t(num), _p(gap)))
+        _check(lib().ripp_srs_powers_g2(_p(beta), ctypes.c_size_t(num), _p(hbp)))
+        tmp = np.zeros((2, 18), dtype=np.uint64); _check(lib().ripp_srs_powers_g1(_p(beta), ctypes.c_size_t(2), _p(tmp))); g_beta = tmp[1].copy()
+        tmp = np.zeros((2, 36), dtype=np.uint64); _check(lib().ripp_srs_powers_g2(_p(alpha), ctypes.c_size_t(2), _p(tmp))); h_alpha = tmp[1].copy()
+        return SRS(gap, hbp, g_beta, h_alpha)
+
+    def get_commitment_keys(self):
+        """(ck_1, ck_2) = even powers (tipa/mod.rs:114-118)."""
+        ck_1 = np.zeros((self.size, 36), dtype=np.uint64); ck_2 = np.zeros((self.size, 18), dtype=np.uint64)
+        _check(lib().ripp_srs_commitment_keys(self._h, _p(ck_1), _p(ck_2))); return ck_1, ck_2
+
+    def get_verifier_key(self):
+        return {"g": self.g_alpha_powers[0].copy(), "h": self.h_beta_powers[0].copy(), "g_beta": self.g_beta, "h_alpha": self.h_alpha}
+
+    def close(self):
+        if self._h:
+            lib().ripp_srs_destroy(self._h); self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class TIPA_TIPP:
+    """TIPA<PairingInnerProduct, AFGHOCommitmentG1, AFGHOCommitmentG2, IdentityCommitment<GT,Fr>, Bls12_381, Blake2b>
+    = PairingInnerProductAB (groth16_aggregation.rs:24-31)."""
+
+    @staticmethod
+    def prove_with_srs_shift(srs, values, ck, r_shift):
+        """tipa/mod.rs:176-231.  values = (m_a, m_b), ck = (ck_a, ck_b).  Returns a dict with the GIPA proof in ROUND order."""
+        m_a, m_b, ck_a, ck_b = _c(values[0], 18), _c(values[1], 36), _c(ck[0], 36), _c(ck[1], 18)
+        n = len(m_a); assert len(m_b) == len(ck_a) == len(ck_b) == n
+        r_shift = np.ascontiguousarray(r_shift, dtype=np.uint64).reshape(4)
+        rounds = max(n.bit_length() - 1, 1)
+        o = dict(steps=np.zeros((rounds * 6, 72), dtype=np.uint64), tr=np.zeros((rounds, 4), dtype=np.uint64), base_a=np.zeros(18, dtype=np.uint64),
+                 base_b=np.zeros(36, dtype=np.uint64), final_ck_a=np.zeros(36, dtype=np.uint64), final_ck_b=np.zeros(18, dtype=np.uint64),
+                 opening_a=np.zeros(36, dtype=np.uint64), opening_b=np.zeros(18, dtype=np.uint64), kzg_c=np.zeros(4, dtype=np.uint64))
+        st = RippStats()
+        _check(lib().ripp_tipa_tipp_prove(srs._h, _p(m_a), _p(m_b), _p(ck_a), _p(ck_b), ctypes.c_size_t(n), _p(r_shift), _p(o["steps"]), _p(o["tr"]),
+                                          _p(o["base_a"]), _p(o["base_b"]), _p(o["final_ck_a"]), _p(o["final_ck_b"]), _p(o["opening_a"]), _p(o["opening_b"]),
+                                          _p(o["kzg_c"]), ctypes.byref(st)))
+        o["stats"] = st.as_dict(); return o
+
+    @staticmethod
+    def prove(srs, values, ck):
+        """tipa/mod.rs:168-174: r_shift = 1."""
+        return TIPA_TIPP.prove_with_srs_shift(srs, values, ck, FR_ONE)
+
+
+class TIPAWithSSM:
+    """TIPAWithSSM<MultiexponentiationInnerProduct<G1>, AFGHOCommitmentG1, IdentityCommitment<G1,Fr>, Bls12_381, Blake2b>
+    = MultiExpInnerProductC (groth16_aggregation.rs:42-48)."""
+
+    @staticmethod
+    def prove_with_structured_scalar_message(srs, values, ck):
+        """structured_scalar_message.rs:211-268.  values = (m_a G1 (n,18), m_b Fr (n,4)), ck = (ck_a G2 (n,36),)."""
+        m_a, m_b, ck_a = _c(values[0], 18), _c(values[1], 4), _c(ck[0], 36)
+        n = len(m_a); assert len(m_b) == len(ck_a) == n
+        rounds = max(n.bit_length() - 1, 1)
+        o = dict(com_gt=np.zeros((rounds * 2, 72), dtype=np.uint64), com_g1=np.zeros((rounds * 2, 18), dtype=np.uint64), tr=np.zeros((rounds, 4), dtype=np.uint64),
+                 base_a=np.zeros(18, dtype=np.uint64), base_b=np.zeros(4, dtype=np.uint64), final_ck_a=np.zeros(36, dtype=np.uint64),
+                 opening_a=np.zeros(36, dtype=np.uint64), kzg_c=np.zeros(4, dtype=np.uint64))
+        st = RippStats()
+        _check(lib().ripp_tipa_ssm_prove(srs._h, _p(m_a), _p(m_b), _p(ck_a), ctypes.c_size_t(n), _p(o["com_gt"]), _p(o["com_g1"]), _p(o["tr"]),
+                                         _p(o["base_a"]), _p(o["base_b"]), _p(o["final_ck_a"]), _p(o["opening_a"]), _p(o["kzg_c"]), ctypes.byref(st)))
+        o["stats"] = st.as_dict(); return o
+
+
+def aggregate_proofs(ip_srs, a, b, c):
+    """aggregate_proofs (groth16_aggregation.rs:77-160).  a, c: (n,12) G1Affine; b: (n,24) G2Affine -- the members of n Groth16 proofs.
+    Returns (AggregateProof, stats)."""
+    a, b, c = _c(a, 12), _c(b, 24), _c(c, 12)
+    assert len(a) == len(b) == len(c)
+    pf = AggregateProof(len(a)); st = RippStats()
+    _check(lib().ripp_aggregate_proofs(ip_srs._h, _p(a), _p(b), _p(c), ctypes.c_size_t(len(a)), pf.ref(), ctypes.byref(st)))
+    return pf, st.as_dict()
 
 
 # ------------------------------------------------------------------ host helpers / synthetic inputs

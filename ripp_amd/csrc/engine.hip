@@ -691,32 +691,51 @@ template <> int32_t fold_dev<Fp2>(Engine* e, hipStream_t st, const G2A* hi, cons
 }
 }  // extern "C++"
 
-API int32_t ripp_gipa_tipp_prove(const ripp_g1j* m_a, const ripp_g2j* m_b, const ripp_g2j* ck_a, const ripp_g1j* ck_b, size_t n,
-                                 ripp_gt* com_steps, ripp_fr* transcript, ripp_g1j* base_a, ripp_g2j* base_b,
-                                 ripp_g2j* ck_base_a, ripp_g1j* ck_base_b, ripp_stats* st) {
-    if (n == 0 || (n & (n - 1))) return RIPP_ERR_POW2;                       // assert!(m_a.len().is_power_of_two()), gipa.rs:195
-    LOCK; ENGINE;
-    if (!m_a || !m_b || !ck_a || !ck_b || !base_a || !base_b || !ck_base_a || !ck_base_b || (n > 1 && (!com_steps || !transcript))) return RIPP_ERR_ARG;
-    e->stats = ripp_stats{};
-    const double t_start = now_ms();
-    // device vectors: A = m_a, KB = ck_b (G1);  B = m_b, KA = ck_a (G2); ping-pong buffers for the folds
-    DevBuf dA, dA2, dKB, dKB2, dB, dB2, dKA, dKA2, jac1, jac1b, jac2, jac2b, qt2;
-    struct Cleanup { std::vector<DevBuf*> v; ~Cleanup() { for (auto* b : v) b->release(); } } cleanup{{&dA, &dA2, &dKB, &dKB2, &dB, &dB2, &dKA, &dKA2, &jac1, &jac1b, &jac2, &jac2b, &qt2}};
+// device-resident GIPA/TIPP state: the four vectors (affine) + ping-pong partners + fold scratch
+struct TippVecs {
+    DevBuf A, A2, KB, KB2, B, B2, KA, KA2, jac1, jac1b, jac2, jac2b, qt2;
+    ~TippVecs() { for (DevBuf* b : {&A, &A2, &KB, &KB2, &B, &B2, &KA, &KA2, &jac1, &jac1b, &jac2, &jac2b, &qt2}) b->release(); }
+    int32_t reserve(size_t n) {
+        int32_t rc;
+        for (DevBuf* b : {&A, &A2, &KB, &KB2}) if ((rc = b->reserve(n * sizeof(G1A)))) return rc;
+        for (DevBuf* b : {&B, &B2, &KA, &KA2}) if ((rc = b->reserve(n * sizeof(G2A)))) return rc;
+        if ((rc = jac1.reserve(n * sizeof(G1J))) || (rc = jac2.reserve(n * sizeof(G2J)))) return rc;
+        return RIPP_OK;
+    }
+};
+
+extern "C++" {
+// run one set of folds on the two streams; on an exceptional addition reported by a VM fold, redo with the complete scalar kernels
+template <class Launch> static int32_t folds_with_vm_fallback(Engine* e, size_t split, Launch&& launch) {
     int32_t rc;
-    if ((rc = dA.reserve(n * sizeof(G1A))) || (rc = dKB.reserve(n * sizeof(G1A))) || (rc = dB.reserve(n * sizeof(G2A))) || (rc = dKA.reserve(n * sizeof(G2A))) ||
-        (rc = dA2.reserve(n * sizeof(G1A))) || (rc = dKB2.reserve(n * sizeof(G1A))) || (rc = dB2.reserve(n * sizeof(G2A))) || (rc = dKA2.reserve(n * sizeof(G2A))) ||
-        (rc = jac1.reserve(n * sizeof(G1J))) || (rc = jac2.reserve(n * sizeof(G2J)))) return rc;
-    // upload + normalise the four projective inputs
-    HIPCHK(hipMemcpyAsync(jac1.p, m_a, n * sizeof(G1J), hipMemcpyHostToDevice, e->stream)); if ((rc = e->normalize_dev<Fp>(jac1.as<G1J>(), n, dA.as<G1A>()))) return rc; if ((rc = e->sync())) return rc;
-    HIPCHK(hipMemcpyAsync(jac1.p, ck_b, n * sizeof(G1J), hipMemcpyHostToDevice, e->stream)); if ((rc = e->normalize_dev<Fp>(jac1.as<G1J>(), n, dKB.as<G1A>()))) return rc; if ((rc = e->sync())) return rc;
-    HIPCHK(hipMemcpyAsync(jac2.p, m_b, n * sizeof(G2J), hipMemcpyHostToDevice, e->stream)); if ((rc = e->normalize_dev<Fp2>(jac2.as<G2J>(), n, dB.as<G2A>()))) return rc; if ((rc = e->sync())) return rc;
-    HIPCHK(hipMemcpyAsync(jac2.p, ck_a, n * sizeof(G2J), hipMemcpyHostToDevice, e->stream)); if ((rc = e->normalize_dev<Fp2>(jac2.as<G2J>(), n, dKA.as<G2A>()))) return rc; if ((rc = e->sync())) return rc;
+    const size_t saved_vm_max = e->vm_fold_max;
+    if ((rc = e->vm_flag.reserve(sizeof(uint32_t)))) return rc;
+    for (;;) {
+        HIPCHK(hipMemsetAsync(e->vm_flag.p, 0, sizeof(uint32_t), e->stream));
+        HIPCHK(hipEventRecord(e->ev_fork, e->stream)); HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
+        if ((rc = launch())) { e->vm_fold_max = saved_vm_max; return rc; }
+        HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
+        if ((rc = e->sync())) { e->vm_fold_max = saved_vm_max; return rc; }
+        if (e->vm_fold_max != 0 && split <= e->vm_fold_max) {
+            uint32_t flag = 0; HIPCHK(hipMemcpy(&flag, e->vm_flag.p, sizeof flag, hipMemcpyDeviceToHost));
+            if (flag) { e->vm_fold_max = 0; continue; }
+        }
+        break;
+    }
+    e->vm_fold_max = saved_vm_max;
+    return RIPP_OK;
+}
+}  // extern "C++"
+
+// GIPA::_prove (gipa.rs:181-312) on vectors already resident (and normalised) in v.A (m_a), v.B (m_b), v.KA (ck_a), v.KB (ck_b)
+static int32_t gipa_tipp_core(Engine* e, TippVecs& v, size_t n, ripp_gt* com_steps, ripp_fr* transcript, G1A& ha, G2A& hb, G2A& hka, G1A& hkb) {
+    int32_t rc;
     size_t len = n, round = 0;
     Fr prev_c = Fr::zero();
     std::vector<Fp12> rows(6 * N_LINES);
     while (len > 1) {
         const size_t split = len / 2;
-        const G1A *A = dA.as<G1A>(), *KB = dKB.as<G1A>(); const G2A *B = dB.as<G2A>(), *KA = dKA.as<G2A>();
+        const G1A *A = v.A.as<G1A>(), *KB = v.KB.as<G1A>(); const G2A *B = v.B.as<G2A>(), *KA = v.KA.as<G2A>();
         //            com_1.0 (m_a_1,ck_a_1)  com_1.1 (ck_b_1,m_b_1)  com_1.2 (m_a_1,m_b_1)  com_2.0 (m_a_2,ck_a_2)  com_2.1 (ck_b_2,m_b_2)  com_2.2 (m_a_2,m_b_2)   gipa.rs:209-231
         const G1A* as[6] = {A + split,             KB + split,            A + split,             A,                     KB,                    A};
         const G2A* bs[6] = {KA,                    B,                     B,                     KA + split,            B + split,             B + split};
@@ -735,32 +754,335 @@ API int32_t ripp_gipa_tipp_prove(const ripp_g1j* m_a, const ripp_g2j* m_b, const
         prev_c = c;
         // folds (gipa.rs:262-290): hi = upper half, lo = lower half for all four vectors
         const double tf = now_ms();
-        const size_t saved_vm_max = e->vm_fold_max;
-        if ((rc = e->vm_flag.reserve(sizeof(uint32_t)))) return rc;
-      redo_folds:
-        HIPCHK(hipMemsetAsync(e->vm_flag.p, 0, sizeof(uint32_t), e->stream));
-        HIPCHK(hipEventRecord(e->ev_fork, e->stream)); HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
-        if ((rc = fold_dev<Fp>(e, e->stream2, A + split, A, split, c, jac1, qt2, dA2.as<G1A>()))) return rc;          // m_a  <- m_a_1 * c + m_a_2
-        if ((rc = fold_dev<Fp>(e, e->stream2, KB + split, KB, split, c, jac1b, qt2, dKB2.as<G1A>()))) return rc;       // ck_b <- ck_b_1 * c + ck_b_2
-        HIPCHK(hipEventRecord(e->ev_join, e->stream2));
-        if ((rc = fold_dev<Fp2>(e, e->stream, B + split, B, split, c_inv, jac2, e->qtab, dB2.as<G2A>()))) return rc;   // m_b  <- m_b_2 * c_inv + m_b_1
-        if ((rc = fold_dev<Fp2>(e, e->stream, KA + split, KA, split, c_inv, jac2b, e->qtab, dKA2.as<G2A>()))) return rc; // ck_a <- ck_a_2 * c_inv + ck_a_1
-        HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
-        if ((rc = e->sync())) return rc;
-        if (e->vm_fold_max != 0 && split <= e->vm_fold_max) {          // exceptional addition met by a VM fold: redo with the complete scalar kernels
-            uint32_t flag = 0; HIPCHK(hipMemcpy(&flag, e->vm_flag.p, sizeof flag, hipMemcpyDeviceToHost));
-            if (flag) { e->vm_fold_max = 0; goto redo_folds; }
-        }
-        e->vm_fold_max = saved_vm_max;
+        rc = folds_with_vm_fallback(e, split, [&]() -> int32_t {
+            int32_t r2;
+            if ((r2 = fold_dev<Fp>(e, e->stream2, A + split, A, split, c, v.jac1, v.qt2, v.A2.as<G1A>()))) return r2;          // m_a  <- m_a_1 * c + m_a_2
+            if ((r2 = fold_dev<Fp>(e, e->stream2, KB + split, KB, split, c, v.jac1b, v.qt2, v.KB2.as<G1A>()))) return r2;       // ck_b <- ck_b_1 * c + ck_b_2
+            HIPCHK(hipEventRecord(e->ev_join, e->stream2));
+            if ((r2 = fold_dev<Fp2>(e, e->stream, B + split, B, split, c_inv, v.jac2, e->qtab, v.B2.as<G2A>()))) return r2;     // m_b  <- m_b_2 * c_inv + m_b_1
+            return fold_dev<Fp2>(e, e->stream, KA + split, KA, split, c_inv, v.jac2b, e->qtab, v.KA2.as<G2A>());                // ck_a <- ck_a_2 * c_inv + ck_a_1
+        });
+        if (rc) return rc;
         e->stats.fold_ms += now_ms() - tf;
-        std::swap(dA, dA2); std::swap(dKB, dKB2); std::swap(dB, dB2); std::swap(dKA, dKA2);
+        std::swap(v.A, v.A2); std::swap(v.KB, v.KB2); std::swap(v.B, v.B2); std::swap(v.KA, v.KA2);
         len = split; ++round;
     }
+    HIPCHK(hipMemcpy(&ha, v.A.p, sizeof ha, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(&hkb, v.KB.p, sizeof hkb, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&hb, v.B.p, sizeof hb, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(&hka, v.KA.p, sizeof hka, hipMemcpyDeviceToHost));
+    return RIPP_OK;
+}
+
+// upload the four projective inputs of a TIPP instance and normalise them into v
+static int32_t tipp_upload(Engine* e, TippVecs& v, const ripp_g1j* m_a, const ripp_g2j* m_b, const ripp_g2j* ck_a, const ripp_g1j* ck_b, size_t n) {
+    int32_t rc; if ((rc = v.reserve(n))) return rc;
+    HIPCHK(hipMemcpyAsync(v.jac1.p, m_a, n * sizeof(G1J), hipMemcpyHostToDevice, e->stream)); if ((rc = e->normalize_dev<Fp>(v.jac1.as<G1J>(), n, v.A.as<G1A>()))) return rc; if ((rc = e->sync())) return rc;
+    HIPCHK(hipMemcpyAsync(v.jac1.p, ck_b, n * sizeof(G1J), hipMemcpyHostToDevice, e->stream)); if ((rc = e->normalize_dev<Fp>(v.jac1.as<G1J>(), n, v.KB.as<G1A>()))) return rc; if ((rc = e->sync())) return rc;
+    HIPCHK(hipMemcpyAsync(v.jac2.p, m_b, n * sizeof(G2J), hipMemcpyHostToDevice, e->stream)); if ((rc = e->normalize_dev<Fp2>(v.jac2.as<G2J>(), n, v.B.as<G2A>()))) return rc; if ((rc = e->sync())) return rc;
+    HIPCHK(hipMemcpyAsync(v.jac2.p, ck_a, n * sizeof(G2J), hipMemcpyHostToDevice, e->stream)); if ((rc = e->normalize_dev<Fp2>(v.jac2.as<G2J>(), n, v.KA.as<G2A>()))) return rc; return e->sync();
+}
+
+API int32_t ripp_gipa_tipp_prove(const ripp_g1j* m_a, const ripp_g2j* m_b, const ripp_g2j* ck_a, const ripp_g1j* ck_b, size_t n,
+                                 ripp_gt* com_steps, ripp_fr* transcript, ripp_g1j* base_a, ripp_g2j* base_b,
+                                 ripp_g2j* ck_base_a, ripp_g1j* ck_base_b, ripp_stats* st) {
+    if (n == 0 || (n & (n - 1))) return RIPP_ERR_POW2;                       // assert!(m_a.len().is_power_of_two()), gipa.rs:195
+    LOCK; ENGINE;
+    if (!m_a || !m_b || !ck_a || !ck_b || !base_a || !base_b || !ck_base_a || !ck_base_b || (n > 1 && (!com_steps || !transcript))) return RIPP_ERR_ARG;
+    e->stats = ripp_stats{};
+    const double t_start = now_ms();
+    TippVecs v; int32_t rc;
+    if ((rc = tipp_upload(e, v, m_a, m_b, ck_a, ck_b, n))) return rc;
     G1A ha, hkb; G2A hb, hka;
-    HIPCHK(hipMemcpy(&ha, dA.p, sizeof ha, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(&hkb, dKB.p, sizeof hkb, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(&hb, dB.p, sizeof hb, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(&hka, dKA.p, sizeof hka, hipMemcpyDeviceToHost));
+    if ((rc = gipa_tipp_core(e, v, n, com_steps, transcript, ha, hb, hka, hkb))) return rc;
     const G1J ja = to_jac(ha), jkb = to_jac(hkb); const G2J jb = to_jac(hb), jka = to_jac(hka);
     std::memcpy(base_a, &ja, sizeof ja); std::memcpy(base_b, &jb, sizeof jb); std::memcpy(ck_base_a, &jka, sizeof jka); std::memcpy(ck_base_b, &jkb, sizeof jkb);
+    e->collect_kernel_stats();
+    e->stats.total_ms = now_ms() - t_start;
+    if (st) *st = e->stats;
+    return RIPP_OK;
+}
+
+// ---- TIPA: SRS handle, KZG openings (ip_proofs/src/tipa/mod.rs) ---------------------------------------------------------
+struct ripp_srs { DevBuf gap, hbp; size_t num = 0; };   // normalised g_alpha_powers / h_beta_powers, resident in HBM
+
+API int32_t ripp_srs_create(const ripp_g1j* g_alpha_powers, const ripp_g2j* h_beta_powers, size_t num, ripp_srs** out) {
+    LOCK; ENGINE; if (!g_alpha_powers || !h_beta_powers || !out || !(num & 1)) return RIPP_ERR_ARG;
+    const size_t n = (num + 1) / 2; if (n & (n - 1)) return RIPP_ERR_POW2;
+    ripp_srs* s = new ripp_srs(); s->num = num;
+    int32_t rc; G1J* dj1; G2J* dj2;
+    if ((rc = s->gap.reserve(num * sizeof(G1A))) || (rc = s->hbp.reserve(num * sizeof(G2A))) ||
+        (rc = upload<G1J>(e, e->jacG1, g_alpha_powers, num, &dj1)) || (rc = e->normalize_dev<Fp>(dj1, num, s->gap.as<G1A>())) ||
+        (rc = upload<G2J>(e, e->jacG2, h_beta_powers, num, &dj2)) || (rc = e->normalize_dev<Fp2>(dj2, num, s->hbp.as<G2A>())) || (rc = e->sync())) {
+        s->gap.release(); s->hbp.release(); delete s; return rc;
+    }
+    *out = s; return RIPP_OK;
+}
+API void ripp_srs_destroy(ripp_srs* s) { if (!s) return; LOCK; s->gap.release(); s->hbp.release(); delete s; }
+
+extern "C++" {
+// structured_generators_scalar_power (tipa/mod.rs:372-391): the powers s^i are a sequential host recurrence, the num scalar
+// multiplications of the one generator run on the device
+template <class F> static int32_t srs_powers(const Affine<F>& g, const ripp_fr* s_in, size_t num, void* out) {
+    LOCK; ENGINE; if (!s_in || (num && !out)) return RIPP_ERR_ARG; if (!num) return RIPP_OK;
+    Fr s; std::memcpy(&s, s_in, sizeof s);
+    std::vector<Fr> pw(num); pw[0] = Fr::one(); for (size_t i = 1; i < num; ++i) pw[i] = mul(pw[i - 1], s);
+    DevBuf& jac = std::is_same<F, Fp>::value ? e->jacG1 : e->jacG2; DevBuf& aff = std::is_same<F, Fp>::value ? e->affG1 : e->affG2;
+    int32_t rc; Fr* dk;
+    if ((rc = upload<Fr>(e, e->tmpR, pw.data(), num, &dk)) || (rc = jac.reserve(num * sizeof(Jac<F>))) || (rc = aff.reserve(sizeof(Affine<F>)))) return rc;
+    HIPCHK(hipMemcpyAsync(aff.p, &g, sizeof g, hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scale_pts<F>), dim3(nblk(num, 256)), dim3(256), 0, e->stream, aff.as<Affine<F>>(), 0u, dk, (uint32_t)num, jac.as<Jac<F>>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, jac.p, num * sizeof(Jac<F>), hipMemcpyDeviceToHost, e->stream));
+    return e->sync();
+}
+
+// polynomial_coefficients_from_transcript (tipa/mod.rs:406-422) before the zero interleave: co[j] multiplies X^(2j)
+static std::vector<Fr> ck_poly_coeffs(const std::vector<Fr>& tr, const Fr& r_shift) {
+    std::vector<Fr> co((size_t)1 << tr.size()); co[0] = Fr::one(); Fr p2r = r_shift; size_t cnt = 1;
+    for (size_t i = 0; i < tr.size(); ++i) {
+        const Fr xr = mul(tr[i], p2r);
+        for (size_t j = 0; j < ((size_t)1 << i); ++j) co[cnt + j] = mul(co[j], xr);
+        cnt += (size_t)1 << i; p2r = mul(p2r, p2r);
+    }
+    return co;
+}
+// prove_commitment_key_kzg_opening (tipa/mod.rs:304-337): quotient of p(X) - p(c) by (X - c) by synthetic division on the
+// host (O(n) Fr products), then the 2n-1 term MSM against the resident SRS powers on the device
+template <class F> static int32_t kzg_opening_dev(Engine* e, const Affine<F>* powers, size_t num, const std::vector<Fr>& tr, const Fr& r_shift, const Fr& c, Jac<F>* out) {
+    const std::vector<Fr> co = ck_poly_coeffs(tr, r_shift);
+    if (2 * co.size() - 1 != num) { set_err("SRS size does not match the transcript length (assert_eq! at tipa/mod.rs:313)"); return RIPP_ERR_ARG; }
+    std::vector<Fr> q(num); q[num - 1] = Fr::zero();
+    Fr carry = Fr::zero();
+    for (size_t k = num - 1; k >= 1; --k) {                       // q[k-1] = p[k] + c q[k];  p[k] = co[k/2] for even k, else 0
+        Fr t = mul(carry, c); if (!(k & 1)) t = add(t, co[k >> 1]);
+        q[k - 1] = t; carry = t;
+    }
+    int32_t rc; Fr* dq;
+    if ((rc = upload<Fr>(e, e->tmpR, q.data(), num, &dq))) return rc;
+    if ((rc = e->sync())) return rc;                               // q is a local: finish the copy before it goes away
+    return e->msm_dev<F>(powers, dq, num, out);
+}
+}  // extern "C++"
+API int32_t ripp_srs_powers_g1(const ripp_fr* s, size_t num, ripp_g1j* out) { return srs_powers<Fp>(g1_generator(), s, num, out); }
+API int32_t ripp_srs_powers_g2(const ripp_fr* s, size_t num, ripp_g2j* out) { return srs_powers<Fp2>(g2_generator(), s, num, out); }
+
+extern "C++" {
+// strided device gather of the even SRS powers (get_commitment_keys, tipa/mod.rs:114-118)
+template <class T> static int32_t gather_even(Engine* e, const T* src, size_t n, T* dst) {
+    HIPCHK(hipMemcpy2DAsync(dst, sizeof(T), src, 2 * sizeof(T), sizeof(T), n, hipMemcpyDeviceToDevice, e->stream)); return RIPP_OK;
+}
+}
+API int32_t ripp_srs_commitment_keys(const ripp_srs* s, ripp_g2j* ck_1, ripp_g1j* ck_2) {
+    LOCK; ENGINE; if (!s || !ck_1 || !ck_2) return RIPP_ERR_ARG;
+    const size_t n = (s->num + 1) / 2; int32_t rc;
+    if ((rc = e->affG1.reserve(n * sizeof(G1A))) || (rc = e->affG2.reserve(n * sizeof(G2A)))) return rc;
+    if ((rc = gather_even<G2A>(e, const_cast<ripp_srs*>(s)->hbp.as<G2A>(), n, e->affG2.as<G2A>())) || (rc = gather_even<G1A>(e, const_cast<ripp_srs*>(s)->gap.as<G1A>(), n, e->affG1.as<G1A>()))) return rc;
+    std::vector<G1A> h1(n); std::vector<G2A> h2(n);
+    HIPCHK(hipMemcpyAsync(h1.data(), e->affG1.p, n * sizeof(G1A), hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipMemcpyAsync(h2.data(), e->affG2.p, n * sizeof(G2A), hipMemcpyDeviceToHost, e->stream));
+    if ((rc = e->sync())) return rc;
+    G1J* o1 = reinterpret_cast<G1J*>(ck_2); G2J* o2 = reinterpret_cast<G2J*>(ck_1);
+    for (size_t i = 0; i < n; ++i) { o1[i] = to_jac(h1[i]); o2[i] = to_jac(h2[i]); }
+    return RIPP_OK;
+}
+
+// the KZG half of TIPA::prove_with_srs_shift (tipa/mod.rs:186-223) once GIPA has produced transcript and final keys
+static int32_t tipp_kzg(Engine* e, const ripp_srs* srs, const ripp_fr* transcript, size_t rounds, const Fr& r_shift, const G2A& hka, const G1A& hkb,
+                        G2J* opening_a, G1J* opening_b, Fr* kzg_c) {
+    std::vector<Fr> tr(rounds), tri(rounds);
+    for (size_t i = 0; i < rounds; ++i) { std::memcpy(&tr[i], &transcript[rounds - 1 - i], sizeof(Fr)); tri[i] = inv(tr[i]); }   // aux.r_transcript and its inverses, :190-191
+    const Fr r_inv = inv(r_shift);                                                                                          // :192
+    const Fr c = fs::kzg_challenge(tr[0], hka, &hkb);                                                                       // :194-209
+    ripp_srs* s = const_cast<ripp_srs*>(srs); int32_t rc;
+    if ((rc = kzg_opening_dev<Fp2>(e, s->hbp.as<G2A>(), s->num, tri, r_inv, c, opening_a))) return rc;                      // :212-217
+    if ((rc = kzg_opening_dev<Fp>(e, s->gap.as<G1A>(), s->num, tr, Fr::one(), c, opening_b))) return rc;                    // :218-223
+    *kzg_c = c; return RIPP_OK;
+}
+
+API int32_t ripp_tipa_tipp_prove(const ripp_srs* srs, const ripp_g1j* m_a, const ripp_g2j* m_b, const ripp_g2j* ck_a, const ripp_g1j* ck_b, size_t n,
+                                 const ripp_fr* r_shift, ripp_gt* com_steps, ripp_fr* transcript, ripp_g1j* base_a, ripp_g2j* base_b,
+                                 ripp_g2j* final_ck_a, ripp_g1j* final_ck_b, ripp_g2j* opening_a, ripp_g1j* opening_b, ripp_fr* kzg_challenge, ripp_stats* st) {
+    if (n < 2 || (n & (n - 1))) return RIPP_ERR_POW2;                        // n = 1 would unwrap an empty transcript (tipa/mod.rs:200-202)
+    LOCK; ENGINE;
+    if (!srs || !m_a || !m_b || !ck_a || !ck_b || !r_shift || !com_steps || !transcript || !base_a || !base_b || !final_ck_a || !final_ck_b || !opening_a || !opening_b || !kzg_challenge) return RIPP_ERR_ARG;
+    if (srs->num != 2 * n - 1) { set_err("SRS holds " + std::to_string(srs->num) + " powers, need 2n-1 = " + std::to_string(2 * n - 1)); return RIPP_ERR_ARG; }
+    e->stats = ripp_stats{};
+    const double t_start = now_ms();
+    TippVecs v; int32_t rc;
+    if ((rc = tipp_upload(e, v, m_a, m_b, ck_a, ck_b, n))) return rc;
+    G1A ha, hkb; G2A hb, hka;
+    if ((rc = gipa_tipp_core(e, v, n, com_steps, transcript, ha, hb, hka, hkb))) return rc;
+    size_t rounds = 0; while (((size_t)1 << rounds) < n) ++rounds;
+    Fr rs; std::memcpy(&rs, r_shift, sizeof rs);
+    G2J oa; G1J ob; Fr c;
+    if ((rc = tipp_kzg(e, srs, transcript, rounds, rs, hka, hkb, &oa, &ob, &c))) return rc;
+    const G1J ja = to_jac(ha), jkb = to_jac(hkb); const G2J jb = to_jac(hb), jka = to_jac(hka);
+    std::memcpy(base_a, &ja, sizeof ja); std::memcpy(base_b, &jb, sizeof jb); std::memcpy(final_ck_a, &jka, sizeof jka); std::memcpy(final_ck_b, &jkb, sizeof jkb);
+    std::memcpy(opening_a, &oa, sizeof oa); std::memcpy(opening_b, &ob, sizeof ob); std::memcpy(kzg_challenge, &c, sizeof c);
+    e->collect_kernel_stats();
+    e->stats.total_ms = now_ms() - t_start;
+    if (st) *st = e->stats;
+    return RIPP_OK;
+}
+
+// ---- TIPAWithSSM (MIPP with a structured scalar vector), ip_proofs/src/tipa/structured_scalar_message.rs ------------------
+struct SsmVecs {
+    DevBuf A, A2, S, S2, KA, KA2, jac1, jac2, qt2;
+    ~SsmVecs() { for (DevBuf* b : {&A, &A2, &S, &S2, &KA, &KA2, &jac1, &jac2, &qt2}) b->release(); }
+    int32_t reserve(size_t n) {
+        int32_t rc;
+        if ((rc = A.reserve(n * sizeof(G1A))) || (rc = A2.reserve(n * sizeof(G1A))) || (rc = S.reserve(n * sizeof(Fr))) || (rc = S2.reserve(n * sizeof(Fr))) ||
+            (rc = KA.reserve(n * sizeof(G2A))) || (rc = KA2.reserve(n * sizeof(G2A))) || (rc = jac1.reserve(n * sizeof(G1J))) || (rc = jac2.reserve(n * sizeof(G2J)))) return rc;
+        return RIPP_OK;
+    }
+};
+
+// GIPA<MultiexponentiationInnerProduct<G1>, AFGHO-G1, SSMPlaceholder, Identity<G1>>::_prove (gipa.rs:181-312) + the KZG opening of
+// ck_a (ssm.rs:225-254).  Per round: two pairing products share one line launch, two G1 MSMs over the halves.
+static int32_t tipa_ssm_core(Engine* e, const ripp_srs* srs, SsmVecs& v, size_t n, ripp_gt* com_gt, ripp_g1j* com_g1, ripp_fr* transcript,
+                             G1A& ha, Fr& hs, G2A& hka, G2J* opening_a, Fr* kzg_c) {
+    int32_t rc;
+    size_t len = n, round = 0;
+    Fr prev_c = Fr::zero();
+    std::vector<Fp12> rows(2 * N_LINES);
+    while (len > 1) {
+        const size_t split = len / 2;
+        const G1A* A = v.A.as<G1A>(); const G2A* KA = v.KA.as<G2A>(); const Fr* S = v.S.as<Fr>();
+        const G1A* as[2] = {A + split, A}; const G2A* bs[2] = {KA, KA + split};     // com_1.0 = (m_a_1, ck_a_1), com_2.0 = (m_a_2, ck_a_2)   gipa.rs:209-231
+        const double tp = now_ms();
+        if ((rc = e->step_products(as, bs, 2, split, rows.data()))) return rc;
+        G1J ip[2];
+        if ((rc = e->msm_dev<Fp>(A + split, S, split, &ip[0]))) return rc;           // IP::inner_product(m_a_1, m_b_1)
+        if ((rc = e->msm_dev<Fp>(A, S + split, split, &ip[1]))) return rc;           // IP::inner_product(m_a_2, m_b_2)
+        e->stats.miller_products_ms += now_ms() - tp;
+        const double th = now_ms();
+        Fp12 gt[2];
+        { auto fut = std::async(std::launch::async, [&rows]() { return final_exponentiation(miller_combine(rows.data() + N_LINES)); });
+          gt[0] = final_exponentiation(miller_combine(rows.data())); gt[1] = fut.get(); }
+        const G1A ipa[2] = {to_affine(ip[0]), to_affine(ip[1])};
+        Fr c_inv; const Fr c = fs::gipa_ssm_challenge(round ? &prev_c : nullptr, gt, ipa, c_inv);
+        e->stats.host_ms += now_ms() - th;
+        std::memcpy(&com_gt[2 * round], gt, sizeof gt); std::memcpy(&com_g1[2 * round], ip, sizeof ip); std::memcpy(&transcript[round], &c, sizeof c);
+        prev_c = c;
+        const double tf = now_ms();
+        rc = folds_with_vm_fallback(e, split, [&]() -> int32_t {
+            int32_t r2;
+            if ((r2 = fold_dev<Fp>(e, e->stream2, A + split, A, split, c, v.jac1, v.qt2, v.A2.as<G1A>()))) return r2;               // m_a  <- m_a_1 * c + m_a_2
+            hipLaunchKernelGGL(k_fold_fr, dim3(nblk(split, 256)), dim3(256), 0, e->stream2, S + split, S, (uint32_t)split, c_inv, v.S2.as<Fr>());   // m_b  <- m_b_2 * c_inv + m_b_1
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(e->ev_join, e->stream2));
+            return fold_dev<Fp2>(e, e->stream, KA + split, KA, split, c_inv, v.jac2, e->qtab, v.KA2.as<G2A>());                      // ck_a <- ck_a_2 * c_inv + ck_a_1
+        });
+        if (rc) return rc;
+        e->stats.fold_ms += now_ms() - tf;
+        std::swap(v.A, v.A2); std::swap(v.S, v.S2); std::swap(v.KA, v.KA2);
+        len = split; ++round;
+    }
+    HIPCHK(hipMemcpy(&ha, v.A.p, sizeof ha, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(&hs, v.S.p, sizeof hs, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(&hka, v.KA.p, sizeof hka, hipMemcpyDeviceToHost));
+    const size_t rounds = round;
+    std::vector<Fr> tri(rounds);
+    for (size_t i = 0; i < rounds; ++i) { Fr t; std::memcpy(&t, &transcript[rounds - 1 - i], sizeof t); tri[i] = inv(t); }         // ssm.rs:227-229
+    Fr first; std::memcpy(&first, &transcript[rounds - 1], sizeof first);
+    const Fr c = fs::kzg_challenge(first, hka, nullptr);                                                                           // ssm.rs:231-246
+    ripp_srs* s = const_cast<ripp_srs*>(srs);
+    if ((rc = kzg_opening_dev<Fp2>(e, s->hbp.as<G2A>(), s->num, tri, Fr::one(), c, opening_a))) return rc;                           // ssm.rs:249-254
+    *kzg_c = c; return RIPP_OK;
+}
+
+API int32_t ripp_tipa_ssm_prove(const ripp_srs* srs, const ripp_g1j* m_a, const ripp_fr* m_b, const ripp_g2j* ck_a, size_t n,
+                                ripp_gt* com_gt, ripp_g1j* com_g1, ripp_fr* transcript, ripp_g1j* base_a, ripp_fr* base_b,
+                                ripp_g2j* final_ck_a, ripp_g2j* opening_a, ripp_fr* kzg_challenge, ripp_stats* st) {
+    if (n < 2 || (n & (n - 1))) return RIPP_ERR_POW2;
+    LOCK; ENGINE;
+    if (!srs || !m_a || !m_b || !ck_a || !com_gt || !com_g1 || !transcript || !base_a || !base_b || !final_ck_a || !opening_a || !kzg_challenge) return RIPP_ERR_ARG;
+    if (srs->num != 2 * n - 1) { set_err("SRS holds " + std::to_string(srs->num) + " powers, need 2n-1 = " + std::to_string(2 * n - 1)); return RIPP_ERR_ARG; }
+    e->stats = ripp_stats{};
+    const double t_start = now_ms();
+    SsmVecs v; int32_t rc; if ((rc = v.reserve(n))) return rc;
+    HIPCHK(hipMemcpyAsync(v.jac1.p, m_a, n * sizeof(G1J), hipMemcpyHostToDevice, e->stream)); if ((rc = e->normalize_dev<Fp>(v.jac1.as<G1J>(), n, v.A.as<G1A>()))) return rc;
+    HIPCHK(hipMemcpyAsync(v.jac2.p, ck_a, n * sizeof(G2J), hipMemcpyHostToDevice, e->stream)); if ((rc = e->normalize_dev<Fp2>(v.jac2.as<G2J>(), n, v.KA.as<G2A>()))) return rc;
+    HIPCHK(hipMemcpyAsync(v.S.p, m_b, n * sizeof(Fr), hipMemcpyHostToDevice, e->stream)); if ((rc = e->sync())) return rc;
+    G1A ha; Fr hs; G2A hka; G2J oa; Fr c;
+    if ((rc = tipa_ssm_core(e, srs, v, n, com_gt, com_g1, transcript, ha, hs, hka, &oa, &c))) return rc;
+    const G1J ja = to_jac(ha); const G2J jka = to_jac(hka);
+    std::memcpy(base_a, &ja, sizeof ja); std::memcpy(base_b, &hs, sizeof hs); std::memcpy(final_ck_a, &jka, sizeof jka); std::memcpy(opening_a, &oa, sizeof oa); std::memcpy(kzg_challenge, &c, sizeof c);
+    e->collect_kernel_stats();
+    e->stats.total_ms = now_ms() - t_start;
+    if (st) *st = e->stats;
+    return RIPP_OK;
+}
+
+// ---- Groth16 aggregation: aggregate_proofs (ip_proofs/src/applications/groth16_aggregation.rs:77-160) ---------------------
+static_assert(sizeof(ripp_aggregate_proof) == 4 * sizeof(Fp12) + sizeof(G1J) + sizeof(Fr) + 2 * sizeof(void*) + 2 * (sizeof(G1J) + sizeof(G2J)) + sizeof(G2J) + sizeof(G1J) + sizeof(Fr)
+              + 3 * sizeof(void*) + sizeof(G1J) + sizeof(Fr) + 2 * sizeof(G2J) + sizeof(Fr), "ripp_aggregate_proof layout");
+
+API int32_t ripp_aggregate_proofs(const ripp_srs* srs, const ripp_g1a* a, const ripp_g2a* b, const ripp_g1a* c, size_t n, ripp_aggregate_proof* out, ripp_stats* st) {
+    if (n < 2 || (n & (n - 1))) return RIPP_ERR_POW2;
+    LOCK; ENGINE;
+    if (!srs || !a || !b || !c || !out || !out->ab_com_steps || !out->ab_transcript || !out->c_com_gt || !out->c_com_g1 || !out->c_transcript) return RIPP_ERR_ARG;
+    if (srs->num != 2 * n - 1) { set_err("SRS holds " + std::to_string(srs->num) + " powers, need 2n-1 = " + std::to_string(2 * n - 1)); return RIPP_ERR_ARG; }
+    e->stats = ripp_stats{};
+    const double t_start = now_ms();
+    ripp_srs* s = const_cast<ripp_srs*>(srs);
+    TippVecs v; SsmVecs w; DevBuf dCK1, dRv, dRiv; int32_t rc;
+    struct Cleanup { DevBuf &x, &y, &z; ~Cleanup() { x.release(); y.release(); z.release(); } } cleanup{dCK1, dRv, dRiv};
+    if ((rc = v.reserve(n)) || (rc = w.reserve(n)) || (rc = dCK1.reserve(n * sizeof(G2A))) || (rc = dRv.reserve(n * sizeof(Fr))) || (rc = dRiv.reserve(n * sizeof(Fr)))) return rc;
+    // a -> v.A2 (unscaled), b -> v.B, c -> w.A;  ck_1 -> dCK1 and w.KA, ck_2 -> v.KB   (get_commitment_keys, tipa/mod.rs:114-118)
+    HIPCHK(hipMemcpyAsync(v.A2.p, a, n * sizeof(G1A), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(v.B.p, b, n * sizeof(G2A), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(w.A.p, c, n * sizeof(G1A), hipMemcpyHostToDevice, e->stream));
+    if ((rc = gather_even<G2A>(e, s->hbp.as<G2A>(), n, dCK1.as<G2A>())) || (rc = gather_even<G1A>(e, s->gap.as<G1A>(), n, v.KB.as<G1A>()))) return rc;
+    HIPCHK(hipMemcpyAsync(w.KA.p, dCK1.p, n * sizeof(G2A), hipMemcpyDeviceToDevice, e->stream));
+    std::vector<Fp12> rows(3 * N_LINES);
+    auto finish = [&rows](int k) { return final_exponentiation(miller_combine(rows.data() + (size_t)k * N_LINES)); };
+    {   // com_a = IP(a, ck_1), com_b = IP(ck_2, b), com_c = IP(c, ck_1): one line launch over three products   (:100-102)
+        const G1A* as[3] = {v.A2.as<G1A>(), v.KB.as<G1A>(), w.A.as<G1A>()}; const G2A* bs[3] = {dCK1.as<G2A>(), v.B.as<G2A>(), dCK1.as<G2A>()};
+        if ((rc = e->step_products(as, bs, 3, n, rows.data()))) return rc;
+        auto f1 = std::async(std::launch::async, finish, 1); auto f2 = std::async(std::launch::async, finish, 2);
+        const Fp12 ca = finish(0), cb = f1.get(), cc = f2.get();
+        std::memcpy(&out->com_a, &ca, sizeof ca); std::memcpy(&out->com_b, &cb, sizeof cb); std::memcpy(&out->com_c, &cc, sizeof cc);
+    }
+    Fp12 com_a, com_b, com_c; std::memcpy(&com_a, &out->com_a, sizeof com_a); std::memcpy(&com_b, &out->com_b, sizeof com_b); std::memcpy(&com_c, &out->com_c, sizeof com_c);
+    const Fr r = fs::aggregation_challenge(com_a, com_b, com_c);                                                        // :105-116
+    std::memcpy(&out->r, &r, sizeof r);
+    // r_vec = (1, r, r^2, ...) (:118) and its element-wise inverses (:130) = powers of r^-1
+    std::vector<Fr> rv(n), riv(n); const Fr r_inv = inv(r);
+    rv[0] = Fr::one(); riv[0] = Fr::one(); for (size_t i = 1; i < n; ++i) { rv[i] = mul(rv[i - 1], r); riv[i] = mul(riv[i - 1], r_inv); }
+    HIPCHK(hipMemcpyAsync(dRv.p, rv.data(), n * sizeof(Fr), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(dRiv.p, riv.data(), n * sizeof(Fr), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(w.S.p, dRv.p, n * sizeof(Fr), hipMemcpyDeviceToDevice, e->stream));
+    // a_r = a_i * r^i (:119-123) -> v.A;  ck_1_r = ck_1_i * r^-i (:127-131) -> v.KA
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scale_pts<Fp>), dim3(nblk(n, 256)), dim3(256), 0, e->stream, v.A2.as<G1A>(), 1u, dRv.as<Fr>(), (uint32_t)n, v.jac1.as<G1J>());
+    HIPCHK(hipGetLastError());
+    if ((rc = e->normalize_dev<Fp>(v.jac1.as<G1J>(), n, v.A.as<G1A>()))) return rc;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scale_pts<Fp2>), dim3(nblk(n, 64)), dim3(64), 0, e->stream, dCK1.as<G2A>(), 1u, dRiv.as<Fr>(), (uint32_t)n, v.jac2.as<G2J>());
+    HIPCHK(hipGetLastError());
+    if ((rc = e->normalize_dev<Fp2>(v.jac2.as<G2J>(), n, v.KA.as<G2A>()))) return rc;
+    {   // ip_ab = IP(a_r, b) (:124) and the sanity product IP(a_r, ck_1_r) (:133-136) in one launch
+        const G1A* as[2] = {v.A.as<G1A>(), v.A.as<G1A>()}; const G2A* bs[2] = {v.B.as<G2A>(), v.KA.as<G2A>()};
+        if ((rc = e->step_products(as, bs, 2, n, rows.data()))) return rc;
+        auto f1 = std::async(std::launch::async, finish, 1);
+        const Fp12 ip_ab = finish(0), chk = f1.get();
+        std::memcpy(&out->ip_ab, &ip_ab, sizeof ip_ab);
+        if (!(chk == com_a)) { set_err("commitment key shift check failed (assert_eq! at groth16_aggregation.rs:133-136)"); return RIPP_ERR_ARG; }
+    }
+    G1J agg_c; if ((rc = e->msm_dev<Fp>(w.A.as<G1A>(), dRv.as<Fr>(), n, &agg_c))) return rc;                           // :125
+    std::memcpy(&out->agg_c, &agg_c, sizeof agg_c);
+    size_t rounds = 0; while (((size_t)1 << rounds) < n) ++rounds;
+    {   // tipa_proof_ab = TIPA::prove_with_srs_shift(srs, (a_r, b), (ck_1_r, ck_2), r)   (:138-143)
+        G1A ha, hkb; G2A hb, hka;
+        if ((rc = gipa_tipp_core(e, v, n, out->ab_com_steps, out->ab_transcript, ha, hb, hka, hkb))) return rc;
+        G2J oa; G1J ob; Fr kc;
+        if ((rc = tipp_kzg(e, srs, out->ab_transcript, rounds, r, hka, hkb, &oa, &ob, &kc))) return rc;
+        const G1J ja = to_jac(ha), jkb = to_jac(hkb); const G2J jb = to_jac(hb), jka = to_jac(hka);
+        std::memcpy(&out->ab_base_a, &ja, sizeof ja); std::memcpy(&out->ab_base_b, &jb, sizeof jb); std::memcpy(&out->ab_final_ck_a, &jka, sizeof jka); std::memcpy(&out->ab_final_ck_b, &jkb, sizeof jkb);
+        std::memcpy(&out->ab_opening_a, &oa, sizeof oa); std::memcpy(&out->ab_opening_b, &ob, sizeof ob); std::memcpy(&out->ab_kzg_c, &kc, sizeof kc);
+    }
+    {   // tipa_proof_c = TIPAWithSSM::prove_with_structured_scalar_message(srs, (c, r_vec), ck_1)   (:145-149)
+        G1A ha; Fr hs; G2A hka; G2J oa; Fr kc;
+        if ((rc = tipa_ssm_core(e, srs, w, n, out->c_com_gt, out->c_com_g1, out->c_transcript, ha, hs, hka, &oa, &kc))) return rc;
+        const G1J ja = to_jac(ha); const G2J jka = to_jac(hka);
+        std::memcpy(&out->c_base_a, &ja, sizeof ja); std::memcpy(&out->c_base_b, &hs, sizeof hs); std::memcpy(&out->c_final_ck_a, &jka, sizeof jka);
+        std::memcpy(&out->c_opening_a, &oa, sizeof oa); std::memcpy(&out->c_kzg_c, &kc, sizeof kc);
+    }
     e->collect_kernel_stats();
     e->stats.total_ms = now_ms() - t_start;
     if (st) *st = e->stats;

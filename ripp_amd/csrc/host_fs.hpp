@@ -211,4 +211,58 @@ inline Fr gipa_tipp_challenge(const Fr* prev, const Fp12 com[6], Fr& c_inv) {
     }
 }
 
+// Fr::from_random_bytes(&digest) of ark-ff 0.4 (Fp::from_random_bytes_with_flags::<EmptyFlags>): the first 32 bytes are
+// read little-endian, the bits above MODULUS_BIT_SIZE = 255 are cleared, and the value is rejected when it is >= r.
+inline bool fr_from_random_bytes(const uint8_t dig[64], Fr& out) {
+    Fr t; std::memcpy(t.l, dig, 32); t.l[7] &= 0x7fffffffu;
+    uint32_t borrow = 0; for (int i = 0; i < 8; ++i) (void)subb32(t.l[i], FrParams::mod(i), borrow);
+    if (!borrow) return false;
+    out = to_mont(t); return true;
+}
+
+// KZG challenge point of TIPA (ip_proofs/src/tipa/mod.rs:194-209) and TIPAWithSSM (structured_scalar_message.rs:231-246):
+//   nonce (usize BE) || r_transcript.first() || ck_a_final (G2, uncompressed) [|| ck_b_final (G1)]  -> Blake2b -> from_random_bytes
+inline Fr kzg_challenge(const Fr& first, const G2A& ck_a_final, const G1A* ck_b_final) {
+    for (uint64_t nonce = 0;; ++nonce) {
+        uint8_t buf[8 + 32 + 192 + 96], *p = buf;
+        for (int i = 0; i < 8; ++i) *p++ = (uint8_t)(nonce >> (56 - 8 * i));
+        ser_fr(first, p); p += 32; ser_g2(ck_a_final, p); p += 192;
+        if (ck_b_final) { ser_g1(*ck_b_final, p); p += 96; }
+        uint8_t dig[64]; Blake2b h; h.update(buf, (size_t)(p - buf)); h.finish(dig);
+        Fr c; if (fr_from_random_bytes(dig, c)) return c;
+    }
+}
+
+// GIPA challenge with SSMPlaceholderCommitment on the right and IdentityCommitment<G1> for the inner product
+// (gipa.rs:235-258 instantiated as in groth16_aggregation.rs:42-48): per side  GT (576) || Fr::zero() (32) || u64 1 || G1 (96).
+inline Fr gipa_ssm_challenge(const Fr* prev, const Fp12 gt[2], const G1A g1[2], Fr& c_inv) {
+    for (uint64_t nonce = 0;; ++nonce) {
+        uint8_t buf[8 + 32 + 2 * (576 + 32 + 8 + 96)], *p = buf;
+        for (int i = 0; i < 8; ++i) *p++ = (uint8_t)(nonce >> (56 - 8 * i));
+        ser_fr(prev ? *prev : Fr::zero(), p); p += 32;
+        for (int k = 0; k < 2; ++k) {
+            ser_gt(gt[k], p); p += 576;
+            std::memset(p, 0, 32); p += 32;
+            const uint64_t one = 1; std::memcpy(p, &one, 8); p += 8;
+            ser_g1(g1[k], p); p += 96;
+        }
+        uint8_t dig[64]; Blake2b h; h.update(buf, (size_t)(p - buf)); h.finish(dig);
+        uint64_t hi = 0, lo = 0;
+        for (int i = 0; i < 8; ++i) { hi = (hi << 8) | dig[i]; lo = (lo << 8) | dig[8 + i]; }
+        const Fr c128 = fr_from_u128(lo, hi);
+        if (!c128.is_zero()) { c_inv = c128; return inv(c128); }
+    }
+}
+
+// random-linear-combination challenge of aggregate_proofs (groth16_aggregation.rs:105-116)
+inline Fr aggregation_challenge(const Fp12& com_a, const Fp12& com_b, const Fp12& com_c) {
+    for (uint64_t nonce = 0;; ++nonce) {
+        uint8_t buf[8 + 3 * 576], *p = buf;
+        for (int i = 0; i < 8; ++i) *p++ = (uint8_t)(nonce >> (56 - 8 * i));
+        ser_gt(com_a, p); p += 576; ser_gt(com_b, p); p += 576; ser_gt(com_c, p); p += 576;
+        uint8_t dig[64]; Blake2b h; h.update(buf, (size_t)(p - buf)); h.finish(dig);
+        Fr r; if (fr_from_random_bytes(dig, r)) return r;
+    }
+}
+
 }}  // namespace ripp::fs

@@ -278,6 +278,32 @@ __global__ void __launch_bounds__(256) k_normalize(const Jac<F>* __restrict__ in
     }
 }
 
+// ---- per-element scalar multiplication, either group: out[i] = k[i] * base[i * base_stride]
+// (a_r = a_i * r^i and ck_1_r = ck_i * r^-i of groth16_aggregation.rs:119-131; base_stride = 0 broadcasts one base,
+//  which is structured_generators_scalar_power of tipa/mod.rs:372-391).  Plain MSB-first double-and-add: every lane
+// has its own scalar, so the add is data-dependent and executes under the wave's EXEC mask.
+template <class F>
+__global__ void __launch_bounds__(256) k_scale_pts(const Affine<F>* __restrict__ base, uint32_t base_stride, const Fr* __restrict__ k_mont, uint32_t n, Jac<F>* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Fr k = from_mont(k_mont[i]);
+    const Affine<F> p = base[(size_t)i * base_stride];
+    Jac<F> acc = jac_inf<F>();
+#pragma unroll 1
+    for (int bit = 254; bit >= 0; --bit) {
+        acc = dbl(acc);
+        if ((k.l[bit >> 5] >> (bit & 31)) & 1u) acc = add_mixed(acc, p);
+    }
+    out[i] = acc;
+}
+
+// scalar-vector fold of GIPA with a structured scalar message: out[i] = hi[i] * s + lo[i]  (gipa.rs:270-274 with Message = Fr)
+__global__ void __launch_bounds__(256) k_fold_fr(const Fr* __restrict__ hi, const Fr* __restrict__ lo, uint32_t half, Fr s, Fr* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= half) return;
+    out[i] = add(mul(hi[i], s), lo[i]);
+}
+
 // ---- synthetic inputs (bench harness) ---------------------------------------------------
 template <class F>
 __global__ void __launch_bounds__(256) k_synth_points(Affine<F> g, uint64_t start, uint64_t first, uint64_t stride_, uint32_t n, Jac<F>* __restrict__ out) {
