@@ -186,6 +186,28 @@ typedef struct {
 int32_t ripp_aggregate_proofs(const ripp_srs* srs, const ripp_g1a* a, const ripp_g2a* b, const ripp_g1a* c, size_t n,
                               ripp_aggregate_proof* out, ripp_stats* stats);
 
+/* ---- verifiers: O(log n) GT / group exponentiations on the host, pairings and MSMs on the device --
+ * Every function writes *accept = 1 / 0 and returns RIPP_OK when the check itself ran. */
+/* VerifierSRS (tipa/mod.rs:104-110, get_verifier_key :120-127) */
+typedef struct { ripp_g1j g; ripp_g2j h; ripp_g1j g_beta; ripp_g2j h_alpha; } ripp_verifier_srs;
+/* ark_groth16::VerifyingKey as read by verify_aggregate_proof (groth16_aggregation.rs:211-227) */
+typedef struct { ripp_g1a alpha_g1; ripp_g2a beta_g2, gamma_g2, delta_g2; const ripp_g1a* gamma_abc_g1; size_t gamma_abc_len; } ripp_groth16_vk;
+/* GIPA::verify (gipa.rs:135-160), TIPP instantiation: com = (com_a, com_b, com_t[0]); steps in ROUND order.  The final keys are two
+ * n-term MSMs on the device (the reference folds them sequentially, gipa.rs:383-396 with a TODO to use an MSM). */
+int32_t ripp_gipa_tipp_verify(const ripp_g2j* ck_a, const ripp_g1j* ck_b, size_t n, const ripp_gt com[3], const ripp_gt* com_steps, size_t rounds,
+                              const ripp_g1j* base_a, const ripp_g2j* base_b, int32_t* accept);
+/* TIPA::verify_with_srs_shift (tipa/mod.rs:242-301) */
+int32_t ripp_tipa_tipp_verify(const ripp_verifier_srs* v_srs, const ripp_gt com[3], const ripp_gt* com_steps, size_t rounds,
+                              const ripp_g1j* base_a, const ripp_g2j* base_b, const ripp_g2j* final_ck_a, const ripp_g1j* final_ck_b,
+                              const ripp_g2j* opening_a, const ripp_g1j* opening_b, const ripp_fr* r_shift, int32_t* accept);
+/* TIPAWithSSM::verify_with_structured_scalar_message (structured_scalar_message.rs:270-331); com = (com_a in GT, com_t in G1) */
+int32_t ripp_tipa_ssm_verify(const ripp_verifier_srs* v_srs, const ripp_gt* com_a, const ripp_g1j* com_t, const ripp_fr* scalar_b,
+                             const ripp_gt* com_gt, const ripp_g1j* com_g1, size_t rounds, const ripp_g1j* base_a,
+                             const ripp_g2j* final_ck_a, const ripp_g2j* opening_a, int32_t* accept);
+/* verify_aggregate_proof (groth16_aggregation.rs:162-231); public_inputs[n][m] row-major, vk->gamma_abc_len == m + 1 */
+int32_t ripp_verify_aggregate_proof(const ripp_verifier_srs* v_srs, const ripp_groth16_vk* vk, const ripp_fr* public_inputs, size_t n, size_t m,
+                                    const ripp_aggregate_proof* proof, int32_t* accept);
+
 /* ---- host-side helpers (no device needed): what the host code around the kernels computes ---------------- */
 int32_t ripp_final_exp(const ripp_gt* miller_value, ripp_gt* out);                 /* Pairing::final_exponentiation */
 int32_t ripp_miller_combine(const ripp_gt* step_products /* [68] */, ripp_gt* out); /* stage (3) of pairing.hpp */

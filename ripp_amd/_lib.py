@@ -38,6 +38,17 @@ class AggregateProofStruct(ctypes.Structure):
         ("c_base_a", _u64(18)), ("c_base_b", _u64(4)), ("c_final_ck_a", _u64(36)), ("c_opening_a", _u64(36)), ("c_kzg_c", _u64(4))]
 
 
+class VerifierSRSStruct(ctypes.Structure):
+    """`ripp_verifier_srs` (VerifierSRS, tipa/mod.rs:104-110)."""
+    _fields_ = [("g", _u64(18)), ("h", _u64(36)), ("g_beta", _u64(18)), ("h_alpha", _u64(36))]
+
+
+class Groth16VKStruct(ctypes.Structure):
+    """`ripp_groth16_vk` (the members of ark_groth16::VerifyingKey that verify_aggregate_proof reads)."""
+    _fields_ = [("alpha_g1", _u64(12)), ("beta_g2", _u64(24)), ("gamma_g2", _u64(24)), ("delta_g2", _u64(24)),
+                ("gamma_abc_g1", ctypes.c_void_p), ("gamma_abc_len", ctypes.c_size_t)]
+
+
 class AggregateProof:
     """Owner of an AggregateProofStruct and of its step arrays (numpy); `field(name)` views a fixed-size member."""
 

@@ -11,11 +11,11 @@ Values are numpy uint64 arrays in the flat C-ABI layouts (little-endian Montgome
 """
 import ctypes
 import numpy as np
-from ._lib import lib, last_error, RippStats, AggregateProof, RIPP_OK, RIPP_ERR_LENGTH, RIPP_ERR_POW2, RIPP_ERR_DEVICE
+from ._lib import lib, last_error, RippStats, AggregateProof, VerifierSRSStruct, Groth16VKStruct, RIPP_OK, RIPP_ERR_LENGTH, RIPP_ERR_POW2, RIPP_ERR_DEVICE
 
 __all__ = ["InnerProductError", "DeviceError", "PairingInnerProduct", "MultiexponentiationInnerProductG1",
            "MultiexponentiationInnerProductG2", "AFGHOCommitmentG1", "AFGHOCommitmentG2", "PedersenCommitmentG1",
-           "PedersenCommitmentG2", "SIPP", "SippJob", "GIPA_TIPP", "SRS", "TIPA_TIPP", "TIPAWithSSM", "aggregate_proofs", "AggregateProof", "product_of_pairings", "product_of_pairings_with_coeffs",
+           "PedersenCommitmentG2", "SIPP", "SippJob", "GIPA_TIPP", "SRS", "TIPA_TIPP", "TIPAWithSSM", "aggregate_proofs", "verify_aggregate_proof", "AggregateProof", "product_of_pairings", "product_of_pairings_with_coeffs",
            "normalize_batch_g1", "normalize_batch_g2", "fold_g1_affine", "fold_g2_affine", "fold_g1", "fold_g2",
            "scale_g1_affine", "synth_g1", "synth_g2", "synth_fr", "init", "device_count", "final_exponentiation",
            "ser_gt", "ser_g1", "ser_g2", "ser_fr", "sipp_seed_digest", "gt_mul"]
@@ -335,7 +335,31 @@ class GIPA_TIPP:
         return proof, aux, {"round_order_steps": steps.reshape(rounds * 6, 72), "round_order_transcript": tr, "stats": st.as_dict()}
 
 
+    @staticmethod
+    def verify(ck_a, ck_b, com, round_order_steps, r_base):
+        """GIPA::verify (gipa.rs:135-160): com = (com_a, com_b, com_t[0]); steps in ROUND order as returned by prove_with_aux."""
+        ck_a, ck_b = _c(ck_a, 36), _c(ck_b, 18); n = len(ck_a)
+        com = np.ascontiguousarray(np.stack([np.asarray(x, dtype=np.uint64).reshape(72) for x in com]))
+        steps = np.ascontiguousarray(round_order_steps, dtype=np.uint64).reshape(-1, 72)
+        ba = np.ascontiguousarray(r_base[0], dtype=np.uint64).reshape(18); bb = np.ascontiguousarray(r_base[1], dtype=np.uint64).reshape(36)
+        acc = ctypes.c_int32(0)
+        _check(lib().ripp_gipa_tipp_verify(_p(ck_a), _p(ck_b), ctypes.c_size_t(n), _p(com), _p(steps), ctypes.c_size_t(len(steps) // 6), _p(ba), _p(bb), ctypes.byref(acc)))
+        return bool(acc.value)
+
+
 # ------------------------------------------------------------------ TIPA, TIPAWithSSM, Groth16 aggregation
+def _vsrs(v):
+    s = VerifierSRSStruct()
+    for k in ("g", "h", "g_beta", "h_alpha"):
+        arr = np.ascontiguousarray(v[k], dtype=np.uint64).reshape(-1)
+        ctypes.memmove(getattr(s, k), arr.ctypes.data, arr.nbytes)
+    return s
+
+
+def _a(x, n):
+    return np.ascontiguousarray(x, dtype=np.uint64).reshape(n)
+
+
 FR_ONE = np.array([0x00000001fffffffe, 0x5884b7fa00034802, 0x998c4fefecbc4ff5, 0x1824b159acc5056f], dtype=np.uint64)   # Fr::one(), Montgomery form
 
 
@@ -407,6 +431,22 @@ class TIPA_TIPP:
         """tipa/mod.rs:168-174: r_shift = 1."""
         return TIPA_TIPP.prove_with_srs_shift(srs, values, ck, FR_ONE)
 
+    @staticmethod
+    def verify_with_srs_shift(v_srs, com, proof, r_shift):
+        """tipa/mod.rs:242-301.  v_srs: dict from SRS.get_verifier_key(); com = (com_a, com_b, com_t[0]); proof: dict of prove_with_srs_shift."""
+        vs = _vsrs(v_srs)
+        com = np.ascontiguousarray(np.stack([np.asarray(x, dtype=np.uint64).reshape(72) for x in com]))
+        steps = np.ascontiguousarray(proof["steps"], dtype=np.uint64).reshape(-1, 72)
+        acc = ctypes.c_int32(0)
+        _check(lib().ripp_tipa_tipp_verify(ctypes.byref(vs), _p(com), _p(steps), ctypes.c_size_t(len(steps) // 6), _p(_a(proof["base_a"], 18)), _p(_a(proof["base_b"], 36)),
+                                           _p(_a(proof["final_ck_a"], 36)), _p(_a(proof["final_ck_b"], 18)), _p(_a(proof["opening_a"], 36)), _p(_a(proof["opening_b"], 18)),
+                                           _p(_a(r_shift, 4)), ctypes.byref(acc)))
+        return bool(acc.value)
+
+    @staticmethod
+    def verify(v_srs, com, proof):
+        return TIPA_TIPP.verify_with_srs_shift(v_srs, com, proof, FR_ONE)
+
 
 class TIPAWithSSM:
     """TIPAWithSSM<MultiexponentiationInnerProduct<G1>, AFGHOCommitmentG1, IdentityCommitment<G1,Fr>, Bls12_381, Blake2b>
@@ -425,6 +465,33 @@ class TIPAWithSSM:
         _check(lib().ripp_tipa_ssm_prove(srs._h, _p(m_a), _p(m_b), _p(ck_a), ctypes.c_size_t(n), _p(o["com_gt"]), _p(o["com_g1"]), _p(o["tr"]),
                                          _p(o["base_a"]), _p(o["base_b"]), _p(o["final_ck_a"]), _p(o["opening_a"]), _p(o["kzg_c"]), ctypes.byref(st)))
         o["stats"] = st.as_dict(); return o
+
+
+    @staticmethod
+    def verify_with_structured_scalar_message(v_srs, com, scalar_b, proof):
+        """structured_scalar_message.rs:270-331.  com = (com_a GT, com_t G1 projective)."""
+        vs = _vsrs(v_srs)
+        com_gt = np.ascontiguousarray(proof["com_gt"], dtype=np.uint64).reshape(-1, 72); com_g1 = np.ascontiguousarray(proof["com_g1"], dtype=np.uint64).reshape(-1, 18)
+        acc = ctypes.c_int32(0)
+        _check(lib().ripp_tipa_ssm_verify(ctypes.byref(vs), _p(_a(com[0], 72)), _p(_a(com[1], 18)), _p(_a(scalar_b, 4)), _p(com_gt), _p(com_g1),
+                                          ctypes.c_size_t(len(com_gt) // 2), _p(_a(proof["base_a"], 18)), _p(_a(proof["final_ck_a"], 36)), _p(_a(proof["opening_a"], 36)),
+                                          ctypes.byref(acc)))
+        return bool(acc.value)
+
+
+def verify_aggregate_proof(ip_verifier_srs, vk, public_inputs, proof):
+    """verify_aggregate_proof (groth16_aggregation.rs:162-231).  vk = (alpha_g1 (12,), beta_g2, gamma_g2, delta_g2 (24,), gamma_abc_g1 (m+1,12));
+    public_inputs (n, m, 4)."""
+    vs = _vsrs(ip_verifier_srs)
+    alpha, beta, gamma, delta, abc = vk
+    abc = _c(abc, 12); k = Groth16VKStruct()
+    for name, arr in (("alpha_g1", _a(alpha, 12)), ("beta_g2", _a(beta, 24)), ("gamma_g2", _a(gamma, 24)), ("delta_g2", _a(delta, 24))):
+        ctypes.memmove(getattr(k, name), arr.ctypes.data, arr.nbytes)
+    k.gamma_abc_g1 = abc.ctypes.data; k.gamma_abc_len = len(abc)
+    pub = np.ascontiguousarray(public_inputs, dtype=np.uint64); n, m = pub.shape[0], pub.shape[1]
+    acc = ctypes.c_int32(0)
+    _check(lib().ripp_verify_aggregate_proof(ctypes.byref(vs), ctypes.byref(k), _p(pub), ctypes.c_size_t(n), ctypes.c_size_t(m), proof.ref(), ctypes.byref(acc)))
+    return bool(acc.value)
 
 
 def aggregate_proofs(ip_srs, a, b, c):

@@ -1089,6 +1089,178 @@ API int32_t ripp_aggregate_proofs(const ripp_srs* srs, const ripp_g1a* a, const 
     return RIPP_OK;
 }
 
+// ---- verifiers (gipa.rs:135-160, 322-415; tipa/mod.rs:242-301, 340-404; ssm.rs:270-331; groth16_aggregation.rs:162-231) -------
+// Host: challenge replay and the O(log n) exponentiations of single GT / group elements (what the reference's verifier does
+// serially).  Device: every pairing and the n-term MSMs.
+extern "C++" {
+static Fp12 gt_pow_host(const Fp12& x, const Fr& k) {
+    const Fr c = from_mont(k); Fp12 acc = Fp12::one(); bool st = false;
+    for (int i = 255; i >= 0; --i) { if (st) acc = sqr(acc); if ((c.l[i >> 5] >> (i & 31)) & 1u) { acc = st ? mul(acc, x) : x; st = true; } }
+    return acc;
+}
+template <class F> static Jac<F> smul_host(const Affine<F>& p, const Fr& k) { const Fr c = from_mont(k); return scalar_mul_bits(p, c.l, 255); }
+template <class F> static Jac<F> load_jac(const void* p) { Jac<F> r; std::memcpy(&r, p, sizeof r); return r; }
+static Fp12 load_gt(const ripp_gt* p) { Fp12 r; std::memcpy(&r, p, sizeof r); return r; }
+static Fr load_fr(const ripp_fr* p) { Fr r; std::memcpy(&r, p, sizeof r); return r; }
+
+// prod_i e(a_i, b_i) for a handful of host points
+static int32_t pairing_host_pts(Engine* e, const std::vector<G1A>& a, const std::vector<G2A>& b, Fp12* out) {
+    G1A* da; G2A* db; int32_t rc; ripp_gt z;
+    if ((rc = upload<G1A>(e, e->tmpA, a.data(), a.size(), &da)) || (rc = upload<G2A>(e, e->tmpB, b.data(), b.size(), &db))) return rc;
+    if ((rc = pairing_product_dev(e, da, db, a.size(), &z))) return rc;
+    std::memcpy(out, &z, sizeof z); return RIPP_OK;
+}
+// e(a1, b1) == e(a2, b2)  as  e(a1, b1) * e(-a2, b2) == 1: one two-pair product, one final exponentiation
+static int32_t pairing_eq(Engine* e, const G1J& a1, const G2J& b1, const G1J& a2, const G2J& b2, bool* ok) {
+    Fp12 z; int32_t rc = pairing_host_pts(e, {to_affine(a1), neg(to_affine(a2))}, {to_affine(b1), to_affine(b2)}, &z); if (rc) return rc;
+    *ok = (z == Fp12::one()); return RIPP_OK;
+}
+// polynomial_evaluation_product_form_from_transcript (tipa/mod.rs:393-404)
+static Fr ck_poly_eval(const std::vector<Fr>& tr, const Fr& z, const Fr& r_shift) {
+    Fr p = mul(mul(z, z), r_shift), acc = Fr::one();
+    for (const Fr& x : tr) { acc = mul(acc, add(Fr::one(), mul(x, p))); p = mul(p, p); }
+    return acc;
+}
+struct VSrs { G1J g, g_beta; G2J h, h_alpha; };
+static VSrs load_vsrs(const ripp_verifier_srs* v) { return {load_jac<Fp>(&v->g), load_jac<Fp>(&v->g_beta), load_jac<Fp2>(&v->h), load_jac<Fp2>(&v->h_alpha)}; }
+// verify_commitment_key_g2_kzg_opening (tipa/mod.rs:340-354): e(g, ck_final - h*eval) == e(g_beta - g*c, opening)
+static int32_t kzg_verify_g2(Engine* e, const VSrs& v, const G2J& ck_final, const G2J& opening, const std::vector<Fr>& tr, const Fr& r_shift, const Fr& c, bool* ok) {
+    const Fr ev = ck_poly_eval(tr, c, r_shift);
+    const G2J l2 = add(ck_final, neg(smul_host(to_affine(v.h), ev)));
+    const G1J r1 = add(v.g_beta, neg(smul_host(to_affine(v.g), c)));
+    return pairing_eq(e, v.g, l2, r1, opening, ok);
+}
+// verify_commitment_key_g1_kzg_opening (tipa/mod.rs:356-370): e(ck_final - g*eval, h) == e(opening, h_alpha - h*c)
+static int32_t kzg_verify_g1(Engine* e, const VSrs& v, const G1J& ck_final, const G1J& opening, const std::vector<Fr>& tr, const Fr& r_shift, const Fr& c, bool* ok) {
+    const Fr ev = ck_poly_eval(tr, c, r_shift);
+    const G1J l1 = add(ck_final, neg(smul_host(to_affine(v.g), ev)));
+    const G2J r2 = add(v.h_alpha, neg(smul_host(to_affine(v.h), c)));
+    return pairing_eq(e, l1, v.h, opening, r2, ok);
+}
+// _compute_recursive_challenges (gipa.rs:322-363), TIPP instantiation; tr in ROUND order
+static void tipp_replay(const ripp_gt com[3], const ripp_gt* com_steps, size_t rounds, std::vector<Fr>& tr, Fp12 out[3]) {
+    Fp12 acc[3] = {load_gt(&com[0]), load_gt(&com[1]), load_gt(&com[2])};
+    tr.resize(rounds);
+    for (size_t k = 0; k < rounds; ++k) {
+        Fp12 s[6]; std::memcpy(s, &com_steps[6 * k], sizeof s);
+        Fr c_inv; const Fr c = fs::gipa_tipp_challenge(k ? &tr[k - 1] : nullptr, s, c_inv);
+        std::future<Fp12> f[5];
+        for (int j = 1; j < 6; ++j) f[j - 1] = std::async(std::launch::async, [&s, j, c, c_inv]() { return gt_pow_host(s[j], j < 3 ? c : c_inv); });
+        Fp12 p[6]; p[0] = gt_pow_host(s[0], c); for (int j = 1; j < 6; ++j) p[j] = f[j - 1].get();
+        for (int j = 0; j < 3; ++j) acc[j] = mul(acc[j], mul(p[j], p[j + 3]));       // com + com_1 * c + com_2 * c_inv  (gipa.rs:358-360)
+        tr[k] = c;
+    }
+    out[0] = acc[0]; out[1] = acc[1]; out[2] = acc[2];
+}
+}  // extern "C++"
+
+API int32_t ripp_gipa_tipp_verify(const ripp_g2j* ck_a, const ripp_g1j* ck_b, size_t n, const ripp_gt com[3], const ripp_gt* com_steps, size_t rounds,
+                                  const ripp_g1j* base_a, const ripp_g2j* base_b, int32_t* accept) {
+    if (n == 0 || (n & (n - 1))) return RIPP_ERR_POW2;
+    if (!ck_a || !ck_b || !com || !base_a || !base_b || !accept || (rounds && !com_steps) || ((size_t)1 << rounds) != n) return RIPP_ERR_ARG;
+    std::vector<Fr> tr; Fp12 bc[3]; tipp_replay(com, com_steps, rounds, tr, bc);
+    // _compute_final_commitment_keys (gipa.rs:365-399) on the reversed transcript: exponent vectors by doubling, then one MSM per key
+    std::vector<Fr> ea(n), eb(n); ea[0] = Fr::one(); eb[0] = Fr::one(); size_t cnt = 1;
+    for (size_t i = 0; i < rounds; ++i) {
+        const Fr c = tr[rounds - 1 - i], ci = inv(c);
+        for (size_t j = 0; j < ((size_t)1 << i); ++j) { ea[cnt + j] = mul(ea[j], ci); eb[cnt + j] = mul(eb[j], c); }
+        cnt += (size_t)1 << i;
+    }
+    ripp_g2j ka; ripp_g1j kb; int32_t rc;
+    if ((rc = ripp_msm_g2_j(ck_a, n, reinterpret_cast<const ripp_fr*>(ea.data()), n, &ka))) return rc;
+    if ((rc = ripp_msm_g1_j(ck_b, n, reinterpret_cast<const ripp_fr*>(eb.data()), n, &kb))) return rc;
+    LOCK; ENGINE;
+    const G1A a = to_affine(load_jac<Fp>(base_a)), kba = to_affine(load_jac<Fp>(&kb)); const G2A b = to_affine(load_jac<Fp2>(base_b)), kaa = to_affine(load_jac<Fp2>(&ka));
+    Fp12 e1, e2, e3;                                                          // _verify_base_commitment (gipa.rs:401-415)
+    if ((rc = pairing_host_pts(e, {a}, {kaa}, &e1)) || (rc = pairing_host_pts(e, {kba}, {b}, &e2)) || (rc = pairing_host_pts(e, {a}, {b}, &e3))) return rc;
+    *accept = (e1 == bc[0] && e2 == bc[1] && e3 == bc[2]) ? 1 : 0;
+    return RIPP_OK;
+}
+
+API int32_t ripp_tipa_tipp_verify(const ripp_verifier_srs* v_srs, const ripp_gt com[3], const ripp_gt* com_steps, size_t rounds,
+                                  const ripp_g1j* base_a, const ripp_g2j* base_b, const ripp_g2j* final_ck_a, const ripp_g1j* final_ck_b,
+                                  const ripp_g2j* opening_a, const ripp_g1j* opening_b, const ripp_fr* r_shift, int32_t* accept) {
+    if (!v_srs || !com || !com_steps || !base_a || !base_b || !final_ck_a || !final_ck_b || !opening_a || !opening_b || !r_shift || !accept || rounds == 0) return RIPP_ERR_ARG;
+    LOCK; ENGINE;
+    const VSrs v = load_vsrs(v_srs);
+    std::vector<Fr> trf; Fp12 bc[3]; tipp_replay(com, com_steps, rounds, trf, bc);                                       // :249-251
+    std::vector<Fr> tr(rounds), tri(rounds); for (size_t i = 0; i < rounds; ++i) { tr[i] = trf[rounds - 1 - i]; tri[i] = inv(tr[i]); }
+    const G2J ka = load_jac<Fp2>(final_ck_a), oa = load_jac<Fp2>(opening_a); const G1J kb = load_jac<Fp>(final_ck_b), ob = load_jac<Fp>(opening_b);
+    const G2A kaa = to_affine(ka); const G1A kba = to_affine(kb);
+    const Fr c = fs::kzg_challenge(tr[0], kaa, &kba);                                                                    // :257-272
+    bool ok_a = false, ok_b = false; int32_t rc;
+    if ((rc = kzg_verify_g2(e, v, ka, oa, tri, inv(load_fr(r_shift)), c, &ok_a))) return rc;                             // :274-281
+    if ((rc = kzg_verify_g1(e, v, kb, ob, tr, Fr::one(), c, &ok_b))) return rc;                                          // :282-289
+    const G1A a = to_affine(load_jac<Fp>(base_a)); const G2A b = to_affine(load_jac<Fp2>(base_b));
+    Fp12 e1, e2, e3;                                                                                                     // :292-298
+    if ((rc = pairing_host_pts(e, {a}, {kaa}, &e1)) || (rc = pairing_host_pts(e, {kba}, {b}, &e2)) || (rc = pairing_host_pts(e, {a}, {b}, &e3))) return rc;
+    *accept = (ok_a && ok_b && e1 == bc[0] && e2 == bc[1] && e3 == bc[2]) ? 1 : 0;
+    return RIPP_OK;
+}
+
+API int32_t ripp_tipa_ssm_verify(const ripp_verifier_srs* v_srs, const ripp_gt* com_a, const ripp_g1j* com_t, const ripp_fr* scalar_b,
+                                 const ripp_gt* com_gt, const ripp_g1j* com_g1, size_t rounds, const ripp_g1j* base_a,
+                                 const ripp_g2j* final_ck_a, const ripp_g2j* opening_a, int32_t* accept) {
+    if (!v_srs || !com_a || !com_t || !scalar_b || !com_gt || !com_g1 || !base_a || !final_ck_a || !opening_a || !accept || rounds == 0) return RIPP_ERR_ARG;
+    LOCK; ENGINE;
+    const VSrs v = load_vsrs(v_srs);
+    Fp12 ca = load_gt(com_a); G1J ct = load_jac<Fp>(com_t);
+    std::vector<Fr> trf(rounds);
+    for (size_t k = 0; k < rounds; ++k) {                                                                                // gipa.rs:329-360
+        const Fp12 gt[2] = {load_gt(&com_gt[2 * k]), load_gt(&com_gt[2 * k + 1])};
+        const G1A g1[2] = {to_affine(load_jac<Fp>(&com_g1[2 * k])), to_affine(load_jac<Fp>(&com_g1[2 * k + 1]))};
+        Fr c_inv; const Fr c = fs::gipa_ssm_challenge(k ? &trf[k - 1] : nullptr, gt, g1, c_inv);
+        auto f = std::async(std::launch::async, [&gt, c_inv]() { return gt_pow_host(gt[1], c_inv); });
+        ca = mul(ca, mul(gt_pow_host(gt[0], c), f.get()));
+        ct = add(add(ct, smul_host(g1[0], c)), smul_host(g1[1], c_inv));
+        trf[k] = c;
+    }
+    std::vector<Fr> tri(rounds); for (size_t i = 0; i < rounds; ++i) tri[i] = inv(trf[rounds - 1 - i]);
+    const G2J ka = load_jac<Fp2>(final_ck_a), oa = load_jac<Fp2>(opening_a); const G2A kaa = to_affine(ka);
+    const Fr c = fs::kzg_challenge(trf[rounds - 1], kaa, nullptr);                                                       // ssm.rs:289-303
+    bool ok_a = false; int32_t rc;
+    if ((rc = kzg_verify_g2(e, v, ka, oa, tri, Fr::one(), c, &ok_a))) return rc;                                         // ssm.rs:305-312
+    Fr p2b = load_fr(scalar_b), b_base = Fr::one();                                                                      // ssm.rs:315-321
+    for (size_t i = 0; i < rounds; ++i) { b_base = mul(b_base, add(Fr::one(), mul(tri[i], p2b))); p2b = mul(p2b, p2b); }
+    const G1A a = to_affine(load_jac<Fp>(base_a));
+    Fp12 e1; if ((rc = pairing_host_pts(e, {a}, {kaa}, &e1))) return rc;                                                 // ssm.rs:324-328
+    *accept = (ok_a && e1 == ca && eq(smul_host(a, b_base), ct)) ? 1 : 0;
+    return RIPP_OK;
+}
+
+API int32_t ripp_verify_aggregate_proof(const ripp_verifier_srs* v_srs, const ripp_groth16_vk* vk, const ripp_fr* public_inputs, size_t n, size_t m,
+                                        const ripp_aggregate_proof* pf, int32_t* accept) {
+    if (n < 2 || (n & (n - 1))) return RIPP_ERR_POW2;
+    if (!v_srs || !vk || !vk->gamma_abc_g1 || (m && !public_inputs) || !pf || !accept) return RIPP_ERR_ARG;
+    if (vk->gamma_abc_len != m + 1) { set_err("assert_eq!(vk.gamma_abc_g1.len(), public_inputs[0].len() + 1) (groth16_aggregation.rs:214)"); return RIPP_ERR_ARG; }
+    size_t rounds = 0; while (((size_t)1 << rounds) < n) ++rounds;
+    const Fr r = fs::aggregation_challenge(load_gt(&pf->com_a), load_gt(&pf->com_b), load_gt(&pf->com_c));             // :172-184
+    int32_t ok_ab = 0, ok_c = 0, rc;
+    const ripp_gt com_ab[3] = {pf->com_a, pf->com_b, pf->ip_ab};
+    if ((rc = ripp_tipa_tipp_verify(v_srs, com_ab, pf->ab_com_steps, rounds, &pf->ab_base_a, &pf->ab_base_b, &pf->ab_final_ck_a, &pf->ab_final_ck_b,   // :187-198
+                                    &pf->ab_opening_a, &pf->ab_opening_b, reinterpret_cast<const ripp_fr*>(&r), &ok_ab))) return rc;
+    if ((rc = ripp_tipa_ssm_verify(v_srs, &pf->com_c, &pf->agg_c, reinterpret_cast<const ripp_fr*>(&r), pf->c_com_gt, pf->c_com_g1, rounds, &pf->c_base_a,   // :199-205
+                                   &pf->c_final_ck_a, &pf->c_opening_a, &ok_c))) return rc;
+    LOCK; ENGINE;
+    // r_sum = (r^n - 1) / (r - 1)   (:209-210)
+    Fr rn = Fr::one(); std::vector<Fr> rv(n); for (size_t i = 0; i < n; ++i) { rv[i] = rn; rn = mul(rn, r); }
+    const Fr r_sum = mul(sub(rn, Fr::one()), inv(sub(r, Fr::one())));
+    G1A alpha; G2A beta, gamma, delta; std::memcpy(&alpha, &vk->alpha_g1, sizeof alpha); std::memcpy(&beta, &vk->beta_g2, sizeof beta);
+    std::memcpy(&gamma, &vk->gamma_g2, sizeof gamma); std::memcpy(&delta, &vk->delta_g2, sizeof delta);
+    const G1A* abc = reinterpret_cast<const G1A*>(vk->gamma_abc_g1);
+    G1J g_ic = smul_host(abc[0], r_sum);                                                                                 // :215-226
+    const Fr* pub = reinterpret_cast<const Fr*>(public_inputs);
+    for (size_t i = 0; i < m; ++i) {
+        Fr ip = Fr::zero(); for (size_t k = 0; k < n; ++k) ip = add(ip, mul(pub[k * m + i], rv[k]));                     // ScalarInnerProduct(inputs[:, i], r_vec)
+        g_ic = add(g_ic, smul_host(abc[i + 1], ip));
+    }
+    // ip_ab == e(alpha * r_sum, beta) + e(g_ic, gamma) + e(agg_c, delta)   (:211, 227-229): one three-pair product
+    Fp12 rhs;
+    if ((rc = pairing_host_pts(e, {to_affine(smul_host(alpha, r_sum)), to_affine(g_ic), to_affine(load_jac<Fp>(&pf->agg_c))}, {beta, gamma, delta}, &rhs))) return rc;
+    *accept = (ok_ab && ok_c && load_gt(&pf->ip_ab) == rhs) ? 1 : 0;
+    return RIPP_OK;
+}
+
 // ---- SIPP ----------------------------------------------------------------------------------------------------------
 API int32_t ripp_sipp_job_create(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr* r, size_t n_local, int32_t rank, int32_t world, ripp_sipp_job** job) {
     LOCK; ENGINE; if (!a || !b || !r || !job || n_local == 0 || world < 1 || rank < 0 || rank >= world) return RIPP_ERR_ARG;

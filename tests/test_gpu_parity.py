@@ -236,3 +236,7 @@ def test_gipa_tipp_prove_vs_oracle(engine, orc, n):
         assert orc.gipa_tipp_verify(ck_a, ck_b, com, raw["round_order_steps"], proof["r_base"][0], proof["r_base"][1]) == 1
         bad = raw["round_order_steps"].copy(); bad[0] = bad[1]
         assert orc.gipa_tipp_verify(ck_a, ck_b, com, bad, proof["r_base"][0], proof["r_base"][1]) == 0
+        # the product's GIPA::verify (gipa.rs:135-160), final keys by MSM on the device
+        assert engine.GIPA_TIPP.verify(ck_a, ck_b, com, raw["round_order_steps"], proof["r_base"])
+        assert not engine.GIPA_TIPP.verify(ck_a, ck_b, com, bad, proof["r_base"])
+        assert not engine.GIPA_TIPP.verify(ck_a, ck_b, com, raw["round_order_steps"], (proof["r_base"][0], aux["ck_base"][0]))

@@ -47,6 +47,16 @@ def test_tipa_tipp_prove_vs_oracle(engine, orc, n, shift):
         assert same_g2(engine, orc, got[k], exp[k]), k
     com = [engine.AFGHOCommitmentG1.commit(ck_a, m_a), engine.AFGHOCommitmentG2.commit(ck_b, m_b), engine.PairingInnerProduct.inner_product(m_a, m_b)]
     assert orc.tipa_tipp_verify(*h.verifier_srs(osrs), com, got, r_shift) == 1
+    # the product's own verifier (tipa/mod.rs:242-301): accepts, and rejects what the oracle's verifier rejects
+    vk = srs.get_verifier_key()
+    assert engine.TIPA_TIPP.verify_with_srs_shift(vk, com, got, r_shift)
+    for field, repl in (("opening_a", "final_ck_a"), ("final_ck_b", "base_a"), ("base_b", "opening_a")):
+        bad = dict(got); bad[field] = got[repl]
+        assert not engine.TIPA_TIPP.verify_with_srs_shift(vk, com, bad, r_shift) and orc.tipa_tipp_verify(*h.verifier_srs(osrs), com, bad, r_shift) == 0
+    assert not engine.TIPA_TIPP.verify_with_srs_shift(vk, [com[0], com[1], com[0]], got, r_shift)
+    assert not engine.TIPA_TIPP.verify_with_srs_shift(vk, com, got, orc.fr_array([shift + 1])[0])
+    bad = dict(got); bad["steps"] = got["steps"].copy(); bad["steps"][0] = got["steps"][3]
+    assert not engine.TIPA_TIPP.verify_with_srs_shift(vk, com, bad, r_shift)
     srs.close()
 
 
@@ -75,6 +85,12 @@ def test_tipa_ssm_prove_vs_oracle(engine, orc, n):
     g, hh, g_beta, _ = h.verifier_srs(osrs)
     com_a = engine.AFGHOCommitmentG1.commit(ck_a, m_a); com_t = engine.MultiexponentiationInnerProductG1.inner_product(m_a, m_b)
     assert orc.tipa_ssm_verify(g, hh, g_beta, com_a, com_t, orc.fr_array([b])[0], got) == 1
+    vk = {"g": g, "h": hh, "g_beta": g_beta, "h_alpha": osrs[3]}
+    assert engine.TIPAWithSSM.verify_with_structured_scalar_message(vk, (com_a, com_t), orc.fr_array([b])[0], got)
+    assert not engine.TIPAWithSSM.verify_with_structured_scalar_message(vk, (com_a, com_t), orc.fr_array([b + 1])[0], got)
+    assert not engine.TIPAWithSSM.verify_with_structured_scalar_message(vk, (com_a, got["base_a"]), orc.fr_array([b])[0], got)
+    bad = dict(got); bad["opening_a"] = got["final_ck_a"]
+    assert not engine.TIPAWithSSM.verify_with_structured_scalar_message(vk, (com_a, com_t), orc.fr_array([b])[0], bad)
     srs.close()
 
 
@@ -100,6 +116,13 @@ def test_aggregate_proofs_vs_oracle(engine, orc, n):
     assert orc.verify_aggregate_proof(h.verifier_srs(osrs), vk, pub, got) == 1
     pub2 = pub.copy(); pub2[0, 0] = pub[1, 0]
     assert orc.verify_aggregate_proof(h.verifier_srs(osrs), vk, pub2, got) == 0
+    # the product's verify_aggregate_proof (groth16_aggregation.rs:162-231)
+    vs = srs.get_verifier_key()
+    assert engine.verify_aggregate_proof(vs, vk, pub, got)
+    assert not engine.verify_aggregate_proof(vs, vk, pub2, got)
+    c2 = c.copy(); c2[0] = c[1]                       # one invalid Groth16 proof among the n
+    bad, _ = engine.aggregate_proofs(srs, a, b, c2)
+    assert not engine.verify_aggregate_proof(vs, vk, pub, bad) and orc.verify_aggregate_proof(h.verifier_srs(osrs), vk, pub, bad) == 0
     srs.close()
 
 
@@ -121,5 +144,8 @@ def test_aggregate_proofs_config5_size(engine, orc):
     ssm = dict(com_gt=got.c_com_gt, com_g1=got.c_com_g1, base_a=np.ascontiguousarray(got.field("c_base_a")), final_ck_a=np.ascontiguousarray(got.field("c_final_ck_a")),
                opening_a=np.ascontiguousarray(got.field("c_opening_a")))
     assert orc.tipa_ssm_verify(g, hh, g_beta, np.ascontiguousarray(got.field("com_c")), np.ascontiguousarray(got.field("agg_c")), np.ascontiguousarray(r), ssm) == 1
+    tipp["tr"] = got.ab_transcript
+    assert engine.TIPA_TIPP.verify_with_srs_shift(vs, [got.field("com_a"), got.field("com_b"), got.field("ip_ab")], tipp, r)
+    assert engine.TIPAWithSSM.verify_with_structured_scalar_message(vs, (got.field("com_c"), got.field("agg_c")), r, ssm)
     print("aggregate_proofs n=2^14:", {k: round(v, 1) for k, v in stats.items() if k.endswith("_ms") and v})
     srs.close()
