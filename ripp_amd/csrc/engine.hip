@@ -981,6 +981,7 @@ static int32_t tipa_ssm_core(Engine* e, const ripp_srs* srs, SsmVecs& v, size_t 
     std::vector<Fr> tri(rounds);
     for (size_t i = 0; i < rounds; ++i) { Fr t; std::memcpy(&t, &transcript[rounds - 1 - i], sizeof t); tri[i] = inv(t); }         // ssm.rs:227-229
     Fr first; std::memcpy(&first, &transcript[rounds - 1], sizeof first);
+    if (trace_on()) fprintf(stderr, "[ripp] ssm: GIPA rounds done (products+msm %.1f ms, host %.1f ms, folds %.1f ms cumulative)\n", e->stats.miller_products_ms, e->stats.host_ms, e->stats.fold_ms);
     const Fr c = fs::kzg_challenge(first, hka, nullptr);                                                                           // ssm.rs:231-246
     ripp_srs* s = const_cast<ripp_srs*>(srs);
     if ((rc = kzg_opening_dev<Fp2>(e, s->hbp.as<G2A>(), s->num, tri, Fr::one(), c, opening_a))) return rc;                           // ssm.rs:249-254
@@ -1043,6 +1044,7 @@ API int32_t ripp_aggregate_proofs(const ripp_srs* srs, const ripp_g1a* a, const 
     Fp12 com_a, com_b, com_c; std::memcpy(&com_a, &out->com_a, sizeof com_a); std::memcpy(&com_b, &out->com_b, sizeof com_b); std::memcpy(&com_c, &out->com_c, sizeof com_c);
     const Fr r = fs::aggregation_challenge(com_a, com_b, com_c);                                                        // :105-116
     std::memcpy(&out->r, &r, sizeof r);
+    if (trace_on()) fprintf(stderr, "[ripp] aggregate: upload + 3 commitments done at t=%.1f ms\n", now_ms() - t_start);
     // r_vec = (1, r, r^2, ...) (:118) and its element-wise inverses (:130) = powers of r^-1
     std::vector<Fr> rv(n), riv(n); const Fr r_inv = inv(r);
     rv[0] = Fr::one(); riv[0] = Fr::one(); for (size_t i = 1; i < n; ++i) { rv[i] = mul(rv[i - 1], r); riv[i] = mul(riv[i - 1], r_inv); }
@@ -1064,17 +1066,21 @@ API int32_t ripp_aggregate_proofs(const ripp_srs* srs, const ripp_g1a* a, const 
         std::memcpy(&out->ip_ab, &ip_ab, sizeof ip_ab);
         if (!(chk == com_a)) { set_err("commitment key shift check failed (assert_eq! at groth16_aggregation.rs:133-136)"); return RIPP_ERR_ARG; }
     }
+    if (trace_on()) fprintf(stderr, "[ripp] aggregate: scaling + ip_ab + key check done at t=%.1f ms\n", now_ms() - t_start);
     G1J agg_c; if ((rc = e->msm_dev<Fp>(w.A.as<G1A>(), dRv.as<Fr>(), n, &agg_c))) return rc;                           // :125
     std::memcpy(&out->agg_c, &agg_c, sizeof agg_c);
+    if (trace_on()) fprintf(stderr, "[ripp] aggregate: agg_c MSM done at t=%.1f ms\n", now_ms() - t_start);
     size_t rounds = 0; while (((size_t)1 << rounds) < n) ++rounds;
     {   // tipa_proof_ab = TIPA::prove_with_srs_shift(srs, (a_r, b), (ck_1_r, ck_2), r)   (:138-143)
         G1A ha, hkb; G2A hb, hka;
         if ((rc = gipa_tipp_core(e, v, n, out->ab_com_steps, out->ab_transcript, ha, hb, hka, hkb))) return rc;
+        if (trace_on()) fprintf(stderr, "[ripp] aggregate: TIPP GIPA rounds done at t=%.1f ms\n", now_ms() - t_start);
         G2J oa; G1J ob; Fr kc;
         if ((rc = tipp_kzg(e, srs, out->ab_transcript, rounds, r, hka, hkb, &oa, &ob, &kc))) return rc;
         const G1J ja = to_jac(ha), jkb = to_jac(hkb); const G2J jb = to_jac(hb), jka = to_jac(hka);
         std::memcpy(&out->ab_base_a, &ja, sizeof ja); std::memcpy(&out->ab_base_b, &jb, sizeof jb); std::memcpy(&out->ab_final_ck_a, &jka, sizeof jka); std::memcpy(&out->ab_final_ck_b, &jkb, sizeof jkb);
         std::memcpy(&out->ab_opening_a, &oa, sizeof oa); std::memcpy(&out->ab_opening_b, &ob, sizeof ob); std::memcpy(&out->ab_kzg_c, &kc, sizeof kc);
+        if (trace_on()) fprintf(stderr, "[ripp] aggregate: TIPP KZG openings done at t=%.1f ms\n", now_ms() - t_start);
     }
     {   // tipa_proof_c = TIPAWithSSM::prove_with_structured_scalar_message(srs, (c, r_vec), ck_1)   (:145-149)
         G1A ha; Fr hs; G2A hka; G2J oa; Fr kc;
