@@ -54,6 +54,13 @@ struct DevBuf {
     template <class T> T* as() { return reinterpret_cast<T*>(p); }
 };
 
+// scratch of ONE in-flight MSM (two MSMs of a GIPA-with-SSM round run side by side on two streams)
+struct MsmScratch {
+    DevBuf digits, hist, offs, cursor, slotoffs, spw, sorted, slots, buckets, seg, seg2, win, out;
+    void* host_out = nullptr;            // pinned landing zone for the result
+    void release() { for (DevBuf* b : {&digits, &hist, &offs, &cursor, &slotoffs, &spw, &sorted, &slots, &buckets, &seg, &seg2, &win, &out}) b->release(); if (host_out) (void)hipHostFree(host_out); host_out = nullptr; }
+};
+
 struct Timer {   // HIP-event stopwatch on the engine stream
     hipEvent_t a{}, b{};
     int32_t init() { HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); return RIPP_OK; }
@@ -68,7 +75,9 @@ struct Engine {
     // scratch
     DevBuf lines, partA, partB, jacG1, jacG2, tmpA, tmpB, tmpR, affG1, affG2;
     DevBuf qtab;                          // [u^j]Q table of the GLS G2 fold
-    DevBuf m_digits, m_hist, m_offs, m_cursor, m_slotoffs, m_spw, m_sorted, m_slots, m_buckets, m_seg, m_win, m_out;   // MSM scratch
+    MsmScratch msm_scratch[2];
+    DevBuf kzg_q[2];                      // quotient-polynomial coefficients of the (up to two concurrent) KZG openings
+    hipStream_t stream3 = nullptr;        // second MSM of a pair
     Fp12* pinned_rows = nullptr;          // pinned host landing zone for per-step products
     size_t pinned_rows_cap = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_lines, ev_prod;   // per-launch event pairs of the two dominant kernels
@@ -87,6 +96,7 @@ struct Engine {
         HIPCHK(hipSetDevice(dev));
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&stream3, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
         { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n_simd = pr.multiProcessorCount * 4; }
         auto env_sz = [](const char* k, size_t& v) { if (const char* s = std::getenv(k)) v = (size_t)std::strtoull(s, nullptr, 10); };
@@ -95,7 +105,9 @@ struct Engine {
         return RIPP_OK;
     }
     void destroy() {
-        for (DevBuf* b : {&lines, &partA, &partB, &jacG1, &jacG2, &tmpA, &tmpB, &tmpR, &affG1, &affG2, &qtab, &vm_flag, &m_digits, &m_hist, &m_offs, &m_cursor, &m_slotoffs, &m_spw, &m_sorted, &m_slots, &m_buckets, &m_seg, &m_win, &m_out}) b->release();
+        for (DevBuf* b : {&lines, &partA, &partB, &jacG1, &jacG2, &tmpA, &tmpB, &tmpR, &affG1, &affG2, &qtab, &vm_flag}) b->release();
+        msm_scratch[0].release(); msm_scratch[1].release(); kzg_q[0].release(); kzg_q[1].release();
+        if (stream3) (void)hipStreamDestroy(stream3);
         if (pinned_rows) (void)hipHostFree(pinned_rows);
         for (auto& e : ev_lines) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         for (auto& e : ev_prod) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -139,31 +151,54 @@ struct Engine {
 
 
     // ---- Pippenger MSM over device-resident affine bases and Montgomery scalars; result (Jacobian) to host --------
-    template <class F> int32_t msm_dev(const Affine<F>* bases, const Fr* scalars, size_t n, Jac<F>* out_host) {
-        if (n == 0) { *out_host = jac_inf<F>(); return RIPP_OK; }
+    // msm_launch enqueues the whole pipeline on `st` with scratch `ms` and leaves the result in ms.host_out (valid after a
+    // sync of `st`); msm_dev is the synchronous single-MSM form.
+    template <class F> int32_t msm_launch(MsmScratch& ms, hipStream_t st, const Affine<F>* bases, const Fr* scalars, size_t n) {
+        if (!ms.host_out) HIPCHK(hipHostMalloc(&ms.host_out, sizeof(G2J), hipHostMallocDefault));
+        if (n == 0) { *reinterpret_cast<Jac<F>*>(ms.host_out) = jac_inf<F>(); return RIPP_OK; }
         const MsmPlan p = msm_plan(n);
         const size_t nwb = (size_t)p.nwin * p.nb;
-        const uint32_t max_slots = (uint32_t)(n / MSM_CH + std::min<size_t>(p.nb, n) + 1);
-        const uint32_t nseg = (p.nb + MSM_SEG - 1) / MSM_SEG;
+        const uint32_t max_slots = (uint32_t)(n / p.ch + std::min<size_t>(p.nb, n) + 1);
+        uint32_t nseg = (p.nb + p.seg - 1) / p.seg;
         int32_t rc;
-        if ((rc = m_digits.reserve((size_t)p.nwin * n * sizeof(uint16_t))) || (rc = m_hist.reserve(nwb * 4)) || (rc = m_offs.reserve(nwb * 4)) ||
-            (rc = m_cursor.reserve(nwb * 4)) || (rc = m_slotoffs.reserve(nwb * 4)) || (rc = m_spw.reserve(p.nwin * 4)) ||
-            (rc = m_sorted.reserve((size_t)p.nwin * n * 4)) || (rc = m_slots.reserve((size_t)p.nwin * max_slots * sizeof(Jac<F>))) ||
-            (rc = m_buckets.reserve(nwb * sizeof(Jac<F>))) || (rc = m_seg.reserve((size_t)p.nwin * nseg * sizeof(Jac<F>))) ||
-            (rc = m_win.reserve(64 * sizeof(Jac<F>))) || (rc = m_out.reserve(sizeof(Jac<F>)))) return rc;
-        HIPCHK(hipMemsetAsync(m_hist.p, 0, nwb * 4, stream));
-        hipLaunchKernelGGL(k_msm_digits, dim3(nblk(n, 256)), dim3(256), 0, stream, scalars, p, m_digits.as<uint16_t>(), m_hist.as<uint32_t>());
-        hipLaunchKernelGGL(k_msm_scan, dim3(p.nwin), dim3(1024), 0, stream, m_hist.as<uint32_t>(), p, m_offs.as<uint32_t>(), m_cursor.as<uint32_t>(), m_slotoffs.as<uint32_t>(), m_spw.as<uint32_t>());
-        hipLaunchKernelGGL(k_msm_scatter, dim3(nblk(n, 256)), dim3(256), 0, stream, m_digits.as<uint16_t>(), p, m_cursor.as<uint32_t>(), m_sorted.as<uint32_t>());
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_slot_sum<F>), dim3(nblk(max_slots, 64), p.nwin), dim3(64), 0, stream, bases, p, m_hist.as<uint32_t>(), m_offs.as<uint32_t>(),
-                           m_slotoffs.as<uint32_t>(), m_spw.as<uint32_t>(), m_sorted.as<uint32_t>(), m_slots.as<Jac<F>>(), max_slots);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_bucket_merge<F>), dim3(nblk(p.nb, 64), p.nwin), dim3(64), 0, stream, p, m_hist.as<uint32_t>(), m_slotoffs.as<uint32_t>(),
-                           m_slots.as<Jac<F>>(), max_slots, m_buckets.as<Jac<F>>());
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_segments<F>), dim3(nblk(nseg, 64), p.nwin), dim3(64), 0, stream, p, m_buckets.as<Jac<F>>(), m_seg.as<Jac<F>>(), nseg);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_finish<F>), dim3(1), dim3(64), 0, stream, p, m_seg.as<Jac<F>>(), nseg, m_win.as<Jac<F>>(), m_out.as<Jac<F>>());
+        if ((rc = ms.digits.reserve((size_t)p.nwin * n * sizeof(uint16_t))) || (rc = ms.hist.reserve(nwb * 4)) || (rc = ms.offs.reserve(nwb * 4)) ||
+            (rc = ms.cursor.reserve(nwb * 4)) || (rc = ms.slotoffs.reserve(nwb * 4)) || (rc = ms.spw.reserve(p.nwin * 4)) ||
+            (rc = ms.sorted.reserve((size_t)p.nwin * n * 4)) || (rc = ms.slots.reserve((size_t)p.nwin * max_slots * sizeof(Jac<F>))) ||
+            (rc = ms.buckets.reserve(nwb * sizeof(Jac<F>))) || (rc = ms.seg.reserve((size_t)p.nwin * nseg * sizeof(Jac<F>))) ||
+            (rc = ms.seg2.reserve((size_t)p.nwin * ((nseg + MSM_SEG_FAN - 1) / MSM_SEG_FAN) * sizeof(Jac<F>))) ||
+            (rc = ms.win.reserve(64 * sizeof(Jac<F>))) || (rc = ms.out.reserve(sizeof(Jac<F>)))) return rc;
+        HIPCHK(hipMemsetAsync(ms.hist.p, 0, nwb * 4, st));
+        hipLaunchKernelGGL(k_msm_digits, dim3(nblk(n, 256)), dim3(256), 0, st, scalars, p, ms.digits.as<uint16_t>(), ms.hist.as<uint32_t>());
+        hipLaunchKernelGGL(k_msm_scan, dim3(p.nwin), dim3(1024), 0, st, ms.hist.as<uint32_t>(), p, ms.offs.as<uint32_t>(), ms.cursor.as<uint32_t>(), ms.slotoffs.as<uint32_t>(), ms.spw.as<uint32_t>());
+        hipLaunchKernelGGL(k_msm_scatter, dim3(nblk(n, 256)), dim3(256), 0, st, ms.digits.as<uint16_t>(), p, ms.cursor.as<uint32_t>(), ms.sorted.as<uint32_t>());
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_slot_sum<F>), dim3(nblk(max_slots, 64), p.nwin), dim3(64), 0, st, bases, p, ms.hist.as<uint32_t>(), ms.offs.as<uint32_t>(),
+                           ms.slotoffs.as<uint32_t>(), ms.spw.as<uint32_t>(), ms.sorted.as<uint32_t>(), ms.slots.as<Jac<F>>(), max_slots);
+        const uint32_t grouped = n > (size_t)MSM_SLOT_GROUP * p.ch ? 1u : 0u;      // otherwise no bucket can hold more than MSM_SLOT_GROUP slots
+        if (grouped)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_slot_group<F>), dim3(nblk(max_slots, 64), p.nwin), dim3(64), 0, st, p, ms.hist.as<uint32_t>(), ms.slotoffs.as<uint32_t>(),
+                               ms.spw.as<uint32_t>(), ms.slots.as<Jac<F>>(), max_slots);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_bucket_merge<F>), dim3(nblk(p.nb, 64), p.nwin), dim3(64), 0, st, p, ms.hist.as<uint32_t>(), ms.slotoffs.as<uint32_t>(),
+                           ms.slots.as<Jac<F>>(), max_slots, ms.buckets.as<Jac<F>>(), grouped);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_segments<F>), dim3(nblk(nseg, 64), p.nwin), dim3(64), 0, st, p, ms.buckets.as<Jac<F>>(), ms.seg.as<Jac<F>>(), nseg);
+        Jac<F>* cur = ms.seg.as<Jac<F>>(); Jac<F>* nxt = ms.seg2.as<Jac<F>>();
+        while (nseg > (uint32_t)MSM_SEG_FAN) {                 // tree over the segment sums: chains of <= 16 additions
+            const uint32_t nout = (nseg + MSM_SEG_FAN - 1) / MSM_SEG_FAN;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_seg_reduce<F>), dim3(nblk(nout, 64), p.nwin), dim3(64), 0, st, cur, nseg, nxt, nout);
+            std::swap(cur, nxt); nseg = nout;
+        }
+        if (std::getenv("RIPP_NO_VM"))
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_finish<F>), dim3(1), dim3(64), 0, st, p, cur, nseg, ms.win.as<Jac<F>>(), ms.out.as<Jac<F>>());
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_finish_vm<F>), dim3(1), dim3(64), VM_EPW * VmCurve<F>::SLOTS * sizeof(Fp), st, p, cur, nseg, ms.win.as<Jac<F>>(), ms.out.as<Jac<F>>());
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(out_host, m_out.p, sizeof(Jac<F>), hipMemcpyDeviceToHost, stream));
-        return sync();
+        HIPCHK(hipMemcpyAsync(ms.host_out, ms.out.p, sizeof(Jac<F>), hipMemcpyDeviceToHost, st));
+        return RIPP_OK;
+    }
+    template <class F> int32_t msm_dev(const Affine<F>* bases, const Fr* scalars, size_t n, Jac<F>* out_host) {
+        int32_t rc = msm_launch<F>(msm_scratch[0], stream, bases, scalars, n); if (rc) return rc;
+        if ((rc = sync())) return rc;
+        *out_host = *reinterpret_cast<const Jac<F>*>(msm_scratch[0].host_out);
+        return RIPP_OK;
     }
 
     // ---- pairing product: per-step products of `nprod` products of M pairs each ---------------------------
@@ -846,20 +881,27 @@ static std::vector<Fr> ck_poly_coeffs(const std::vector<Fr>& tr, const Fr& r_shi
     return co;
 }
 // prove_commitment_key_kzg_opening (tipa/mod.rs:304-337): quotient of p(X) - p(c) by (X - c) by synthetic division on the
-// host (O(n) Fr products), then the 2n-1 term MSM against the resident SRS powers on the device
-template <class F> static int32_t kzg_opening_dev(Engine* e, const Affine<F>* powers, size_t num, const std::vector<Fr>& tr, const Fr& r_shift, const Fr& c, Jac<F>* out) {
+// host (O(n) Fr products); the 2n-1 term MSM against the resident SRS powers then runs on the device
+static int32_t kzg_quotient(const std::vector<Fr>& tr, const Fr& r_shift, const Fr& c, size_t num, std::vector<Fr>& q) {
     const std::vector<Fr> co = ck_poly_coeffs(tr, r_shift);
     if (2 * co.size() - 1 != num) { set_err("SRS size does not match the transcript length (assert_eq! at tipa/mod.rs:313)"); return RIPP_ERR_ARG; }
-    std::vector<Fr> q(num); q[num - 1] = Fr::zero();
+    q.assign(num, Fr::zero());
     Fr carry = Fr::zero();
     for (size_t k = num - 1; k >= 1; --k) {                       // q[k-1] = p[k] + c q[k];  p[k] = co[k/2] for even k, else 0
         Fr t = mul(carry, c); if (!(k & 1)) t = add(t, co[k >> 1]);
         q[k - 1] = t; carry = t;
     }
-    int32_t rc; Fr* dq;
-    if ((rc = upload<Fr>(e, e->tmpR, q.data(), num, &dq))) return rc;
-    if ((rc = e->sync())) return rc;                               // q is a local: finish the copy before it goes away
-    return e->msm_dev<F>(powers, dq, num, out);
+    return RIPP_OK;
+}
+template <class F> static int32_t kzg_opening_launch(Engine* e, int slot, hipStream_t st, const Affine<F>* powers, const std::vector<Fr>& q) {
+    int32_t rc; if ((rc = e->kzg_q[slot].reserve(q.size() * sizeof(Fr)))) return rc;
+    HIPCHK(hipMemcpyAsync(e->kzg_q[slot].p, q.data(), q.size() * sizeof(Fr), hipMemcpyHostToDevice, st));
+    return e->msm_launch<F>(e->msm_scratch[slot], st, powers, e->kzg_q[slot].as<Fr>(), q.size());
+}
+template <class F> static int32_t kzg_opening_dev(Engine* e, const Affine<F>* powers, size_t num, const std::vector<Fr>& tr, const Fr& r_shift, const Fr& c, Jac<F>* out) {
+    std::vector<Fr> q; int32_t rc;
+    if ((rc = kzg_quotient(tr, r_shift, c, num, q)) || (rc = kzg_opening_launch<F>(e, 0, e->stream, powers, q)) || (rc = e->sync())) return rc;
+    *out = *reinterpret_cast<const Jac<F>*>(e->msm_scratch[0].host_out); return RIPP_OK;
 }
 }  // extern "C++"
 API int32_t ripp_srs_powers_g1(const ripp_fr* s, size_t num, ripp_g1j* out) { return srs_powers<Fp>(g1_generator(), s, num, out); }
@@ -892,8 +934,15 @@ static int32_t tipp_kzg(Engine* e, const ripp_srs* srs, const ripp_fr* transcrip
     const Fr r_inv = inv(r_shift);                                                                                          // :192
     const Fr c = fs::kzg_challenge(tr[0], hka, &hkb);                                                                       // :194-209
     ripp_srs* s = const_cast<ripp_srs*>(srs); int32_t rc;
-    if ((rc = kzg_opening_dev<Fp2>(e, s->hbp.as<G2A>(), s->num, tri, r_inv, c, opening_a))) return rc;                      // :212-217
-    if ((rc = kzg_opening_dev<Fp>(e, s->gap.as<G1A>(), s->num, tr, Fr::one(), c, opening_b))) return rc;                    // :218-223
+    // the two openings are independent: quotients on two host threads, MSMs side by side on two streams
+    std::vector<Fr> qa, qb;
+    auto fb = std::async(std::launch::async, [&]() { return kzg_quotient(tr, Fr::one(), c, s->num, qb); });
+    rc = kzg_quotient(tri, r_inv, c, s->num, qa); const int32_t rcb = fb.get();
+    if (rc || rcb) return rc ? rc : rcb;
+    if ((rc = kzg_opening_launch<Fp2>(e, 0, e->stream, s->hbp.as<G2A>(), qa))) return rc;                                     // :212-217
+    if ((rc = kzg_opening_launch<Fp>(e, 1, e->stream3, s->gap.as<G1A>(), qb))) return rc;                                      // :218-223
+    if ((rc = e->sync())) return rc; HIPCHK(hipStreamSynchronize(e->stream3));
+    *opening_a = *reinterpret_cast<const G2J*>(e->msm_scratch[0].host_out); *opening_b = *reinterpret_cast<const G1J*>(e->msm_scratch[1].host_out);
     *kzg_c = c; return RIPP_OK;
 }
 
@@ -948,10 +997,12 @@ static int32_t tipa_ssm_core(Engine* e, const ripp_srs* srs, SsmVecs& v, size_t 
         const G1A* A = v.A.as<G1A>(); const G2A* KA = v.KA.as<G2A>(); const Fr* S = v.S.as<Fr>();
         const G1A* as[2] = {A + split, A}; const G2A* bs[2] = {KA, KA + split};     // com_1.0 = (m_a_1, ck_a_1), com_2.0 = (m_a_2, ck_a_2)   gipa.rs:209-231
         const double tp = now_ms();
+        // the two inner products of the round run on their own streams beside the pairing products (independent work)
+        if ((rc = e->msm_launch<Fp>(e->msm_scratch[0], e->stream2, A + split, S, split))) return rc;           // IP::inner_product(m_a_1, m_b_1)
+        if ((rc = e->msm_launch<Fp>(e->msm_scratch[1], e->stream3, A, S + split, split))) return rc;           // IP::inner_product(m_a_2, m_b_2)
         if ((rc = e->step_products(as, bs, 2, split, rows.data()))) return rc;
-        G1J ip[2];
-        if ((rc = e->msm_dev<Fp>(A + split, S, split, &ip[0]))) return rc;           // IP::inner_product(m_a_1, m_b_1)
-        if ((rc = e->msm_dev<Fp>(A, S + split, split, &ip[1]))) return rc;           // IP::inner_product(m_a_2, m_b_2)
+        HIPCHK(hipStreamSynchronize(e->stream2)); HIPCHK(hipStreamSynchronize(e->stream3));
+        const G1J ip[2] = {*reinterpret_cast<const G1J*>(e->msm_scratch[0].host_out), *reinterpret_cast<const G1J*>(e->msm_scratch[1].host_out)};
         e->stats.miller_products_ms += now_ms() - tp;
         const double th = now_ms();
         Fp12 gt[2];

@@ -11,23 +11,32 @@
 //                     Slots bound the work of one lane, so skewed scalar sets (all-equal scalars put every term in
 //                     one bucket per window) cannot serialise the launch.
 //   k_msm_bucket_merge lane per bucket: sum of its slots
-//   k_msm_segments    lane per 64-bucket segment: running-sum reduction  sum_d d*B_d  of the segment
-//   k_msm_finish      one lane: segment sums -> window sums -> Horner over windows
+//   k_msm_segments    lane per segment of `seg` buckets: running-sum reduction  sum_d d*B_d  of the segment
+//   k_msm_seg_reduce  lane per 16 segment sums (repeated until <= 16 per window remain)
+//   k_msm_finish_vm   one workgroup: lane per window adds the remaining segment sums, then the Horner recurrence over the
+//                     windows (255 doublings + nwin additions, ONE dependent chain) runs on the lane-parallel field VM
+//                     (vm.hpp: 16 lanes per point, complete projective addition, depth-2 doubling) instead of one lane.
+// Every stage after the scatter is a chain of dependent group operations per lane (~30-60 us each for a lone wave), so the
+// chain lengths -- not the operation count -- set the time for n <= 2^16: slots of 32 terms and segments of <= 16 buckets
+// there; slots of 256 terms once the launch fills the chip.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "bls12_381/curve.hpp"
+#include "vm.hpp"
 
 namespace ripp {
 
-constexpr int MSM_CH = 256;          // max terms summed by one lane in k_msm_slot_sum
-constexpr int MSM_SEG = 64;          // buckets per lane in k_msm_segments
+constexpr int MSM_SEG_FAN = 16;      // segment sums added per lane in k_msm_seg_reduce / in phase 1 of the finish
 
-struct MsmPlan { int c, nwin; uint32_t nb; uint32_t n; };
+struct MsmPlan { int c, nwin; uint32_t nb; uint32_t n; uint32_t ch, seg; };   // ch: max terms per slot, seg: buckets per segment lane
 
 inline MsmPlan msm_plan(size_t n) {
     int lg = 0; while (((size_t)1 << (lg + 1)) <= n) ++lg;
     int c = lg - 6; if (c < 4) c = 4; if (c > 13) c = 13;
-    MsmPlan p; p.c = c; p.nwin = (255 + c - 1) / c; p.nb = 1u << c; p.n = (uint32_t)n; return p;
+    MsmPlan p; p.c = c; p.nwin = (255 + c - 1) / c; p.nb = 1u << c; p.n = (uint32_t)n;
+    p.ch = n <= ((size_t)1 << 16) ? 32u : 256u;
+    p.seg = p.nb / 4 < 16 ? p.nb / 4 : 16;
+    return p;
 }
 
 __global__ void __launch_bounds__(256) k_msm_digits(const Fr* __restrict__ scalars, MsmPlan p, uint16_t* __restrict__ digits, uint32_t* __restrict__ hist) {
@@ -51,7 +60,7 @@ __global__ void __launch_bounds__(1024) k_msm_scan(const uint32_t* __restrict__ 
     const int w = blockIdx.x, t = threadIdx.x;
     const uint32_t per = (p.nb + 1023) / 1024;
     uint32_t sum = 0, ssum = 0;
-    for (uint32_t k = 0; k < per; ++k) { const uint32_t d = t * per + k; if (d < p.nb) { const uint32_t c = hist[(size_t)w * p.nb + d]; sum += c; ssum += (c + MSM_CH - 1) / MSM_CH; } }
+    for (uint32_t k = 0; k < per; ++k) { const uint32_t d = t * per + k; if (d < p.nb) { const uint32_t c = hist[(size_t)w * p.nb + d]; sum += c; ssum += (c + p.ch - 1) / p.ch; } }
     sh_a[t] = sum; sh_b[t] = ssum; __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
         uint32_t a = 0, b = 0; if (t >= off) { a = sh_a[t - off]; b = sh_b[t - off]; }
@@ -60,7 +69,7 @@ __global__ void __launch_bounds__(1024) k_msm_scan(const uint32_t* __restrict__ 
     uint32_t run = sh_a[t] - sum, srun = sh_b[t] - ssum;
     for (uint32_t k = 0; k < per; ++k) {
         const uint32_t d = t * per + k;
-        if (d < p.nb) { const uint32_t c = hist[(size_t)w * p.nb + d]; offs[(size_t)w * p.nb + d] = run; cursor[(size_t)w * p.nb + d] = run; slot_offs[(size_t)w * p.nb + d] = srun; run += c; srun += (c + MSM_CH - 1) / MSM_CH; }
+        if (d < p.nb) { const uint32_t c = hist[(size_t)w * p.nb + d]; offs[(size_t)w * p.nb + d] = run; cursor[(size_t)w * p.nb + d] = run; slot_offs[(size_t)w * p.nb + d] = srun; run += c; srun += (c + p.ch - 1) / p.ch; }
     }
     if (t == 1023) slots_per_window[w] = sh_b[1023];
 }
@@ -88,50 +97,157 @@ __global__ void __launch_bounds__(64) k_msm_slot_sum(const Affine<F>* __restrict
     while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (so[mid] <= s) lo = mid; else hi = mid - 1; }
     // lo may sit on an empty bucket that shares its offset with the owning one: walk down to the bucket that really has the slot
     uint32_t d = lo;
-    while (d > 0 && (hist[(size_t)w * p.nb + d] + MSM_CH - 1) / MSM_CH + so[d] <= s) --d;
+    while (d > 0 && (hist[(size_t)w * p.nb + d] + p.ch - 1) / p.ch + so[d] <= s) --d;
     const uint32_t part = s - so[d];
     const uint32_t cnt = hist[(size_t)w * p.nb + d];
-    const uint32_t begin = offs[(size_t)w * p.nb + d] + part * MSM_CH;
-    const uint32_t end = min(offs[(size_t)w * p.nb + d] + cnt, begin + MSM_CH);
+    const uint32_t begin = offs[(size_t)w * p.nb + d] + part * p.ch;
+    const uint32_t end = min(offs[(size_t)w * p.nb + d] + cnt, begin + p.ch);
     Jac<F> acc = jac_inf<F>();
 #pragma unroll 1
     for (uint32_t k = begin; k < end; ++k) acc = add_mixed(acc, bases[sorted[(size_t)w * p.n + k]]);
     slot_sums[(size_t)w * max_slots + s] = acc;
 }
 
-// lane per (window, bucket): bucket = sum of its slots
+// Buckets that collect many slots (the short TOP window puts n / 2^(255 mod c) terms into each of its few buckets; skewed scalar sets
+// do the same anywhere) would serialise the merge: first add the slots in groups of MSM_SLOT_GROUP, in place -- lane per slot, group
+// leaders do the work -- so that the final per-bucket merge walks ceil(ns / MSM_SLOT_GROUP) partial sums.
+constexpr uint32_t MSM_SLOT_GROUP = 8;
+template <class F>
+__global__ void __launch_bounds__(64) k_msm_slot_group(MsmPlan p, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ slot_offs,
+                                                        const uint32_t* __restrict__ slots_per_window, Jac<F>* __restrict__ slot_sums, uint32_t max_slots) {
+    const int w = blockIdx.y;
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= slots_per_window[w]) return;
+    const uint32_t* so = slot_offs + (size_t)w * p.nb;
+    uint32_t lo = 0, hi = p.nb - 1;
+    while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (so[mid] <= s) lo = mid; else hi = mid - 1; }
+    uint32_t d = lo;
+    while (d > 0 && (hist[(size_t)w * p.nb + d] + p.ch - 1) / p.ch + so[d] <= s) --d;
+    const uint32_t ns = (hist[(size_t)w * p.nb + d] + p.ch - 1) / p.ch, k0 = s - so[d];
+    if (ns <= MSM_SLOT_GROUP || (k0 % MSM_SLOT_GROUP) != 0) return;
+    const uint32_t k1 = min(k0 + MSM_SLOT_GROUP, ns);
+    Jac<F>* base = slot_sums + (size_t)w * max_slots + so[d];
+    Jac<F> acc = base[k0];
+#pragma unroll 1
+    for (uint32_t k = k0 + 1; k < k1; ++k) acc = add(acc, base[k]);
+    base[k0] = acc;
+}
+
+// lane per (window, bucket): bucket = sum of its slots (of its slot-group sums when the bucket has more than MSM_SLOT_GROUP slots)
 template <class F>
 __global__ void __launch_bounds__(64) k_msm_bucket_merge(MsmPlan p, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ slot_offs,
-                                                          const Jac<F>* __restrict__ slot_sums, uint32_t max_slots, Jac<F>* __restrict__ buckets) {
+                                                          const Jac<F>* __restrict__ slot_sums, uint32_t max_slots, Jac<F>* __restrict__ buckets, uint32_t grouped) {
     const int w = blockIdx.y;
     const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= p.nb) return;
-    const uint32_t cnt = hist[(size_t)w * p.nb + d], ns = (cnt + MSM_CH - 1) / MSM_CH, s0 = slot_offs[(size_t)w * p.nb + d];
+    const uint32_t cnt = hist[(size_t)w * p.nb + d], ns = (cnt + p.ch - 1) / p.ch, s0 = slot_offs[(size_t)w * p.nb + d];
+    const uint32_t step = (grouped && ns > MSM_SLOT_GROUP) ? MSM_SLOT_GROUP : 1u;
     Jac<F> acc = jac_inf<F>();
 #pragma unroll 1
-    for (uint32_t k = 0; k < ns; ++k) { const Jac<F> t = slot_sums[(size_t)w * max_slots + s0 + k]; acc = (k == 0) ? t : add(acc, t); }
+    for (uint32_t k = 0; k < ns; k += step) { const Jac<F> t = slot_sums[(size_t)w * max_slots + s0 + k]; acc = (k == 0) ? t : add(acc, t); }
     buckets[(size_t)w * p.nb + d] = acc;
 }
 
-// lane per (window, segment of MSM_SEG buckets): seg = sum_{d in segment} d * B_d
+// lane per (window, segment of p.seg buckets): seg = sum_{d in segment} d * B_d
 template <class F>
 __global__ void __launch_bounds__(64) k_msm_segments(MsmPlan p, const Jac<F>* __restrict__ buckets, Jac<F>* __restrict__ seg_out, uint32_t nseg) {
     const int w = blockIdx.y;
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nseg) return;
-    const uint32_t lo = j * MSM_SEG, hi = min(lo + MSM_SEG, p.nb);      // buckets [lo, hi); bucket 0 is always empty
+    const uint32_t lo = j * p.seg, hi = min(lo + p.seg, p.nb);      // buckets [lo, hi); bucket 0 is always empty
     Jac<F> run = jac_inf<F>(), acc = jac_inf<F>();
 #pragma unroll 1
     for (uint32_t d = hi; d-- > lo;) { run = add(run, buckets[(size_t)w * p.nb + d]); acc = add(acc, run); }
     // acc = sum (d - lo + 1) B_d ; add (lo - 1) * run   (for lo == 0: subtract run)
     if (lo == 0) { acc = add(acc, neg(run)); }
-    else {
-        const uint32_t m = lo - 1; Jac<F> t = jac_inf<F>();
+    else if (lo > 1) {
+        const uint32_t m = lo - 1; Jac<F> t = run;
 #pragma unroll 1
-        for (int b = 31; b >= 0; --b) { t = dbl(t); if ((m >> b) & 1u) t = add(t, run); }
+        for (int b = 30 - __clz(m); b >= 0; --b) { t = dbl(t); if ((m >> b) & 1u) t = add(t, run); }
         acc = add(acc, t);
     }
     seg_out[(size_t)w * nseg + j] = acc;
+}
+
+// lane per (window, group of MSM_SEG_FAN segment sums)
+template <class F>
+__global__ void __launch_bounds__(64) k_msm_seg_reduce(const Jac<F>* __restrict__ in, uint32_t nin, Jac<F>* __restrict__ out, uint32_t nout) {
+    const int w = blockIdx.y;
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nout) return;
+    const uint32_t lo = j * MSM_SEG_FAN, hi = min(lo + MSM_SEG_FAN, nin);
+    Jac<F> acc = in[(size_t)w * nin + lo];
+#pragma unroll 1
+    for (uint32_t k = lo + 1; k < hi; ++k) acc = add(acc, in[(size_t)w * nin + k]);
+    out[(size_t)w * nout + j] = acc;
+}
+
+// ---- Horner over the windows on the field VM ------------------------------------------------------------------------
+template <class F> struct VmCurve;
+template <> struct VmCurve<Fp> {
+    static constexpr int NF = 1;
+    static constexpr int SLOTS = (vmprog::g1_hdbl_g16_nslots > vmprog::g1_cadd_g16_nslots) ? vmprog::g1_hdbl_g16_nslots : vmprog::g1_cadd_g16_nslots;
+    static constexpr int SX = vmprog::g1_cadd_g16_in_X0, SY = vmprog::g1_cadd_g16_in_Y0, SZ = vmprog::g1_cadd_g16_in_Z0;
+    static constexpr int QX = vmprog::g1_cadd_g16_in_qx0, QY = vmprog::g1_cadd_g16_in_qy0, QZ = vmprog::g1_cadd_g16_in_qz0;
+    static_assert(vmprog::g1_hdbl_g16_in_X0 == SX && vmprog::g1_hdbl_g16_in_Y0 == SY && vmprog::g1_hdbl_g16_in_Z0 == SZ, "accumulator slots");
+    static_assert(vmprog::g1_cadd_g16_out_X0 == SX && vmprog::g1_cadd_g16_out_Y0 == SY && vmprog::g1_cadd_g16_out_Z0 == SZ, "accumulator slots");
+    __device__ static void dbl_(Fp* ws, int lg) { vm_run(ws, vmprog::g1_hdbl_g16_kind, vmprog::g1_hdbl_g16_ops, vmprog::g1_hdbl_g16_nlayers, lg); }
+    __device__ static void add_(Fp* ws, int lg) { vm_run(ws, vmprog::g1_cadd_g16_kind, vmprog::g1_cadd_g16_ops, vmprog::g1_cadd_g16_nlayers, lg); }
+    __device__ static void put(Fp* ws, int slot, const Fp& v) { ws[slot] = v; }
+    __device__ static Fp get(const Fp* ws, int slot) { return ws[slot]; }
+};
+template <> struct VmCurve<Fp2> {
+    static constexpr int NF = 2;
+    static constexpr int SLOTS = (vmprog::g2_hdbl_g16_nslots > vmprog::g2_cadd_g16_nslots) ? vmprog::g2_hdbl_g16_nslots : vmprog::g2_cadd_g16_nslots;
+    static constexpr int SX = vmprog::g2_cadd_g16_in_X0, SY = vmprog::g2_cadd_g16_in_Y0, SZ = vmprog::g2_cadd_g16_in_Z0;
+    static constexpr int QX = vmprog::g2_cadd_g16_in_qx0, QY = vmprog::g2_cadd_g16_in_qy0, QZ = vmprog::g2_cadd_g16_in_qz0;
+    static_assert(vmprog::g2_hdbl_g16_in_X0 == SX && vmprog::g2_hdbl_g16_in_Y0 == SY && vmprog::g2_hdbl_g16_in_Z0 == SZ, "accumulator slots");
+    static_assert(vmprog::g2_cadd_g16_out_X0 == SX && vmprog::g2_cadd_g16_out_Y0 == SY && vmprog::g2_cadd_g16_out_Z0 == SZ, "accumulator slots");
+    static_assert(vmprog::g2_cadd_g16_in_X1 == SX + 1 && vmprog::g2_cadd_g16_in_qz1 == QZ + 1 && vmprog::g2_hdbl_g16_in_Z1 == SZ + 1, "c0/c1 adjacent");
+    __device__ static void dbl_(Fp* ws, int lg) { vm_run(ws, vmprog::g2_hdbl_g16_kind, vmprog::g2_hdbl_g16_ops, vmprog::g2_hdbl_g16_nlayers, lg); }
+    __device__ static void add_(Fp* ws, int lg) { vm_run(ws, vmprog::g2_cadd_g16_kind, vmprog::g2_cadd_g16_ops, vmprog::g2_cadd_g16_nlayers, lg); }
+    __device__ static void put(Fp* ws, int slot, const Fp2& v) { ws[slot] = v.c0; ws[slot + 1] = v.c1; }
+    __device__ static Fp2 get(const Fp* ws, int slot) { return {ws[slot], ws[slot + 1]}; }
+};
+
+// one block of 64 lanes.  Phase 1: lane w adds the <= MSM_SEG_FAN remaining segment sums of window w and rewrites the window sum as a
+// homogeneous projective point (X Z : Y : Z^3) -- (0 : 1 : 0) for the identity.  Phase 2: lanes 0..15 run
+//     T <- W_top;  for w = top-1 .. 0:  T <- 2^c T (c VM doublings);  T <- T + W_w (complete VM addition)
+// and lane 0 converts T back to Jacobian.  The complete addition law has no exceptional case, so no fallback is needed.
+template <class F>
+__global__ void __launch_bounds__(64) k_msm_finish_vm(MsmPlan p, const Jac<F>* __restrict__ seg, uint32_t nseg, Jac<F>* __restrict__ win_h, Jac<F>* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char vm_smem[];
+    using C = VmCurve<F>;
+    Fp* const lds = reinterpret_cast<Fp*>(vm_smem);
+    const int lane = threadIdx.x, lg = lane & (VM_G - 1), grp = lane / VM_G;
+    Fp* const ws = lds + (size_t)grp * C::SLOTS;
+    if ((uint32_t)lane < (uint32_t)p.nwin) {
+        Jac<F> acc = seg[(size_t)lane * nseg];
+#pragma unroll 1
+        for (uint32_t j = 1; j < nseg; ++j) acc = add(acc, seg[(size_t)lane * nseg + j]);
+        Jac<F> h;
+        if (acc.z.is_zero()) { h.x = F::zero(); h.y = F::one(); h.z = F::zero(); }
+        else { h.x = fmul(acc.x, acc.z); h.y = acc.y; h.z = fmul(fsqr(acc.z), acc.z); }
+        win_h[lane] = h;
+    }
+    __syncthreads();
+    const bool lead = (lane == 0);
+    if (lg == 0) ws[0] = Fp::zero();
+    if (lead) { const Jac<F> t = win_h[p.nwin - 1]; C::put(ws, C::SX, t.x); C::put(ws, C::SY, t.y); C::put(ws, C::SZ, t.z); }
+    else if (lg == 0) { C::put(ws, C::SX, F::zero()); C::put(ws, C::SY, F::one()); C::put(ws, C::SZ, F::zero()); }   // idle groups: a valid point
+#pragma unroll 1
+    for (int w = p.nwin - 2; w >= 0; --w) {
+#pragma unroll 1
+        for (int k = 0; k < p.c; ++k) C::dbl_(ws, lg);
+        if (lg == 0) { const Jac<F> t = win_h[w]; C::put(ws, C::QX, t.x); C::put(ws, C::QY, t.y); C::put(ws, C::QZ, t.z); }
+        C::add_(ws, lg);
+    }
+    if (lead) {
+        const F X = C::get(ws, C::SX), Y = C::get(ws, C::SY), Z = C::get(ws, C::SZ);
+        Jac<F> r = jac_inf<F>();
+        if (!Z.is_zero()) { r.x = fmul(X, Z); r.y = fmul(Y, fsqr(Z)); r.z = Z; }
+        out[0] = r;
+    }
 }
 
 template <class F>

@@ -356,6 +356,23 @@ def prog_hom_add(deg):
     return p
 
 
+def prog_hom_cadd(deg):
+    """T <- T + Q with BOTH operands homogeneous projective: the complete addition law of Renes-Costello-Batina (2016, Alg. 7,
+    a = 0).  No exceptional case: T = +-Q and the point at infinity (0:1:0) on either side are all handled by the same
+    straight-line code -- 12 products, depth 2.  b3 = 3b = 12 on G1, 12(1+u) on G2."""
+    p = Prog("g%d_cadd" % deg)
+    X1, Y1, Z1 = fin(p, "X", deg), fin(p, "Y", deg), fin(p, "Z", deg)
+    X2, Y2, Z2 = fin(p, "qx", deg), fin(p, "qy", deg), fin(p, "qz", deg)
+    t0, t1, t2 = X1.mul(X2).mat(), Y1.mul(Y2).mat(), Z1.mul(Z2).mat()
+    t3 = ((X1 + Y1).mul(X2 + Y2) - (t0 + t1)).mat()            # X1 Y2 + X2 Y1
+    t4 = ((Y1 + Z1).mul(Y2 + Z2) - (t1 + t2)).mat()            # Y1 Z2 + Y2 Z1
+    t5 = ((X1 + Z1).mul(X2 + Z2) - (t0 + t2)).mat()            # X1 Z2 + X2 Z1
+    b3t2, b3t5 = t2.mul_xi().scale(12).mat(), t5.mul_xi().scale(12).mat()
+    m, pl, t03 = (t1 - b3t2).mat(), (t1 + b3t2).mat(), t0.scale(3).mat()
+    fout(p, "X", t3.mul(m) - t4.mul(b3t5), into="X"); fout(p, "Y", m.mul(pl) + b3t5.mul(t03), into="Y"); fout(p, "Z", pl.mul(t4) + t03.mul(t3), into="Z")
+    return p
+
+
 class F6:
     def __init__(s, c0, c1, c2): s.c0, s.c1, s.c2 = c0, c1, c2
     def __add__(s, o): return F6(s.c0 + o.c0, s.c1 + o.c1, s.c2 + o.c2)
@@ -516,6 +533,28 @@ def validate():
             c = compile_prog(prog_hom_add(deg), G); progs[("g%d_hadd" % deg, G)] = c
             out = run_compiled(c, pack(["X", "Y", "Z", "qx", "qy"], Th + Q))
             zi = fi(unpack(out, "Z")); assert (fm(unpack(out, "X"), zi), fm(unpack(out, "Y"), zi)) == aff_add(T, Q), ("hadd", deg, G)
+            # complete addition: generic, doubling, inverse, and infinity on either side
+            c = compile_prog(prog_hom_cadd(deg), G); progs[("g%d_cadd" % deg, G)] = c
+            z2 = rf() if deg == 1 else rf2()
+            zero = 0 if deg == 1 else (0, 0); one = 1 if deg == 1 else (1, 0)
+            fneg = (lambda a: (-a) % P) if deg == 1 else (lambda a: ((-a[0]) % P, (-a[1]) % P))
+            hom = lambda pt, zz: (fm(pt[0], zz), fm(pt[1], zz), zz)
+            inf = (zero, fm(one, z2), zero)
+            names = ["X", "Y", "Z", "qx", "qy", "qz"]
+            def aff_of(out):
+                Zo = unpack(out, "Z")
+                if Zo == zero: return None
+                zi = fi(Zo); return fm(unpack(out, "X"), zi), fm(unpack(out, "Y"), zi)
+            assert aff_of(run_compiled(c, pack(names, Th + hom(Q, z2)))) == aff_add(T, Q), ("cadd", deg, G)
+            assert aff_of(run_compiled(c, pack(names, Th + hom(T, z2)))) == aff_add(T, T), ("cadd dbl", deg, G)
+            assert aff_of(run_compiled(c, pack(names, Th + hom((T[0], fneg(T[1])), z2)))) is None, ("cadd inverse", deg, G)
+            assert aff_of(run_compiled(c, pack(names, inf + hom(Q, z2)))) == Q, ("cadd inf + Q", deg, G)
+            assert aff_of(run_compiled(c, pack(names, Th + inf))) == T, ("cadd T + inf", deg, G)
+            assert aff_of(run_compiled(c, pack(names, inf + inf))) is None, ("cadd inf + inf", deg, G)
+            o2 = run_compiled(c, pack(names, inf + inf)); assert unpack(o2, "Y") != zero     # stays a valid representative of infinity
+            # the doubling program maps infinity to infinity
+            cd = progs[("g%d_hdbl" % deg, G)]
+            o2 = run_compiled(cd, pack(["X", "Y", "Z", "qx", "qy"], inf + Q)); assert unpack(o2, "Z") == zero and unpack(o2, "X") == zero and unpack(o2, "Y") != zero
     return progs
 
 
