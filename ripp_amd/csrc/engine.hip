@@ -70,7 +70,7 @@ struct Timer {   // HIP-event stopwatch on the engine stream
 struct Engine {
     int device = -1;
     hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: the G1 half of a fold runs beside the G2 half
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
     int n_simd = 1024;
     // scratch
     DevBuf lines, partA, partB, jacG1, jacG2, tmpA, tmpB, tmpR, affG1, affG2;
@@ -97,7 +97,7 @@ struct Engine {
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&stream3, hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_join3, hipEventDisableTiming));
         { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n_simd = pr.multiProcessorCount * 4; }
         auto env_sz = [](const char* k, size_t& v) { if (const char* s = std::getenv(k)) v = (size_t)std::strtoull(s, nullptr, 10); };
         env_sz("RIPP_VM_LINES_MAX", vm_lines_max); env_sz("RIPP_VM_FOLD_MAX", vm_fold_max); env_sz("RIPP_VM_TREE_MAX", vm_tree_max); env_sz("RIPP_GLS_SPLIT_MAX", gls_split_max);
@@ -113,7 +113,7 @@ struct Engine {
         for (auto& e : ev_prod) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         if (stream) (void)hipStreamDestroy(stream);
         if (stream2) (void)hipStreamDestroy(stream2);
-        if (ev_fork) (void)hipEventDestroy(ev_fork); if (ev_join) (void)hipEventDestroy(ev_join);
+        if (ev_fork) (void)hipEventDestroy(ev_fork); if (ev_join) (void)hipEventDestroy(ev_join); if (ev_join3) (void)hipEventDestroy(ev_join3);
     }
     int32_t ensure_pinned_rows(size_t rows) {
         if (rows <= pinned_rows_cap) return RIPP_OK;
@@ -747,9 +747,10 @@ template <class Launch> static int32_t folds_with_vm_fallback(Engine* e, size_t 
     if ((rc = e->vm_flag.reserve(sizeof(uint32_t)))) return rc;
     for (;;) {
         HIPCHK(hipMemsetAsync(e->vm_flag.p, 0, sizeof(uint32_t), e->stream));
-        HIPCHK(hipEventRecord(e->ev_fork, e->stream)); HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
+        HIPCHK(hipEventRecord(e->ev_fork, e->stream)); HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0)); HIPCHK(hipStreamWaitEvent(e->stream3, e->ev_fork, 0));
         if ((rc = launch())) { e->vm_fold_max = saved_vm_max; return rc; }
-        HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
+        HIPCHK(hipEventRecord(e->ev_join, e->stream2)); HIPCHK(hipEventRecord(e->ev_join3, e->stream3));
+        HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0)); HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join3, 0));
         if ((rc = e->sync())) { e->vm_fold_max = saved_vm_max; return rc; }
         if (e->vm_fold_max != 0 && split <= e->vm_fold_max) {
             uint32_t flag = 0; HIPCHK(hipMemcpy(&flag, e->vm_flag.p, sizeof flag, hipMemcpyDeviceToHost));
@@ -792,8 +793,7 @@ static int32_t gipa_tipp_core(Engine* e, TippVecs& v, size_t n, ripp_gt* com_ste
         rc = folds_with_vm_fallback(e, split, [&]() -> int32_t {
             int32_t r2;
             if ((r2 = fold_dev<Fp>(e, e->stream2, A + split, A, split, c, v.jac1, v.qt2, v.A2.as<G1A>()))) return r2;          // m_a  <- m_a_1 * c + m_a_2
-            if ((r2 = fold_dev<Fp>(e, e->stream2, KB + split, KB, split, c, v.jac1b, v.qt2, v.KB2.as<G1A>()))) return r2;       // ck_b <- ck_b_1 * c + ck_b_2
-            HIPCHK(hipEventRecord(e->ev_join, e->stream2));
+            if ((r2 = fold_dev<Fp>(e, e->stream3, KB + split, KB, split, c, v.jac1b, v.qt2, v.KB2.as<G1A>()))) return r2;       // ck_b <- ck_b_1 * c + ck_b_2
             if ((r2 = fold_dev<Fp2>(e, e->stream, B + split, B, split, c_inv, v.jac2, e->qtab, v.B2.as<G2A>()))) return r2;     // m_b  <- m_b_2 * c_inv + m_b_1
             return fold_dev<Fp2>(e, e->stream, KA + split, KA, split, c_inv, v.jac2b, e->qtab, v.KA2.as<G2A>());                // ck_a <- ck_a_2 * c_inv + ck_a_1
         });
@@ -1017,9 +1017,8 @@ static int32_t tipa_ssm_core(Engine* e, const ripp_srs* srs, SsmVecs& v, size_t 
         rc = folds_with_vm_fallback(e, split, [&]() -> int32_t {
             int32_t r2;
             if ((r2 = fold_dev<Fp>(e, e->stream2, A + split, A, split, c, v.jac1, v.qt2, v.A2.as<G1A>()))) return r2;               // m_a  <- m_a_1 * c + m_a_2
-            hipLaunchKernelGGL(k_fold_fr, dim3(nblk(split, 256)), dim3(256), 0, e->stream2, S + split, S, (uint32_t)split, c_inv, v.S2.as<Fr>());   // m_b  <- m_b_2 * c_inv + m_b_1
+            hipLaunchKernelGGL(k_fold_fr, dim3(nblk(split, 256)), dim3(256), 0, e->stream3, S + split, S, (uint32_t)split, c_inv, v.S2.as<Fr>());   // m_b  <- m_b_2 * c_inv + m_b_1
             HIPCHK(hipGetLastError());
-            HIPCHK(hipEventRecord(e->ev_join, e->stream2));
             return fold_dev<Fp2>(e, e->stream, KA + split, KA, split, c_inv, v.jac2, e->qtab, v.KA2.as<G2A>());                      // ck_a <- ck_a_2 * c_inv + ck_a_1
         });
         if (rc) return rc;

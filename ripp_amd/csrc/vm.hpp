@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(128) k_vm_fp12_tree(const uint4* __restrict__ 
 // ---- scalar multiplication d * Q in latency form (homogeneous projective double-and-add on the VM) -----------------
 // G2: blockIdx.y = j selects the GLS image [u^j]Q and its NAF digit string; result (Jacobian) -> parts[j][i].
 // `flag` is set when an addition met lambda == 0 (T = +-Q): the caller then redoes the launch with the scalar kernel.
-constexpr int VM_G2_SLOTS = (vmprog::g2_hdbl_g16_nslots > vmprog::g2_hadd_g16_nslots) ? vmprog::g2_hdbl_g16_nslots : vmprog::g2_hadd_g16_nslots;
+constexpr int VM_G2_SLOTS = (vmprog::g2_hdbl_g16_nslots > vmprog::g2_cadd_g16_nslots) ? vmprog::g2_hdbl_g16_nslots : vmprog::g2_cadd_g16_nslots;
 __global__ void __launch_bounds__(256) k_vm_fold_g2_split(const G2A* __restrict__ hi, uint32_t half, GlsDigits dg, G2J* __restrict__ parts, uint32_t* __restrict__ flag) {
     extern __shared__ __attribute__((aligned(16))) unsigned char vm_smem[];
     Fp* const lds = reinterpret_cast<Fp*>(vm_smem);
@@ -170,9 +170,10 @@ __global__ void __launch_bounds__(256) k_vm_fold_g2_split(const G2A* __restrict_
     Fp* const ws = lds + (size_t)(wave * VM_EPW + grp) * VM_G2_SLOTS;
     const bool active = i < half;
     namespace vp = vmprog;
-    enum { SX = 2, SY = 4, SZ = 6, SQX = 8, SQY = 10 };        // vmprog::g2_h*_g16_in: X0 X1 Y0 Y1 Z0 Z1 qx0 qx1 qy0 qy1
+    enum { SX = vp::g2_cadd_g16_in_X0, SY = vp::g2_cadd_g16_in_Y0, SZ = vp::g2_cadd_g16_in_Z0, SQX = vp::g2_cadd_g16_in_qx0, SQY = vp::g2_cadd_g16_in_qy0, SQZ = vp::g2_cadd_g16_in_qz0 };
+    static_assert(vp::g2_hdbl_g16_in_X0 == SX && vp::g2_hdbl_g16_in_Y0 == SY && vp::g2_hdbl_g16_in_Z0 == SZ, "accumulator slots shared by the two programs");
     G2A q = aff_inf<Fp2>(); bool qinf = true;
-    if (active && lg == 0) { q = gls_image(hi[i], j); qinf = is_inf(q); ws[0] = Fp::zero(); ws[SQX] = q.x.c0; ws[SQX + 1] = q.x.c1; }
+    if (active && lg == 0) { q = gls_image(hi[i], j); qinf = is_inf(q); ws[0] = Fp::zero(); }
     int pos = dg.len - 1;
     while (pos >= 0 && dg.d[j][pos] == 0) --pos;               // uniform: digits are shared by the whole launch
     const bool any = pos >= 0;
@@ -180,30 +181,30 @@ __global__ void __launch_bounds__(256) k_vm_fold_g2_split(const G2A* __restrict_
         const Fp2 y0 = dg.d[j][pos] < 0 ? neg(q.y) : q.y;
         ws[SX] = q.x.c0; ws[SX + 1] = q.x.c1; ws[SY] = y0.c0; ws[SY + 1] = y0.c1; ws[SZ] = Fp::one(); ws[SZ + 1] = Fp::zero();
     }
-    bool exc = false;
+    // additions use the COMPLETE projective law (g2_cadd: depth 2, no exceptional case), the addend (q.x : +-q.y : 1) is rewritten
+    // before each one because the doubling program may use those slots as temporaries
+    (void)flag;
 #pragma unroll 1
     for (--pos; pos >= 0; --pos) {
         vm_run(ws, vp::g2_hdbl_g16_kind, vp::g2_hdbl_g16_ops, vp::g2_hdbl_g16_nlayers, lg);
         const int d = dg.d[j][pos];
         if (d != 0) {
-            if (active && lg == 0) { const Fp2 y = d < 0 ? neg(q.y) : q.y; ws[SQY] = y.c0; ws[SQY + 1] = y.c1; }
-            vm_run(ws, vp::g2_hadd_g16_kind, vp::g2_hadd_g16_ops, vp::g2_hadd_g16_nlayers, lg);
-            if (active && lg == 0) { const Fp l0 = ws[vp::g2_hadd_g16_out[6]], l1 = ws[vp::g2_hadd_g16_out[7]]; exc |= (l0.is_zero() && l1.is_zero()); }
+            if (active && lg == 0) { const Fp2 y = d < 0 ? neg(q.y) : q.y; ws[SQX] = q.x.c0; ws[SQX + 1] = q.x.c1; ws[SQY] = y.c0; ws[SQY + 1] = y.c1; ws[SQZ] = Fp::one(); ws[SQZ + 1] = Fp::zero(); }
+            vm_run(ws, vp::g2_cadd_g16_kind, vp::g2_cadd_g16_ops, vp::g2_cadd_g16_nlayers, lg);
         }
     }
     if (active && lg == 0) {
         G2J r = jac_inf<Fp2>();
         if (any && !qinf) {
             const Fp2 X = {ws[SX], ws[SX + 1]}, Y = {ws[SY], ws[SY + 1]}, Z = {ws[SZ], ws[SZ + 1]};
-            r.x = mul(X, Z); r.y = mul(Y, sqr(Z)); r.z = Z;      // (X/Z, Y/Z) -> Jacobian (XZ, YZ^2, Z)
-            if (exc) atomicOr(flag, 1u);
+            if (!Z.is_zero()) { r.x = mul(X, Z); r.y = mul(Y, sqr(Z)); r.z = Z; }      // (X/Z, Y/Z) -> Jacobian (XZ, YZ^2, Z)
         }
         parts[(size_t)j * half + i] = r;
     }
 }
 
 // G1: single NAF digit string (the 128-bit SIPP challenge); out[i] = s*hi[i] + lo[i] (Jacobian)
-constexpr int VM_G1_SLOTS = (vmprog::g1_hdbl_g16_nslots > vmprog::g1_hadd_g16_nslots) ? vmprog::g1_hdbl_g16_nslots : vmprog::g1_hadd_g16_nslots;
+constexpr int VM_G1_SLOTS = (vmprog::g1_hdbl_g16_nslots > vmprog::g1_cadd_g16_nslots) ? vmprog::g1_hdbl_g16_nslots : vmprog::g1_cadd_g16_nslots;
 __global__ void __launch_bounds__(256) k_vm_fold_g1(const G1A* __restrict__ hi, const G1A* __restrict__ lo, uint32_t half, NafDigits dg, G1J* __restrict__ out, uint32_t* __restrict__ flag) {
     extern __shared__ __attribute__((aligned(16))) unsigned char vm_smem[];
     Fp* const lds = reinterpret_cast<Fp*>(vm_smem);
@@ -212,30 +213,29 @@ __global__ void __launch_bounds__(256) k_vm_fold_g1(const G1A* __restrict__ hi, 
     Fp* const ws = lds + (size_t)(wave * VM_EPW + grp) * VM_G1_SLOTS;
     const bool active = i < half;
     namespace vp = vmprog;
-    enum { SX = 2, SY = 3, SZ = 4, SQX = 5, SQY = 6 };
+    enum { SX = vp::g1_cadd_g16_in_X0, SY = vp::g1_cadd_g16_in_Y0, SZ = vp::g1_cadd_g16_in_Z0, SQX = vp::g1_cadd_g16_in_qx0, SQY = vp::g1_cadd_g16_in_qy0, SQZ = vp::g1_cadd_g16_in_qz0 };
+    static_assert(vp::g1_hdbl_g16_in_X0 == SX && vp::g1_hdbl_g16_in_Y0 == SY && vp::g1_hdbl_g16_in_Z0 == SZ, "accumulator slots shared by the two programs");
     G1A q = aff_inf<Fp>(); bool qinf = true;
-    if (active && lg == 0) { q = hi[i]; qinf = is_inf(q); ws[0] = Fp::zero(); ws[SQX] = q.x; }
+    if (active && lg == 0) { q = hi[i]; qinf = is_inf(q); ws[0] = Fp::zero(); }
     int pos = dg.len - 1;
     while (pos >= 0 && dg.d[pos] == 0) --pos;
     const bool any = pos >= 0;
     if (any && active && lg == 0) { ws[SX] = q.x; ws[SY] = dg.d[pos] < 0 ? neg(q.y) : q.y; ws[SZ] = Fp::one(); }
-    bool exc = false;
+    (void)flag;                                                 // complete addition (g1_cadd): nothing to report
 #pragma unroll 1
     for (--pos; pos >= 0; --pos) {
         vm_run(ws, vp::g1_hdbl_g16_kind, vp::g1_hdbl_g16_ops, vp::g1_hdbl_g16_nlayers, lg);
         const int d = dg.d[pos];
         if (d != 0) {
-            if (active && lg == 0) ws[SQY] = d < 0 ? neg(q.y) : q.y;
-            vm_run(ws, vp::g1_hadd_g16_kind, vp::g1_hadd_g16_ops, vp::g1_hadd_g16_nlayers, lg);
-            if (active && lg == 0) exc |= ws[vp::g1_hadd_g16_out[3]].is_zero();
+            if (active && lg == 0) { ws[SQX] = q.x; ws[SQY] = d < 0 ? neg(q.y) : q.y; ws[SQZ] = Fp::one(); }
+            vm_run(ws, vp::g1_cadd_g16_kind, vp::g1_cadd_g16_ops, vp::g1_cadd_g16_nlayers, lg);
         }
     }
     if (active && lg == 0) {
         G1J r = jac_inf<Fp>();
         if (any && !qinf) {
             const Fp X = ws[SX], Y = ws[SY], Z = ws[SZ];
-            r.x = fmul(X, Z); r.y = fmul(Y, fsqr(Z)); r.z = Z;
-            if (exc) atomicOr(flag, 1u);
+            if (!Z.is_zero()) { r.x = fmul(X, Z); r.y = fmul(Y, fsqr(Z)); r.z = Z; }
         }
         out[i] = add_mixed(r, lo[i]);
     }
