@@ -208,6 +208,27 @@ int32_t ripp_tipa_ssm_verify(const ripp_verifier_srs* v_srs, const ripp_gt* com_
 int32_t ripp_verify_aggregate_proof(const ripp_verifier_srs* v_srs, const ripp_groth16_vk* vk, const ripp_fr* public_inputs, size_t n, size_t m,
                                     const ripp_aggregate_proof* proof, int32_t* accept);
 
+/* ---- wire format: ark-serialize 0.4 images of the proof structs, host only ---------------------
+ * compress = 0: `serialize_uncompressed`, 1: `serialize_compressed`.  Steps are passed in ROUND order and written reversed, as
+ * GIPAProof stores them (gipa.rs:298-299).  Serialisers return the image size and write it when cap is large enough (out may be
+ * NULL to query); deserialisers validate like `deserialize_*` with Validate::Yes (range, curve equation, prime-order subgroup) and
+ * return RIPP_ERR_ARG on a malformed image.
+ *   GIPAProof (gipa.rs:24-51): pass final_ck_a == NULL.   TIPAProof (tipa/mod.rs:41-65): all members. */
+size_t  ripp_ser_tipa_tipp_proof(const ripp_gt* com_steps, size_t rounds, const ripp_g1j* base_a, const ripp_g2j* base_b,
+                                 const ripp_g2j* final_ck_a, const ripp_g1j* final_ck_b, const ripp_g2j* opening_a, const ripp_g1j* opening_b,
+                                 int32_t compress, uint8_t* out, size_t cap);
+int32_t ripp_de_tipa_tipp_proof(const uint8_t* in, size_t len, int32_t compress, int32_t with_tipa, size_t max_rounds, size_t* rounds,
+                                ripp_gt* com_steps, ripp_g1j* base_a, ripp_g2j* base_b,
+                                ripp_g2j* final_ck_a, ripp_g1j* final_ck_b, ripp_g2j* opening_a, ripp_g1j* opening_b);
+/* TIPAWithSSMProof (tipa/structured_scalar_message.rs:138-156) */
+size_t  ripp_ser_tipa_ssm_proof(const ripp_gt* com_gt, const ripp_g1j* com_g1, size_t rounds, const ripp_g1j* base_a, const ripp_fr* base_b,
+                                const ripp_g2j* final_ck_a, const ripp_g2j* opening_a, int32_t compress, uint8_t* out, size_t cap);
+int32_t ripp_de_tipa_ssm_proof(const uint8_t* in, size_t len, int32_t compress, size_t max_rounds, size_t* rounds,
+                               ripp_gt* com_gt, ripp_g1j* com_g1, ripp_g1j* base_a, ripp_fr* base_b, ripp_g2j* final_ck_a, ripp_g2j* opening_a);
+/* single group elements, compressed (48 / 96 bytes) */
+size_t  ripp_ser_g1_compressed(const ripp_g1a* p, uint8_t out[48]);
+size_t  ripp_ser_g2_compressed(const ripp_g2a* p, uint8_t out[96]);
+
 /* ---- host-side helpers (no device needed): what the host code around the kernels computes ---------------- */
 int32_t ripp_final_exp(const ripp_gt* miller_value, ripp_gt* out);                 /* Pairing::final_exponentiation */
 int32_t ripp_miller_combine(const ripp_gt* step_products /* [68] */, ripp_gt* out); /* stage (3) of pairing.hpp */

@@ -15,7 +15,7 @@ from ._lib import lib, last_error, RippStats, AggregateProof, VerifierSRSStruct,
 
 __all__ = ["InnerProductError", "DeviceError", "PairingInnerProduct", "MultiexponentiationInnerProductG1",
            "MultiexponentiationInnerProductG2", "AFGHOCommitmentG1", "AFGHOCommitmentG2", "PedersenCommitmentG1",
-           "PedersenCommitmentG2", "SIPP", "SippJob", "GIPA_TIPP", "SRS", "TIPA_TIPP", "TIPAWithSSM", "aggregate_proofs", "verify_aggregate_proof", "AggregateProof", "product_of_pairings", "product_of_pairings_with_coeffs",
+           "PedersenCommitmentG2", "SIPP", "SippJob", "GIPA_TIPP", "SRS", "TIPA_TIPP", "TIPAWithSSM", "aggregate_proofs", "verify_aggregate_proof", "AggregateProof", "ser_tipa_tipp_proof", "de_tipa_tipp_proof", "ser_tipa_ssm_proof", "de_tipa_ssm_proof", "ser_g1_compressed", "ser_g2_compressed", "product_of_pairings", "product_of_pairings_with_coeffs",
            "normalize_batch_g1", "normalize_batch_g2", "fold_g1_affine", "fold_g2_affine", "fold_g1", "fold_g2",
            "scale_g1_affine", "synth_g1", "synth_g2", "synth_fr", "init", "device_count", "final_exponentiation",
            "ser_gt", "ser_g1", "ser_g2", "ser_fr", "sipp_seed_digest", "gt_mul"]
@@ -502,6 +502,56 @@ def aggregate_proofs(ip_srs, a, b, c):
     pf = AggregateProof(len(a)); st = RippStats()
     _check(lib().ripp_aggregate_proofs(ip_srs._h, _p(a), _p(b), _p(c), ctypes.c_size_t(len(a)), pf.ref(), ctypes.byref(st)))
     return pf, st.as_dict()
+
+
+# ------------------------------------------------------------------ wire format (CanonicalSerialize images of the proof structs)
+def ser_tipa_tipp_proof(proof, compress=True, with_tipa=True):
+    """TIPAProof (tipa/mod.rs:41-65) -- or GIPAProof (gipa.rs:24-51) with with_tipa=False -- from a prove_with_srs_shift dict."""
+    steps = np.ascontiguousarray(proof["steps"], dtype=np.uint64).reshape(-1, 72); rounds = len(steps) // 6
+    z = ctypes.c_void_p(None)
+    args = [_p(steps), ctypes.c_size_t(rounds), _p(_a(proof["base_a"], 18)), _p(_a(proof["base_b"], 36))]
+    args += [_p(_a(proof["final_ck_a"], 36)), _p(_a(proof["final_ck_b"], 18)), _p(_a(proof["opening_a"], 36)), _p(_a(proof["opening_b"], 18))] if with_tipa else [z, z, z, z]
+    lib().ripp_ser_tipa_tipp_proof.restype = ctypes.c_size_t
+    n = lib().ripp_ser_tipa_tipp_proof(*args, ctypes.c_int32(int(compress)), z, ctypes.c_size_t(0))
+    out = np.zeros(n, dtype=np.uint8)
+    assert lib().ripp_ser_tipa_tipp_proof(*args, ctypes.c_int32(int(compress)), _p(out), ctypes.c_size_t(n)) == n
+    return bytes(out)
+
+
+def de_tipa_tipp_proof(data, compress=True, with_tipa=True, max_rounds=64):
+    buf = np.frombuffer(bytes(data), dtype=np.uint8).copy()
+    o = dict(steps=np.zeros((max_rounds * 6, 72), dtype=np.uint64), base_a=np.zeros(18, dtype=np.uint64), base_b=np.zeros(36, dtype=np.uint64),
+             final_ck_a=np.zeros(36, dtype=np.uint64), final_ck_b=np.zeros(18, dtype=np.uint64), opening_a=np.zeros(36, dtype=np.uint64), opening_b=np.zeros(18, dtype=np.uint64))
+    rounds = ctypes.c_size_t(0)
+    _check(lib().ripp_de_tipa_tipp_proof(_p(buf), ctypes.c_size_t(len(buf)), ctypes.c_int32(int(compress)), ctypes.c_int32(int(with_tipa)), ctypes.c_size_t(max_rounds),
+                                         ctypes.byref(rounds), _p(o["steps"]), _p(o["base_a"]), _p(o["base_b"]), _p(o["final_ck_a"]), _p(o["final_ck_b"]), _p(o["opening_a"]), _p(o["opening_b"])))
+    o["steps"] = o["steps"][: rounds.value * 6].copy(); return o
+
+
+def ser_tipa_ssm_proof(proof, compress=True):
+    """TIPAWithSSMProof (tipa/structured_scalar_message.rs:138-156) from a prove_with_structured_scalar_message dict."""
+    com_gt = np.ascontiguousarray(proof["com_gt"], dtype=np.uint64).reshape(-1, 72); com_g1 = np.ascontiguousarray(proof["com_g1"], dtype=np.uint64).reshape(-1, 18)
+    rounds = len(com_gt) // 2; z = ctypes.c_void_p(None)
+    args = [_p(com_gt), _p(com_g1), ctypes.c_size_t(rounds), _p(_a(proof["base_a"], 18)), _p(_a(proof["base_b"], 4)), _p(_a(proof["final_ck_a"], 36)), _p(_a(proof["opening_a"], 36)), ctypes.c_int32(int(compress))]
+    lib().ripp_ser_tipa_ssm_proof.restype = ctypes.c_size_t
+    n = lib().ripp_ser_tipa_ssm_proof(*args, z, ctypes.c_size_t(0))
+    out = np.zeros(n, dtype=np.uint8)
+    assert lib().ripp_ser_tipa_ssm_proof(*args, _p(out), ctypes.c_size_t(n)) == n
+    return bytes(out)
+
+
+def de_tipa_ssm_proof(data, compress=True, max_rounds=64):
+    buf = np.frombuffer(bytes(data), dtype=np.uint8).copy()
+    o = dict(com_gt=np.zeros((max_rounds * 2, 72), dtype=np.uint64), com_g1=np.zeros((max_rounds * 2, 18), dtype=np.uint64), base_a=np.zeros(18, dtype=np.uint64),
+             base_b=np.zeros(4, dtype=np.uint64), final_ck_a=np.zeros(36, dtype=np.uint64), opening_a=np.zeros(36, dtype=np.uint64))
+    rounds = ctypes.c_size_t(0)
+    _check(lib().ripp_de_tipa_ssm_proof(_p(buf), ctypes.c_size_t(len(buf)), ctypes.c_int32(int(compress)), ctypes.c_size_t(max_rounds), ctypes.byref(rounds),
+                                        _p(o["com_gt"]), _p(o["com_g1"]), _p(o["base_a"]), _p(o["base_b"]), _p(o["final_ck_a"]), _p(o["opening_a"])))
+    o["com_gt"] = o["com_gt"][: rounds.value * 2].copy(); o["com_g1"] = o["com_g1"][: rounds.value * 2].copy(); return o
+
+
+def ser_g1_compressed(p): return _ser(lib().ripp_ser_g1_compressed, p, 48)
+def ser_g2_compressed(p): return _ser(lib().ripp_ser_g2_compressed, p, 96)
 
 
 # ------------------------------------------------------------------ host helpers / synthetic inputs

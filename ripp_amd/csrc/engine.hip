@@ -21,6 +21,7 @@
 #include "msm.hpp"
 #include "vm.hpp"
 #include "host_fs.hpp"
+#include "wire.hpp"
 
 using namespace ripp;
 
@@ -1472,6 +1473,87 @@ API int32_t ripp_sipp_challenge(uint8_t seed[32], const ripp_gt* z_l, const ripp
     fs::FiatShamirRng rng; rng.from_digest(seed); Fp12 a, b; std::memcpy(&a, z_l, sizeof a); std::memcpy(&b, z_r, sizeof b);
     const Fr c = fs::sipp_challenge(rng, a, b); std::memcpy(seed, rng.seed, 32); std::memcpy(x, &c, sizeof c); return RIPP_OK;
 }
+
+// ---- wire format (wire.hpp) -----------------------------------------------------------------------------------------------
+extern "C++" {
+static size_t emit(const wire::Writer& w, uint8_t* out, size_t cap) { if (out && cap >= w.b.size()) std::memcpy(out, w.b.data(), w.b.size()); return w.b.size(); }
+static G1A aff1(const ripp_g1j* p) { return to_affine(load_jac<Fp>(p)); }
+static G2A aff2(const ripp_g2j* p) { return to_affine(load_jac<Fp2>(p)); }
+template <class F> static void store_jac(void* dst, const Affine<F>& a) { const Jac<F> j = to_jac(a); std::memcpy(dst, &j, sizeof j); }
+}
+API size_t ripp_ser_tipa_tipp_proof(const ripp_gt* com_steps, size_t rounds, const ripp_g1j* base_a, const ripp_g2j* base_b,
+                                    const ripp_g2j* final_ck_a, const ripp_g1j* final_ck_b, const ripp_g2j* opening_a, const ripp_g1j* opening_b,
+                                    int32_t compress, uint8_t* out, size_t cap) {
+    if (!base_a || !base_b || (rounds && !com_steps) || (final_ck_a && (!final_ck_b || !opening_a || !opening_b))) return 0;
+    const bool c = compress != 0; wire::Writer w;
+    w.u64(rounds);                                                                // r_commitment_steps: Vec<(com_1, com_2)>, last round first
+    for (size_t k = rounds; k-- > 0;) {
+        for (int side = 0; side < 2; ++side) {                                     // (LMC::Output, RMC::Output, IPC::Output = IdentityOutput(Vec<GT>))
+            w.gt(load_gt(&com_steps[6 * k + 3 * side])); w.gt(load_gt(&com_steps[6 * k + 3 * side + 1]));
+            w.u64(1); w.gt(load_gt(&com_steps[6 * k + 3 * side + 2]));
+        }
+    }
+    w.g1(aff1(base_a), c); w.g2(aff2(base_b), c);                                  // r_base
+    if (final_ck_a) { w.g2(aff2(final_ck_a), c); w.g1(aff1(final_ck_b), c); w.g2(aff2(opening_a), c); w.g1(aff1(opening_b), c); }   // final_ck, final_ck_proof
+    return emit(w, out, cap);
+}
+API int32_t ripp_de_tipa_tipp_proof(const uint8_t* in, size_t len, int32_t compress, int32_t with_tipa, size_t max_rounds, size_t* rounds,
+                                    ripp_gt* com_steps, ripp_g1j* base_a, ripp_g2j* base_b,
+                                    ripp_g2j* final_ck_a, ripp_g1j* final_ck_b, ripp_g2j* opening_a, ripp_g1j* opening_b) {
+    if (!in || !rounds || !base_a || !base_b || (with_tipa && (!final_ck_a || !final_ck_b || !opening_a || !opening_b))) return RIPP_ERR_ARG;
+    const bool c = compress != 0; wire::Reader r{in, len};
+    const uint64_t n = r.u64();
+    if (!r.ok || n > max_rounds || (n && !com_steps)) { set_err("proof image: bad step count"); return RIPP_ERR_ARG; }
+    for (uint64_t i = 0; i < n && r.ok; ++i) {
+        const size_t k = (size_t)(n - 1 - i);
+        for (int side = 0; side < 2 && r.ok; ++side) {
+            Fp12 a, b, t; r.gt(a); r.gt(b); if (r.u64() != 1) r.ok = false; r.gt(t);
+            if (r.ok) { std::memcpy(&com_steps[6 * k + 3 * side], &a, sizeof a); std::memcpy(&com_steps[6 * k + 3 * side + 1], &b, sizeof b); std::memcpy(&com_steps[6 * k + 3 * side + 2], &t, sizeof t); }
+        }
+    }
+    G1A a1, kb, ob; G2A b2, ka, oa;
+    r.g1(a1, c); r.g2(b2, c);
+    if (with_tipa) { r.g2(ka, c); r.g1(kb, c); r.g2(oa, c); r.g1(ob, c); }
+    if (!r.ok || r.left != 0) { set_err("proof image: malformed, out-of-range or off-curve member, or trailing bytes"); return RIPP_ERR_ARG; }
+    *rounds = (size_t)n; store_jac<Fp>(base_a, a1); store_jac<Fp2>(base_b, b2);
+    if (with_tipa) { store_jac<Fp2>(final_ck_a, ka); store_jac<Fp>(final_ck_b, kb); store_jac<Fp2>(opening_a, oa); store_jac<Fp>(opening_b, ob); }
+    return RIPP_OK;
+}
+API size_t ripp_ser_tipa_ssm_proof(const ripp_gt* com_gt, const ripp_g1j* com_g1, size_t rounds, const ripp_g1j* base_a, const ripp_fr* base_b,
+                                   const ripp_g2j* final_ck_a, const ripp_g2j* opening_a, int32_t compress, uint8_t* out, size_t cap) {
+    if (!base_a || !base_b || !final_ck_a || !opening_a || (rounds && (!com_gt || !com_g1))) return 0;
+    const bool c = compress != 0; wire::Writer w;
+    w.u64(rounds);
+    for (size_t k = rounds; k-- > 0;)
+        for (int side = 0; side < 2; ++side) {                                     // (GT, Fr::zero() placeholder, IdentityOutput(Vec<G1>))
+            w.gt(load_gt(&com_gt[2 * k + side])); w.fr(Fr::zero()); w.u64(1); w.g1(aff1(&com_g1[2 * k + side]), c);
+        }
+    w.g1(aff1(base_a), c); w.fr(load_fr(base_b));                                  // r_base = (G1, Fr)
+    w.g2(aff2(final_ck_a), c); w.g2(aff2(opening_a), c);
+    return emit(w, out, cap);
+}
+API int32_t ripp_de_tipa_ssm_proof(const uint8_t* in, size_t len, int32_t compress, size_t max_rounds, size_t* rounds,
+                                   ripp_gt* com_gt, ripp_g1j* com_g1, ripp_g1j* base_a, ripp_fr* base_b, ripp_g2j* final_ck_a, ripp_g2j* opening_a) {
+    if (!in || !rounds || !base_a || !base_b || !final_ck_a || !opening_a) return RIPP_ERR_ARG;
+    const bool c = compress != 0; wire::Reader r{in, len};
+    const uint64_t n = r.u64();
+    if (!r.ok || n > max_rounds || (n && (!com_gt || !com_g1))) { set_err("proof image: bad step count"); return RIPP_ERR_ARG; }
+    for (uint64_t i = 0; i < n && r.ok; ++i) {
+        const size_t k = (size_t)(n - 1 - i);
+        for (int side = 0; side < 2 && r.ok; ++side) {
+            Fp12 g; Fr z; G1A t; r.gt(g); r.fr(z); if (r.u64() != 1) r.ok = false; r.g1(t, c);
+            if (r.ok && !z.is_zero()) r.ok = false;                                // SSMPlaceholderCommitment::commit is always zero (ssm.rs:44-46)
+            if (r.ok) { std::memcpy(&com_gt[2 * k + side], &g, sizeof g); store_jac<Fp>(&com_g1[2 * k + side], t); }
+        }
+    }
+    G1A a1; Fr sb; G2A ka, oa;
+    r.g1(a1, c); r.fr(sb); r.g2(ka, c); r.g2(oa, c);
+    if (!r.ok || r.left != 0) { set_err("proof image: malformed, out-of-range or off-curve member, or trailing bytes"); return RIPP_ERR_ARG; }
+    *rounds = (size_t)n; store_jac<Fp>(base_a, a1); std::memcpy(base_b, &sb, sizeof sb); store_jac<Fp2>(final_ck_a, ka); store_jac<Fp2>(opening_a, oa);
+    return RIPP_OK;
+}
+API size_t ripp_ser_g1_compressed(const ripp_g1a* p, uint8_t out[48]) { G1A x; std::memcpy(&x, p, sizeof x); wire::put_g1(x, true, out); return 48; }
+API size_t ripp_ser_g2_compressed(const ripp_g2a* p, uint8_t out[96]) { G2A x; std::memcpy(&x, p, sizeof x); wire::put_g2(x, true, out); return 96; }
 
 // ---- synthetic inputs ---------------------------------------------------------------------------------------------------
 extern "C++" {
