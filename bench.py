@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_PAIR = 288          # one affine G1 (96 B) + one affine G2 (192 B) read once
 HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP_MUL_PEAK_G = 59.6              # measured chip rate of the 381-bit Montgomery multiplier (G products/s, tools/ubench/fpbench.hip)
 
 
 def cpu_baseline(log_n_sample):
@@ -155,6 +156,12 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": dom[2] * ALG_BYTES_PER_PAIR / max(dom[1], 1),
                          "avg_launch_ms": dom[0] / max(dom[1], 1), "launches_per_step": dom[1], "pairs_per_step": dom[2],
+                         # the roof that actually binds: 381-bit Montgomery products on the VALU.  Algorithmic Fp products per pair of the
+                         # kernel (k_line_products: 68 sparse mul_by_014 of 13 Fp2 = 39 Fp products; k_miller_lines: 63 doubling steps of 25
+                         # + 5 addition steps of 41) against the multiplier's measured chip rate (profiles/r01_fpbench_cios_baseline.txt).
+                         "int_alu": (lambda fpm: {"unit": "G Fp-mul/s", "achieved": dom[2] * fpm / (dom[0] * 1e-3) / 1e9 if dom[0] > 0 else 0.0, "peak": FP_MUL_PEAK_G,
+                                                  "frac": (dom[2] * fpm / (dom[0] * 1e-3) / 1e9 / FP_MUL_PEAK_G) if dom[0] > 0 else 0.0,
+                                                  "fp_products_per_pair": fpm})(68 * 39 if dom[3] == "k_line_products" else 63 * 25 + 5 * 41),
                          "note": "integer-ALU bound (381-bit Montgomery arithmetic, ~5e3 Fp products per 288 input bytes); see DESIGN.md"},
             "phase_ms": {k: round(v, 3) for k, v in stats.items() if k.endswith("_ms")},
         }

@@ -1446,9 +1446,15 @@ API int32_t ripp_sipp_prove(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr*
 
 API int32_t ripp_sipp_seed_digest(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr* r, size_t n, const ripp_gt* value, uint8_t digest[32]) {
     if (!value || !digest || (n && (!a || !b || !r))) return RIPP_ERR_ARG;
-    std::vector<G1A> ha(n); std::vector<G2A> hb(n); std::vector<Fr> hr(n); Fp12 v;
+    Fp12 v; std::memcpy(&v, value, sizeof(Fp12));
+    // the flat C-ABI structs ARE the engine's types (static_asserts at the top of this file): hash in place -- no 336 MB copy on the
+    // critical path -- whenever the caller's buffers meet the engine types' 16-byte alignment
+    if ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)r) & 15u) == 0) {
+        statement_digest(reinterpret_cast<const G1A*>(a), reinterpret_cast<const G2A*>(b), reinterpret_cast<const Fr*>(r), n, v, digest);
+        return RIPP_OK;
+    }
+    std::vector<G1A> ha(n); std::vector<G2A> hb(n); std::vector<Fr> hr(n);
     if (n) { std::memcpy(ha.data(), a, n * sizeof(G1A)); std::memcpy(hb.data(), b, n * sizeof(G2A)); std::memcpy(hr.data(), r, n * sizeof(Fr)); }
-    std::memcpy(&v, value, sizeof(Fp12));
     statement_digest(ha.data(), hb.data(), hr.data(), n, v, digest);
     return RIPP_OK;
 }
