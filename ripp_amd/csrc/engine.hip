@@ -326,6 +326,24 @@ GlsDigits gls_digits(const Fr& s_mont) {
     return g;
 }
 
+// s = s1 + s2 * lambda (lambda = u^2 - 1 ~ sqrt(r)) by binary long division of the canonical scalar; both halves NAF-recoded
+GlvDigits glv_digits(const Fr& s_mont) {
+    const Fr c = from_mont(s_mont);
+    const uint32_t lam[8] = RIPP_GLV_LAMBDA;
+    uint32_t rem[9] = {0}, quo[8] = {0};
+    for (int bit = 255; bit >= 0; --bit) {                      // rem = rem * 2 + bit;  if rem >= lambda: rem -= lambda, quotient bit = 1
+        for (int i = 8; i > 0; --i) rem[i] = (rem[i] << 1) | (rem[i - 1] >> 31);
+        rem[0] = (rem[0] << 1) | ((c.l[bit >> 5] >> (bit & 31)) & 1u);
+        bool ge = rem[8] != 0;
+        if (!ge) { ge = true; for (int i = 7; i >= 0; --i) { if (rem[i] != lam[i]) { ge = rem[i] > lam[i]; break; } } }
+        if (ge) { uint32_t borrow = 0; for (int i = 0; i < 8; ++i) rem[i] = subb32(rem[i], lam[i], borrow); rem[8] -= borrow; quo[bit >> 5] |= 1u << (bit & 31); }
+    }
+    GlvDigits g; std::memset(&g, 0, sizeof g);
+    const int l1 = naf_recode(rem, 5, g.d1, 131), l2 = naf_recode(quo, 5, g.d2, 131);
+    g.len = l1 > l2 ? l1 : l2;
+    return g;
+}
+
 template <class T> int32_t upload(Engine* e, DevBuf& buf, const void* host, size_t n, T** dev) {
     int32_t rc = buf.reserve(std::max<size_t>(n, 1) * sizeof(T)); if (rc != RIPP_OK) return rc;
     if (n) HIPCHK(hipMemcpyAsync(buf.p, host, n * sizeof(T), hipMemcpyHostToDevice, e->stream));
@@ -702,10 +720,11 @@ extern "C++" {
 template <class F> static int32_t fold_dev(Engine* e, hipStream_t st, const Affine<F>* hi, const Affine<F>* lo, size_t half, const Fr& s, DevBuf& jac, DevBuf& qt, Affine<F>* out);
 template <> int32_t fold_dev<Fp>(Engine* e, hipStream_t st, const G1A* hi, const G1A* lo, size_t half, const Fr& s, DevBuf& jac, DevBuf&, G1A* out) {
     int32_t rc; if ((rc = jac.reserve(half * sizeof(G1J)))) return rc;
-    if (half <= e->vm_fold_max && !std::getenv("RIPP_NO_VM"))     // latency form; e->vm_flag reports exceptional additions
-        hipLaunchKernelGGL(k_vm_fold_g1, dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VM_G1_SLOTS * sizeof(Fp), st, hi, lo, (uint32_t)half, naf_digits(s), jac.as<G1J>(), e->vm_flag.as<uint32_t>());
+    // GIPA folds G1 vectors with the full-width challenge c: split it through the GLV endomorphism (128 doublings instead of 255)
+    if (half <= e->vm_fold_max && !std::getenv("RIPP_NO_VM"))     // latency form (complete additions, nothing to flag)
+        hipLaunchKernelGGL(k_vm_fold_g1_glv, dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VM_G1_SLOTS * sizeof(Fp), st, hi, lo, (uint32_t)half, glv_digits(s), jac.as<G1J>());
     else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_affine_naf<Fp>), dim3(nblk(half, 256)), dim3(256), 0, st, hi, lo, (uint32_t)half, naf_digits(s), jac.as<G1J>());
+        hipLaunchKernelGGL(k_fold_g1_glv, dim3(nblk(half, 256)), dim3(256), 0, st, hi, lo, (uint32_t)half, glv_digits(s), jac.as<G1J>());
     HIPCHK(hipGetLastError());
     return e->normalize_dev<Fp>(jac.as<G1J>(), half, out, st);
 }

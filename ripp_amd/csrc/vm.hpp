@@ -241,4 +241,40 @@ __global__ void __launch_bounds__(256) k_vm_fold_g1(const G1A* __restrict__ hi, 
     }
 }
 
+// G1 fold with a full-width scalar in latency form: the GLV halves of kernels.hpp::k_fold_g1_glv on the field VM
+// (128 VM doublings, complete additions of +-P and +-phi(P)).
+__global__ void __launch_bounds__(256) k_vm_fold_g1_glv(const G1A* __restrict__ hi, const G1A* __restrict__ lo, uint32_t half, GlvDigits dg, G1J* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char vm_smem[];
+    Fp* const lds = reinterpret_cast<Fp*>(vm_smem);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lg = lane & (VM_G - 1), grp = lane / VM_G;
+    const uint32_t i = (blockIdx.x * 4 + wave) * VM_EPW + grp;
+    Fp* const ws = lds + (size_t)(wave * VM_EPW + grp) * VM_G1_SLOTS;
+    const bool active = i < half;
+    namespace vp = vmprog;
+    enum { SX = vp::g1_cadd_g16_in_X0, SY = vp::g1_cadd_g16_in_Y0, SZ = vp::g1_cadd_g16_in_Z0, SQX = vp::g1_cadd_g16_in_qx0, SQY = vp::g1_cadd_g16_in_qy0, SQZ = vp::g1_cadd_g16_in_qz0 };
+    G1A q = aff_inf<Fp>(); Fp bx = Fp::zero(); bool qinf = true;
+    if (active && lg == 0) { q = hi[i]; qinf = is_inf(q); bx = fmul(q.x, fp_const(RIPP_GLV_BETA)); ws[0] = Fp::zero(); ws[SX] = Fp::zero(); ws[SY] = Fp::one(); ws[SZ] = Fp::zero(); }   // T = identity (0:1:0)
+#pragma unroll 1
+    for (int pos = dg.len - 1; pos >= 0; --pos) {
+        vm_run(ws, vp::g1_hdbl_g16_kind, vp::g1_hdbl_g16_ops, vp::g1_hdbl_g16_nlayers, lg);
+        const int d1 = dg.d1[pos], d2 = dg.d2[pos];
+        if (d1 != 0) {
+            if (active && lg == 0) { ws[SQX] = q.x; ws[SQY] = d1 < 0 ? neg(q.y) : q.y; ws[SQZ] = Fp::one(); }
+            vm_run(ws, vp::g1_cadd_g16_kind, vp::g1_cadd_g16_ops, vp::g1_cadd_g16_nlayers, lg);
+        }
+        if (d2 != 0) {
+            if (active && lg == 0) { ws[SQX] = bx; ws[SQY] = d2 < 0 ? neg(q.y) : q.y; ws[SQZ] = Fp::one(); }
+            vm_run(ws, vp::g1_cadd_g16_kind, vp::g1_cadd_g16_ops, vp::g1_cadd_g16_nlayers, lg);
+        }
+    }
+    if (active && lg == 0) {
+        G1J r = jac_inf<Fp>();
+        if (!qinf) {
+            const Fp X = ws[SX], Y = ws[SY], Z = ws[SZ];
+            if (!Z.is_zero()) { r.x = fmul(X, Z); r.y = fmul(Y, fsqr(Z)); r.z = Z; }
+        }
+        out[i] = add_mixed(r, lo[i]);
+    }
+}
+
 }  // namespace ripp
