@@ -174,12 +174,12 @@ struct Engine {
         hipLaunchKernelGGL(k_msm_scatter, dim3(nblk(n, 256)), dim3(256), 0, st, ms.digits.as<uint16_t>(), p, ms.cursor.as<uint32_t>(), ms.sorted.as<uint32_t>());
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_slot_sum<F>), dim3(nblk(max_slots, 64), p.nwin), dim3(64), 0, st, bases, p, ms.hist.as<uint32_t>(), ms.offs.as<uint32_t>(),
                            ms.slotoffs.as<uint32_t>(), ms.spw.as<uint32_t>(), ms.sorted.as<uint32_t>(), ms.slots.as<Jac<F>>(), max_slots);
-        const uint32_t grouped = n > (size_t)MSM_SLOT_GROUP * p.ch ? 1u : 0u;      // otherwise no bucket can hold more than MSM_SLOT_GROUP slots
-        if (grouped)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_slot_group<F>), dim3(nblk(max_slots, 64), p.nwin), dim3(64), 0, st, p, ms.hist.as<uint32_t>(), ms.slotoffs.as<uint32_t>(),
-                               ms.spw.as<uint32_t>(), ms.slots.as<Jac<F>>(), max_slots);
+        uint32_t passes = 0;                                                       // a bucket holds at most n / ch + 1 slots
+        for (uint32_t stride = 1; passes < (uint32_t)MSM_GROUP_PASSES && n / p.ch + 1 > (size_t)MSM_SLOT_GROUP * stride; stride *= MSM_SLOT_GROUP, ++passes)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_slot_group<F>), dim3(nblk(max_slots, 64), p.nwin), dim3(64), 0, st, p, ms.hist.as<uint32_t>(),
+                               ms.slotoffs.as<uint32_t>(), ms.spw.as<uint32_t>(), ms.slots.as<Jac<F>>(), max_slots, stride);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_bucket_merge<F>), dim3(nblk(p.nb, 64), p.nwin), dim3(64), 0, st, p, ms.hist.as<uint32_t>(), ms.slotoffs.as<uint32_t>(),
-                           ms.slots.as<Jac<F>>(), max_slots, ms.buckets.as<Jac<F>>(), grouped);
+                           ms.slots.as<Jac<F>>(), max_slots, ms.buckets.as<Jac<F>>(), passes);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_segments<F>), dim3(nblk(nseg, 64), p.nwin), dim3(64), 0, st, p, ms.buckets.as<Jac<F>>(), ms.seg.as<Jac<F>>(), nseg);
         Jac<F>* cur = ms.seg.as<Jac<F>>(); Jac<F>* nxt = ms.seg2.as<Jac<F>>();
         while (nseg > (uint32_t)MSM_SEG_FAN) {                 // tree over the segment sums: chains of <= 16 additions

@@ -21,6 +21,7 @@
 // there; slots of 256 terms once the launch fills the chip.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "bls12_381/curve.hpp"
 #include "vm.hpp"
 
@@ -34,7 +35,8 @@ inline MsmPlan msm_plan(size_t n) {
     int lg = 0; while (((size_t)1 << (lg + 1)) <= n) ++lg;
     int c = lg - 6; if (c < 4) c = 4; if (c > 13) c = 13;
     MsmPlan p; p.c = c; p.nwin = (255 + c - 1) / c; p.nb = 1u << c; p.n = (uint32_t)n;
-    p.ch = n <= ((size_t)1 << 16) ? 32u : 256u;
+    p.ch = n > ((size_t)1 << 20) ? 64u : 32u;   // measured crossover (tools/msm_sweep.py): slots of 32 fill the chip best up to 2^20 terms
+    if (const char* e = std::getenv("RIPP_MSM_CH")) p.ch = (uint32_t)std::strtoul(e, nullptr, 10);
     p.seg = p.nb / 4 < 16 ? p.nb / 4 : 16;
     return p;
 }
@@ -85,7 +87,7 @@ __global__ void __launch_bounds__(256) k_msm_scatter(const uint16_t* __restrict_
 
 // grid.y = window; lane = slot index within the window (max_slots lanes per window, surplus lanes exit)
 template <class F>
-__global__ void __launch_bounds__(64) k_msm_slot_sum(const Affine<F>* __restrict__ bases, MsmPlan p, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offs,
+__global__ void __launch_bounds__(64, 2) k_msm_slot_sum(const Affine<F>* __restrict__ bases, MsmPlan p, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offs,
                                                       const uint32_t* __restrict__ slot_offs, const uint32_t* __restrict__ slots_per_window,
                                                       const uint32_t* __restrict__ sorted, Jac<F>* __restrict__ slot_sums, uint32_t max_slots) {
     const int w = blockIdx.y;
@@ -109,14 +111,16 @@ __global__ void __launch_bounds__(64) k_msm_slot_sum(const Affine<F>* __restrict
 }
 
 // Buckets that collect many slots (the short TOP window puts n / 2^(255 mod c) terms into each of its few buckets; skewed scalar sets
-// do the same anywhere) would serialise the merge: first add the slots in groups of MSM_SLOT_GROUP, in place -- lane per slot, group
-// leaders do the work -- so that the final per-bucket merge walks ceil(ns / MSM_SLOT_GROUP) partial sums.
+// do the same anywhere) would serialise the merge.  The slot sums of such a bucket are first added in groups of MSM_SLOT_GROUP, in
+// place and hierarchically: pass j (stride 8^j) lets the leader of every 8 * 8^j slots add the 8 partial sums below it, for buckets
+// with more than 8 * 8^j slots.  After P passes the per-bucket merge walks at most max(8, ns / 8^P) partial sums.
 constexpr uint32_t MSM_SLOT_GROUP = 8;
+constexpr int MSM_GROUP_PASSES = 3;
 template <class F>
 __global__ void __launch_bounds__(64) k_msm_slot_group(MsmPlan p, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ slot_offs,
-                                                        const uint32_t* __restrict__ slots_per_window, Jac<F>* __restrict__ slot_sums, uint32_t max_slots) {
+                                                        const uint32_t* __restrict__ slots_per_window, Jac<F>* __restrict__ slot_sums, uint32_t max_slots, uint32_t stride) {
     const int w = blockIdx.y;
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;                     // slot index in the window; leaders are relative to their BUCKET's first slot
     if (s >= slots_per_window[w]) return;
     const uint32_t* so = slot_offs + (size_t)w * p.nb;
     uint32_t lo = 0, hi = p.nb - 1;
@@ -124,24 +128,24 @@ __global__ void __launch_bounds__(64) k_msm_slot_group(MsmPlan p, const uint32_t
     uint32_t d = lo;
     while (d > 0 && (hist[(size_t)w * p.nb + d] + p.ch - 1) / p.ch + so[d] <= s) --d;
     const uint32_t ns = (hist[(size_t)w * p.nb + d] + p.ch - 1) / p.ch, k0 = s - so[d];
-    if (ns <= MSM_SLOT_GROUP || (k0 % MSM_SLOT_GROUP) != 0) return;
-    const uint32_t k1 = min(k0 + MSM_SLOT_GROUP, ns);
+    if (ns <= MSM_SLOT_GROUP * stride || (k0 % (MSM_SLOT_GROUP * stride)) != 0) return;
     Jac<F>* base = slot_sums + (size_t)w * max_slots + so[d];
     Jac<F> acc = base[k0];
 #pragma unroll 1
-    for (uint32_t k = k0 + 1; k < k1; ++k) acc = add(acc, base[k]);
+    for (uint32_t k = k0 + stride; k < k0 + MSM_SLOT_GROUP * stride && k < ns; k += stride) acc = add(acc, base[k]);
     base[k0] = acc;
 }
 
-// lane per (window, bucket): bucket = sum of its slots (of its slot-group sums when the bucket has more than MSM_SLOT_GROUP slots)
+// lane per (window, bucket): bucket = sum of its slots (of its group sums when the bucket went through `passes` grouping passes)
 template <class F>
 __global__ void __launch_bounds__(64) k_msm_bucket_merge(MsmPlan p, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ slot_offs,
-                                                          const Jac<F>* __restrict__ slot_sums, uint32_t max_slots, Jac<F>* __restrict__ buckets, uint32_t grouped) {
+                                                          const Jac<F>* __restrict__ slot_sums, uint32_t max_slots, Jac<F>* __restrict__ buckets, uint32_t passes) {
     const int w = blockIdx.y;
     const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= p.nb) return;
     const uint32_t cnt = hist[(size_t)w * p.nb + d], ns = (cnt + p.ch - 1) / p.ch, s0 = slot_offs[(size_t)w * p.nb + d];
-    const uint32_t step = (grouped && ns > MSM_SLOT_GROUP) ? MSM_SLOT_GROUP : 1u;
+    uint32_t step = 1;
+    for (uint32_t j = 0; j < passes && ns > MSM_SLOT_GROUP * step; ++j) step *= MSM_SLOT_GROUP;
     Jac<F> acc = jac_inf<F>();
 #pragma unroll 1
     for (uint32_t k = 0; k < ns; k += step) { const Jac<F> t = slot_sums[(size_t)w * max_slots + s0 + k]; acc = (k == 0) ? t : add(acc, t); }

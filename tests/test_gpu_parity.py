@@ -117,6 +117,24 @@ def test_msm_adversarial_scalars(engine, orc):
         assert np.array_equal(got, orc.g1_to_affine(orc.msm_g1_a(b1, s)).reshape(1, 12))
 
 
+@pytest.mark.parametrize("lg", [15, 17, 18])
+def test_msm_mid_sizes_vs_oracle(engine, orc, lg):
+    """Sizes where the window width leaves a SHORT top window (c = lg - 6: 255 mod 9/11/12 = 3/2/3 bits, i.e. 7/3/7 buckets holding
+    n/8 .. n/4 terms each): the hierarchical slot grouping of msm.hpp must reproduce the oracle's sums; plus a skewed set at the
+    same size (every term in one bucket per window)."""
+    n = 1 << lg
+    s = engine.synth_fr(77, n); b1 = engine.synth_g1(31, n)
+    got = engine.normalize_batch_g1(engine.MultiexponentiationInnerProductG1.inner_product(orc.to_jac_g1(b1), s))
+    assert np.array_equal(got, orc.g1_to_affine(orc.msm_g1_a(b1, s)).reshape(1, 12))
+    if lg <= 17:
+        b2 = engine.synth_g2(41, n)
+        got = engine.normalize_batch_g2(engine.MultiexponentiationInnerProductG2.inner_product(orc.to_jac_g2(b2), s))
+        assert np.array_equal(got, orc.g2_to_affine(orc.msm_g2_a(b2, s)).reshape(1, 24))
+        same = np.repeat(orc.fr_array([0x1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF % orc.R]), n, axis=0)
+        got = engine.normalize_batch_g1(engine.MultiexponentiationInnerProductG1.inner_product(orc.to_jac_g1(b1), same))
+        assert np.array_equal(got, orc.g1_to_affine(orc.msm_g1_a(b1, same)).reshape(1, 12))
+
+
 def test_folds_and_normalise_vs_oracle(engine, orc):
     n = 300; half = n // 2
     a, b = orc.gen_g1(31, n), orc.gen_g2(37, n)

@@ -4,7 +4,7 @@ sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 import numpy as np, ripp_amd as R
 from ripp_amd._lib import lib
 R.init(0)
-N = 1 << 16
+N = 1 << max([int(x) for x in sys.argv[1:]] or [16])
 a, b, s = R.synth_g1(1000, N), R.synth_g2(2000, N), R.synth_fr(2, N)
 p = lambda x: x.ctypes.data_as(ctypes.c_void_p)
 for lg in [int(x) for x in (sys.argv[1:] or range(0, 17))]:
