@@ -59,6 +59,24 @@ def main():
     rng = m.FiatShamirRng(b"falafel")      # the seed string of the reference's own SIPP test (sipp/src/lib.rs:234)
     fx["fsrng"] = {"seed": "falafel", "u128_0": h(rng.next_u128()), "absorb": "00ff", }
     rng.absorb(bytes.fromhex("00ff")); fx["fsrng"]["u128_after_absorb"] = h(rng.next_u128())
+    # one TIPA proof, n = 4, with an SRS shift (ip_proofs/src/tipa/mod.rs:176-231; TIPP instantiation, D = Blake2b): produced AND
+    # verified by the big-integer model (tests/model/tipa_model.py); the wire images come from oracle/wire_format.py (also integers)
+    import tipa_model as T
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle"))
+    import wire_format as W
+    n, alpha, beta, rs = 4, 0xA1FA0007, 0xBE7A0009, 0x1D2C3B4A59687766554433221100FFEEDDCCBBAA998877
+    gap = [m.g1_mul(pow(alpha, i, m.R)) for i in range(2 * n - 1)]; hbp = [m.g2_mul(pow(beta, i, m.R)) for i in range(2 * n - 1)]
+    g_beta, h_alpha = m.g1_mul(beta), m.g2_mul(alpha)
+    ck_1 = [m.g2_mul(pow(rs, -i, m.R), hbp[2 * i]) for i in range(n)]; ck_2 = [gap[2 * i] for i in range(n)]     # ck_1 shifted by r^-i
+    m_a = [m.g1_mul(101 + 7 * i) for i in range(n)]; m_b = [m.g2_mul(211 + 5 * i) for i in range(n)]
+    steps, tr, ba, bb, ka, kb, oa, ob, kc = T.prove_tipa_tipp(gap, hbp, m_a, m_b, ck_1, ck_2, rs)
+    com = [m.pairing_product(m_a, ck_1), m.pairing_product(ck_2, m_b), m.pairing_product(m_a, m_b)]
+    assert T.verify_tipa_tipp((gap[0], hbp[0], g_beta, h_alpha), com, steps, ba, bb, ka, kb, oa, ob, rs)
+    tower = lambda f: [c for pair in m.f12_to_tower(f) for c in pair]
+    fx["tipa4"] = {"alpha": h(alpha), "beta": h(beta), "r_shift": h(rs), "m_a": [pg1(p) for p in m_a], "m_b": [pg2(q) for q in m_b],
+                   "com": [m.ser_gt(x).hex() for x in com], "transcript": [h(c) for c in tr], "kzg_challenge": h(kc),
+                   "proof_uncompressed": W.tipa_tipp_proof([[tower(x) for x in s] for s in steps], ba, bb, ka, kb, oa, ob, False).hex(),
+                   "proof_compressed": W.tipa_tipp_proof([[tower(x) for x in s] for s in steps], ba, bb, ka, kb, oa, ob, True).hex()}
     with open(os.path.join(HERE, "bls12_381_vectors.json"), "w") as f:
         json.dump(fx, f, indent=1)
     print("wrote", os.path.join(HERE, "bls12_381_vectors.json"))

@@ -56,3 +56,12 @@ def fake_groth16(n, m, seed):
         ci = (ai * bi - al * be - ga * s) * pow(de, -1, R) % R
         a[i], b[i], c[i] = mul1(ai), mul2(bi), mul1(ci); pub[i] = o.fr_array(xs)
     return vk, pub, a, b, c
+
+
+def tipa4_instance(v):
+    """Inputs of the golden `tipa4` vector (tests/golden/gen_fixtures.py) in the flat limb layouts: (srs, m_a, m_b, ck_a shifted by r^-i, ck_b, r_shift)."""
+    n = 4; alpha, beta, rs = int(v["alpha"], 16), int(v["beta"], 16), int(v["r_shift"], 16)
+    srs = make_srs(n, alpha, beta); ck_a, ck_b = commitment_keys(srs)
+    ck_a = np.stack([o.to_jac_g2(o.g2_mul_a(o.g2_to_affine(ck_a[i]), o.fr_array([pow(rs, -i, o.R)])[0]))[0] for i in range(n)])
+    m_a, m_b = o.to_jac_g1(g1arr(v["m_a"])), o.to_jac_g2(g2arr(v["m_b"]))
+    return srs, m_a, m_b, ck_a, ck_b, o.fr_array([rs])[0]

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 import helpers as h
+from helpers import gt_from_bytes
 
 pytestmark = pytest.mark.gpu
 
@@ -57,6 +58,21 @@ def test_tipa_tipp_prove_vs_oracle(engine, orc, n, shift):
     assert not engine.TIPA_TIPP.verify_with_srs_shift(vk, com, got, orc.fr_array([shift + 1])[0])
     bad = dict(got); bad["steps"] = got["steps"].copy(); bad["steps"][0] = got["steps"][3]
     assert not engine.TIPA_TIPP.verify_with_srs_shift(vk, com, bad, r_shift)
+    srs.close()
+
+
+def test_golden_tipa_vector(engine, orc, vectors):
+    """The engine's TIPA proof of the golden `tipa4` instance (made and verified by the big-integer model) serialises to the committed
+    wire images byte for byte, compressed and uncompressed."""
+    v = vectors["tipa4"]
+    osrs, m_a, m_b, ck_a, ck_b, r_shift = h.tipa4_instance(v)
+    srs = engine.SRS(osrs[0], osrs[1], osrs[2], osrs[3])
+    got = engine.TIPA_TIPP.prove_with_srs_shift(srs, (m_a, m_b), (ck_a, ck_b), r_shift)
+    assert [hex(orc.limbs_to_fr(t)) for t in got["tr"]] == v["transcript"] and hex(orc.limbs_to_fr(got["kzg_c"])) == v["kzg_challenge"]
+    assert engine.ser_tipa_tipp_proof(got, compress=False).hex() == v["proof_uncompressed"]
+    assert engine.ser_tipa_tipp_proof(got, compress=True).hex() == v["proof_compressed"]
+    com = [gt_from_bytes(x) for x in v["com"]]
+    assert engine.TIPA_TIPP.verify_with_srs_shift(srs.get_verifier_key(), com, got, r_shift)
     srs.close()
 
 

@@ -99,3 +99,38 @@ def test_aggregate_proofs_accepts_valid_and_rejects_invalid():
             break
         nonce += 1
     assert o.limbs_to_fr(pf.field("r")) == v
+
+
+def test_tipa_proof_accepted_by_the_independent_python_verifier():
+    """A TIPA proof made by the oracle (n = 4, SRS shift r != 1) must be accepted by tests/model/tipa_model.py -- a verifier written from
+    the protocol on Python integers with hashlib's BLAKE2b -- and a tampered one rejected.  This pins transcript layout,
+    from_random_bytes, the KZG equations and the transcript order independently of the C/HIP code."""
+    import tipa_model as T
+    n = 4; srs = h.make_srs(n, 0xabc1, 0xdef2); ck_a, ck_b = h.commitment_keys(srs)
+    r = 0x1d2c3b4a59687766554433221100ffeeddccbbaa998877 % o.R
+    ck_a = np.stack([o.to_jac_g2(o.g2_mul_a(o.g2_to_affine(ck_a[i]), o.fr_array([pow(r, -i, o.R)])[0]))[0] for i in range(n)])
+    m_a, m_b = o.blind_g1(o.gen_g1(3, n), 1), o.blind_g2(o.gen_g2(5, n), 2)
+    rc, pf = o.tipa_tipp_prove(srs[0], srs[1], m_a, m_b, ck_a, ck_b, o.fr_array([r])[0]); assert rc == 0
+    gt = lambda f: T.gt_from_tower([o.limbs_to_fp(f[6 * i:6 * i + 6]) for i in range(12)])
+    p1 = lambda pj: o.g1_from_row(o.g1_to_affine(np.ascontiguousarray(pj))); p2 = lambda pj: o.g2_from_row(o.g2_to_affine(np.ascontiguousarray(pj)))
+    com = [gt(o.pairing_product_j(m_a, ck_a)[1]), gt(o.pairing_product_j(ck_b, m_b)[1]), gt(o.pairing_product_j(m_a, m_b)[1])]
+    rounds = len(pf["steps"]) // 6
+    steps = [[gt(pf["steps"][6 * k + j]) for j in range(6)] for k in range(rounds)]
+    g, hh, g_beta, h_alpha = h.verifier_srs(srs)
+    vs = (p1(g), p2(hh), p1(g_beta), p2(h_alpha))
+    args = (p1(pf["base_a"]), p2(pf["base_b"]), p2(pf["final_ck_a"]), p1(pf["final_ck_b"]), p2(pf["opening_a"]), p1(pf["opening_b"]))
+    assert T.verify_tipa_tipp(vs, com, steps, *args, r)
+    assert not T.verify_tipa_tipp(vs, com, steps, *args, 1)
+
+
+def test_golden_tipa_vector_oracle_and_wire_format(vectors):
+    """The `tipa4` golden vector was produced and verified by the big-integer model; the oracle must reproduce its transcript, KZG
+    challenge and -- through the product's host-only serialiser -- both wire images byte for byte."""
+    import ripp_amd
+    v = vectors["tipa4"]
+    srs, m_a, m_b, ck_a, ck_b, r_shift = h.tipa4_instance(v)
+    rc, pf = o.tipa_tipp_prove(srs[0], srs[1], m_a, m_b, ck_a, ck_b, r_shift); assert rc == 0
+    assert [hex(o.limbs_to_fr(t)) for t in pf["tr"]] == v["transcript"] and hex(o.limbs_to_fr(pf["kzg_c"])) == v["kzg_challenge"]
+    assert [o.ser_gt(o.pairing_product_j(m_a, ck_a)[1]).hex(), o.ser_gt(o.pairing_product_j(ck_b, m_b)[1]).hex(), o.ser_gt(o.pairing_product_j(m_a, m_b)[1]).hex()] == v["com"]
+    assert ripp_amd.ser_tipa_tipp_proof(pf, compress=False).hex() == v["proof_uncompressed"]
+    assert ripp_amd.ser_tipa_tipp_proof(pf, compress=True).hex() == v["proof_compressed"]
