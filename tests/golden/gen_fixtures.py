@@ -77,6 +77,20 @@ def main():
                    "com": [m.ser_gt(x).hex() for x in com], "transcript": [h(c) for c in tr], "kzg_challenge": h(kc),
                    "proof_uncompressed": W.tipa_tipp_proof([[tower(x) for x in s] for s in steps], ba, bb, ka, kb, oa, ob, False).hex(),
                    "proof_compressed": W.tipa_tipp_proof([[tower(x) for x in s] for s in steps], ba, bb, ka, kb, oa, ob, True).hex()}
+    # aggregate_proofs on n = 4 synthetic (A, B, C) triples (applications/groth16_aggregation.rs:77-160): produced by the model, both
+    # sub-proofs verified by the model's verifiers
+    A4 = [m.g1_mul(1001 + 3 * i) for i in range(n)]; B4 = [m.g2_mul(2003 + 11 * i) for i in range(n)]; C4 = [m.g1_mul(3001 + 13 * i) for i in range(n)]
+    ag = T.aggregate_proofs(gap, hbp, A4, B4, C4)
+    vs = (gap[0], hbp[0], g_beta, h_alpha)
+    st2, tr2, ba2, bb2, ka2, kb2, oa2, ob2, kc2 = ag["tipp"]
+    assert T.verify_tipa_tipp(vs, [ag["com_a"], ag["com_b"], ag["ip_ab"]], st2, ba2, bb2, ka2, kb2, oa2, ob2, ag["r"])
+    gts, g1s, tr3, ba3, bb3, ka3, oa3, kc3 = ag["ssm"]
+    assert T.verify_tipa_ssm(vs, ag["com_c"], ag["agg_c"], ag["r"], gts, g1s, ba3, ka3, oa3)
+    fx["aggregate4"] = {"alpha": h(alpha), "beta": h(beta), "a": [pg1(p) for p in A4], "b": [pg2(q) for q in B4], "c": [pg1(p) for p in C4],
+                        "r": h(ag["r"]), "com_a": m.ser_gt(ag["com_a"]).hex(), "com_b": m.ser_gt(ag["com_b"]).hex(), "com_c": m.ser_gt(ag["com_c"]).hex(),
+                        "ip_ab": m.ser_gt(ag["ip_ab"]).hex(), "agg_c": m.ser_g1(ag["agg_c"]).hex(),
+                        "tipa_proof_ab": W.tipa_tipp_proof([[tower(x) for x in s_] for s_ in st2], ba2, bb2, ka2, kb2, oa2, ob2, False).hex(),
+                        "tipa_proof_c": W.tipa_ssm_proof([[tower(x) for x in g_] for g_ in gts], g1s, ba3, bb3, ka3, oa3, False).hex()}
     with open(os.path.join(HERE, "bls12_381_vectors.json"), "w") as f:
         json.dump(fx, f, indent=1)
     print("wrote", os.path.join(HERE, "bls12_381_vectors.json"))

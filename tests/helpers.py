@@ -65,3 +65,23 @@ def tipa4_instance(v):
     ck_a = np.stack([o.to_jac_g2(o.g2_mul_a(o.g2_to_affine(ck_a[i]), o.fr_array([pow(rs, -i, o.R)])[0]))[0] for i in range(n)])
     m_a, m_b = o.to_jac_g1(g1arr(v["m_a"])), o.to_jac_g2(g2arr(v["m_b"]))
     return srs, m_a, m_b, ck_a, ck_b, o.fr_array([rs])[0]
+
+
+def aggregate_subproofs(pf):
+    """AggregateProof (ripp_amd._lib) -> the dict forms the wire-format serialisers take: (tipa_proof_ab, tipa_proof_c)."""
+    f = lambda k: np.ascontiguousarray(pf.field(k))
+    ab = dict(steps=pf.ab_com_steps, tr=pf.ab_transcript, base_a=f("ab_base_a"), base_b=f("ab_base_b"), final_ck_a=f("ab_final_ck_a"), final_ck_b=f("ab_final_ck_b"),
+              opening_a=f("ab_opening_a"), opening_b=f("ab_opening_b"))
+    c = dict(com_gt=pf.c_com_gt, com_g1=pf.c_com_g1, tr=pf.c_transcript, base_a=f("c_base_a"), base_b=f("c_base_b"), final_ck_a=f("c_final_ck_a"), opening_a=f("c_opening_a"))
+    return ab, c
+
+
+def check_aggregate_golden(v, pf, ser_gt, ser_g1_of_jac, ser_tipp, ser_ssm):
+    """compare an AggregateProof with the golden `aggregate4` vector (model-made): scalar r, the four GT values, agg_c, both sub-proof images"""
+    assert hex(o.limbs_to_fr(pf.field("r"))) == v["r"]
+    for k in ("com_a", "com_b", "com_c", "ip_ab"):
+        assert ser_gt(np.ascontiguousarray(pf.field(k))).hex() == v[k], k
+    assert ser_g1_of_jac(np.ascontiguousarray(pf.field("agg_c"))).hex() == v["agg_c"]
+    ab, c = aggregate_subproofs(pf)
+    assert ser_tipp(ab, compress=False).hex() == v["tipa_proof_ab"]
+    assert ser_ssm(c, compress=False).hex() == v["tipa_proof_c"]

@@ -76,6 +76,16 @@ def test_golden_tipa_vector(engine, orc, vectors):
     srs.close()
 
 
+def test_golden_aggregate_vector(engine, orc, vectors):
+    """The engine's aggregate_proofs on the golden `aggregate4` instance (made by the big-integer model) reproduces every member."""
+    v = vectors["aggregate4"]
+    osrs = h.make_srs(4, int(v["alpha"], 16), int(v["beta"], 16))
+    srs = engine.SRS(osrs[0], osrs[1], osrs[2], osrs[3])
+    pf, _ = engine.aggregate_proofs(srs, h.g1arr(v["a"]), h.g2arr(v["b"]), h.g1arr(v["c"]))
+    h.check_aggregate_golden(v, pf, engine.ser_gt, lambda j: engine.ser_g1(engine.normalize_batch_g1(j.reshape(1, 18))[0]), engine.ser_tipa_tipp_proof, engine.ser_tipa_ssm_proof)
+    srs.close()
+
+
 def test_tipa_rejects_mismatched_srs(engine, orc):
     osrs = h.make_srs(8, 5, 6); srs = engine.SRS(osrs[0], osrs[1])
     m_a, m_b = orc.blind_g1(orc.gen_g1(7, 4), 1), orc.blind_g2(orc.gen_g2(9, 4), 2)

@@ -134,3 +134,13 @@ def test_golden_tipa_vector_oracle_and_wire_format(vectors):
     assert [o.ser_gt(o.pairing_product_j(m_a, ck_a)[1]).hex(), o.ser_gt(o.pairing_product_j(ck_b, m_b)[1]).hex(), o.ser_gt(o.pairing_product_j(m_a, m_b)[1]).hex()] == v["com"]
     assert ripp_amd.ser_tipa_tipp_proof(pf, compress=False).hex() == v["proof_uncompressed"]
     assert ripp_amd.ser_tipa_tipp_proof(pf, compress=True).hex() == v["proof_compressed"]
+
+
+def test_golden_aggregate_vector_oracle(vectors):
+    """`aggregate4`: aggregate_proofs on four (A, B, C) triples, produced by the big-integer model (both sub-proofs accepted by the model's
+    verifiers).  The oracle must reproduce r, the commitments, ip_ab, agg_c and both sub-proof wire images byte for byte."""
+    import ripp_amd
+    v = vectors["aggregate4"]
+    srs = h.make_srs(4, int(v["alpha"], 16), int(v["beta"], 16))
+    rc, pf = o.aggregate_proofs(srs[0], srs[1], h.g1arr(v["a"]), h.g2arr(v["b"]), h.g1arr(v["c"])); assert rc == 0
+    h.check_aggregate_golden(v, pf, o.ser_gt, lambda j: o.ser_g1(o.g1_to_affine(j)), ripp_amd.ser_tipa_tipp_proof, ripp_amd.ser_tipa_ssm_proof)
