@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(256) k_normalize(const Jac<F>* __restrict__ in
 //  which is structured_generators_scalar_power of tipa/mod.rs:372-391).  Plain MSB-first double-and-add: every lane
 // has its own scalar, so the add is data-dependent and executes under the wave's EXEC mask.
 template <class F>
-__global__ void __launch_bounds__(256) k_scale_pts(const Affine<F>* __restrict__ base, uint32_t base_stride, const Fr* __restrict__ k_mont, uint32_t n, Jac<F>* __restrict__ out) {
+__global__ void __launch_bounds__(256, 2) k_scale_pts(const Affine<F>* __restrict__ base, uint32_t base_stride, const Fr* __restrict__ k_mont, uint32_t n, Jac<F>* __restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const Fr k = from_mont(k_mont[i]);
