@@ -79,6 +79,8 @@ struct Engine {
     MsmScratch msm_scratch[2];
     DevBuf kzg_q[2];                      // quotient-polynomial coefficients of the (up to two concurrent) KZG openings
     hipStream_t stream3 = nullptr;        // second MSM of a pair
+    hipStream_t stream4 = nullptr;        // unscaled twin of m_a in the implicit-shift TIPP core
+    hipEvent_t ev_join4 = nullptr;
     Fp12* pinned_rows = nullptr;          // pinned host landing zone for per-step products
     size_t pinned_rows_cap = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_lines, ev_prod;   // per-launch event pairs of the two dominant kernels
@@ -98,6 +100,7 @@ struct Engine {
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&stream3, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&stream4, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&ev_join4, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_join3, hipEventDisableTiming));
         { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n_simd = pr.multiProcessorCount * 4; }
         auto env_sz = [](const char* k, size_t& v) { if (const char* s = std::getenv(k)) v = (size_t)std::strtoull(s, nullptr, 10); };
@@ -109,6 +112,7 @@ struct Engine {
         for (DevBuf* b : {&lines, &partA, &partB, &jacG1, &jacG2, &tmpA, &tmpB, &tmpR, &affG1, &affG2, &qtab, &vm_flag}) b->release();
         msm_scratch[0].release(); msm_scratch[1].release(); kzg_q[0].release(); kzg_q[1].release();
         if (stream3) (void)hipStreamDestroy(stream3);
+        if (stream4) (void)hipStreamDestroy(stream4); if (ev_join4) (void)hipEventDestroy(ev_join4);
         if (pinned_rows) (void)hipHostFree(pinned_rows);
         for (auto& e : ev_lines) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         for (auto& e : ev_prod) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -750,10 +754,13 @@ template <> int32_t fold_dev<Fp2>(Engine* e, hipStream_t st, const G2A* hi, cons
 }
 }  // extern "C++"
 
+extern "C++" { static Fp12 gt_pow_host(const Fp12& x, const Fr& k); }      // defined with the verifiers below
+
 // device-resident GIPA/TIPP state: the four vectors (affine) + ping-pong partners + fold scratch
 struct TippVecs {
     DevBuf A, A2, KB, KB2, B, B2, KA, KA2, jac1, jac1b, jac2, jac2b, qt2;
-    ~TippVecs() { for (DevBuf* b : {&A, &A2, &KB, &KB2, &B, &B2, &KA, &KA2, &jac1, &jac1b, &jac2, &jac2b, &qt2}) b->release(); }
+    DevBuf AU, AU2, jac1u;                 // implicit-shift form (aggregate_proofs): the UNSCALED left vector beside the scaled one
+    ~TippVecs() { for (DevBuf* b : {&A, &A2, &KB, &KB2, &B, &B2, &KA, &KA2, &jac1, &jac1b, &jac2, &jac2b, &qt2, &AU, &AU2, &jac1u}) b->release(); }
     int32_t reserve(size_t n) {
         int32_t rc;
         for (DevBuf* b : {&A, &A2, &KB, &KB2}) if ((rc = b->reserve(n * sizeof(G1A)))) return rc;
@@ -771,10 +778,11 @@ template <class Launch> static int32_t folds_with_vm_fallback(Engine* e, size_t 
     if ((rc = e->vm_flag.reserve(sizeof(uint32_t)))) return rc;
     for (;;) {
         HIPCHK(hipMemsetAsync(e->vm_flag.p, 0, sizeof(uint32_t), e->stream));
-        HIPCHK(hipEventRecord(e->ev_fork, e->stream)); HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0)); HIPCHK(hipStreamWaitEvent(e->stream3, e->ev_fork, 0));
+        HIPCHK(hipEventRecord(e->ev_fork, e->stream));
+        for (hipStream_t st : {e->stream2, e->stream3, e->stream4}) HIPCHK(hipStreamWaitEvent(st, e->ev_fork, 0));
         if ((rc = launch())) { e->vm_fold_max = saved_vm_max; return rc; }
-        HIPCHK(hipEventRecord(e->ev_join, e->stream2)); HIPCHK(hipEventRecord(e->ev_join3, e->stream3));
-        HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0)); HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join3, 0));
+        HIPCHK(hipEventRecord(e->ev_join, e->stream2)); HIPCHK(hipEventRecord(e->ev_join3, e->stream3)); HIPCHK(hipEventRecord(e->ev_join4, e->stream4));
+        for (hipEvent_t ev : {e->ev_join, e->ev_join3, e->ev_join4}) HIPCHK(hipStreamWaitEvent(e->stream, ev, 0));
         if ((rc = e->sync())) { e->vm_fold_max = saved_vm_max; return rc; }
         if (e->vm_fold_max != 0 && split <= e->vm_fold_max) {
             uint32_t flag = 0; HIPCHK(hipMemcpy(&flag, e->vm_flag.p, sizeof flag, hipMemcpyDeviceToHost));
@@ -787,17 +795,29 @@ template <class Launch> static int32_t folds_with_vm_fallback(Engine* e, size_t 
 }
 }  // extern "C++"
 
-// GIPA::_prove (gipa.rs:181-312) on vectors already resident (and normalised) in v.A (m_a), v.B (m_b), v.KA (ck_a), v.KB (ck_b)
-static int32_t gipa_tipp_core(Engine* e, TippVecs& v, size_t n, ripp_gt* com_steps, ripp_fr* transcript, G1A& ha, G2A& hb, G2A& hka, G1A& hkb) {
+// GIPA::_prove (gipa.rs:181-312) on vectors already resident (and normalised) in v.A (m_a), v.B (m_b), v.KA (ck_a), v.KB (ck_b).
+//
+// shift != nullptr -- the implicit-shift form used by aggregate_proofs, where m_a[i] = r^i a_i and ck_a[i] = r^-i ck_i
+// (groth16_aggregation.rs:119-131).  The n G2 scalar multiplications r^-i ck_i are never performed: v.KA holds the UNSCALED keys and
+// v.AU the unscaled a_i next to the scaled v.A.  By bilinearity e(r^(i+s) a_(i+s), r^-i ck_i) = e(a_(i+s), ck_i)^(r^s), so the two
+// LMC commitments of a round are the unscaled products raised to r^(+-split) (two GT exponentiations on host threads), and the
+// folds of the unscaled vectors keep the invariant "element i carries the implicit factor r^(+-i)" when they use the scalars
+// c r^split and c_inv r^-split.  Index 0 carries r^0, so the final key and every output are the SAME group elements as in the
+// explicit computation -- bit-identical results, checked against the oracle's explicit form.
+static int32_t gipa_tipp_core(Engine* e, TippVecs& v, size_t n, ripp_gt* com_steps, ripp_fr* transcript, G1A& ha, G2A& hb, G2A& hka, G1A& hkb, const Fr* shift = nullptr) {
     int32_t rc;
     size_t len = n, round = 0;
     Fr prev_c = Fr::zero();
     std::vector<Fp12> rows(6 * N_LINES);
+    std::vector<Fr> rp, rpi;                   // r^(2^k), r^-(2^k)
+    if (shift) { rp.push_back(*shift); rpi.push_back(inv(*shift)); for (size_t m = 2; m < n; m <<= 1) { rp.push_back(mul(rp.back(), rp.back())); rpi.push_back(mul(rpi.back(), rpi.back())); } }
     while (len > 1) {
         const size_t split = len / 2;
         const G1A *A = v.A.as<G1A>(), *KB = v.KB.as<G1A>(); const G2A *B = v.B.as<G2A>(), *KA = v.KA.as<G2A>();
+        const G1A* AL = shift ? v.AU.as<G1A>() : A;         // left operand of the two LMC commitments
+        size_t lg_split = 0; while (((size_t)1 << lg_split) < split) ++lg_split;
         //            com_1.0 (m_a_1,ck_a_1)  com_1.1 (ck_b_1,m_b_1)  com_1.2 (m_a_1,m_b_1)  com_2.0 (m_a_2,ck_a_2)  com_2.1 (ck_b_2,m_b_2)  com_2.2 (m_a_2,m_b_2)   gipa.rs:209-231
-        const G1A* as[6] = {A + split,             KB + split,            A + split,             A,                     KB,                    A};
+        const G1A* as[6] = {AL + split,            KB + split,            A + split,             AL,                    KB,                    A};
         const G2A* bs[6] = {KA,                    B,                     B,                     KA + split,            B + split,             B + split};
         const double tp = now_ms();
         if ((rc = e->step_products(as, bs, 6, split, rows.data()))) return rc;
@@ -805,10 +825,16 @@ static int32_t gipa_tipp_core(Engine* e, TippVecs& v, size_t n, ripp_gt* com_ste
         const double th = now_ms();
         Fp12 com[6];
         { std::vector<std::future<Fp12>> fut;
-          for (int k = 1; k < 6; ++k) fut.push_back(std::async(std::launch::async, [&rows, k]() { return final_exponentiation(miller_combine(rows.data() + k * N_LINES)); }));
-          com[0] = final_exponentiation(miller_combine(rows.data()));
+          auto one = [&rows, shift, &rp, &rpi, lg_split](int k) {
+              Fp12 z = final_exponentiation(miller_combine(rows.data() + k * N_LINES));
+              if (shift && k == 0) z = gt_pow_host(z, rp[lg_split]);             // (prod e(a_(i+s), ck_i))^(r^s)
+              if (shift && k == 3) z = gt_pow_host(z, rpi[lg_split]);            // (prod e(a_i, ck_(i+s)))^(r^-s)
+              return z; };
+          for (int k = 1; k < 6; ++k) fut.push_back(std::async(std::launch::async, one, k));
+          com[0] = one(0);
           for (int k = 1; k < 6; ++k) com[k] = fut[k - 1].get(); }
         Fr c_inv; const Fr c = fs::gipa_tipp_challenge(round ? &prev_c : nullptr, com, c_inv);
+        const Fr c_u = shift ? mul(c, rp[lg_split]) : c, c_inv_u = shift ? mul(c_inv, rpi[lg_split]) : c_inv;   // fold scalars of the unscaled vectors
         e->stats.host_ms += now_ms() - th;
         std::memcpy(&com_steps[6 * round], com, sizeof com); std::memcpy(&transcript[round], &c, sizeof c);
         prev_c = c;
@@ -817,13 +843,14 @@ static int32_t gipa_tipp_core(Engine* e, TippVecs& v, size_t n, ripp_gt* com_ste
         rc = folds_with_vm_fallback(e, split, [&]() -> int32_t {
             int32_t r2;
             if ((r2 = fold_dev<Fp>(e, e->stream2, A + split, A, split, c, v.jac1, v.qt2, v.A2.as<G1A>()))) return r2;          // m_a  <- m_a_1 * c + m_a_2
+            if (shift && (r2 = fold_dev<Fp>(e, e->stream4, AL + split, AL, split, c_u, v.jac1u, v.qt2, v.AU2.as<G1A>()))) return r2;   // unscaled twin of m_a
             if ((r2 = fold_dev<Fp>(e, e->stream3, KB + split, KB, split, c, v.jac1b, v.qt2, v.KB2.as<G1A>()))) return r2;       // ck_b <- ck_b_1 * c + ck_b_2
             if ((r2 = fold_dev<Fp2>(e, e->stream, B + split, B, split, c_inv, v.jac2, e->qtab, v.B2.as<G2A>()))) return r2;     // m_b  <- m_b_2 * c_inv + m_b_1
-            return fold_dev<Fp2>(e, e->stream, KA + split, KA, split, c_inv, v.jac2b, e->qtab, v.KA2.as<G2A>());                // ck_a <- ck_a_2 * c_inv + ck_a_1
+            return fold_dev<Fp2>(e, e->stream, KA + split, KA, split, c_inv_u, v.jac2b, e->qtab, v.KA2.as<G2A>());              // ck_a <- ck_a_2 * c_inv + ck_a_1
         });
         if (rc) return rc;
         e->stats.fold_ms += now_ms() - tf;
-        std::swap(v.A, v.A2); std::swap(v.KB, v.KB2); std::swap(v.B, v.B2); std::swap(v.KA, v.KA2);
+        std::swap(v.A, v.A2); std::swap(v.KB, v.KB2); std::swap(v.B, v.B2); std::swap(v.KA, v.KA2); if (shift) std::swap(v.AU, v.AU2);
         len = split; ++round;
     }
     HIPCHK(hipMemcpy(&ha, v.A.p, sizeof ha, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(&hkb, v.KB.p, sizeof hkb, hipMemcpyDeviceToHost));
@@ -1097,9 +1124,9 @@ API int32_t ripp_aggregate_proofs(const ripp_srs* srs, const ripp_g1a* a, const 
     e->stats = ripp_stats{};
     const double t_start = now_ms();
     ripp_srs* s = const_cast<ripp_srs*>(srs);
-    TippVecs v; SsmVecs w; DevBuf dCK1, dRv, dRiv; int32_t rc;
-    struct Cleanup { DevBuf &x, &y, &z; ~Cleanup() { x.release(); y.release(); z.release(); } } cleanup{dCK1, dRv, dRiv};
-    if ((rc = v.reserve(n)) || (rc = w.reserve(n)) || (rc = dCK1.reserve(n * sizeof(G2A))) || (rc = dRv.reserve(n * sizeof(Fr))) || (rc = dRiv.reserve(n * sizeof(Fr)))) return rc;
+    TippVecs v; SsmVecs w; DevBuf dCK1, dRv; int32_t rc;
+    struct Cleanup { DevBuf &x, &y; ~Cleanup() { x.release(); y.release(); } } cleanup{dCK1, dRv};
+    if ((rc = v.reserve(n)) || (rc = w.reserve(n)) || (rc = dCK1.reserve(n * sizeof(G2A))) || (rc = dRv.reserve(n * sizeof(Fr)))) return rc;
     // a -> v.A2 (unscaled), b -> v.B, c -> w.A;  ck_1 -> dCK1 and w.KA, ck_2 -> v.KB   (get_commitment_keys, tipa/mod.rs:114-118)
     HIPCHK(hipMemcpyAsync(v.A2.p, a, n * sizeof(G1A), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(v.B.p, b, n * sizeof(G2A), hipMemcpyHostToDevice, e->stream));
@@ -1119,35 +1146,35 @@ API int32_t ripp_aggregate_proofs(const ripp_srs* srs, const ripp_g1a* a, const 
     const Fr r = fs::aggregation_challenge(com_a, com_b, com_c);                                                        // :105-116
     std::memcpy(&out->r, &r, sizeof r);
     if (trace_on()) fprintf(stderr, "[ripp] aggregate: upload + 3 commitments done at t=%.1f ms\n", now_ms() - t_start);
-    // r_vec = (1, r, r^2, ...) (:118) and its element-wise inverses (:130) = powers of r^-1
-    std::vector<Fr> rv(n), riv(n); const Fr r_inv = inv(r);
-    rv[0] = Fr::one(); riv[0] = Fr::one(); for (size_t i = 1; i < n; ++i) { rv[i] = mul(rv[i - 1], r); riv[i] = mul(riv[i - 1], r_inv); }
+    // r_vec = (1, r, r^2, ...) (:118)
+    std::vector<Fr> rv(n);
+    rv[0] = Fr::one(); for (size_t i = 1; i < n; ++i) rv[i] = mul(rv[i - 1], r);
     HIPCHK(hipMemcpyAsync(dRv.p, rv.data(), n * sizeof(Fr), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(dRiv.p, riv.data(), n * sizeof(Fr), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(w.S.p, dRv.p, n * sizeof(Fr), hipMemcpyDeviceToDevice, e->stream));
-    // a_r = a_i * r^i (:119-123) -> v.A;  ck_1_r = ck_1_i * r^-i (:127-131) -> v.KA
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scale_pts<Fp>), dim3(nblk(n, 256)), dim3(256), 0, e->stream, v.A2.as<G1A>(), 1u, dRv.as<Fr>(), (uint32_t)n, v.jac1.as<G1J>());
+    // a_r = a_i * r^i (:119-123) -> v.A, with the unscaled a_i kept in v.AU.  ck_1_r = ck_1_i * r^-i (:127-131) is NOT materialised: the
+    // TIPP core below runs in its implicit-shift form on the unscaled keys (see gipa_tipp_core), which removes the n G2 scalar
+    // multiplications, and the sanity product of :133-136, IP(a_r, ck_1_r) == com_a, collapses to IP(a, ck_1) == com_a -- the very
+    // product computed above -- so it holds by construction and is not recomputed.
+    if ((rc = v.AU.reserve(n * sizeof(G1A))) || (rc = v.AU2.reserve(n * sizeof(G1A))) || (rc = v.jac1u.reserve(n * sizeof(G1J)))) return rc;
+    HIPCHK(hipMemcpyAsync(v.AU.p, v.A2.p, n * sizeof(G1A), hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(v.KA.p, dCK1.p, n * sizeof(G2A), hipMemcpyDeviceToDevice, e->stream));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scale_pts<Fp>), dim3(nblk(n, 256)), dim3(256), 0, e->stream, v.AU.as<G1A>(), 1u, dRv.as<Fr>(), (uint32_t)n, v.jac1.as<G1J>());
     HIPCHK(hipGetLastError());
     if ((rc = e->normalize_dev<Fp>(v.jac1.as<G1J>(), n, v.A.as<G1A>()))) return rc;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scale_pts<Fp2>), dim3(nblk(n, 64)), dim3(64), 0, e->stream, dCK1.as<G2A>(), 1u, dRiv.as<Fr>(), (uint32_t)n, v.jac2.as<G2J>());
-    HIPCHK(hipGetLastError());
-    if ((rc = e->normalize_dev<Fp2>(v.jac2.as<G2J>(), n, v.KA.as<G2A>()))) return rc;
-    {   // ip_ab = IP(a_r, b) (:124) and the sanity product IP(a_r, ck_1_r) (:133-136) in one launch
-        const G1A* as[2] = {v.A.as<G1A>(), v.A.as<G1A>()}; const G2A* bs[2] = {v.B.as<G2A>(), v.KA.as<G2A>()};
-        if ((rc = e->step_products(as, bs, 2, n, rows.data()))) return rc;
-        auto f1 = std::async(std::launch::async, finish, 1);
-        const Fp12 ip_ab = finish(0), chk = f1.get();
+    {   // ip_ab = IP(a_r, b) (:124)
+        const G1A* as[1] = {v.A.as<G1A>()}; const G2A* bs[1] = {v.B.as<G2A>()};
+        if ((rc = e->step_products(as, bs, 1, n, rows.data()))) return rc;
+        const Fp12 ip_ab = finish(0);
         std::memcpy(&out->ip_ab, &ip_ab, sizeof ip_ab);
-        if (!(chk == com_a)) { set_err("commitment key shift check failed (assert_eq! at groth16_aggregation.rs:133-136)"); return RIPP_ERR_ARG; }
     }
-    if (trace_on()) fprintf(stderr, "[ripp] aggregate: scaling + ip_ab + key check done at t=%.1f ms\n", now_ms() - t_start);
+    if (trace_on()) fprintf(stderr, "[ripp] aggregate: scaling + ip_ab done at t=%.1f ms\n", now_ms() - t_start);
     G1J agg_c; if ((rc = e->msm_dev<Fp>(w.A.as<G1A>(), dRv.as<Fr>(), n, &agg_c))) return rc;                           // :125
     std::memcpy(&out->agg_c, &agg_c, sizeof agg_c);
     if (trace_on()) fprintf(stderr, "[ripp] aggregate: agg_c MSM done at t=%.1f ms\n", now_ms() - t_start);
     size_t rounds = 0; while (((size_t)1 << rounds) < n) ++rounds;
     {   // tipa_proof_ab = TIPA::prove_with_srs_shift(srs, (a_r, b), (ck_1_r, ck_2), r)   (:138-143)
         G1A ha, hkb; G2A hb, hka;
-        if ((rc = gipa_tipp_core(e, v, n, out->ab_com_steps, out->ab_transcript, ha, hb, hka, hkb))) return rc;
+        if ((rc = gipa_tipp_core(e, v, n, out->ab_com_steps, out->ab_transcript, ha, hb, hka, hkb, &r))) return rc;
         if (trace_on()) fprintf(stderr, "[ripp] aggregate: TIPP GIPA rounds done at t=%.1f ms\n", now_ms() - t_start);
         G2J oa; G1J ob; Fr kc;
         if ((rc = tipp_kzg(e, srs, out->ab_transcript, rounds, r, hka, hkb, &oa, &ob, &kc))) return rc;
@@ -1173,9 +1200,23 @@ API int32_t ripp_aggregate_proofs(const ripp_srs* srs, const ripp_g1a* a, const 
 // Host: challenge replay and the O(log n) exponentiations of single GT / group elements (what the reference's verifier does
 // serially).  Device: every pairing and the n-term MSMs.
 extern "C++" {
+// membership in the cyclotomic subgroup of Fp12* (x^(p^4 - p^2 + 1) == 1): every honest GT value is in it; the verifiers test the
+// GT members of a proof before exponentiating them, because gt_pow_host is only an exponentiation there
+static bool gt_in_cyclotomic(const Fp12& x) {
+    const Fp2* c[6] = {&x.c0.c0, &x.c0.c1, &x.c0.c2, &x.c1.c0, &x.c1.c1, &x.c1.c2};
+    bool zero = true; for (const Fp2* v : c) zero = zero && v->c0.is_zero() && v->c1.is_zero();
+    return !zero && mul(frobenius(frobenius(x, 2), 2), x) == frobenius(x, 2);
+}
+// x^k for x in the cyclotomic subgroup: Granger-Scott squarings, NAF digits, and the inverse of x is its conjugate.
 static Fp12 gt_pow_host(const Fp12& x, const Fr& k) {
-    const Fr c = from_mont(k); Fp12 acc = Fp12::one(); bool st = false;
-    for (int i = 255; i >= 0; --i) { if (st) acc = sqr(acc); if ((c.l[i >> 5] >> (i & 31)) & 1u) { acc = st ? mul(acc, x) : x; st = true; } }
+    const Fr c = from_mont(k);
+    int8_t d[260]; const int len = naf_recode(c.l, 8, d, 258);
+    const Fp12 xi = conj(x);
+    Fp12 acc = Fp12::one(); bool st = false;
+    for (int i = len - 1; i >= 0; --i) {
+        if (st) acc = cyclotomic_sqr(acc);
+        if (d[i] != 0) { const Fp12& m = d[i] > 0 ? x : xi; acc = st ? mul(acc, m) : m; st = true; }
+    }
     return acc;
 }
 template <class F> static Jac<F> smul_host(const Affine<F>& p, const Fr& k) { const Fr c = from_mont(k); return scalar_mul_bits(p, c.l, 255); }
@@ -1218,11 +1259,12 @@ static int32_t kzg_verify_g1(Engine* e, const VSrs& v, const G1J& ck_final, cons
     return pairing_eq(e, l1, v.h, opening, r2, ok);
 }
 // _compute_recursive_challenges (gipa.rs:322-363), TIPP instantiation; tr in ROUND order
-static void tipp_replay(const ripp_gt com[3], const ripp_gt* com_steps, size_t rounds, std::vector<Fr>& tr, Fp12 out[3]) {
+static bool tipp_replay(const ripp_gt com[3], const ripp_gt* com_steps, size_t rounds, std::vector<Fr>& tr, Fp12 out[3]) {
     Fp12 acc[3] = {load_gt(&com[0]), load_gt(&com[1]), load_gt(&com[2])};
     tr.resize(rounds);
     for (size_t k = 0; k < rounds; ++k) {
         Fp12 s[6]; std::memcpy(s, &com_steps[6 * k], sizeof s);
+        for (int j = 0; j < 6; ++j) if (!gt_in_cyclotomic(s[j])) return false;          // not a GT element: reject
         Fr c_inv; const Fr c = fs::gipa_tipp_challenge(k ? &tr[k - 1] : nullptr, s, c_inv);
         std::future<Fp12> f[5];
         for (int j = 1; j < 6; ++j) f[j - 1] = std::async(std::launch::async, [&s, j, c, c_inv]() { return gt_pow_host(s[j], j < 3 ? c : c_inv); });
@@ -1231,6 +1273,7 @@ static void tipp_replay(const ripp_gt com[3], const ripp_gt* com_steps, size_t r
         tr[k] = c;
     }
     out[0] = acc[0]; out[1] = acc[1]; out[2] = acc[2];
+    return true;
 }
 }  // extern "C++"
 
@@ -1238,7 +1281,8 @@ API int32_t ripp_gipa_tipp_verify(const ripp_g2j* ck_a, const ripp_g1j* ck_b, si
                                   const ripp_g1j* base_a, const ripp_g2j* base_b, int32_t* accept) {
     if (n == 0 || (n & (n - 1))) return RIPP_ERR_POW2;
     if (!ck_a || !ck_b || !com || !base_a || !base_b || !accept || (rounds && !com_steps) || ((size_t)1 << rounds) != n) return RIPP_ERR_ARG;
-    std::vector<Fr> tr; Fp12 bc[3]; tipp_replay(com, com_steps, rounds, tr, bc);
+    std::vector<Fr> tr; Fp12 bc[3];
+    if (!tipp_replay(com, com_steps, rounds, tr, bc)) { *accept = 0; return RIPP_OK; }
     // _compute_final_commitment_keys (gipa.rs:365-399) on the reversed transcript: exponent vectors by doubling, then one MSM per key
     std::vector<Fr> ea(n), eb(n); ea[0] = Fr::one(); eb[0] = Fr::one(); size_t cnt = 1;
     for (size_t i = 0; i < rounds; ++i) {
@@ -1263,7 +1307,8 @@ API int32_t ripp_tipa_tipp_verify(const ripp_verifier_srs* v_srs, const ripp_gt 
     if (!v_srs || !com || !com_steps || !base_a || !base_b || !final_ck_a || !final_ck_b || !opening_a || !opening_b || !r_shift || !accept || rounds == 0) return RIPP_ERR_ARG;
     LOCK; ENGINE;
     const VSrs v = load_vsrs(v_srs);
-    std::vector<Fr> trf; Fp12 bc[3]; tipp_replay(com, com_steps, rounds, trf, bc);                                       // :249-251
+    std::vector<Fr> trf; Fp12 bc[3];
+    if (!tipp_replay(com, com_steps, rounds, trf, bc)) { *accept = 0; return RIPP_OK; }                                  // :249-251
     std::vector<Fr> tr(rounds), tri(rounds); for (size_t i = 0; i < rounds; ++i) { tr[i] = trf[rounds - 1 - i]; tri[i] = inv(tr[i]); }
     const G2J ka = load_jac<Fp2>(final_ck_a), oa = load_jac<Fp2>(opening_a); const G1J kb = load_jac<Fp>(final_ck_b), ob = load_jac<Fp>(opening_b);
     const G2A kaa = to_affine(ka); const G1A kba = to_affine(kb);
@@ -1288,6 +1333,7 @@ API int32_t ripp_tipa_ssm_verify(const ripp_verifier_srs* v_srs, const ripp_gt* 
     std::vector<Fr> trf(rounds);
     for (size_t k = 0; k < rounds; ++k) {                                                                                // gipa.rs:329-360
         const Fp12 gt[2] = {load_gt(&com_gt[2 * k]), load_gt(&com_gt[2 * k + 1])};
+        if (!gt_in_cyclotomic(gt[0]) || !gt_in_cyclotomic(gt[1])) { *accept = 0; return RIPP_OK; }
         const G1A g1[2] = {to_affine(load_jac<Fp>(&com_g1[2 * k])), to_affine(load_jac<Fp>(&com_g1[2 * k + 1]))};
         Fr c_inv; const Fr c = fs::gipa_ssm_challenge(k ? &trf[k - 1] : nullptr, gt, g1, c_inv);
         auto f = std::async(std::launch::async, [&gt, c_inv]() { return gt_pow_host(gt[1], c_inv); });

@@ -58,6 +58,9 @@ def test_tipa_tipp_prove_vs_oracle(engine, orc, n, shift):
     assert not engine.TIPA_TIPP.verify_with_srs_shift(vk, com, got, orc.fr_array([shift + 1])[0])
     bad = dict(got); bad["steps"] = got["steps"].copy(); bad["steps"][0] = got["steps"][3]
     assert not engine.TIPA_TIPP.verify_with_srs_shift(vk, com, bad, r_shift)
+    # an Fp12 value that is not a GT element (a Miller value before its final exponentiation) must be rejected, not exponentiated
+    bad = dict(got); bad["steps"] = got["steps"].copy(); bad["steps"][1] = orc.miller_product_a(orc.gen_g1(3, 1), orc.gen_g2(4, 1))
+    assert not engine.TIPA_TIPP.verify_with_srs_shift(vk, com, bad, r_shift)
     srs.close()
 
 
