@@ -63,6 +63,8 @@ int32_t ripp_msm_g2_j(const ripp_g2j* bases, size_t n_left, const ripp_fr* scala
 /* VariableBaseMSM::msm on affine bases (sipp/src/lib.rs:174-175) */
 int32_t ripp_msm_g1_a(const ripp_g1a* bases, const ripp_fr* scalars, size_t n, ripp_g1j* out);
 int32_t ripp_msm_g2_a(const ripp_g2a* bases, const ripp_fr* scalars, size_t n, ripp_g2j* out);
+/* ScalarInnerProduct::inner_product (inner_products/src/lib.rs:144-166): sum_i l_i * r_i in Fr; RIPP_ERR_LENGTH as above */
+int32_t ripp_scalar_inner_product(const ripp_fr* left, size_t nl, const ripp_fr* right, size_t nr, ripp_fr* out);
 
 /* ---- halving-round fold  out[i] = s * hi[i] + lo[i],  i < half ------------------------------------------ */
 /* SIPP form: affine in, batch-normalised affine out  -- sipp/src/lib.rs:87-92 (G1) and :95-100 (G2) */

@@ -14,7 +14,7 @@ import numpy as np
 from ._lib import lib, last_error, RippStats, AggregateProof, VerifierSRSStruct, Groth16VKStruct, RIPP_OK, RIPP_ERR_LENGTH, RIPP_ERR_POW2, RIPP_ERR_DEVICE
 
 __all__ = ["InnerProductError", "DeviceError", "PairingInnerProduct", "MultiexponentiationInnerProductG1",
-           "MultiexponentiationInnerProductG2", "AFGHOCommitmentG1", "AFGHOCommitmentG2", "PedersenCommitmentG1",
+           "MultiexponentiationInnerProductG2", "ScalarInnerProduct", "AFGHOCommitmentG1", "AFGHOCommitmentG2", "PedersenCommitmentG1",
            "PedersenCommitmentG2", "SIPP", "SippJob", "GIPA_TIPP", "SRS", "TIPA_TIPP", "TIPAWithSSM", "aggregate_proofs", "verify_aggregate_proof", "AggregateProof", "ser_tipa_tipp_proof", "de_tipa_tipp_proof", "ser_tipa_ssm_proof", "de_tipa_ssm_proof", "ser_g1_compressed", "ser_g2_compressed", "product_of_pairings", "product_of_pairings_with_coeffs",
            "normalize_batch_g1", "normalize_batch_g2", "fold_g1_affine", "fold_g2_affine", "fold_g1", "fold_g2",
            "scale_g1_affine", "synth_g1", "synth_g2", "synth_fr", "init", "device_count", "final_exponentiation",
@@ -97,6 +97,17 @@ class MultiexponentiationInnerProductG2:
         l, r = _c(left, 36), _c(right, 4)
         out = np.zeros(36, dtype=np.uint64)
         _check(lib().ripp_msm_g2_j(_p(l), ctypes.c_size_t(len(l)), _p(r), ctypes.c_size_t(len(r)), _p(out)), len(l), len(r))
+        return out
+
+
+class ScalarInnerProduct:
+    """inner_products/src/lib.rs:144-166: left, right (n,4) Fr -> Fr (4,)."""
+
+    @staticmethod
+    def inner_product(left, right):
+        l, r = _c(left, 4), _c(right, 4)
+        out = np.zeros(4, dtype=np.uint64)
+        _check(lib().ripp_scalar_inner_product(_p(l), ctypes.c_size_t(len(l)), _p(r), ctypes.c_size_t(len(r)), _p(out)), len(l), len(r))
         return out
 
 

@@ -686,6 +686,26 @@ API int32_t ripp_msm_g2_j(const ripp_g2j* b, size_t nl, const ripp_fr* s, size_t
 API int32_t ripp_msm_g1_a(const ripp_g1a* b, const ripp_fr* s, size_t n, ripp_g1j* out) { return msm_impl<Fp, false>(b, n, s, n, out); }
 API int32_t ripp_msm_g2_a(const ripp_g2a* b, const ripp_fr* s, size_t n, ripp_g2j* out) { return msm_impl<Fp2, false>(b, n, s, n, out); }
 
+// ---- ScalarInnerProduct (inner_products/src/lib.rs:144-166) ----------------------------------------------------------------
+API int32_t ripp_scalar_inner_product(const ripp_fr* l, size_t nl, const ripp_fr* r, size_t nr, ripp_fr* out) {
+    if (nl != nr) { set_err("left length, right length: " + std::to_string(nl) + ", " + std::to_string(nr)); return RIPP_ERR_LENGTH; }
+    LOCK; ENGINE; if (!out || (nl && (!l || !r))) return RIPP_ERR_ARG;
+    Fr acc = Fr::zero();
+    if (nl) {
+        const unsigned blocks = std::min<unsigned>(1024, nblk(nl, 256));
+        Fr *dl, *dr; int32_t rc;
+        if ((rc = upload<Fr>(e, e->tmpR, l, nl, &dl)) || (rc = upload<Fr>(e, e->tmpA, r, nl, &dr)) || (rc = e->tmpB.reserve(blocks * sizeof(Fr)))) return rc;
+        hipLaunchKernelGGL(k_fr_dot, dim3(blocks), dim3(256), 0, e->stream, dl, dr, (uint32_t)nl, e->tmpB.as<Fr>());
+        HIPCHK(hipGetLastError());
+        std::vector<Fr> part(blocks);
+        HIPCHK(hipMemcpyAsync(part.data(), e->tmpB.p, blocks * sizeof(Fr), hipMemcpyDeviceToHost, e->stream));
+        if ((rc = e->sync())) return rc;
+        for (const Fr& p : part) acc = add(acc, p);
+    }
+    std::memcpy(out, &acc, sizeof acc);
+    return RIPP_OK;
+}
+
 // ---- SIPP verifier (sipp/src/lib.rs:109-180) ----------------------------------------------------------------------------
 API int32_t ripp_sipp_verify(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr* r, size_t n, const ripp_gt* claimed, const ripp_gt* proof, size_t proof_rounds, int32_t* accept) {
     if (!a || !b || !r || !claimed || !proof || !accept) return RIPP_ERR_ARG;

@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(64, RIPP_OCC) k_fold_g2_gls(const G2A* __restr
 // every wave still has uniform control flow (one digit string per wave); 65 dbl + ~22 adds per lane instead of
 // 65 + ~87.  k_fold_g2_combine then sums the four partial points and adds lo.  1.9x the total work of the
 // single-lane form, so the engine uses it only below a size threshold.
-__global__ void __launch_bounds__(64) k_fold_g2_gls_split(const G2A* __restrict__ hi, uint32_t half, GlsDigits dg, G2J* __restrict__ parts /* [4][half] */) {
+__global__ void __launch_bounds__(64, 2) k_fold_g2_gls_split(const G2A* __restrict__ hi, uint32_t half, GlsDigits dg, G2J* __restrict__ parts /* [4][half] */) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= half) return;
     const int j = blockIdx.y;
@@ -323,6 +323,17 @@ __global__ void __launch_bounds__(256) k_fold_fr(const Fr* __restrict__ hi, cons
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= half) return;
     out[i] = add(mul(hi[i], s), lo[i]);
+}
+
+// ScalarInnerProduct::inner_product (inner_products/src/lib.rs:149-166): sum_i l_i * r_i in Fr.  Each lane sums a strided subset, one
+// LDS tree per block, one partial per block (the host adds the <= 1024 partials).
+__global__ void __launch_bounds__(256) k_fr_dot(const Fr* __restrict__ l, const Fr* __restrict__ r, uint32_t n, Fr* __restrict__ partials) {
+    __shared__ Fr sh[256];
+    Fr acc = Fr::zero();
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) acc = add(acc, mul(l[i], r[i]));
+    sh[threadIdx.x] = acc; __syncthreads();
+    for (uint32_t s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) sh[threadIdx.x] = add(sh[threadIdx.x], sh[threadIdx.x + s]); __syncthreads(); }
+    if (threadIdx.x == 0) partials[blockIdx.x] = sh[0];
 }
 
 // ---- synthetic inputs (bench harness) ---------------------------------------------------

@@ -107,6 +107,23 @@ def test_msm_vs_oracle(engine, orc, n):
         assert np.array_equal(engine.normalize_batch_g2(engine.MultiexponentiationInnerProductG2.inner_product(orc.blind_g2(b2, 9), s)), orc.g2_to_affine(orc.msm_g2_a(b2, s)).reshape(1, 24))
 
 
+@pytest.mark.parametrize("n", [0, 1, 255, 256, 257, 100003])
+def test_scalar_inner_product(engine, orc, n):
+    """ScalarInnerProduct (inner_products/src/lib.rs:144-166) against Python integers; length mismatch raises as the other products do."""
+    l, r = orc.gen_scalars(5, n), orc.gen_scalars(6, n)
+    exp = sum(orc.limbs_to_fr(a) * orc.limbs_to_fr(b) for a, b in zip(l[:2000], r[:2000])) % orc.R if n <= 2000 else None
+    got = orc.limbs_to_fr(engine.ScalarInnerProduct.inner_product(l, r))
+    if exp is not None:
+        assert got == exp
+    else:   # linearity: <l, r> = <l[:k], r[:k]> + <l[k:], r[k:]>
+        k = 777
+        assert got == (orc.limbs_to_fr(engine.ScalarInnerProduct.inner_product(l[:k], r[:k])) + orc.limbs_to_fr(engine.ScalarInnerProduct.inner_product(l[k:], r[k:]))) % orc.R
+        assert orc.limbs_to_fr(engine.ScalarInnerProduct.inner_product(l[:k], r[:k])) == sum(orc.limbs_to_fr(a) * orc.limbs_to_fr(b) for a, b in zip(l[:k], r[:k])) % orc.R
+    if n:
+        with pytest.raises(engine.InnerProductError):
+            engine.ScalarInnerProduct.inner_product(l, r[:-1])
+
+
 def test_msm_adversarial_scalars(engine, orc):
     """all-zero, all-one, all-(r-1), few distinct values (bucket skew) -- SURVEY.md section 8d config 3."""
     n = 1 << 11
