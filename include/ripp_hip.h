@@ -65,6 +65,13 @@ int32_t ripp_msm_g1_a(const ripp_g1a* bases, const ripp_fr* scalars, size_t n, r
 int32_t ripp_msm_g2_a(const ripp_g2a* bases, const ripp_fr* scalars, size_t n, ripp_g2j* out);
 /* ScalarInnerProduct::inner_product (inner_products/src/lib.rs:144-166): sum_i l_i * r_i in Fr; RIPP_ERR_LENGTH as above */
 int32_t ripp_scalar_inner_product(const ripp_fr* left, size_t nl, const ripp_fr* right, size_t nr, ripp_fr* out);
+/* Sharded evaluation (vectors partitioned by index residue, one process per GPU): this rank's share of a
+ * pairing product = the Miller value of its pairs BEFORE the final exponentiation.  All-gather the shares (576 B each), multiply
+ * them (ripp_combine_partials) and apply ripp_final_exp ONCE: the result equals ripp_pairing_product_j of the whole vectors.  A
+ * sharded MSM is ripp_msm_g{1,2}_j per shard + ripp_sum_g{1,2}_j of the gathered points. */
+int32_t ripp_pairing_miller_j(const ripp_g1j* left, size_t nl, const ripp_g2j* right, size_t nr, ripp_gt* miller_value);
+int32_t ripp_sum_g1_j(const ripp_g1j* pts, size_t n, ripp_g1j* out);
+int32_t ripp_sum_g2_j(const ripp_g2j* pts, size_t n, ripp_g2j* out);
 
 /* ---- halving-round fold  out[i] = s * hi[i] + lo[i],  i < half ------------------------------------------ */
 /* SIPP form: affine in, batch-normalised affine out  -- sipp/src/lib.rs:87-92 (G1) and :95-100 (G2) */

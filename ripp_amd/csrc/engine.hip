@@ -641,6 +641,23 @@ API int32_t ripp_pairing_product_j(const ripp_g1j* l, size_t nl, const ripp_g2j*
     if ((rc = e->normalize_dev<Fp2>(dr, nr, e->affG2.as<G2A>()))) return rc;
     return pairing_product_dev(e, e->affG1.as<G1A>(), e->affG2.as<G2A>(), nl, out);
 }
+// this rank's share of a sharded pairing product: the Miller value of its pairs, BEFORE the final exponentiation.
+// prod over ranks of these (ripp_combine_partials), then ONE ripp_final_exp, equals ripp_pairing_product_j of the whole vectors.
+API int32_t ripp_pairing_miller_j(const ripp_g1j* l, size_t nl, const ripp_g2j* r, size_t nr, ripp_gt* out) {
+    if (nl != nr) { set_err("left length, right length: " + std::to_string(nl) + ", " + std::to_string(nr)); return RIPP_ERR_LENGTH; }
+    LOCK; ENGINE; if (!out || (nl && (!l || !r))) return RIPP_ERR_ARG;
+    G1J* dl; G2J* dr; int32_t rc;
+    if ((rc = upload<G1J>(e, e->jacG1, l, nl, &dl)) || (rc = upload<G2J>(e, e->jacG2, r, nr, &dr))) return rc;
+    if ((rc = e->affG1.reserve(std::max<size_t>(nl, 1) * sizeof(G1A))) || (rc = e->affG2.reserve(std::max<size_t>(nl, 1) * sizeof(G2A)))) return rc;
+    if ((rc = e->normalize_dev<Fp>(dl, nl, e->affG1.as<G1A>())) || (rc = e->normalize_dev<Fp2>(dr, nr, e->affG2.as<G2A>()))) return rc;
+    Fp12 rows[N_LINES];
+    const G1A* as[1] = {e->affG1.as<G1A>()}; const G2A* bs[1] = {e->affG2.as<G2A>()};
+    if ((rc = e->step_products(as, bs, 1, nl, rows))) return rc;
+    const Fp12 z = miller_combine(rows);
+    std::memcpy(out, &z, sizeof z);
+    e->collect_kernel_stats();
+    return RIPP_OK;
+}
 API int32_t ripp_pairing_product_coeffs_a(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr* r, size_t n, ripp_gt* out) {
     LOCK; ENGINE; if (!out || (n && (!a || !b || !r))) return RIPP_ERR_ARG;
     G1A* da; G2A* db; Fr* dr; int32_t rc;
@@ -1563,6 +1580,9 @@ API int32_t ripp_sipp_seed_digest(const ripp_g1a* a, const ripp_g2a* b, const ri
 // ---- host helpers ----------------------------------------------------------------------------------------------------
 API int32_t ripp_final_exp(const ripp_gt* f, ripp_gt* out) { if (!f || !out) return RIPP_ERR_ARG; Fp12 x; std::memcpy(&x, f, sizeof x); const Fp12 r = final_exponentiation(x); std::memcpy(out, &r, sizeof r); return RIPP_OK; }
 API int32_t ripp_miller_combine(const ripp_gt* rows, ripp_gt* out) { if (!rows || !out) return RIPP_ERR_ARG; std::vector<Fp12> L(N_LINES); std::memcpy(L.data(), rows, N_LINES * sizeof(Fp12)); const Fp12 r = miller_combine(L.data()); std::memcpy(out, &r, sizeof r); return RIPP_OK; }
+// sum of a few projective points on the host (the cross-rank reduction of sharded MSM partials: G-1 additions)
+API int32_t ripp_sum_g1_j(const ripp_g1j* pts, size_t n, ripp_g1j* out) { if (!out || (n && !pts)) return RIPP_ERR_ARG; G1J acc = jac_inf<Fp>(); for (size_t i = 0; i < n; ++i) { G1J p; std::memcpy(&p, &pts[i], sizeof p); acc = add(acc, p); } std::memcpy(out, &acc, sizeof acc); return RIPP_OK; }
+API int32_t ripp_sum_g2_j(const ripp_g2j* pts, size_t n, ripp_g2j* out) { if (!out || (n && !pts)) return RIPP_ERR_ARG; G2J acc = jac_inf<Fp2>(); for (size_t i = 0; i < n; ++i) { G2J p; std::memcpy(&p, &pts[i], sizeof p); acc = add(acc, p); } std::memcpy(out, &acc, sizeof acc); return RIPP_OK; }
 API int32_t ripp_gt_mul(const ripp_gt* a, const ripp_gt* b, ripp_gt* out) { if (!a || !b || !out) return RIPP_ERR_ARG; Fp12 x, y; std::memcpy(&x, a, sizeof x); std::memcpy(&y, b, sizeof y); const Fp12 r = mul(x, y); std::memcpy(out, &r, sizeof r); return RIPP_OK; }
 API int32_t ripp_gt_pow(const ripp_gt* a, const ripp_fr* k, ripp_gt* out) {
     if (!a || !k || !out) return RIPP_ERR_ARG; Fp12 x; Fr km; std::memcpy(&x, a, sizeof x); std::memcpy(&km, k, sizeof km);

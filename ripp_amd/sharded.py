@@ -54,6 +54,54 @@ def shard(arr, rank, world):
     return np.ascontiguousarray(arr[rank::world])
 
 
+class HipPrimitives:
+    """The three device calls the sharded inner products need (ripp_amd.api over the C ABI); tests inject an oracle-backed stand-in."""
+
+    def __init__(self):
+        from . import api
+        self.api = api
+
+    def pairing_miller(self, left, right):
+        import ctypes
+        from ._lib import lib
+        l, r = self.api._c(left, 18), self.api._c(right, 36); out = np.zeros(72, dtype=np.uint64)
+        self.api._check(lib().ripp_pairing_miller_j(self.api._p(l), ctypes.c_size_t(len(l)), self.api._p(r), ctypes.c_size_t(len(r)), self.api._p(out)), len(l), len(r))
+        return out
+
+    def final_exp(self, f): return self.api.final_exponentiation(f)
+    def gt_mul(self, a, b): return self.api.gt_mul(a, b)
+    def msm_g1(self, bases, scalars): return self.api.MultiexponentiationInnerProductG1.inner_product(bases, scalars)
+    def msm_g2(self, bases, scalars): return self.api.MultiexponentiationInnerProductG2.inner_product(bases, scalars)
+
+    def sum_points(self, pts, cols):
+        import ctypes
+        from ._lib import lib
+        pts = np.ascontiguousarray(pts, dtype=np.uint64).reshape(-1, cols); out = np.zeros(cols, dtype=np.uint64)
+        fn = lib().ripp_sum_g1_j if cols == 18 else lib().ripp_sum_g2_j
+        self.api._check(fn(self.api._p(pts), ctypes.c_size_t(len(pts)), self.api._p(out))); return out
+
+
+def sharded_pairing_inner_product(comm, left_shard, right_shard, prim=None):
+    """PairingInnerProduct::inner_product (inner_products/src/lib.rs:52-75) over vectors sharded by index residue: every rank
+    evaluates the Miller loops of ITS pairs, the 576-byte Miller values are all-gathered and multiplied, and the single final
+    exponentiation is applied to the product (replicated: every rank returns the same GT value)."""
+    prim = prim or HipPrimitives()
+    parts = comm.all_gather(prim.pairing_miller(left_shard, right_shard))
+    acc = parts[0]
+    for p in parts[1:]:
+        acc = prim.gt_mul(acc, p)
+    return prim.final_exp(acc)
+
+
+def sharded_msm(comm, bases_shard, scalars_shard, group="g1", prim=None):
+    """MultiexponentiationInnerProduct::inner_product (inner_products/src/lib.rs:119-142) over sharded vectors: one Pippenger MSM per
+    rank, all-gather of the partial sums (one projective point each), G-1 additions."""
+    prim = prim or HipPrimitives()
+    cols = 18 if group == "g1" else 36
+    part = (prim.msm_g1 if group == "g1" else prim.msm_g2)(bases_shard, scalars_shard)
+    return prim.sum_points(np.stack(comm.all_gather(np.ascontiguousarray(part, dtype=np.uint64).reshape(cols))), cols)
+
+
 class ShardedSippProver:
     """Drives one SIPP proof (sipp/src/lib.rs:42-106) across `comm.world` ranks.
 

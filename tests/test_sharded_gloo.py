@@ -104,3 +104,74 @@ def test_sharded_prover_world2_gloo_matches_single_process(n):
 def test_sharded_prover_world2_real_engine(engine, n):
     """Two ranks, both driving cuda:0 through the C ABI's staged interface, gloo as the transport."""
     _run(2, n, use_gpu=True)
+
+
+# ---------------------------------------------------------------- sharded inner products (SURVEY.md section 8e)
+class OraclePrimitives:
+    """Stand-in for ripp_amd.sharded.HipPrimitives computing with the CPU oracle."""
+
+    def __init__(self):
+        import orclib as o
+        self.o = o
+
+    def pairing_miller(self, left, right): return self.o.miller_product_a(self.o.normalize_g1(left), self.o.normalize_g2(right))
+    def final_exp(self, f): return self.o.final_exp(f)
+    def gt_mul(self, a, b): return self.o.gt_mul(a, b)
+    def msm_g1(self, bases, scalars): return self.o.msm_g1_j(bases, scalars)[1]
+    def msm_g2(self, bases, scalars): return self.o.msm_g2_j(bases, scalars)[1]
+
+    def sum_points(self, pts, cols):
+        o = self.o; acc = pts[0].copy()
+        import ctypes
+        for p in pts[1:]:
+            out = np.zeros(cols, dtype=np.uint64)
+            (o.lib().orc_g1_add_j if cols == 18 else o.lib().orc_g2_add_j)(o._p(acc), o._p(np.ascontiguousarray(p)), o._p(out)); acc = out
+        return acc
+
+
+def _ip_worker(rank, world, port, n, use_gpu, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    for p in (os.path.dirname(HERE), HERE, os.path.join(HERE, "model")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import orclib as o
+    from ripp_amd.sharded import TorchComm, shard, sharded_pairing_inner_product, sharded_msm
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        a, b, s = o.blind_g1(o.gen_g1(31, n), 1), o.blind_g2(o.gen_g2(41, n), 2), o.gen_scalars(9, n)
+        if use_gpu:
+            import ripp_amd as R
+            R.init(0); prim = None
+        else:
+            prim = OraclePrimitives()
+        comm = TorchComm("cpu")
+        ip = sharded_pairing_inner_product(comm, shard(a, rank, world), shard(b, rank, world), prim)
+        m1 = sharded_msm(comm, shard(a, rank, world), shard(s, rank, world), "g1", prim)
+        m2 = sharded_msm(comm, shard(b, rank, world), shard(s, rank, world), "g2", prim)
+        ok = np.array_equal(ip, o.pairing_product_j(a, b)[1])
+        ok = ok and np.array_equal(o.g1_to_affine(m1), o.g1_to_affine(o.msm_g1_j(a, s)[1])) and np.array_equal(o.g2_to_affine(m2), o.g2_to_affine(o.msm_g2_j(b, s)[1]))
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_ip(world, n, use_gpu):
+    import torch.multiprocessing as mp
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_ip_worker, args=(world, _free_port(), n, use_gpu, ret), nprocs=world, join=True)
+    assert dict(ret) == {r: True for r in range(world)}
+
+
+@pytest.mark.parametrize("n", [2, 10])
+def test_sharded_inner_products_world2_gloo(n):
+    """PairingInnerProduct and both MSMs over residue-sharded vectors: all-gather of one Miller value / one point per rank, one final
+    exponentiation -- equal to the unsharded result (host logic on CPU, oracle-backed primitives)."""
+    os.environ.setdefault("OMP_NUM_THREADS", "4")
+    _run_ip(2, n, use_gpu=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [6, 1000])
+def test_sharded_inner_products_world2_real_engine(engine, n):
+    _run_ip(2, n, use_gpu=True)
