@@ -33,23 +33,32 @@ __device__ __forceinline__ Fp vm_cneg(const Fp& x, bool f) {
 }
 
 // Run one program on this lane's element.  `ws` = LDS workspace of the element, `lg` = lane index within the group.
+// A lone wave issues one VALU instruction per ~8 cycles, so every instruction of a layer is latency: the operand preparation
+// (conditional negations, the second term of each operand, shifts, halving) is skipped whenever NO lane of the wave needs it -- the
+// test is wave-uniform (`__any`), so there is no divergence.  Slot 0 holds zero, hence "second term absent" == slot index 0.
+__device__ __forceinline__ Fp vm_operand(const Fp* ws, unsigned s0, unsigned s1, bool n0, bool n1) {
+    Fp x = ws[s0];
+    if (__any(n0)) x = vm_cneg(x, n0);
+    if (__any(s1 != 0u)) { Fp y = ws[s1]; if (__any(n1)) y = vm_cneg(y, n1); x = add(x, y); }
+    return x;
+}
 __device__ __forceinline__ void vm_run(Fp* ws, const unsigned char* __restrict__ kind, const VmOp* __restrict__ ops, int nlayers, int lg) {
 #pragma unroll 1
     for (int l = 0; l < nlayers; ++l) {
         const VmOp op = ops[l * VM_G + lg];
-        const Fp x0 = ws[op.a0], x1 = ws[op.a1], x2 = ws[op.a2], x3 = ws[op.a3];
         const unsigned f = op.flags;
         Fp r;
         if (kind[l] == 0) {                                    // MUL layer (uniform over the wave)
-            const Fp A = add(vm_cneg(x0, f & 1u), vm_cneg(x1, f & 2u));
-            const Fp B = add(vm_cneg(x2, f & 4u), vm_cneg(x3, f & 8u));
+            const Fp A = vm_operand(ws, op.a0, op.a1, f & 1u, f & 2u);
+            const Fp B = vm_operand(ws, op.a2, op.a3, f & 4u, f & 8u);
             r = mul(A, B);
         } else {                                                // LIN layer
-            r = add(add(vm_cneg(x0, f & 1u), vm_cneg(x1, f & 2u)), add(vm_cneg(x2, f & 4u), vm_cneg(x3, f & 8u)));
+            r = vm_operand(ws, op.a0, op.a1, f & 1u, f & 2u);
+            if (__any((op.a2 | op.a3) != 0u)) r = add(r, vm_operand(ws, op.a2, op.a3, f & 4u, f & 8u));
             const unsigned sh = (f >> 5) & 3u;
             if (__any(sh != 0u)) {
 #pragma unroll 1
-                for (unsigned k = 0; k < 3; ++k) { const Fp d = dbl(r); const bool t = k < sh;
+                for (unsigned k = 0; k < 3; ++k) { if (!__any(k < sh)) break; const Fp d = dbl(r); const bool t = k < sh;
 #pragma unroll
                     for (int i = 0; i < 12; ++i) r.l[i] = t ? d.l[i] : r.l[i]; }
             }
