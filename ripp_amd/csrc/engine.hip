@@ -7,6 +7,10 @@
 // sipp/src/lib.rs:56-60,80-85,94.
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <memory>
 #include <future>
 #include <chrono>
 #include <cstdio>
@@ -33,6 +37,31 @@ namespace {
 
 std::mutex g_mu;
 std::string g_err;
+
+// Persistent host workers for the per-round serial glue (final exponentiations, GT powers, KZG quotients).  std::async spawns a
+// thread per call, which costs ~0.1 ms and occasionally 1-2 ms -- on the critical path of every one of the 20 rounds of a proof.
+class HostPool {
+public:
+    explicit HostPool(unsigned n) { for (unsigned i = 0; i < n; ++i) th_.emplace_back([this]() { run(); }); }
+    ~HostPool() { { std::lock_guard<std::mutex> lk(mu_); stop_ = true; } cv_.notify_all(); for (auto& t : th_) t.join(); }
+    template <class F> auto submit(F&& f) -> std::future<decltype(f())> {
+        auto task = std::make_shared<std::packaged_task<decltype(f())()>>(std::forward<F>(f));
+        auto fut = task->get_future();
+        { std::lock_guard<std::mutex> lk(mu_); q_.emplace_back([task]() { (*task)(); }); }
+        cv_.notify_one();
+        return fut;
+    }
+private:
+    void run() {
+        for (;;) {
+            std::function<void()> job;
+            { std::unique_lock<std::mutex> lk(mu_); cv_.wait(lk, [this]() { return stop_ || !q_.empty(); }); if (stop_ && q_.empty()) return; job = std::move(q_.front()); q_.pop_front(); }
+            job();
+        }
+    }
+    std::vector<std::thread> th_; std::deque<std::function<void()>> q_; std::mutex mu_; std::condition_variable cv_; bool stop_ = false;
+};
+HostPool& host_pool() { static HostPool pool(6); return pool; }
 struct Engine;
 Engine* g_engine = nullptr;
 
@@ -867,7 +896,7 @@ static int32_t gipa_tipp_core(Engine* e, TippVecs& v, size_t n, ripp_gt* com_ste
               if (shift && k == 0) z = gt_pow_host(z, rp[lg_split]);             // (prod e(a_(i+s), ck_i))^(r^s)
               if (shift && k == 3) z = gt_pow_host(z, rpi[lg_split]);            // (prod e(a_i, ck_(i+s)))^(r^-s)
               return z; };
-          for (int k = 1; k < 6; ++k) fut.push_back(std::async(std::launch::async, one, k));
+          for (int k = 1; k < 6; ++k) fut.push_back(host_pool().submit([one, k]() { return one(k); }));
           com[0] = one(0);
           for (int k = 1; k < 6; ++k) com[k] = fut[k - 1].get(); }
         Fr c_inv; const Fr c = fs::gipa_tipp_challenge(round ? &prev_c : nullptr, com, c_inv);
@@ -1024,7 +1053,7 @@ static int32_t tipp_kzg(Engine* e, const ripp_srs* srs, const ripp_fr* transcrip
     ripp_srs* s = const_cast<ripp_srs*>(srs); int32_t rc;
     // the two openings are independent: quotients on two host threads, MSMs side by side on two streams
     std::vector<Fr> qa, qb;
-    auto fb = std::async(std::launch::async, [&]() { return kzg_quotient(tr, Fr::one(), c, s->num, qb); });
+    auto fb = host_pool().submit([&]() { return kzg_quotient(tr, Fr::one(), c, s->num, qb); });
     rc = kzg_quotient(tri, r_inv, c, s->num, qa); const int32_t rcb = fb.get();
     if (rc || rcb) return rc ? rc : rcb;
     if ((rc = kzg_opening_launch<Fp2>(e, 0, e->stream, s->hbp.as<G2A>(), qa))) return rc;                                     // :212-217
@@ -1094,7 +1123,7 @@ static int32_t tipa_ssm_core(Engine* e, const ripp_srs* srs, SsmVecs& v, size_t 
         e->stats.miller_products_ms += now_ms() - tp;
         const double th = now_ms();
         Fp12 gt[2];
-        { auto fut = std::async(std::launch::async, [&rows]() { return final_exponentiation(miller_combine(rows.data() + N_LINES)); });
+        { auto fut = host_pool().submit([&rows]() { return final_exponentiation(miller_combine(rows.data() + N_LINES)); });
           gt[0] = final_exponentiation(miller_combine(rows.data())); gt[1] = fut.get(); }
         const G1A ipa[2] = {to_affine(ip[0]), to_affine(ip[1])};
         Fr c_inv; const Fr c = fs::gipa_ssm_challenge(round ? &prev_c : nullptr, gt, ipa, c_inv);
@@ -1175,7 +1204,7 @@ API int32_t ripp_aggregate_proofs(const ripp_srs* srs, const ripp_g1a* a, const 
     {   // com_a = IP(a, ck_1), com_b = IP(ck_2, b), com_c = IP(c, ck_1): one line launch over three products   (:100-102)
         const G1A* as[3] = {v.A2.as<G1A>(), v.KB.as<G1A>(), w.A.as<G1A>()}; const G2A* bs[3] = {dCK1.as<G2A>(), v.B.as<G2A>(), dCK1.as<G2A>()};
         if ((rc = e->step_products(as, bs, 3, n, rows.data()))) return rc;
-        auto f1 = std::async(std::launch::async, finish, 1); auto f2 = std::async(std::launch::async, finish, 2);
+        auto f1 = host_pool().submit([&finish]() { return finish(1); }); auto f2 = host_pool().submit([&finish]() { return finish(2); });
         const Fp12 ca = finish(0), cb = f1.get(), cc = f2.get();
         std::memcpy(&out->com_a, &ca, sizeof ca); std::memcpy(&out->com_b, &cb, sizeof cb); std::memcpy(&out->com_c, &cc, sizeof cc);
     }
@@ -1304,7 +1333,7 @@ static bool tipp_replay(const ripp_gt com[3], const ripp_gt* com_steps, size_t r
         for (int j = 0; j < 6; ++j) if (!gt_in_cyclotomic(s[j])) return false;          // not a GT element: reject
         Fr c_inv; const Fr c = fs::gipa_tipp_challenge(k ? &tr[k - 1] : nullptr, s, c_inv);
         std::future<Fp12> f[5];
-        for (int j = 1; j < 6; ++j) f[j - 1] = std::async(std::launch::async, [&s, j, c, c_inv]() { return gt_pow_host(s[j], j < 3 ? c : c_inv); });
+        for (int j = 1; j < 6; ++j) f[j - 1] = host_pool().submit([&s, j, c, c_inv]() { return gt_pow_host(s[j], j < 3 ? c : c_inv); });
         Fp12 p[6]; p[0] = gt_pow_host(s[0], c); for (int j = 1; j < 6; ++j) p[j] = f[j - 1].get();
         for (int j = 0; j < 3; ++j) acc[j] = mul(acc[j], mul(p[j], p[j + 3]));       // com + com_1 * c + com_2 * c_inv  (gipa.rs:358-360)
         tr[k] = c;
@@ -1373,7 +1402,7 @@ API int32_t ripp_tipa_ssm_verify(const ripp_verifier_srs* v_srs, const ripp_gt* 
         if (!gt_in_cyclotomic(gt[0]) || !gt_in_cyclotomic(gt[1])) { *accept = 0; return RIPP_OK; }
         const G1A g1[2] = {to_affine(load_jac<Fp>(&com_g1[2 * k])), to_affine(load_jac<Fp>(&com_g1[2 * k + 1]))};
         Fr c_inv; const Fr c = fs::gipa_ssm_challenge(k ? &trf[k - 1] : nullptr, gt, g1, c_inv);
-        auto f = std::async(std::launch::async, [&gt, c_inv]() { return gt_pow_host(gt[1], c_inv); });
+        auto f = host_pool().submit([&gt, c_inv]() { return gt_pow_host(gt[1], c_inv); });
         ca = mul(ca, mul(gt_pow_host(gt[0], c), f.get()));
         ct = add(add(ct, smul_host(g1[0], c)), smul_host(g1[1], c_inv));
         trf[k] = c;
@@ -1466,7 +1495,7 @@ API int32_t ripp_sipp_job_round_partials(ripp_sipp_job* j, ripp_gt* partials) {
     if (j->len < 2) { set_err("shard exhausted: gather the remaining elements onto one rank"); return RIPP_ERR_ARG; }
     Fp12 rows[2 * N_LINES];
     int32_t rc = job_round_partials(e, j, rows); if (rc) return rc;
-    auto fut = std::async(std::launch::async, [&rows]() { return miller_combine(rows + N_LINES); });
+    auto fut = host_pool().submit([&rows]() { return miller_combine(rows + N_LINES); });
     const Fp12 ml = miller_combine(rows), mr = fut.get();
     std::memcpy(&partials[0], &ml, sizeof ml); std::memcpy(&partials[1], &mr, sizeof mr);
     return RIPP_OK;
@@ -1475,7 +1504,7 @@ API int32_t ripp_sipp_job_round_finish(ripp_sipp_job* j, const ripp_gt* combined
     LOCK; ENGINE; if (!j || !combined || !z_l || !z_r || !x) return RIPP_ERR_ARG;
     const double t0 = now_ms();
     Fp12 mv[2]; std::memcpy(mv, combined, sizeof mv);
-    auto fut = std::async(std::launch::async, [&mv]() { return final_exponentiation(mv[1]); });
+    auto fut = host_pool().submit([&mv]() { return final_exponentiation(mv[1]); });
     const Fp12 zl = final_exponentiation(mv[0]);
     const Fp12 zr = fut.get();
     if (!j->seeded) { if (!seed_digest) return RIPP_ERR_ARG; j->rng.from_digest(seed_digest); j->seeded = true; }
@@ -1527,7 +1556,7 @@ API int32_t ripp_sipp_job_prove(ripp_sipp_job* j, const ripp_gt* value, ripp_gt*
         const double tr0 = now_ms();
         if ((rc = job_round_partials(e, j, rows))) return rc;
         const double t0 = now_ms();
-        auto fut = std::async(std::launch::async, [&rows]() { return final_exponentiation(miller_combine(rows + N_LINES)); });
+        auto fut = host_pool().submit([&rows]() { return final_exponentiation(miller_combine(rows + N_LINES)); });
         const Fp12 zl = final_exponentiation(miller_combine(rows));
         const Fp12 zr = fut.get();
         if (!j->seeded) {
