@@ -183,6 +183,26 @@ def test_sipp_prove_vs_oracle(engine, orc, n):
         assert not engine.SIPP.verify(a, b, r, value, bad)
 
 
+@pytest.mark.parametrize("n", [8, 64, 4096])
+def test_sipp_degenerate_statement_vs_oracle(engine, orc, n):
+    """Zero coefficients (r_i = 0 -> the scaled a_i is the identity), identities on both sides, repeated and negated points (folds
+    meet P + P and P - P), on the scalar kernels (n = 4096 in its first rounds) and on the VM kernels: the proof must still equal the
+    oracle's byte for byte and verify."""
+    a, b, r = orc.gen_g1(70, n), orc.gen_g2(80, n), orc.gen_scalars(9, n)
+    r[1] = 0; r[n // 2] = 0
+    a[2] = 0; b[3] = 0; a[n - 1] = 0; b[n - 1] = 0
+    a[5] = a[4]; b[5] = b[4]; r[5] = r[4]                              # identical neighbours
+    q = (4 + n // 2) % n
+    a[q] = a[4]; b[q] = b[4]; r[q] = r[4]                              # identical partners of a halving round: x*P + P patterns
+    a[6, 6:] = orc.fp_to_limbs((orc.P - orc.limbs_to_fp(a[7, 6:])) % orc.P); a[6, :6] = a[7, :6]   # a_6 = -a_7
+    value = engine.product_of_pairings_with_coeffs(a, b, r)
+    assert np.array_equal(value, orc.product_of_pairings_with_coeffs(a, b, r))
+    proof = engine.SIPP.prove(a, b, r, value)
+    rc, eproof, _ = orc.sipp_prove(a, b, r, value)
+    assert rc == 0 and np.array_equal(proof, eproof)
+    assert engine.SIPP.verify(a, b, r, value, proof)
+
+
 def test_sipp_rejects_non_power_of_two(engine, orc):
     a, b, r = orc.gen_g1(1, 24), orc.gen_g2(1, 24), orc.gen_scalars(1, 24)
     with pytest.raises(AssertionError):

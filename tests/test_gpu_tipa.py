@@ -155,6 +155,26 @@ def test_aggregate_proofs_vs_oracle(engine, orc, n):
     srs.close()
 
 
+def test_aggregate_proofs_degenerate_inputs_vs_oracle(engine, orc):
+    """identities among the (A, B, C) members and repeated triples: every member of the aggregate still equals the oracle's"""
+    n = 16
+    osrs = h.make_srs(n, 0x51, 0x52); srs = engine.SRS(osrs[0], osrs[1], osrs[2], osrs[3])
+    a, b, c = orc.gen_g1(3, n), orc.gen_g2(5, n), orc.gen_g1(7, n)
+    a[2] = 0; b[3] = 0; c[1] = 0; c[9] = 0; a[12] = a[4]; b[12] = b[4]; c[12] = c[4]; a[15] = 0; b[15] = 0; c[15] = 0
+    got, _ = engine.aggregate_proofs(srs, a, b, c)
+    rc, exp = orc.aggregate_proofs(osrs[0], osrs[1], a, b, c); assert rc == 0
+    for k in ("com_a", "com_b", "com_c", "ip_ab", "r", "ab_kzg_c", "c_base_b", "c_kzg_c"):
+        assert np.array_equal(got.field(k), exp.field(k)), k
+    for k in ("ab_com_steps", "ab_transcript", "c_com_gt", "c_transcript"):
+        assert np.array_equal(getattr(got, k), getattr(exp, k)), k
+    for k in ("agg_c", "ab_base_a", "ab_final_ck_b", "ab_opening_b", "c_base_a"):
+        assert same_g1(engine, orc, got.field(k), exp.field(k)), k
+    for k in ("ab_base_b", "ab_final_ck_a", "ab_opening_a", "c_final_ck_a", "c_opening_a"):
+        assert same_g2(engine, orc, got.field(k), exp.field(k)), k
+    assert same_g1(engine, orc, got.c_com_g1, exp.c_com_g1)
+    srs.close()
+
+
 def test_aggregate_proofs_config5_size(engine, orc):
     """n = 2^14 synthetic (A, B, C) triples (random group elements, the prover never checks Groth16
     validity).  The oracle needs minutes at this size, so check the proof through the oracle's TIPA / SSM verifiers (O(log n) work
