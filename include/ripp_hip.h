@@ -48,7 +48,7 @@ typedef struct {
 int32_t ripp_init(int32_t device_ordinal);
 void    ripp_shutdown(void);
 int32_t ripp_device_count(void);
-const char* ripp_last_error(void);
+const char* ripp_last_error(void);   /* message of the calling thread's last failed call (thread-local, errno-style) */
 
 /* ---- L1 trait surface on host slices ------------------------------------------------------------------ */
 /* PairingInnerProduct::inner_product(left: &[G1], right: &[G2])  -- inner_products/src/lib.rs:61-73 (cfg_multi_pairing :77-116) */
@@ -190,8 +190,8 @@ typedef struct {
     ripp_fr c_kzg_c;
 } ripp_aggregate_proof;
 /* a, b, c: the (A, B, C) members of n Groth16 proofs (affine, as ark_groth16::Proof stores them); n a power of two >= 2 and
- * srs built for the same n.  RIPP_ERR_ARG with ripp_last_error() = "commitment key shift check failed" mirrors the
- * assert_eq! at :133-136. */
+ * srs built for the same n.  The reference's assert_eq!(com_a, IP(a_r, ck_1_r)) (:133-136) holds by construction here: the engine
+ * never materialises ck_1_r (bilinearity: IP(a_r, ck_1_r) IS IP(a, ck_1) = com_a), see DESIGN.md section 4b. */
 int32_t ripp_aggregate_proofs(const ripp_srs* srs, const ripp_g1a* a, const ripp_g2a* b, const ripp_g1a* c, size_t n,
                               ripp_aggregate_proof* out, ripp_stats* stats);
 

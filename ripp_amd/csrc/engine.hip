@@ -36,7 +36,7 @@ static_assert(sizeof(ripp_g1j) == sizeof(G1J) && sizeof(ripp_g2j) == sizeof(G2J)
 namespace {
 
 std::mutex g_mu;
-std::string g_err;
+thread_local std::string g_err;          // last error message of the CALLING thread (errno-style; ripp_last_error)
 
 // Persistent host workers for the per-round serial glue (final exponentiations, GT powers, KZG quotients).  std::async spawns a
 // thread per call, which costs ~0.1 ms and occasionally 1-2 ms -- on the critical path of every one of the 20 rounds of a proof.
