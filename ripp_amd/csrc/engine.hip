@@ -785,673 +785,7 @@ API int32_t ripp_sipp_verify(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr
 }
 
 
-// ---- GIPA / TIPP prover (ip_proofs/src/gipa.rs:181-312) ------------------------------------------------------------------
-// The four vectors are kept AFFINE on the device between rounds (each commitment of the reference re-normalises its
-// projective inputs anyway, inner_products/src/lib.rs:80-81; group elements are identical), the six commitments of a
-// round share ONE line launch, and the folds reuse the NAF / GLS kernels: G1 vectors take the full-width c, G2 vectors
-// the 128-bit c_inv -- exactly the reference's choice (gipa.rs:252-256).
-extern "C++" {
-template <class F> static int32_t fold_dev(Engine* e, hipStream_t st, const Affine<F>* hi, const Affine<F>* lo, size_t half, const Fr& s, DevBuf& jac, DevBuf& qt, Affine<F>* out);
-template <> int32_t fold_dev<Fp>(Engine* e, hipStream_t st, const G1A* hi, const G1A* lo, size_t half, const Fr& s, DevBuf& jac, DevBuf&, G1A* out) {
-    int32_t rc; if ((rc = jac.reserve(half * sizeof(G1J)))) return rc;
-    // GIPA folds G1 vectors with the full-width challenge c: split it through the GLV endomorphism (128 doublings instead of 255)
-    if (half <= e->vm_fold_max && !std::getenv("RIPP_NO_VM"))     // latency form (complete additions, nothing to flag)
-        hipLaunchKernelGGL(k_vm_fold_g1_glv, dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VM_G1_SLOTS * sizeof(Fp), st, hi, lo, (uint32_t)half, glv_digits(s), jac.as<G1J>());
-    else
-        hipLaunchKernelGGL(k_fold_g1_glv, dim3(nblk(half, 256)), dim3(256), 0, st, hi, lo, (uint32_t)half, glv_digits(s), jac.as<G1J>());
-    HIPCHK(hipGetLastError());
-    return e->normalize_dev<Fp>(jac.as<G1J>(), half, out, st);
-}
-template <> int32_t fold_dev<Fp2>(Engine* e, hipStream_t st, const G2A* hi, const G2A* lo, size_t half, const Fr& s, DevBuf& jac, DevBuf& qt, G2A* out) {
-    int32_t rc; if ((rc = jac.reserve(half * sizeof(G2J)))) return rc;
-    const size_t qstride = (half + 63) & ~(size_t)63;
-    if ((rc = qt.reserve(std::max<size_t>(4 * G2A_CHUNKS * qstride * sizeof(uint4), 4 * half * sizeof(G2J))))) return rc;
-    if (half <= e->vm_fold_max && !std::getenv("RIPP_NO_VM")) {
-        hipLaunchKernelGGL(k_vm_fold_g2_split, dim3(nblk(half, 4 * VM_EPW), 4), dim3(256), 4 * VM_EPW * VM_G2_SLOTS * sizeof(Fp), st, hi, (uint32_t)half, gls_digits(s), qt.as<G2J>(), e->vm_flag.as<uint32_t>());
-        hipLaunchKernelGGL(k_fold_g2_combine, dim3(nblk(half, 64)), dim3(64), 0, st, qt.as<G2J>(), lo, (uint32_t)half, jac.as<G2J>());
-    } else if (half <= e->gls_split_max) {
-        hipLaunchKernelGGL(k_fold_g2_gls_split, dim3(nblk(half, 64), 4), dim3(64), 0, st, hi, (uint32_t)half, gls_digits(s), qt.as<G2J>());
-        hipLaunchKernelGGL(k_fold_g2_combine, dim3(nblk(half, 64)), dim3(64), 0, st, qt.as<G2J>(), lo, (uint32_t)half, jac.as<G2J>());
-    } else {
-        hipLaunchKernelGGL(k_fold_g2_gls, dim3(nblk(half, 64)), dim3(64), 0, st, hi, lo, (uint32_t)half, gls_digits(s), qt.as<uint4>(), qstride, jac.as<G2J>());
-    }
-    HIPCHK(hipGetLastError());
-    return e->normalize_dev<Fp2>(jac.as<G2J>(), half, out, st);
-}
-}  // extern "C++"
-
-extern "C++" { static Fp12 gt_pow_host(const Fp12& x, const Fr& k); }      // defined with the verifiers below
-
-// device-resident GIPA/TIPP state: the four vectors (affine) + ping-pong partners + fold scratch
-struct TippVecs {
-    DevBuf A, A2, KB, KB2, B, B2, KA, KA2, jac1, jac1b, jac2, jac2b, qt2;
-    DevBuf AU, AU2, jac1u;                 // implicit-shift form (aggregate_proofs): the UNSCALED left vector beside the scaled one
-    ~TippVecs() { for (DevBuf* b : {&A, &A2, &KB, &KB2, &B, &B2, &KA, &KA2, &jac1, &jac1b, &jac2, &jac2b, &qt2, &AU, &AU2, &jac1u}) b->release(); }
-    int32_t reserve(size_t n) {
-        int32_t rc;
-        for (DevBuf* b : {&A, &A2, &KB, &KB2}) if ((rc = b->reserve(n * sizeof(G1A)))) return rc;
-        for (DevBuf* b : {&B, &B2, &KA, &KA2}) if ((rc = b->reserve(n * sizeof(G2A)))) return rc;
-        if ((rc = jac1.reserve(n * sizeof(G1J))) || (rc = jac2.reserve(n * sizeof(G2J)))) return rc;
-        return RIPP_OK;
-    }
-};
-
-extern "C++" {
-// run one set of folds on the two streams; on an exceptional addition reported by a VM fold, redo with the complete scalar kernels
-template <class Launch> static int32_t folds_with_vm_fallback(Engine* e, size_t split, Launch&& launch) {
-    int32_t rc;
-    const size_t saved_vm_max = e->vm_fold_max;
-    if ((rc = e->vm_flag.reserve(sizeof(uint32_t)))) return rc;
-    for (;;) {
-        HIPCHK(hipMemsetAsync(e->vm_flag.p, 0, sizeof(uint32_t), e->stream));
-        HIPCHK(hipEventRecord(e->ev_fork, e->stream));
-        for (hipStream_t st : {e->stream2, e->stream3, e->stream4}) HIPCHK(hipStreamWaitEvent(st, e->ev_fork, 0));
-        if ((rc = launch())) { e->vm_fold_max = saved_vm_max; return rc; }
-        HIPCHK(hipEventRecord(e->ev_join, e->stream2)); HIPCHK(hipEventRecord(e->ev_join3, e->stream3)); HIPCHK(hipEventRecord(e->ev_join4, e->stream4));
-        for (hipEvent_t ev : {e->ev_join, e->ev_join3, e->ev_join4}) HIPCHK(hipStreamWaitEvent(e->stream, ev, 0));
-        if ((rc = e->sync())) { e->vm_fold_max = saved_vm_max; return rc; }
-        if (e->vm_fold_max != 0 && split <= e->vm_fold_max) {
-            uint32_t flag = 0; HIPCHK(hipMemcpy(&flag, e->vm_flag.p, sizeof flag, hipMemcpyDeviceToHost));
-            if (flag) { e->vm_fold_max = 0; continue; }
-        }
-        break;
-    }
-    e->vm_fold_max = saved_vm_max;
-    return RIPP_OK;
-}
-}  // extern "C++"
-
-// GIPA::_prove (gipa.rs:181-312) on vectors already resident (and normalised) in v.A (m_a), v.B (m_b), v.KA (ck_a), v.KB (ck_b).
-//
-// shift != nullptr -- the implicit-shift form used by aggregate_proofs, where m_a[i] = r^i a_i and ck_a[i] = r^-i ck_i
-// (groth16_aggregation.rs:119-131).  The n G2 scalar multiplications r^-i ck_i are never performed: v.KA holds the UNSCALED keys and
-// v.AU the unscaled a_i next to the scaled v.A.  By bilinearity e(r^(i+s) a_(i+s), r^-i ck_i) = e(a_(i+s), ck_i)^(r^s), so the two
-// LMC commitments of a round are the unscaled products raised to r^(+-split) (two GT exponentiations on host threads), and the
-// folds of the unscaled vectors keep the invariant "element i carries the implicit factor r^(+-i)" when they use the scalars
-// c r^split and c_inv r^-split.  Index 0 carries r^0, so the final key and every output are the SAME group elements as in the
-// explicit computation -- bit-identical results, checked against the oracle's explicit form.
-static int32_t gipa_tipp_core(Engine* e, TippVecs& v, size_t n, ripp_gt* com_steps, ripp_fr* transcript, G1A& ha, G2A& hb, G2A& hka, G1A& hkb, const Fr* shift = nullptr) {
-    int32_t rc;
-    size_t len = n, round = 0;
-    Fr prev_c = Fr::zero();
-    std::vector<Fp12> rows(6 * N_LINES);
-    std::vector<Fr> rp, rpi;                   // r^(2^k), r^-(2^k)
-    if (shift) { rp.push_back(*shift); rpi.push_back(inv(*shift)); for (size_t m = 2; m < n; m <<= 1) { rp.push_back(mul(rp.back(), rp.back())); rpi.push_back(mul(rpi.back(), rpi.back())); } }
-    while (len > 1) {
-        const size_t split = len / 2;
-        const G1A *A = v.A.as<G1A>(), *KB = v.KB.as<G1A>(); const G2A *B = v.B.as<G2A>(), *KA = v.KA.as<G2A>();
-        const G1A* AL = shift ? v.AU.as<G1A>() : A;         // left operand of the two LMC commitments
-        size_t lg_split = 0; while (((size_t)1 << lg_split) < split) ++lg_split;
-        //            com_1.0 (m_a_1,ck_a_1)  com_1.1 (ck_b_1,m_b_1)  com_1.2 (m_a_1,m_b_1)  com_2.0 (m_a_2,ck_a_2)  com_2.1 (ck_b_2,m_b_2)  com_2.2 (m_a_2,m_b_2)   gipa.rs:209-231
-        const G1A* as[6] = {AL + split,            KB + split,            A + split,             AL,                    KB,                    A};
-        const G2A* bs[6] = {KA,                    B,                     B,                     KA + split,            B + split,             B + split};
-        const double tp = now_ms();
-        if ((rc = e->step_products(as, bs, 6, split, rows.data()))) return rc;
-        e->stats.miller_products_ms += now_ms() - tp;
-        const double th = now_ms();
-        Fp12 com[6];
-        { std::vector<std::future<Fp12>> fut;
-          auto one = [&rows, shift, &rp, &rpi, lg_split](int k) {
-              Fp12 z = final_exponentiation(miller_combine(rows.data() + k * N_LINES));
-              if (shift && k == 0) z = gt_pow_host(z, rp[lg_split]);             // (prod e(a_(i+s), ck_i))^(r^s)
-              if (shift && k == 3) z = gt_pow_host(z, rpi[lg_split]);            // (prod e(a_i, ck_(i+s)))^(r^-s)
-              return z; };
-          for (int k = 1; k < 6; ++k) fut.push_back(host_pool().submit([one, k]() { return one(k); }));
-          com[0] = one(0);
-          for (int k = 1; k < 6; ++k) com[k] = fut[k - 1].get(); }
-        Fr c_inv; const Fr c = fs::gipa_tipp_challenge(round ? &prev_c : nullptr, com, c_inv);
-        const Fr c_u = shift ? mul(c, rp[lg_split]) : c, c_inv_u = shift ? mul(c_inv, rpi[lg_split]) : c_inv;   // fold scalars of the unscaled vectors
-        e->stats.host_ms += now_ms() - th;
-        std::memcpy(&com_steps[6 * round], com, sizeof com); std::memcpy(&transcript[round], &c, sizeof c);
-        prev_c = c;
-        // folds (gipa.rs:262-290): hi = upper half, lo = lower half for all four vectors
-        const double tf = now_ms();
-        rc = folds_with_vm_fallback(e, split, [&]() -> int32_t {
-            int32_t r2;
-            if ((r2 = fold_dev<Fp>(e, e->stream2, A + split, A, split, c, v.jac1, v.qt2, v.A2.as<G1A>()))) return r2;          // m_a  <- m_a_1 * c + m_a_2
-            if (shift && (r2 = fold_dev<Fp>(e, e->stream4, AL + split, AL, split, c_u, v.jac1u, v.qt2, v.AU2.as<G1A>()))) return r2;   // unscaled twin of m_a
-            if ((r2 = fold_dev<Fp>(e, e->stream3, KB + split, KB, split, c, v.jac1b, v.qt2, v.KB2.as<G1A>()))) return r2;       // ck_b <- ck_b_1 * c + ck_b_2
-            if ((r2 = fold_dev<Fp2>(e, e->stream, B + split, B, split, c_inv, v.jac2, e->qtab, v.B2.as<G2A>()))) return r2;     // m_b  <- m_b_2 * c_inv + m_b_1
-            return fold_dev<Fp2>(e, e->stream, KA + split, KA, split, c_inv_u, v.jac2b, e->qtab, v.KA2.as<G2A>());              // ck_a <- ck_a_2 * c_inv + ck_a_1
-        });
-        if (rc) return rc;
-        e->stats.fold_ms += now_ms() - tf;
-        std::swap(v.A, v.A2); std::swap(v.KB, v.KB2); std::swap(v.B, v.B2); std::swap(v.KA, v.KA2); if (shift) std::swap(v.AU, v.AU2);
-        len = split; ++round;
-    }
-    HIPCHK(hipMemcpy(&ha, v.A.p, sizeof ha, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(&hkb, v.KB.p, sizeof hkb, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(&hb, v.B.p, sizeof hb, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(&hka, v.KA.p, sizeof hka, hipMemcpyDeviceToHost));
-    return RIPP_OK;
-}
-
-// upload the four projective inputs of a TIPP instance and normalise them into v
-static int32_t tipp_upload(Engine* e, TippVecs& v, const ripp_g1j* m_a, const ripp_g2j* m_b, const ripp_g2j* ck_a, const ripp_g1j* ck_b, size_t n) {
-    int32_t rc; if ((rc = v.reserve(n))) return rc;
-    HIPCHK(hipMemcpyAsync(v.jac1.p, m_a, n * sizeof(G1J), hipMemcpyHostToDevice, e->stream)); if ((rc = e->normalize_dev<Fp>(v.jac1.as<G1J>(), n, v.A.as<G1A>()))) return rc; if ((rc = e->sync())) return rc;
-    HIPCHK(hipMemcpyAsync(v.jac1.p, ck_b, n * sizeof(G1J), hipMemcpyHostToDevice, e->stream)); if ((rc = e->normalize_dev<Fp>(v.jac1.as<G1J>(), n, v.KB.as<G1A>()))) return rc; if ((rc = e->sync())) return rc;
-    HIPCHK(hipMemcpyAsync(v.jac2.p, m_b, n * sizeof(G2J), hipMemcpyHostToDevice, e->stream)); if ((rc = e->normalize_dev<Fp2>(v.jac2.as<G2J>(), n, v.B.as<G2A>()))) return rc; if ((rc = e->sync())) return rc;
-    HIPCHK(hipMemcpyAsync(v.jac2.p, ck_a, n * sizeof(G2J), hipMemcpyHostToDevice, e->stream)); if ((rc = e->normalize_dev<Fp2>(v.jac2.as<G2J>(), n, v.KA.as<G2A>()))) return rc; return e->sync();
-}
-
-API int32_t ripp_gipa_tipp_prove(const ripp_g1j* m_a, const ripp_g2j* m_b, const ripp_g2j* ck_a, const ripp_g1j* ck_b, size_t n,
-                                 ripp_gt* com_steps, ripp_fr* transcript, ripp_g1j* base_a, ripp_g2j* base_b,
-                                 ripp_g2j* ck_base_a, ripp_g1j* ck_base_b, ripp_stats* st) {
-    if (n == 0 || (n & (n - 1))) return RIPP_ERR_POW2;                       // assert!(m_a.len().is_power_of_two()), gipa.rs:195
-    LOCK; ENGINE;
-    if (!m_a || !m_b || !ck_a || !ck_b || !base_a || !base_b || !ck_base_a || !ck_base_b || (n > 1 && (!com_steps || !transcript))) return RIPP_ERR_ARG;
-    e->stats = ripp_stats{};
-    const double t_start = now_ms();
-    TippVecs v; int32_t rc;
-    if ((rc = tipp_upload(e, v, m_a, m_b, ck_a, ck_b, n))) return rc;
-    G1A ha, hkb; G2A hb, hka;
-    if ((rc = gipa_tipp_core(e, v, n, com_steps, transcript, ha, hb, hka, hkb))) return rc;
-    const G1J ja = to_jac(ha), jkb = to_jac(hkb); const G2J jb = to_jac(hb), jka = to_jac(hka);
-    std::memcpy(base_a, &ja, sizeof ja); std::memcpy(base_b, &jb, sizeof jb); std::memcpy(ck_base_a, &jka, sizeof jka); std::memcpy(ck_base_b, &jkb, sizeof jkb);
-    e->collect_kernel_stats();
-    e->stats.total_ms = now_ms() - t_start;
-    if (st) *st = e->stats;
-    return RIPP_OK;
-}
-
-// ---- TIPA: SRS handle, KZG openings (ip_proofs/src/tipa/mod.rs) ---------------------------------------------------------
-struct ripp_srs { DevBuf gap, hbp; size_t num = 0; };   // normalised g_alpha_powers / h_beta_powers, resident in HBM
-
-API int32_t ripp_srs_create(const ripp_g1j* g_alpha_powers, const ripp_g2j* h_beta_powers, size_t num, ripp_srs** out) {
-    LOCK; ENGINE; if (!g_alpha_powers || !h_beta_powers || !out || !(num & 1)) return RIPP_ERR_ARG;
-    const size_t n = (num + 1) / 2; if (n & (n - 1)) return RIPP_ERR_POW2;
-    ripp_srs* s = new ripp_srs(); s->num = num;
-    int32_t rc; G1J* dj1; G2J* dj2;
-    if ((rc = s->gap.reserve(num * sizeof(G1A))) || (rc = s->hbp.reserve(num * sizeof(G2A))) ||
-        (rc = upload<G1J>(e, e->jacG1, g_alpha_powers, num, &dj1)) || (rc = e->normalize_dev<Fp>(dj1, num, s->gap.as<G1A>())) ||
-        (rc = upload<G2J>(e, e->jacG2, h_beta_powers, num, &dj2)) || (rc = e->normalize_dev<Fp2>(dj2, num, s->hbp.as<G2A>())) || (rc = e->sync())) {
-        s->gap.release(); s->hbp.release(); delete s; return rc;
-    }
-    *out = s; return RIPP_OK;
-}
-API void ripp_srs_destroy(ripp_srs* s) { if (!s) return; LOCK; s->gap.release(); s->hbp.release(); delete s; }
-
-extern "C++" {
-// structured_generators_scalar_power (tipa/mod.rs:372-391): the powers s^i are a sequential host recurrence, the num scalar
-// multiplications of the one generator run on the device
-template <class F> static int32_t srs_powers(const Affine<F>& g, const ripp_fr* s_in, size_t num, void* out) {
-    LOCK; ENGINE; if (!s_in || (num && !out)) return RIPP_ERR_ARG; if (!num) return RIPP_OK;
-    Fr s; std::memcpy(&s, s_in, sizeof s);
-    std::vector<Fr> pw(num); pw[0] = Fr::one(); for (size_t i = 1; i < num; ++i) pw[i] = mul(pw[i - 1], s);
-    DevBuf& jac = std::is_same<F, Fp>::value ? e->jacG1 : e->jacG2; DevBuf& aff = std::is_same<F, Fp>::value ? e->affG1 : e->affG2;
-    int32_t rc; Fr* dk;
-    if ((rc = upload<Fr>(e, e->tmpR, pw.data(), num, &dk)) || (rc = jac.reserve(num * sizeof(Jac<F>))) || (rc = aff.reserve(sizeof(Affine<F>)))) return rc;
-    HIPCHK(hipMemcpyAsync(aff.p, &g, sizeof g, hipMemcpyHostToDevice, e->stream));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scale_pts<F>), dim3(nblk(num, 256)), dim3(256), 0, e->stream, aff.as<Affine<F>>(), 0u, dk, (uint32_t)num, jac.as<Jac<F>>());
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out, jac.p, num * sizeof(Jac<F>), hipMemcpyDeviceToHost, e->stream));
-    return e->sync();
-}
-
-// polynomial_coefficients_from_transcript (tipa/mod.rs:406-422) before the zero interleave: co[j] multiplies X^(2j)
-static std::vector<Fr> ck_poly_coeffs(const std::vector<Fr>& tr, const Fr& r_shift) {
-    std::vector<Fr> co((size_t)1 << tr.size()); co[0] = Fr::one(); Fr p2r = r_shift; size_t cnt = 1;
-    for (size_t i = 0; i < tr.size(); ++i) {
-        const Fr xr = mul(tr[i], p2r);
-        for (size_t j = 0; j < ((size_t)1 << i); ++j) co[cnt + j] = mul(co[j], xr);
-        cnt += (size_t)1 << i; p2r = mul(p2r, p2r);
-    }
-    return co;
-}
-// prove_commitment_key_kzg_opening (tipa/mod.rs:304-337): quotient of p(X) - p(c) by (X - c) by synthetic division on the
-// host (O(n) Fr products); the 2n-1 term MSM against the resident SRS powers then runs on the device
-static int32_t kzg_quotient(const std::vector<Fr>& tr, const Fr& r_shift, const Fr& c, size_t num, std::vector<Fr>& q) {
-    const std::vector<Fr> co = ck_poly_coeffs(tr, r_shift);
-    if (2 * co.size() - 1 != num) { set_err("SRS size does not match the transcript length (assert_eq! at tipa/mod.rs:313)"); return RIPP_ERR_ARG; }
-    q.assign(num, Fr::zero());
-    Fr carry = Fr::zero();
-    for (size_t k = num - 1; k >= 1; --k) {                       // q[k-1] = p[k] + c q[k];  p[k] = co[k/2] for even k, else 0
-        Fr t = mul(carry, c); if (!(k & 1)) t = add(t, co[k >> 1]);
-        q[k - 1] = t; carry = t;
-    }
-    return RIPP_OK;
-}
-template <class F> static int32_t kzg_opening_launch(Engine* e, int slot, hipStream_t st, const Affine<F>* powers, const std::vector<Fr>& q) {
-    int32_t rc; if ((rc = e->kzg_q[slot].reserve(q.size() * sizeof(Fr)))) return rc;
-    HIPCHK(hipMemcpyAsync(e->kzg_q[slot].p, q.data(), q.size() * sizeof(Fr), hipMemcpyHostToDevice, st));
-    return e->msm_launch<F>(e->msm_scratch[slot], st, powers, e->kzg_q[slot].as<Fr>(), q.size());
-}
-template <class F> static int32_t kzg_opening_dev(Engine* e, const Affine<F>* powers, size_t num, const std::vector<Fr>& tr, const Fr& r_shift, const Fr& c, Jac<F>* out) {
-    std::vector<Fr> q; int32_t rc;
-    if ((rc = kzg_quotient(tr, r_shift, c, num, q)) || (rc = kzg_opening_launch<F>(e, 0, e->stream, powers, q)) || (rc = e->sync())) return rc;
-    *out = *reinterpret_cast<const Jac<F>*>(e->msm_scratch[0].host_out); return RIPP_OK;
-}
-}  // extern "C++"
-API int32_t ripp_srs_powers_g1(const ripp_fr* s, size_t num, ripp_g1j* out) { return srs_powers<Fp>(g1_generator(), s, num, out); }
-API int32_t ripp_srs_powers_g2(const ripp_fr* s, size_t num, ripp_g2j* out) { return srs_powers<Fp2>(g2_generator(), s, num, out); }
-
-extern "C++" {
-// strided device gather of the even SRS powers (get_commitment_keys, tipa/mod.rs:114-118)
-template <class T> static int32_t gather_even(Engine* e, const T* src, size_t n, T* dst) {
-    HIPCHK(hipMemcpy2DAsync(dst, sizeof(T), src, 2 * sizeof(T), sizeof(T), n, hipMemcpyDeviceToDevice, e->stream)); return RIPP_OK;
-}
-}
-API int32_t ripp_srs_commitment_keys(const ripp_srs* s, ripp_g2j* ck_1, ripp_g1j* ck_2) {
-    LOCK; ENGINE; if (!s || !ck_1 || !ck_2) return RIPP_ERR_ARG;
-    const size_t n = (s->num + 1) / 2; int32_t rc;
-    if ((rc = e->affG1.reserve(n * sizeof(G1A))) || (rc = e->affG2.reserve(n * sizeof(G2A)))) return rc;
-    if ((rc = gather_even<G2A>(e, const_cast<ripp_srs*>(s)->hbp.as<G2A>(), n, e->affG2.as<G2A>())) || (rc = gather_even<G1A>(e, const_cast<ripp_srs*>(s)->gap.as<G1A>(), n, e->affG1.as<G1A>()))) return rc;
-    std::vector<G1A> h1(n); std::vector<G2A> h2(n);
-    HIPCHK(hipMemcpyAsync(h1.data(), e->affG1.p, n * sizeof(G1A), hipMemcpyDeviceToHost, e->stream)); HIPCHK(hipMemcpyAsync(h2.data(), e->affG2.p, n * sizeof(G2A), hipMemcpyDeviceToHost, e->stream));
-    if ((rc = e->sync())) return rc;
-    G1J* o1 = reinterpret_cast<G1J*>(ck_2); G2J* o2 = reinterpret_cast<G2J*>(ck_1);
-    for (size_t i = 0; i < n; ++i) { o1[i] = to_jac(h1[i]); o2[i] = to_jac(h2[i]); }
-    return RIPP_OK;
-}
-
-// the KZG half of TIPA::prove_with_srs_shift (tipa/mod.rs:186-223) once GIPA has produced transcript and final keys
-static int32_t tipp_kzg(Engine* e, const ripp_srs* srs, const ripp_fr* transcript, size_t rounds, const Fr& r_shift, const G2A& hka, const G1A& hkb,
-                        G2J* opening_a, G1J* opening_b, Fr* kzg_c) {
-    std::vector<Fr> tr(rounds), tri(rounds);
-    for (size_t i = 0; i < rounds; ++i) { std::memcpy(&tr[i], &transcript[rounds - 1 - i], sizeof(Fr)); tri[i] = inv(tr[i]); }   // aux.r_transcript and its inverses, :190-191
-    const Fr r_inv = inv(r_shift);                                                                                          // :192
-    const Fr c = fs::kzg_challenge(tr[0], hka, &hkb);                                                                       // :194-209
-    ripp_srs* s = const_cast<ripp_srs*>(srs); int32_t rc;
-    // the two openings are independent: quotients on two host threads, MSMs side by side on two streams
-    std::vector<Fr> qa, qb;
-    auto fb = host_pool().submit([&]() { return kzg_quotient(tr, Fr::one(), c, s->num, qb); });
-    rc = kzg_quotient(tri, r_inv, c, s->num, qa); const int32_t rcb = fb.get();
-    if (rc || rcb) return rc ? rc : rcb;
-    if ((rc = kzg_opening_launch<Fp2>(e, 0, e->stream, s->hbp.as<G2A>(), qa))) return rc;                                     // :212-217
-    if ((rc = kzg_opening_launch<Fp>(e, 1, e->stream3, s->gap.as<G1A>(), qb))) return rc;                                      // :218-223
-    if ((rc = e->sync())) return rc; HIPCHK(hipStreamSynchronize(e->stream3));
-    *opening_a = *reinterpret_cast<const G2J*>(e->msm_scratch[0].host_out); *opening_b = *reinterpret_cast<const G1J*>(e->msm_scratch[1].host_out);
-    *kzg_c = c; return RIPP_OK;
-}
-
-API int32_t ripp_tipa_tipp_prove(const ripp_srs* srs, const ripp_g1j* m_a, const ripp_g2j* m_b, const ripp_g2j* ck_a, const ripp_g1j* ck_b, size_t n,
-                                 const ripp_fr* r_shift, ripp_gt* com_steps, ripp_fr* transcript, ripp_g1j* base_a, ripp_g2j* base_b,
-                                 ripp_g2j* final_ck_a, ripp_g1j* final_ck_b, ripp_g2j* opening_a, ripp_g1j* opening_b, ripp_fr* kzg_challenge, ripp_stats* st) {
-    if (n < 2 || (n & (n - 1))) return RIPP_ERR_POW2;                        // n = 1 would unwrap an empty transcript (tipa/mod.rs:200-202)
-    LOCK; ENGINE;
-    if (!srs || !m_a || !m_b || !ck_a || !ck_b || !r_shift || !com_steps || !transcript || !base_a || !base_b || !final_ck_a || !final_ck_b || !opening_a || !opening_b || !kzg_challenge) return RIPP_ERR_ARG;
-    if (srs->num != 2 * n - 1) { set_err("SRS holds " + std::to_string(srs->num) + " powers, need 2n-1 = " + std::to_string(2 * n - 1)); return RIPP_ERR_ARG; }
-    e->stats = ripp_stats{};
-    const double t_start = now_ms();
-    TippVecs v; int32_t rc;
-    if ((rc = tipp_upload(e, v, m_a, m_b, ck_a, ck_b, n))) return rc;
-    G1A ha, hkb; G2A hb, hka;
-    if ((rc = gipa_tipp_core(e, v, n, com_steps, transcript, ha, hb, hka, hkb))) return rc;
-    size_t rounds = 0; while (((size_t)1 << rounds) < n) ++rounds;
-    Fr rs; std::memcpy(&rs, r_shift, sizeof rs);
-    G2J oa; G1J ob; Fr c;
-    if ((rc = tipp_kzg(e, srs, transcript, rounds, rs, hka, hkb, &oa, &ob, &c))) return rc;
-    const G1J ja = to_jac(ha), jkb = to_jac(hkb); const G2J jb = to_jac(hb), jka = to_jac(hka);
-    std::memcpy(base_a, &ja, sizeof ja); std::memcpy(base_b, &jb, sizeof jb); std::memcpy(final_ck_a, &jka, sizeof jka); std::memcpy(final_ck_b, &jkb, sizeof jkb);
-    std::memcpy(opening_a, &oa, sizeof oa); std::memcpy(opening_b, &ob, sizeof ob); std::memcpy(kzg_challenge, &c, sizeof c);
-    e->collect_kernel_stats();
-    e->stats.total_ms = now_ms() - t_start;
-    if (st) *st = e->stats;
-    return RIPP_OK;
-}
-
-// ---- TIPAWithSSM (MIPP with a structured scalar vector), ip_proofs/src/tipa/structured_scalar_message.rs ------------------
-struct SsmVecs {
-    DevBuf A, A2, S, S2, KA, KA2, jac1, jac2, qt2;
-    ~SsmVecs() { for (DevBuf* b : {&A, &A2, &S, &S2, &KA, &KA2, &jac1, &jac2, &qt2}) b->release(); }
-    int32_t reserve(size_t n) {
-        int32_t rc;
-        if ((rc = A.reserve(n * sizeof(G1A))) || (rc = A2.reserve(n * sizeof(G1A))) || (rc = S.reserve(n * sizeof(Fr))) || (rc = S2.reserve(n * sizeof(Fr))) ||
-            (rc = KA.reserve(n * sizeof(G2A))) || (rc = KA2.reserve(n * sizeof(G2A))) || (rc = jac1.reserve(n * sizeof(G1J))) || (rc = jac2.reserve(n * sizeof(G2J)))) return rc;
-        return RIPP_OK;
-    }
-};
-
-// GIPA<MultiexponentiationInnerProduct<G1>, AFGHO-G1, SSMPlaceholder, Identity<G1>>::_prove (gipa.rs:181-312) + the KZG opening of
-// ck_a (ssm.rs:225-254).  Per round: two pairing products share one line launch, two G1 MSMs over the halves.
-static int32_t tipa_ssm_core(Engine* e, const ripp_srs* srs, SsmVecs& v, size_t n, ripp_gt* com_gt, ripp_g1j* com_g1, ripp_fr* transcript,
-                             G1A& ha, Fr& hs, G2A& hka, G2J* opening_a, Fr* kzg_c) {
-    int32_t rc;
-    size_t len = n, round = 0;
-    Fr prev_c = Fr::zero();
-    std::vector<Fp12> rows(2 * N_LINES);
-    while (len > 1) {
-        const size_t split = len / 2;
-        const G1A* A = v.A.as<G1A>(); const G2A* KA = v.KA.as<G2A>(); const Fr* S = v.S.as<Fr>();
-        const G1A* as[2] = {A + split, A}; const G2A* bs[2] = {KA, KA + split};     // com_1.0 = (m_a_1, ck_a_1), com_2.0 = (m_a_2, ck_a_2)   gipa.rs:209-231
-        const double tp = now_ms();
-        // the two inner products of the round run on their own streams beside the pairing products (independent work)
-        if ((rc = e->msm_launch<Fp>(e->msm_scratch[0], e->stream2, A + split, S, split))) return rc;           // IP::inner_product(m_a_1, m_b_1)
-        if ((rc = e->msm_launch<Fp>(e->msm_scratch[1], e->stream3, A, S + split, split))) return rc;           // IP::inner_product(m_a_2, m_b_2)
-        if ((rc = e->step_products(as, bs, 2, split, rows.data()))) return rc;
-        HIPCHK(hipStreamSynchronize(e->stream2)); HIPCHK(hipStreamSynchronize(e->stream3));
-        const G1J ip[2] = {*reinterpret_cast<const G1J*>(e->msm_scratch[0].host_out), *reinterpret_cast<const G1J*>(e->msm_scratch[1].host_out)};
-        e->stats.miller_products_ms += now_ms() - tp;
-        const double th = now_ms();
-        Fp12 gt[2];
-        { auto fut = host_pool().submit([&rows]() { return final_exponentiation(miller_combine(rows.data() + N_LINES)); });
-          gt[0] = final_exponentiation(miller_combine(rows.data())); gt[1] = fut.get(); }
-        const G1A ipa[2] = {to_affine(ip[0]), to_affine(ip[1])};
-        Fr c_inv; const Fr c = fs::gipa_ssm_challenge(round ? &prev_c : nullptr, gt, ipa, c_inv);
-        e->stats.host_ms += now_ms() - th;
-        std::memcpy(&com_gt[2 * round], gt, sizeof gt); std::memcpy(&com_g1[2 * round], ip, sizeof ip); std::memcpy(&transcript[round], &c, sizeof c);
-        prev_c = c;
-        const double tf = now_ms();
-        rc = folds_with_vm_fallback(e, split, [&]() -> int32_t {
-            int32_t r2;
-            if ((r2 = fold_dev<Fp>(e, e->stream2, A + split, A, split, c, v.jac1, v.qt2, v.A2.as<G1A>()))) return r2;               // m_a  <- m_a_1 * c + m_a_2
-            hipLaunchKernelGGL(k_fold_fr, dim3(nblk(split, 256)), dim3(256), 0, e->stream3, S + split, S, (uint32_t)split, c_inv, v.S2.as<Fr>());   // m_b  <- m_b_2 * c_inv + m_b_1
-            HIPCHK(hipGetLastError());
-            return fold_dev<Fp2>(e, e->stream, KA + split, KA, split, c_inv, v.jac2, e->qtab, v.KA2.as<G2A>());                      // ck_a <- ck_a_2 * c_inv + ck_a_1
-        });
-        if (rc) return rc;
-        e->stats.fold_ms += now_ms() - tf;
-        std::swap(v.A, v.A2); std::swap(v.S, v.S2); std::swap(v.KA, v.KA2);
-        len = split; ++round;
-    }
-    HIPCHK(hipMemcpy(&ha, v.A.p, sizeof ha, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(&hs, v.S.p, sizeof hs, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(&hka, v.KA.p, sizeof hka, hipMemcpyDeviceToHost));
-    const size_t rounds = round;
-    std::vector<Fr> tri(rounds);
-    for (size_t i = 0; i < rounds; ++i) { Fr t; std::memcpy(&t, &transcript[rounds - 1 - i], sizeof t); tri[i] = inv(t); }         // ssm.rs:227-229
-    Fr first; std::memcpy(&first, &transcript[rounds - 1], sizeof first);
-    if (trace_on()) fprintf(stderr, "[ripp] ssm: GIPA rounds done (products+msm %.1f ms, host %.1f ms, folds %.1f ms cumulative)\n", e->stats.miller_products_ms, e->stats.host_ms, e->stats.fold_ms);
-    const Fr c = fs::kzg_challenge(first, hka, nullptr);                                                                           // ssm.rs:231-246
-    ripp_srs* s = const_cast<ripp_srs*>(srs);
-    if ((rc = kzg_opening_dev<Fp2>(e, s->hbp.as<G2A>(), s->num, tri, Fr::one(), c, opening_a))) return rc;                           // ssm.rs:249-254
-    *kzg_c = c; return RIPP_OK;
-}
-
-API int32_t ripp_tipa_ssm_prove(const ripp_srs* srs, const ripp_g1j* m_a, const ripp_fr* m_b, const ripp_g2j* ck_a, size_t n,
-                                ripp_gt* com_gt, ripp_g1j* com_g1, ripp_fr* transcript, ripp_g1j* base_a, ripp_fr* base_b,
-                                ripp_g2j* final_ck_a, ripp_g2j* opening_a, ripp_fr* kzg_challenge, ripp_stats* st) {
-    if (n < 2 || (n & (n - 1))) return RIPP_ERR_POW2;
-    LOCK; ENGINE;
-    if (!srs || !m_a || !m_b || !ck_a || !com_gt || !com_g1 || !transcript || !base_a || !base_b || !final_ck_a || !opening_a || !kzg_challenge) return RIPP_ERR_ARG;
-    if (srs->num != 2 * n - 1) { set_err("SRS holds " + std::to_string(srs->num) + " powers, need 2n-1 = " + std::to_string(2 * n - 1)); return RIPP_ERR_ARG; }
-    e->stats = ripp_stats{};
-    const double t_start = now_ms();
-    SsmVecs v; int32_t rc; if ((rc = v.reserve(n))) return rc;
-    HIPCHK(hipMemcpyAsync(v.jac1.p, m_a, n * sizeof(G1J), hipMemcpyHostToDevice, e->stream)); if ((rc = e->normalize_dev<Fp>(v.jac1.as<G1J>(), n, v.A.as<G1A>()))) return rc;
-    HIPCHK(hipMemcpyAsync(v.jac2.p, ck_a, n * sizeof(G2J), hipMemcpyHostToDevice, e->stream)); if ((rc = e->normalize_dev<Fp2>(v.jac2.as<G2J>(), n, v.KA.as<G2A>()))) return rc;
-    HIPCHK(hipMemcpyAsync(v.S.p, m_b, n * sizeof(Fr), hipMemcpyHostToDevice, e->stream)); if ((rc = e->sync())) return rc;
-    G1A ha; Fr hs; G2A hka; G2J oa; Fr c;
-    if ((rc = tipa_ssm_core(e, srs, v, n, com_gt, com_g1, transcript, ha, hs, hka, &oa, &c))) return rc;
-    const G1J ja = to_jac(ha); const G2J jka = to_jac(hka);
-    std::memcpy(base_a, &ja, sizeof ja); std::memcpy(base_b, &hs, sizeof hs); std::memcpy(final_ck_a, &jka, sizeof jka); std::memcpy(opening_a, &oa, sizeof oa); std::memcpy(kzg_challenge, &c, sizeof c);
-    e->collect_kernel_stats();
-    e->stats.total_ms = now_ms() - t_start;
-    if (st) *st = e->stats;
-    return RIPP_OK;
-}
-
-// ---- Groth16 aggregation: aggregate_proofs (ip_proofs/src/applications/groth16_aggregation.rs:77-160) ---------------------
-static_assert(sizeof(ripp_aggregate_proof) == 4 * sizeof(Fp12) + sizeof(G1J) + sizeof(Fr) + 2 * sizeof(void*) + 2 * (sizeof(G1J) + sizeof(G2J)) + sizeof(G2J) + sizeof(G1J) + sizeof(Fr)
-              + 3 * sizeof(void*) + sizeof(G1J) + sizeof(Fr) + 2 * sizeof(G2J) + sizeof(Fr), "ripp_aggregate_proof layout");
-
-API int32_t ripp_aggregate_proofs(const ripp_srs* srs, const ripp_g1a* a, const ripp_g2a* b, const ripp_g1a* c, size_t n, ripp_aggregate_proof* out, ripp_stats* st) {
-    if (n < 2 || (n & (n - 1))) return RIPP_ERR_POW2;
-    LOCK; ENGINE;
-    if (!srs || !a || !b || !c || !out || !out->ab_com_steps || !out->ab_transcript || !out->c_com_gt || !out->c_com_g1 || !out->c_transcript) return RIPP_ERR_ARG;
-    if (srs->num != 2 * n - 1) { set_err("SRS holds " + std::to_string(srs->num) + " powers, need 2n-1 = " + std::to_string(2 * n - 1)); return RIPP_ERR_ARG; }
-    e->stats = ripp_stats{};
-    const double t_start = now_ms();
-    ripp_srs* s = const_cast<ripp_srs*>(srs);
-    TippVecs v; SsmVecs w; DevBuf dCK1, dRv; int32_t rc;
-    struct Cleanup { DevBuf &x, &y; ~Cleanup() { x.release(); y.release(); } } cleanup{dCK1, dRv};
-    if ((rc = v.reserve(n)) || (rc = w.reserve(n)) || (rc = dCK1.reserve(n * sizeof(G2A))) || (rc = dRv.reserve(n * sizeof(Fr)))) return rc;
-    // a -> v.A2 (unscaled), b -> v.B, c -> w.A;  ck_1 -> dCK1 and w.KA, ck_2 -> v.KB   (get_commitment_keys, tipa/mod.rs:114-118)
-    HIPCHK(hipMemcpyAsync(v.A2.p, a, n * sizeof(G1A), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(v.B.p, b, n * sizeof(G2A), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(w.A.p, c, n * sizeof(G1A), hipMemcpyHostToDevice, e->stream));
-    if ((rc = gather_even<G2A>(e, s->hbp.as<G2A>(), n, dCK1.as<G2A>())) || (rc = gather_even<G1A>(e, s->gap.as<G1A>(), n, v.KB.as<G1A>()))) return rc;
-    HIPCHK(hipMemcpyAsync(w.KA.p, dCK1.p, n * sizeof(G2A), hipMemcpyDeviceToDevice, e->stream));
-    std::vector<Fp12> rows(3 * N_LINES);
-    auto finish = [&rows](int k) { return final_exponentiation(miller_combine(rows.data() + (size_t)k * N_LINES)); };
-    {   // com_a = IP(a, ck_1), com_b = IP(ck_2, b), com_c = IP(c, ck_1): one line launch over three products   (:100-102)
-        const G1A* as[3] = {v.A2.as<G1A>(), v.KB.as<G1A>(), w.A.as<G1A>()}; const G2A* bs[3] = {dCK1.as<G2A>(), v.B.as<G2A>(), dCK1.as<G2A>()};
-        if ((rc = e->step_products(as, bs, 3, n, rows.data()))) return rc;
-        auto f1 = host_pool().submit([&finish]() { return finish(1); }); auto f2 = host_pool().submit([&finish]() { return finish(2); });
-        const Fp12 ca = finish(0), cb = f1.get(), cc = f2.get();
-        std::memcpy(&out->com_a, &ca, sizeof ca); std::memcpy(&out->com_b, &cb, sizeof cb); std::memcpy(&out->com_c, &cc, sizeof cc);
-    }
-    Fp12 com_a, com_b, com_c; std::memcpy(&com_a, &out->com_a, sizeof com_a); std::memcpy(&com_b, &out->com_b, sizeof com_b); std::memcpy(&com_c, &out->com_c, sizeof com_c);
-    const Fr r = fs::aggregation_challenge(com_a, com_b, com_c);                                                        // :105-116
-    std::memcpy(&out->r, &r, sizeof r);
-    if (trace_on()) fprintf(stderr, "[ripp] aggregate: upload + 3 commitments done at t=%.1f ms\n", now_ms() - t_start);
-    // r_vec = (1, r, r^2, ...) (:118)
-    std::vector<Fr> rv(n);
-    rv[0] = Fr::one(); for (size_t i = 1; i < n; ++i) rv[i] = mul(rv[i - 1], r);
-    HIPCHK(hipMemcpyAsync(dRv.p, rv.data(), n * sizeof(Fr), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(w.S.p, dRv.p, n * sizeof(Fr), hipMemcpyDeviceToDevice, e->stream));
-    // a_r = a_i * r^i (:119-123) -> v.A, with the unscaled a_i kept in v.AU.  ck_1_r = ck_1_i * r^-i (:127-131) is NOT materialised: the
-    // TIPP core below runs in its implicit-shift form on the unscaled keys (see gipa_tipp_core), which removes the n G2 scalar
-    // multiplications, and the sanity product of :133-136, IP(a_r, ck_1_r) == com_a, collapses to IP(a, ck_1) == com_a -- the very
-    // product computed above -- so it holds by construction and is not recomputed.
-    if ((rc = v.AU.reserve(n * sizeof(G1A))) || (rc = v.AU2.reserve(n * sizeof(G1A))) || (rc = v.jac1u.reserve(n * sizeof(G1J)))) return rc;
-    HIPCHK(hipMemcpyAsync(v.AU.p, v.A2.p, n * sizeof(G1A), hipMemcpyDeviceToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(v.KA.p, dCK1.p, n * sizeof(G2A), hipMemcpyDeviceToDevice, e->stream));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scale_pts<Fp>), dim3(nblk(n, 256)), dim3(256), 0, e->stream, v.AU.as<G1A>(), 1u, dRv.as<Fr>(), (uint32_t)n, v.jac1.as<G1J>());
-    HIPCHK(hipGetLastError());
-    if ((rc = e->normalize_dev<Fp>(v.jac1.as<G1J>(), n, v.A.as<G1A>()))) return rc;
-    {   // ip_ab = IP(a_r, b) (:124)
-        const G1A* as[1] = {v.A.as<G1A>()}; const G2A* bs[1] = {v.B.as<G2A>()};
-        if ((rc = e->step_products(as, bs, 1, n, rows.data()))) return rc;
-        const Fp12 ip_ab = finish(0);
-        std::memcpy(&out->ip_ab, &ip_ab, sizeof ip_ab);
-    }
-    if (trace_on()) fprintf(stderr, "[ripp] aggregate: scaling + ip_ab done at t=%.1f ms\n", now_ms() - t_start);
-    G1J agg_c; if ((rc = e->msm_dev<Fp>(w.A.as<G1A>(), dRv.as<Fr>(), n, &agg_c))) return rc;                           // :125
-    std::memcpy(&out->agg_c, &agg_c, sizeof agg_c);
-    if (trace_on()) fprintf(stderr, "[ripp] aggregate: agg_c MSM done at t=%.1f ms\n", now_ms() - t_start);
-    size_t rounds = 0; while (((size_t)1 << rounds) < n) ++rounds;
-    {   // tipa_proof_ab = TIPA::prove_with_srs_shift(srs, (a_r, b), (ck_1_r, ck_2), r)   (:138-143)
-        G1A ha, hkb; G2A hb, hka;
-        if ((rc = gipa_tipp_core(e, v, n, out->ab_com_steps, out->ab_transcript, ha, hb, hka, hkb, &r))) return rc;
-        if (trace_on()) fprintf(stderr, "[ripp] aggregate: TIPP GIPA rounds done at t=%.1f ms\n", now_ms() - t_start);
-        G2J oa; G1J ob; Fr kc;
-        if ((rc = tipp_kzg(e, srs, out->ab_transcript, rounds, r, hka, hkb, &oa, &ob, &kc))) return rc;
-        const G1J ja = to_jac(ha), jkb = to_jac(hkb); const G2J jb = to_jac(hb), jka = to_jac(hka);
-        std::memcpy(&out->ab_base_a, &ja, sizeof ja); std::memcpy(&out->ab_base_b, &jb, sizeof jb); std::memcpy(&out->ab_final_ck_a, &jka, sizeof jka); std::memcpy(&out->ab_final_ck_b, &jkb, sizeof jkb);
-        std::memcpy(&out->ab_opening_a, &oa, sizeof oa); std::memcpy(&out->ab_opening_b, &ob, sizeof ob); std::memcpy(&out->ab_kzg_c, &kc, sizeof kc);
-        if (trace_on()) fprintf(stderr, "[ripp] aggregate: TIPP KZG openings done at t=%.1f ms\n", now_ms() - t_start);
-    }
-    {   // tipa_proof_c = TIPAWithSSM::prove_with_structured_scalar_message(srs, (c, r_vec), ck_1)   (:145-149)
-        G1A ha; Fr hs; G2A hka; G2J oa; Fr kc;
-        if ((rc = tipa_ssm_core(e, srs, w, n, out->c_com_gt, out->c_com_g1, out->c_transcript, ha, hs, hka, &oa, &kc))) return rc;
-        const G1J ja = to_jac(ha); const G2J jka = to_jac(hka);
-        std::memcpy(&out->c_base_a, &ja, sizeof ja); std::memcpy(&out->c_base_b, &hs, sizeof hs); std::memcpy(&out->c_final_ck_a, &jka, sizeof jka);
-        std::memcpy(&out->c_opening_a, &oa, sizeof oa); std::memcpy(&out->c_kzg_c, &kc, sizeof kc);
-    }
-    e->collect_kernel_stats();
-    e->stats.total_ms = now_ms() - t_start;
-    if (st) *st = e->stats;
-    return RIPP_OK;
-}
-
-// ---- verifiers (gipa.rs:135-160, 322-415; tipa/mod.rs:242-301, 340-404; ssm.rs:270-331; groth16_aggregation.rs:162-231) -------
-// Host: challenge replay and the O(log n) exponentiations of single GT / group elements (what the reference's verifier does
-// serially).  Device: every pairing and the n-term MSMs.
-extern "C++" {
-// membership in the cyclotomic subgroup of Fp12* (x^(p^4 - p^2 + 1) == 1): every honest GT value is in it; the verifiers test the
-// GT members of a proof before exponentiating them, because gt_pow_host is only an exponentiation there
-static bool gt_in_cyclotomic(const Fp12& x) {
-    const Fp2* c[6] = {&x.c0.c0, &x.c0.c1, &x.c0.c2, &x.c1.c0, &x.c1.c1, &x.c1.c2};
-    bool zero = true; for (const Fp2* v : c) zero = zero && v->c0.is_zero() && v->c1.is_zero();
-    return !zero && mul(frobenius(frobenius(x, 2), 2), x) == frobenius(x, 2);
-}
-// x^k for x in the cyclotomic subgroup: Granger-Scott squarings, NAF digits, and the inverse of x is its conjugate.
-static Fp12 gt_pow_host(const Fp12& x, const Fr& k) {
-    const Fr c = from_mont(k);
-    int8_t d[260]; const int len = naf_recode(c.l, 8, d, 258);
-    const Fp12 xi = conj(x);
-    Fp12 acc = Fp12::one(); bool st = false;
-    for (int i = len - 1; i >= 0; --i) {
-        if (st) acc = cyclotomic_sqr(acc);
-        if (d[i] != 0) { const Fp12& m = d[i] > 0 ? x : xi; acc = st ? mul(acc, m) : m; st = true; }
-    }
-    return acc;
-}
-template <class F> static Jac<F> smul_host(const Affine<F>& p, const Fr& k) { const Fr c = from_mont(k); return scalar_mul_bits(p, c.l, 255); }
-template <class F> static Jac<F> load_jac(const void* p) { Jac<F> r; std::memcpy(&r, p, sizeof r); return r; }
-static Fp12 load_gt(const ripp_gt* p) { Fp12 r; std::memcpy(&r, p, sizeof r); return r; }
-static Fr load_fr(const ripp_fr* p) { Fr r; std::memcpy(&r, p, sizeof r); return r; }
-
-// prod_i e(a_i, b_i) for a handful of host points
-static int32_t pairing_host_pts(Engine* e, const std::vector<G1A>& a, const std::vector<G2A>& b, Fp12* out) {
-    G1A* da; G2A* db; int32_t rc; ripp_gt z;
-    if ((rc = upload<G1A>(e, e->tmpA, a.data(), a.size(), &da)) || (rc = upload<G2A>(e, e->tmpB, b.data(), b.size(), &db))) return rc;
-    if ((rc = pairing_product_dev(e, da, db, a.size(), &z))) return rc;
-    std::memcpy(out, &z, sizeof z); return RIPP_OK;
-}
-// e(a1, b1) == e(a2, b2)  as  e(a1, b1) * e(-a2, b2) == 1: one two-pair product, one final exponentiation
-static int32_t pairing_eq(Engine* e, const G1J& a1, const G2J& b1, const G1J& a2, const G2J& b2, bool* ok) {
-    Fp12 z; int32_t rc = pairing_host_pts(e, {to_affine(a1), neg(to_affine(a2))}, {to_affine(b1), to_affine(b2)}, &z); if (rc) return rc;
-    *ok = (z == Fp12::one()); return RIPP_OK;
-}
-// polynomial_evaluation_product_form_from_transcript (tipa/mod.rs:393-404)
-static Fr ck_poly_eval(const std::vector<Fr>& tr, const Fr& z, const Fr& r_shift) {
-    Fr p = mul(mul(z, z), r_shift), acc = Fr::one();
-    for (const Fr& x : tr) { acc = mul(acc, add(Fr::one(), mul(x, p))); p = mul(p, p); }
-    return acc;
-}
-struct VSrs { G1J g, g_beta; G2J h, h_alpha; };
-static VSrs load_vsrs(const ripp_verifier_srs* v) { return {load_jac<Fp>(&v->g), load_jac<Fp>(&v->g_beta), load_jac<Fp2>(&v->h), load_jac<Fp2>(&v->h_alpha)}; }
-// verify_commitment_key_g2_kzg_opening (tipa/mod.rs:340-354): e(g, ck_final - h*eval) == e(g_beta - g*c, opening)
-static int32_t kzg_verify_g2(Engine* e, const VSrs& v, const G2J& ck_final, const G2J& opening, const std::vector<Fr>& tr, const Fr& r_shift, const Fr& c, bool* ok) {
-    const Fr ev = ck_poly_eval(tr, c, r_shift);
-    const G2J l2 = add(ck_final, neg(smul_host(to_affine(v.h), ev)));
-    const G1J r1 = add(v.g_beta, neg(smul_host(to_affine(v.g), c)));
-    return pairing_eq(e, v.g, l2, r1, opening, ok);
-}
-// verify_commitment_key_g1_kzg_opening (tipa/mod.rs:356-370): e(ck_final - g*eval, h) == e(opening, h_alpha - h*c)
-static int32_t kzg_verify_g1(Engine* e, const VSrs& v, const G1J& ck_final, const G1J& opening, const std::vector<Fr>& tr, const Fr& r_shift, const Fr& c, bool* ok) {
-    const Fr ev = ck_poly_eval(tr, c, r_shift);
-    const G1J l1 = add(ck_final, neg(smul_host(to_affine(v.g), ev)));
-    const G2J r2 = add(v.h_alpha, neg(smul_host(to_affine(v.h), c)));
-    return pairing_eq(e, l1, v.h, opening, r2, ok);
-}
-// _compute_recursive_challenges (gipa.rs:322-363), TIPP instantiation; tr in ROUND order
-static bool tipp_replay(const ripp_gt com[3], const ripp_gt* com_steps, size_t rounds, std::vector<Fr>& tr, Fp12 out[3]) {
-    Fp12 acc[3] = {load_gt(&com[0]), load_gt(&com[1]), load_gt(&com[2])};
-    tr.resize(rounds);
-    for (size_t k = 0; k < rounds; ++k) {
-        Fp12 s[6]; std::memcpy(s, &com_steps[6 * k], sizeof s);
-        for (int j = 0; j < 6; ++j) if (!gt_in_cyclotomic(s[j])) return false;          // not a GT element: reject
-        Fr c_inv; const Fr c = fs::gipa_tipp_challenge(k ? &tr[k - 1] : nullptr, s, c_inv);
-        std::future<Fp12> f[5];
-        for (int j = 1; j < 6; ++j) f[j - 1] = host_pool().submit([&s, j, c, c_inv]() { return gt_pow_host(s[j], j < 3 ? c : c_inv); });
-        Fp12 p[6]; p[0] = gt_pow_host(s[0], c); for (int j = 1; j < 6; ++j) p[j] = f[j - 1].get();
-        for (int j = 0; j < 3; ++j) acc[j] = mul(acc[j], mul(p[j], p[j + 3]));       // com + com_1 * c + com_2 * c_inv  (gipa.rs:358-360)
-        tr[k] = c;
-    }
-    out[0] = acc[0]; out[1] = acc[1]; out[2] = acc[2];
-    return true;
-}
-}  // extern "C++"
-
-API int32_t ripp_gipa_tipp_verify(const ripp_g2j* ck_a, const ripp_g1j* ck_b, size_t n, const ripp_gt com[3], const ripp_gt* com_steps, size_t rounds,
-                                  const ripp_g1j* base_a, const ripp_g2j* base_b, int32_t* accept) {
-    if (n == 0 || (n & (n - 1))) return RIPP_ERR_POW2;
-    if (!ck_a || !ck_b || !com || !base_a || !base_b || !accept || (rounds && !com_steps) || ((size_t)1 << rounds) != n) return RIPP_ERR_ARG;
-    std::vector<Fr> tr; Fp12 bc[3];
-    if (!tipp_replay(com, com_steps, rounds, tr, bc)) { *accept = 0; return RIPP_OK; }
-    // _compute_final_commitment_keys (gipa.rs:365-399) on the reversed transcript: exponent vectors by doubling, then one MSM per key
-    std::vector<Fr> ea(n), eb(n); ea[0] = Fr::one(); eb[0] = Fr::one(); size_t cnt = 1;
-    for (size_t i = 0; i < rounds; ++i) {
-        const Fr c = tr[rounds - 1 - i], ci = inv(c);
-        for (size_t j = 0; j < ((size_t)1 << i); ++j) { ea[cnt + j] = mul(ea[j], ci); eb[cnt + j] = mul(eb[j], c); }
-        cnt += (size_t)1 << i;
-    }
-    ripp_g2j ka; ripp_g1j kb; int32_t rc;
-    if ((rc = ripp_msm_g2_j(ck_a, n, reinterpret_cast<const ripp_fr*>(ea.data()), n, &ka))) return rc;
-    if ((rc = ripp_msm_g1_j(ck_b, n, reinterpret_cast<const ripp_fr*>(eb.data()), n, &kb))) return rc;
-    LOCK; ENGINE;
-    const G1A a = to_affine(load_jac<Fp>(base_a)), kba = to_affine(load_jac<Fp>(&kb)); const G2A b = to_affine(load_jac<Fp2>(base_b)), kaa = to_affine(load_jac<Fp2>(&ka));
-    Fp12 e1, e2, e3;                                                          // _verify_base_commitment (gipa.rs:401-415)
-    if ((rc = pairing_host_pts(e, {a}, {kaa}, &e1)) || (rc = pairing_host_pts(e, {kba}, {b}, &e2)) || (rc = pairing_host_pts(e, {a}, {b}, &e3))) return rc;
-    *accept = (e1 == bc[0] && e2 == bc[1] && e3 == bc[2]) ? 1 : 0;
-    return RIPP_OK;
-}
-
-API int32_t ripp_tipa_tipp_verify(const ripp_verifier_srs* v_srs, const ripp_gt com[3], const ripp_gt* com_steps, size_t rounds,
-                                  const ripp_g1j* base_a, const ripp_g2j* base_b, const ripp_g2j* final_ck_a, const ripp_g1j* final_ck_b,
-                                  const ripp_g2j* opening_a, const ripp_g1j* opening_b, const ripp_fr* r_shift, int32_t* accept) {
-    if (!v_srs || !com || !com_steps || !base_a || !base_b || !final_ck_a || !final_ck_b || !opening_a || !opening_b || !r_shift || !accept || rounds == 0) return RIPP_ERR_ARG;
-    LOCK; ENGINE;
-    const VSrs v = load_vsrs(v_srs);
-    std::vector<Fr> trf; Fp12 bc[3];
-    if (!tipp_replay(com, com_steps, rounds, trf, bc)) { *accept = 0; return RIPP_OK; }                                  // :249-251
-    std::vector<Fr> tr(rounds), tri(rounds); for (size_t i = 0; i < rounds; ++i) { tr[i] = trf[rounds - 1 - i]; tri[i] = inv(tr[i]); }
-    const G2J ka = load_jac<Fp2>(final_ck_a), oa = load_jac<Fp2>(opening_a); const G1J kb = load_jac<Fp>(final_ck_b), ob = load_jac<Fp>(opening_b);
-    const G2A kaa = to_affine(ka); const G1A kba = to_affine(kb);
-    const Fr c = fs::kzg_challenge(tr[0], kaa, &kba);                                                                    // :257-272
-    bool ok_a = false, ok_b = false; int32_t rc;
-    if ((rc = kzg_verify_g2(e, v, ka, oa, tri, inv(load_fr(r_shift)), c, &ok_a))) return rc;                             // :274-281
-    if ((rc = kzg_verify_g1(e, v, kb, ob, tr, Fr::one(), c, &ok_b))) return rc;                                          // :282-289
-    const G1A a = to_affine(load_jac<Fp>(base_a)); const G2A b = to_affine(load_jac<Fp2>(base_b));
-    Fp12 e1, e2, e3;                                                                                                     // :292-298
-    if ((rc = pairing_host_pts(e, {a}, {kaa}, &e1)) || (rc = pairing_host_pts(e, {kba}, {b}, &e2)) || (rc = pairing_host_pts(e, {a}, {b}, &e3))) return rc;
-    *accept = (ok_a && ok_b && e1 == bc[0] && e2 == bc[1] && e3 == bc[2]) ? 1 : 0;
-    return RIPP_OK;
-}
-
-API int32_t ripp_tipa_ssm_verify(const ripp_verifier_srs* v_srs, const ripp_gt* com_a, const ripp_g1j* com_t, const ripp_fr* scalar_b,
-                                 const ripp_gt* com_gt, const ripp_g1j* com_g1, size_t rounds, const ripp_g1j* base_a,
-                                 const ripp_g2j* final_ck_a, const ripp_g2j* opening_a, int32_t* accept) {
-    if (!v_srs || !com_a || !com_t || !scalar_b || !com_gt || !com_g1 || !base_a || !final_ck_a || !opening_a || !accept || rounds == 0) return RIPP_ERR_ARG;
-    LOCK; ENGINE;
-    const VSrs v = load_vsrs(v_srs);
-    Fp12 ca = load_gt(com_a); G1J ct = load_jac<Fp>(com_t);
-    std::vector<Fr> trf(rounds);
-    for (size_t k = 0; k < rounds; ++k) {                                                                                // gipa.rs:329-360
-        const Fp12 gt[2] = {load_gt(&com_gt[2 * k]), load_gt(&com_gt[2 * k + 1])};
-        if (!gt_in_cyclotomic(gt[0]) || !gt_in_cyclotomic(gt[1])) { *accept = 0; return RIPP_OK; }
-        const G1A g1[2] = {to_affine(load_jac<Fp>(&com_g1[2 * k])), to_affine(load_jac<Fp>(&com_g1[2 * k + 1]))};
-        Fr c_inv; const Fr c = fs::gipa_ssm_challenge(k ? &trf[k - 1] : nullptr, gt, g1, c_inv);
-        auto f = host_pool().submit([&gt, c_inv]() { return gt_pow_host(gt[1], c_inv); });
-        ca = mul(ca, mul(gt_pow_host(gt[0], c), f.get()));
-        ct = add(add(ct, smul_host(g1[0], c)), smul_host(g1[1], c_inv));
-        trf[k] = c;
-    }
-    std::vector<Fr> tri(rounds); for (size_t i = 0; i < rounds; ++i) tri[i] = inv(trf[rounds - 1 - i]);
-    const G2J ka = load_jac<Fp2>(final_ck_a), oa = load_jac<Fp2>(opening_a); const G2A kaa = to_affine(ka);
-    const Fr c = fs::kzg_challenge(trf[rounds - 1], kaa, nullptr);                                                       // ssm.rs:289-303
-    bool ok_a = false; int32_t rc;
-    if ((rc = kzg_verify_g2(e, v, ka, oa, tri, Fr::one(), c, &ok_a))) return rc;                                         // ssm.rs:305-312
-    Fr p2b = load_fr(scalar_b), b_base = Fr::one();                                                                      // ssm.rs:315-321
-    for (size_t i = 0; i < rounds; ++i) { b_base = mul(b_base, add(Fr::one(), mul(tri[i], p2b))); p2b = mul(p2b, p2b); }
-    const G1A a = to_affine(load_jac<Fp>(base_a));
-    Fp12 e1; if ((rc = pairing_host_pts(e, {a}, {kaa}, &e1))) return rc;                                                 // ssm.rs:324-328
-    *accept = (ok_a && e1 == ca && eq(smul_host(a, b_base), ct)) ? 1 : 0;
-    return RIPP_OK;
-}
-
-API int32_t ripp_verify_aggregate_proof(const ripp_verifier_srs* v_srs, const ripp_groth16_vk* vk, const ripp_fr* public_inputs, size_t n, size_t m,
-                                        const ripp_aggregate_proof* pf, int32_t* accept) {
-    if (n < 2 || (n & (n - 1))) return RIPP_ERR_POW2;
-    if (!v_srs || !vk || !vk->gamma_abc_g1 || (m && !public_inputs) || !pf || !accept) return RIPP_ERR_ARG;
-    if (vk->gamma_abc_len != m + 1) { set_err("assert_eq!(vk.gamma_abc_g1.len(), public_inputs[0].len() + 1) (groth16_aggregation.rs:214)"); return RIPP_ERR_ARG; }
-    size_t rounds = 0; while (((size_t)1 << rounds) < n) ++rounds;
-    const Fr r = fs::aggregation_challenge(load_gt(&pf->com_a), load_gt(&pf->com_b), load_gt(&pf->com_c));             // :172-184
-    int32_t ok_ab = 0, ok_c = 0, rc;
-    const ripp_gt com_ab[3] = {pf->com_a, pf->com_b, pf->ip_ab};
-    if ((rc = ripp_tipa_tipp_verify(v_srs, com_ab, pf->ab_com_steps, rounds, &pf->ab_base_a, &pf->ab_base_b, &pf->ab_final_ck_a, &pf->ab_final_ck_b,   // :187-198
-                                    &pf->ab_opening_a, &pf->ab_opening_b, reinterpret_cast<const ripp_fr*>(&r), &ok_ab))) return rc;
-    if ((rc = ripp_tipa_ssm_verify(v_srs, &pf->com_c, &pf->agg_c, reinterpret_cast<const ripp_fr*>(&r), pf->c_com_gt, pf->c_com_g1, rounds, &pf->c_base_a,   // :199-205
-                                   &pf->c_final_ck_a, &pf->c_opening_a, &ok_c))) return rc;
-    LOCK; ENGINE;
-    // r_sum = (r^n - 1) / (r - 1)   (:209-210)
-    Fr rn = Fr::one(); std::vector<Fr> rv(n); for (size_t i = 0; i < n; ++i) { rv[i] = rn; rn = mul(rn, r); }
-    const Fr r_sum = mul(sub(rn, Fr::one()), inv(sub(r, Fr::one())));
-    G1A alpha; G2A beta, gamma, delta; std::memcpy(&alpha, &vk->alpha_g1, sizeof alpha); std::memcpy(&beta, &vk->beta_g2, sizeof beta);
-    std::memcpy(&gamma, &vk->gamma_g2, sizeof gamma); std::memcpy(&delta, &vk->delta_g2, sizeof delta);
-    const G1A* abc = reinterpret_cast<const G1A*>(vk->gamma_abc_g1);
-    G1J g_ic = smul_host(abc[0], r_sum);                                                                                 // :215-226
-    const Fr* pub = reinterpret_cast<const Fr*>(public_inputs);
-    for (size_t i = 0; i < m; ++i) {
-        Fr ip = Fr::zero(); for (size_t k = 0; k < n; ++k) ip = add(ip, mul(pub[k * m + i], rv[k]));                     // ScalarInnerProduct(inputs[:, i], r_vec)
-        g_ic = add(g_ic, smul_host(abc[i + 1], ip));
-    }
-    // ip_ab == e(alpha * r_sum, beta) + e(g_ic, gamma) + e(agg_c, delta)   (:211, 227-229): one three-pair product
-    Fp12 rhs;
-    if ((rc = pairing_host_pts(e, {to_affine(smul_host(alpha, r_sum)), to_affine(g_ic), to_affine(load_jac<Fp>(&pf->agg_c))}, {beta, gamma, delta}, &rhs))) return rc;
-    *accept = (ok_ab && ok_c && load_gt(&pf->ip_ab) == rhs) ? 1 : 0;
-    return RIPP_OK;
-}
+#include "tipa_api.inc"      // GIPA / TIPA / TIPAWithSSM provers, aggregate_proofs, verifiers
 
 // ---- SIPP ----------------------------------------------------------------------------------------------------------
 // borrow_value != nullptr: one-shot proof -- the caller's (16-byte aligned) buffers outlive the job, so the statement hash runs on them
@@ -1630,86 +964,7 @@ API int32_t ripp_sipp_challenge(uint8_t seed[32], const ripp_gt* z_l, const ripp
     const Fr c = fs::sipp_challenge(rng, a, b); std::memcpy(seed, rng.seed, 32); std::memcpy(x, &c, sizeof c); return RIPP_OK;
 }
 
-// ---- wire format (wire.hpp) -----------------------------------------------------------------------------------------------
-extern "C++" {
-static size_t emit(const wire::Writer& w, uint8_t* out, size_t cap) { if (out && cap >= w.b.size()) std::memcpy(out, w.b.data(), w.b.size()); return w.b.size(); }
-static G1A aff1(const ripp_g1j* p) { return to_affine(load_jac<Fp>(p)); }
-static G2A aff2(const ripp_g2j* p) { return to_affine(load_jac<Fp2>(p)); }
-template <class F> static void store_jac(void* dst, const Affine<F>& a) { const Jac<F> j = to_jac(a); std::memcpy(dst, &j, sizeof j); }
-}
-API size_t ripp_ser_tipa_tipp_proof(const ripp_gt* com_steps, size_t rounds, const ripp_g1j* base_a, const ripp_g2j* base_b,
-                                    const ripp_g2j* final_ck_a, const ripp_g1j* final_ck_b, const ripp_g2j* opening_a, const ripp_g1j* opening_b,
-                                    int32_t compress, uint8_t* out, size_t cap) {
-    if (!base_a || !base_b || (rounds && !com_steps) || (final_ck_a && (!final_ck_b || !opening_a || !opening_b))) return 0;
-    const bool c = compress != 0; wire::Writer w;
-    w.u64(rounds);                                                                // r_commitment_steps: Vec<(com_1, com_2)>, last round first
-    for (size_t k = rounds; k-- > 0;) {
-        for (int side = 0; side < 2; ++side) {                                     // (LMC::Output, RMC::Output, IPC::Output = IdentityOutput(Vec<GT>))
-            w.gt(load_gt(&com_steps[6 * k + 3 * side])); w.gt(load_gt(&com_steps[6 * k + 3 * side + 1]));
-            w.u64(1); w.gt(load_gt(&com_steps[6 * k + 3 * side + 2]));
-        }
-    }
-    w.g1(aff1(base_a), c); w.g2(aff2(base_b), c);                                  // r_base
-    if (final_ck_a) { w.g2(aff2(final_ck_a), c); w.g1(aff1(final_ck_b), c); w.g2(aff2(opening_a), c); w.g1(aff1(opening_b), c); }   // final_ck, final_ck_proof
-    return emit(w, out, cap);
-}
-API int32_t ripp_de_tipa_tipp_proof(const uint8_t* in, size_t len, int32_t compress, int32_t with_tipa, size_t max_rounds, size_t* rounds,
-                                    ripp_gt* com_steps, ripp_g1j* base_a, ripp_g2j* base_b,
-                                    ripp_g2j* final_ck_a, ripp_g1j* final_ck_b, ripp_g2j* opening_a, ripp_g1j* opening_b) {
-    if (!in || !rounds || !base_a || !base_b || (with_tipa && (!final_ck_a || !final_ck_b || !opening_a || !opening_b))) return RIPP_ERR_ARG;
-    const bool c = compress != 0; wire::Reader r{in, len};
-    const uint64_t n = r.u64();
-    if (!r.ok || n > max_rounds || (n && !com_steps)) { set_err("proof image: bad step count"); return RIPP_ERR_ARG; }
-    for (uint64_t i = 0; i < n && r.ok; ++i) {
-        const size_t k = (size_t)(n - 1 - i);
-        for (int side = 0; side < 2 && r.ok; ++side) {
-            Fp12 a, b, t; r.gt(a); r.gt(b); if (r.u64() != 1) r.ok = false; r.gt(t);
-            if (r.ok) { std::memcpy(&com_steps[6 * k + 3 * side], &a, sizeof a); std::memcpy(&com_steps[6 * k + 3 * side + 1], &b, sizeof b); std::memcpy(&com_steps[6 * k + 3 * side + 2], &t, sizeof t); }
-        }
-    }
-    G1A a1, kb, ob; G2A b2, ka, oa;
-    r.g1(a1, c); r.g2(b2, c);
-    if (with_tipa) { r.g2(ka, c); r.g1(kb, c); r.g2(oa, c); r.g1(ob, c); }
-    if (!r.ok || r.left != 0) { set_err("proof image: malformed, out-of-range or off-curve member, or trailing bytes"); return RIPP_ERR_ARG; }
-    *rounds = (size_t)n; store_jac<Fp>(base_a, a1); store_jac<Fp2>(base_b, b2);
-    if (with_tipa) { store_jac<Fp2>(final_ck_a, ka); store_jac<Fp>(final_ck_b, kb); store_jac<Fp2>(opening_a, oa); store_jac<Fp>(opening_b, ob); }
-    return RIPP_OK;
-}
-API size_t ripp_ser_tipa_ssm_proof(const ripp_gt* com_gt, const ripp_g1j* com_g1, size_t rounds, const ripp_g1j* base_a, const ripp_fr* base_b,
-                                   const ripp_g2j* final_ck_a, const ripp_g2j* opening_a, int32_t compress, uint8_t* out, size_t cap) {
-    if (!base_a || !base_b || !final_ck_a || !opening_a || (rounds && (!com_gt || !com_g1))) return 0;
-    const bool c = compress != 0; wire::Writer w;
-    w.u64(rounds);
-    for (size_t k = rounds; k-- > 0;)
-        for (int side = 0; side < 2; ++side) {                                     // (GT, Fr::zero() placeholder, IdentityOutput(Vec<G1>))
-            w.gt(load_gt(&com_gt[2 * k + side])); w.fr(Fr::zero()); w.u64(1); w.g1(aff1(&com_g1[2 * k + side]), c);
-        }
-    w.g1(aff1(base_a), c); w.fr(load_fr(base_b));                                  // r_base = (G1, Fr)
-    w.g2(aff2(final_ck_a), c); w.g2(aff2(opening_a), c);
-    return emit(w, out, cap);
-}
-API int32_t ripp_de_tipa_ssm_proof(const uint8_t* in, size_t len, int32_t compress, size_t max_rounds, size_t* rounds,
-                                   ripp_gt* com_gt, ripp_g1j* com_g1, ripp_g1j* base_a, ripp_fr* base_b, ripp_g2j* final_ck_a, ripp_g2j* opening_a) {
-    if (!in || !rounds || !base_a || !base_b || !final_ck_a || !opening_a) return RIPP_ERR_ARG;
-    const bool c = compress != 0; wire::Reader r{in, len};
-    const uint64_t n = r.u64();
-    if (!r.ok || n > max_rounds || (n && (!com_gt || !com_g1))) { set_err("proof image: bad step count"); return RIPP_ERR_ARG; }
-    for (uint64_t i = 0; i < n && r.ok; ++i) {
-        const size_t k = (size_t)(n - 1 - i);
-        for (int side = 0; side < 2 && r.ok; ++side) {
-            Fp12 g; Fr z; G1A t; r.gt(g); r.fr(z); if (r.u64() != 1) r.ok = false; r.g1(t, c);
-            if (r.ok && !z.is_zero()) r.ok = false;                                // SSMPlaceholderCommitment::commit is always zero (ssm.rs:44-46)
-            if (r.ok) { std::memcpy(&com_gt[2 * k + side], &g, sizeof g); store_jac<Fp>(&com_g1[2 * k + side], t); }
-        }
-    }
-    G1A a1; Fr sb; G2A ka, oa;
-    r.g1(a1, c); r.fr(sb); r.g2(ka, c); r.g2(oa, c);
-    if (!r.ok || r.left != 0) { set_err("proof image: malformed, out-of-range or off-curve member, or trailing bytes"); return RIPP_ERR_ARG; }
-    *rounds = (size_t)n; store_jac<Fp>(base_a, a1); std::memcpy(base_b, &sb, sizeof sb); store_jac<Fp2>(final_ck_a, ka); store_jac<Fp2>(opening_a, oa);
-    return RIPP_OK;
-}
-API size_t ripp_ser_g1_compressed(const ripp_g1a* p, uint8_t out[48]) { G1A x; std::memcpy(&x, p, sizeof x); wire::put_g1(x, true, out); return 48; }
-API size_t ripp_ser_g2_compressed(const ripp_g2a* p, uint8_t out[96]) { G2A x; std::memcpy(&x, p, sizeof x); wire::put_g2(x, true, out); return 96; }
+#include "wire_api.inc"      // CanonicalSerialize / CanonicalDeserialize images of the proof structs
 
 // ---- synthetic inputs ---------------------------------------------------------------------------------------------------
 extern "C++" {
