@@ -391,41 +391,39 @@ void statement_digest(const G1A* a, const G2A* b, const Fr* r, size_t n, const F
     fs::Blake2s h;
     g_digest_hash_ms = g_digest_wait_ms = 0;
     const uint64_t len = (uint64_t)n;
-    const size_t BLK = 1 << 14;
-    unsigned nthreads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    std::vector<uint8_t> buf[2] = {std::vector<uint8_t>(BLK * 192), std::vector<uint8_t>(BLK * 192)};
-    auto ser_block = [&](int which, size_t s, size_t e, int kind) {
-        uint8_t* out = buf[which].data();
-        auto work = [&](size_t lo, size_t hi) {
-            for (size_t i = lo; i < hi; ++i) {
-                if (kind == 0) fs::ser_g1(a[i], out + (i - s) * 96);
-                else if (kind == 1) fs::ser_g2(b[i], out + (i - s) * 192);
-                else fs::ser_fr(r[i], out + (i - s) * 32);
-            } };
-        const size_t cnt = e - s;
-        if (cnt < 256 || nthreads == 1) { work(s, e); return; }
-        std::vector<std::thread> th; const size_t per = (cnt + nthreads - 1) / nthreads;
-        for (unsigned t = 0; t < nthreads; ++t) { size_t lo = s + t * per, hi = std::min(e, lo + per); if (lo < hi) th.emplace_back(work, lo, hi); }
-        for (auto& t : th) t.join();
-    };
+    // The hash is sequential; the Montgomery -> canonical big-endian serialisation feeding it is not.  Segments of BLK items are
+    // serialised by the persistent host workers into a ring of buffers, RING - 1 segments ahead of the hash.
+    constexpr size_t BLK = 1 << 13; constexpr int RING = 6;
     const size_t item[3] = {96, 192, 32};
-    for (int kind = 0; kind < 3; ++kind) {
-        h.update(reinterpret_cast<const uint8_t*>(&len), 8);
-        // double-buffered: serialise block k+1 on workers while block k is being hashed on this thread
-        size_t nblocks = (n + BLK - 1) / BLK;
-        if (nblocks == 0) continue;
-        ser_block(0, 0, std::min(BLK, n), kind);
-        for (size_t k = 0; k < nblocks; ++k) {
-            const size_t s = k * BLK, e = std::min(n, s + BLK);
-            std::thread next;
-            if (k + 1 < nblocks) next = std::thread(ser_block, (int)((k + 1) & 1), e, std::min(n, e + BLK), kind);
-            double t0 = now_ms();
-            h.update(buf[k & 1].data(), (e - s) * item[kind]);
-            double t1 = now_ms();
-            if (next.joinable()) next.join();
-            g_digest_hash_ms += t1 - t0; g_digest_wait_ms += now_ms() - t1;
+    struct Seg { int kind; size_t s, e; };
+    std::vector<Seg> segs;
+    for (int kind = 0; kind < 3; ++kind) for (size_t s0 = 0; s0 < n; s0 += BLK) segs.push_back({kind, s0, std::min(n, s0 + BLK)});
+    std::vector<uint8_t> buf[RING]; for (auto& v : buf) v.resize(BLK * 192);
+    std::vector<std::future<void>> fut(segs.size());
+    auto launch = [&](size_t j) {
+        const Seg sg = segs[j]; uint8_t* out = buf[j % RING].data();
+        fut[j] = host_pool().submit([a, b, r, sg, out]() {
+            for (size_t i = sg.s; i < sg.e; ++i) {
+                if (sg.kind == 0) fs::ser_g1(a[i], out + (i - sg.s) * 96);
+                else if (sg.kind == 1) fs::ser_g2(b[i], out + (i - sg.s) * 192);
+                else fs::ser_fr(r[i], out + (i - sg.s) * 32);
+            } });
+    };
+    for (size_t j = 0; j < segs.size() && j < (size_t)RING - 1; ++j) launch(j);
+    int cur_kind = -1;
+    for (size_t j = 0; j < segs.size(); ++j) {
+        if (segs[j].kind != cur_kind) {      // a new vector starts: its u64 length prefix (ark-serialize Vec), also for empty vectors below
+            for (int k = cur_kind + 1; k <= segs[j].kind; ++k) h.update(reinterpret_cast<const uint8_t*>(&len), 8);
+            cur_kind = segs[j].kind;
         }
+        const double t0 = now_ms();
+        fut[j].get();
+        const double t1 = now_ms();
+        h.update(buf[j % RING].data(), (segs[j].e - segs[j].s) * item[segs[j].kind]);
+        g_digest_wait_ms += t1 - t0; g_digest_hash_ms += now_ms() - t1;
+        if (j + RING - 1 < segs.size()) launch(j + RING - 1);          // its buffer was released by the segment just hashed... one slot later
     }
+    for (int k = cur_kind + 1; k < 3; ++k) h.update(reinterpret_cast<const uint8_t*>(&len), 8);       // n == 0: three empty vectors
     uint8_t gt[576]; fs::ser_gt(value, gt); h.update(gt, 576);
     h.finish(digest);
 }

@@ -4,7 +4,7 @@ import numpy as np, orclib as o, ripp_amd as R
 n=1<<int(sys.argv[1]) if len(sys.argv)>1 else 1<<17
 a,b,r=o.gen_g1(1,n),o.gen_g2(2,n),o.gen_scalars(3,n); v=o.gt_one()
 t=time.time(); d=R.sipp_seed_digest(a,b,r,v); dt=time.time()-t
-print("digest n=2^17: %.3fs -> %.0f MB/s ; ok=%s"%(dt, n*320/dt/1e6, d==o.sipp_seed_digest(a,b,r,v)))
+print("digest: %.3fs -> %.0f MB/s ; ok=%s"%(dt, n*320/dt/1e6, d==o.sipp_seed_digest(a,b,r,v)))
 
 import ctypes
 hm=ctypes.c_double(); wm=ctypes.c_double()
