@@ -88,6 +88,20 @@ struct alignas(16) Mont {   // 16-byte aligned so device loads/stores are dwordx
     RIPP_HD bool operator!=(const Mont& b) const { return !(*this == b); }
 };
 
+#if !defined(__HIP_DEVICE_COMPILE__)
+// Host forms: the same little-endian image read as N/2 64-bit limbs (the per-round final exponentiations and the verifiers'
+// GT / group exponentiations run on the host and sit on the prover's critical path).
+template <class P> RIPP_HD void h_load(const Mont<P>& a, uint64_t* o) { for (int i = 0; i < P::N / 2; ++i) o[i] = (uint64_t)a.l[2 * i] | ((uint64_t)a.l[2 * i + 1] << 32); }
+template <class P> RIPP_HD void h_store(Mont<P>& r, const uint64_t* t) { for (int i = 0; i < P::N / 2; ++i) { r.l[2 * i] = (uint32_t)t[i]; r.l[2 * i + 1] = (uint32_t)(t[i] >> 32); } }
+template <class P> RIPP_HD uint64_t h_mod(int i) { return (uint64_t)P::mod(2 * i) | ((uint64_t)P::mod(2 * i + 1) << 32); }
+template <class P> RIPP_HD void h_reduce_once(uint64_t* t) {       // t < 2p  ->  t mod p
+    constexpr int M = P::N / 2; typedef unsigned __int128 u128;
+    uint64_t d[M], bo = 0;
+    for (int i = 0; i < M; ++i) { const u128 x = (u128)t[i] - h_mod<P>(i) - bo; d[i] = (uint64_t)x; bo = (uint64_t)(x >> 64) & 1; }
+    for (int i = 0; i < M; ++i) t[i] = bo ? t[i] : d[i];
+}
+#endif
+
 // r = (a >= p) ? a - p : a        (a < 2p)
 template <class P>
 RIPP_HD void reduce_once(Mont<P>& a) {
@@ -102,6 +116,11 @@ RIPP_HD void reduce_once(Mont<P>& a) {
 template <class P>
 RIPP_HD Mont<P> add(const Mont<P>& a, const Mont<P>& b) {
     constexpr int N = P::N;
+#if !defined(__HIP_DEVICE_COMPILE__)
+    { constexpr int M = N / 2; typedef unsigned __int128 u128; uint64_t x[M], y[M], c = 0; h_load(a, x); h_load(b, y);
+      for (int i = 0; i < M; ++i) { const u128 z = (u128)x[i] + y[i] + c; x[i] = (uint64_t)z; c = (uint64_t)(z >> 64); }
+      h_reduce_once<P>(x); Mont<P> r; h_store(r, x); return r; }
+#endif
     Mont<P> r; uint32_t c = 0;
 #pragma unroll
     for (int i = 0; i < N; ++i) r.l[i] = addc32(a.l[i], b.l[i], c);
@@ -111,6 +130,13 @@ RIPP_HD Mont<P> add(const Mont<P>& a, const Mont<P>& b) {
 template <class P>
 RIPP_HD Mont<P> sub(const Mont<P>& a, const Mont<P>& b) {
     constexpr int N = P::N;
+#if !defined(__HIP_DEVICE_COMPILE__)
+    { constexpr int M = N / 2; typedef unsigned __int128 u128; uint64_t x[M], y[M], bo = 0; h_load(a, x); h_load(b, y);
+      for (int i = 0; i < M; ++i) { const u128 z = (u128)x[i] - y[i] - bo; x[i] = (uint64_t)z; bo = (uint64_t)(z >> 64) & 1; }
+      const uint64_t mask = 0ull - bo; uint64_t c = 0;
+      for (int i = 0; i < M; ++i) { const u128 z = (u128)x[i] + (h_mod<P>(i) & mask) + c; x[i] = (uint64_t)z; c = (uint64_t)(z >> 64); }
+      Mont<P> r; h_store(r, x); return r; }
+#endif
     Mont<P> r; uint32_t bo = 0;
 #pragma unroll
     for (int i = 0; i < N; ++i) r.l[i] = subb32(a.l[i], b.l[i], bo);
@@ -208,30 +234,30 @@ RIPP_HD Mont<P> mul(const Mont<P>& a, const Mont<P>& b) {
 // speed of the 32-bit portable form; used by the per-round final exponentiations on the critical path.
 template <class P>
 RIPP_HD Mont<P> mul(const Mont<P>& a, const Mont<P>& b) {
+    // CIOS with the two carry chains (a_j b_i and m p_j) kept separate: they are independent, so the out-of-order core overlaps
+    // them; valid without an extra carry word because the top modulus limb is < 2^63 for both fields (p: 0x1a01..., r: 0x73ed...).
     constexpr int M = P::N / 2;
     typedef unsigned __int128 u128;
-    uint64_t al[M], bl[M], pl[M], t[M + 2];
-    for (int i = 0; i < M; ++i) {
-        al[i] = (uint64_t)a.l[2 * i] | ((uint64_t)a.l[2 * i + 1] << 32);
-        bl[i] = (uint64_t)b.l[2 * i] | ((uint64_t)b.l[2 * i + 1] << 32);
-        pl[i] = (uint64_t)P::mod(2 * i) | ((uint64_t)P::mod(2 * i + 1) << 32);
-    }
-    // -p^-1 mod 2^64 from the 32-bit constant by one Newton step:  inv64 = inv32 * (2 + p0 * inv32)   (for NEGATED inverse)
+    uint64_t al[M], bl[M], pl[M], t[M];
+    h_load(a, al); h_load(b, bl);
+    for (int i = 0; i < M; ++i) { pl[i] = h_mod<P>(i); t[i] = 0; }
+    static_assert((P::mod(P::N - 1) >> 31) == 0, "no-carry CIOS needs the top bit of the modulus clear");
     const uint64_t ninv32 = P::INV;
-    const uint64_t inv64 = ninv32 * (2 + pl[0] * ninv32);
-    for (int i = 0; i < M + 2; ++i) t[i] = 0;
+    const uint64_t inv64 = ninv32 * (2 + pl[0] * ninv32);       // -p^-1 mod 2^64 from the 32-bit constant (one Newton step)
     for (int i = 0; i < M; ++i) {
-        uint64_t c = 0;
-        for (int j = 0; j < M; ++j) { const u128 s = (u128)al[j] * bl[i] + t[j] + c; t[j] = (uint64_t)s; c = (uint64_t)(s >> 64); }
-        u128 s2 = (u128)t[M] + c; t[M] = (uint64_t)s2; t[M + 1] = (uint64_t)(s2 >> 64);
-        const uint64_t m = t[0] * inv64;
-        u128 s = (u128)m * pl[0] + t[0]; c = (uint64_t)(s >> 64);
-        for (int j = 1; j < M; ++j) { s = (u128)m * pl[j] + t[j] + c; t[j - 1] = (uint64_t)s; c = (uint64_t)(s >> 64); }
-        s2 = (u128)t[M] + c; t[M - 1] = (uint64_t)s2; t[M] = t[M + 1] + (uint64_t)(s2 >> 64);
+        u128 z = (u128)al[0] * bl[i] + t[0];
+        uint64_t C = (uint64_t)(z >> 64); const uint64_t t0 = (uint64_t)z;
+        const uint64_t m = t0 * inv64;
+        z = (u128)m * pl[0] + t0;
+        uint64_t C2 = (uint64_t)(z >> 64);
+        for (int j = 1; j < M; ++j) {
+            z = (u128)al[j] * bl[i] + t[j] + C; C = (uint64_t)(z >> 64);
+            z = (u128)m * pl[j] + (uint64_t)z + C2; C2 = (uint64_t)(z >> 64); t[j - 1] = (uint64_t)z;
+        }
+        t[M - 1] = C + C2;
     }
-    Mont<P> r;
-    for (int i = 0; i < M; ++i) { r.l[2 * i] = (uint32_t)t[i]; r.l[2 * i + 1] = (uint32_t)(t[i] >> 32); }
-    reduce_once(r);
+    h_reduce_once<P>(t);
+    Mont<P> r; h_store(r, t);
     return r;
 }
 #endif
