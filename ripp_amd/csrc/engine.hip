@@ -377,6 +377,33 @@ GlvDigits glv_digits(const Fr& s_mont) {
     return g;
 }
 
+// digit strings of the folds with a precomputed second base (kernels.hpp, "round-0 folds")
+GlvDigits split64_digits(const Fr& s_mont) {                     // 128-bit challenge -> its two 64-bit halves
+    const Fr c = from_mont(s_mont);
+    GlvDigits g; std::memset(&g, 0, sizeof g);
+    const int l1 = naf_recode(&c.l[0], 2, g.d1, 131), l2 = naf_recode(&c.l[2], 2, g.d2, 131);
+    g.len = l1 > l2 ? l1 : l2;
+    return g;
+}
+bool fits_128(const Fr& s_mont) { const Fr c = from_mont(s_mont); return (c.l[4] | c.l[5] | c.l[6] | c.l[7]) == 0; }
+Gls8Digits gls8_digits(const Fr& s_mont) {                        // base-u digits (u = |x|), each split at bit 32
+    const Fr c = from_mont(s_mont);
+    uint64_t v[4] = {(uint64_t)c.l[0] | ((uint64_t)c.l[1] << 32), (uint64_t)c.l[2] | ((uint64_t)c.l[3] << 32),
+                     (uint64_t)c.l[4] | ((uint64_t)c.l[5] << 32), (uint64_t)c.l[6] | ((uint64_t)c.l[7] << 32)};
+    Gls8Digits g; std::memset(&g, 0, sizeof g);
+    int maxlen = 0;
+    for (int j = 0; j < 4; ++j) {
+        unsigned __int128 rem = 0;
+        for (int i = 3; i >= 0; --i) { const unsigned __int128 cur = (rem << 64) | v[i]; v[i] = (uint64_t)(cur / BLS_X_ABS); rem = cur % BLS_X_ABS; }
+        const uint64_t dj = (uint64_t)rem;
+        const uint32_t lo = (uint32_t)dj, hi = (uint32_t)(dj >> 32);
+        const int l1 = naf_recode(&lo, 1, g.d[j], 35), l2 = naf_recode(&hi, 1, g.d[4 + j], 35);
+        maxlen = std::max(maxlen, std::max(l1, l2));
+    }
+    g.len = maxlen;
+    return g;
+}
+
 template <class T> int32_t upload(Engine* e, DevBuf& buf, const void* host, size_t n, T** dev) {
     int32_t rc = buf.reserve(std::max<size_t>(n, 1) * sizeof(T)); if (rc != RIPP_OK) return rc;
     if (n) HIPCHK(hipMemcpyAsync(buf.p, host, n * sizeof(T), hipMemcpyHostToDevice, e->stream));
@@ -436,6 +463,7 @@ struct ripp_sipp_job {
     int rank = 0, world = 1, world0 = 1;  // world0: sharding of the resident statement; world drops to 1 after the tail import
     DevBuf a0, b0, r0;                    // resident statement shard
     DevBuf a, b, a_next, b_next, jac1, jac2;   // working vectors
+    DevBuf a_pow, b_pow; bool pre_ready = false;   // 2^64 * a_r and 2^32 * b_r of round 0, prepared while the statement hash finishes
     std::vector<G1A> ha; std::vector<G2A> hb; std::vector<Fr> hr;   // host copy of the statement (rank 0 hashes it)
     const G1A* ha_ext = nullptr; const G2A* hb_ext = nullptr; const Fr* hr_ext = nullptr;   // one-shot proofs hash the CALLER's buffers in place
     bool hash_prestarted = false;
@@ -484,6 +512,24 @@ int32_t job_round_partials(Engine* e, ripp_sipp_job* j, Fp12* rows /* [2][68] */
     return rc;
 }
 
+// Round 0 only, single-GPU proofs: enqueue hi2 = 2^64 a_r and 2^32 b_r (normalised) behind the round's pairing products.  The GPU would
+// otherwise idle until the statement hash delivers the first challenge; the fold then needs half the doublings (k_fold_g1_two /
+// k_fold_g2_gls8).  Not worth it for small rounds (latency-bound) -- and skipped when the hash is already done.
+int32_t job_precompute_round0(Engine* e, ripp_sipp_job* j) {
+    const size_t half = j->len / 2;
+    if (half < ((size_t)1 << 16) || j->digest_ready.load() || std::getenv("RIPP_NO_PRECOMPUTE")) return RIPP_OK;
+    int32_t rc;
+    if ((rc = j->a_pow.reserve(half * sizeof(G1A))) || (rc = j->b_pow.reserve(half * sizeof(G2A))) || (rc = j->jac1.reserve(half * sizeof(G1J))) || (rc = j->jac2.reserve(half * sizeof(G2J)))) return rc;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pow2_mul<Fp>), dim3(nblk(half, 256)), dim3(256), 0, e->stream, j->a.as<G1A>() + half, (uint32_t)half, 64, j->jac1.as<G1J>());
+    HIPCHK(hipGetLastError());
+    if ((rc = e->normalize_dev<Fp>(j->jac1.as<G1J>(), half, j->a_pow.as<G1A>()))) return rc;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pow2_mul<Fp2>), dim3(nblk(half, 256)), dim3(256), 0, e->stream, j->b.as<G2A>() + half, (uint32_t)half, 32, j->jac2.as<G2J>());
+    HIPCHK(hipGetLastError());
+    if ((rc = e->normalize_dev<Fp2>(j->jac2.as<G2J>(), half, j->b_pow.as<G2A>()))) return rc;
+    j->pre_ready = true;
+    return RIPP_OK;
+}
+
 int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true) {
     const size_t half = j->len / 2;
     int32_t rc;
@@ -496,15 +542,22 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true)
     // G1 half on stream2, G2 half on the main stream (small rounds leave most of the chip idle otherwise)
     const bool use_vm = allow_vm && half <= e->vm_fold_max && !std::getenv("RIPP_NO_VM");
     if (use_vm) { if ((rc = e->vm_flag.reserve(sizeof(uint32_t))) != RIPP_OK) return rc; HIPCHK(hipMemsetAsync(e->vm_flag.p, 0, sizeof(uint32_t), e->stream)); }
+    const bool pre = j->pre_ready && fits_128(x); j->pre_ready = false;      // second bases prepared in the hash window (job_precompute_round0)
     HIPCHK(hipEventRecord(e->ev_fork, e->stream));
     HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
-    if (use_vm)
+    if (pre)
+        hipLaunchKernelGGL(k_fold_g1_two, dim3(nblk(half, 256)), dim3(256), 0, e->stream2, a + half, j->a_pow.as<G1A>(), a, (uint32_t)half, split64_digits(x), j->jac1.as<G1J>());
+    else if (use_vm)
         hipLaunchKernelGGL(k_vm_fold_g1, dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VM_G1_SLOTS * sizeof(Fp), e->stream2, a + half, a, (uint32_t)half, naf_digits(x), j->jac1.as<G1J>(), e->vm_flag.as<uint32_t>());
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_affine_naf<Fp>), dim3(nblk(half, 256)), dim3(256), 0, e->stream2, a + half, a, (uint32_t)half, naf_digits(x), j->jac1.as<G1J>());
     HIPCHK(hipGetLastError());
     if ((rc = e->normalize_dev<Fp>(j->jac1.as<G1J>(), half, j->a_next.as<G1A>(), e->stream2)) != RIPP_OK) return rc;
     HIPCHK(hipEventRecord(e->ev_join, e->stream2));
+    if (pre) {
+        if ((rc = e->qtab.reserve(8 * G2A_CHUNKS * qstride * sizeof(uint4))) != RIPP_OK) return rc;
+        hipLaunchKernelGGL(k_fold_g2_gls8, dim3(nblk(half, 64)), dim3(64), 0, e->stream, b + half, j->b_pow.as<G2A>(), b, (uint32_t)half, gls8_digits(x_inv), e->qtab.as<uint4>(), qstride, j->jac2.as<G2J>());
+    } else
     if (use_vm) {
         if ((rc = e->qtab.reserve(std::max<size_t>(4 * G2A_CHUNKS * qstride * sizeof(uint4), 4 * half * sizeof(G2J)))) != RIPP_OK) return rc;
         hipLaunchKernelGGL(k_vm_fold_g2_split, dim3(nblk(half, 4 * VM_EPW), 4), dim3(256), 4 * VM_EPW * VM_G2_SLOTS * sizeof(Fp), e->stream, b + half, (uint32_t)half, gls_digits(x_inv), e->qtab.as<G2J>(), e->vm_flag.as<uint32_t>());
@@ -817,7 +870,7 @@ API int32_t ripp_sipp_job_create(const ripp_g1a* a, const ripp_g2a* b, const rip
 API void ripp_sipp_job_destroy(ripp_sipp_job* j) {
     if (!j) return; LOCK;
     if (j->hash_thread.joinable()) j->hash_thread.join();
-    for (DevBuf* b : {&j->a0, &j->b0, &j->r0, &j->a, &j->b, &j->a_next, &j->b_next, &j->jac1, &j->jac2}) b->release();
+    for (DevBuf* b : {&j->a0, &j->b0, &j->r0, &j->a, &j->b, &j->a_next, &j->b_next, &j->jac1, &j->jac2, &j->a_pow, &j->b_pow}) b->release();
     delete j;
 }
 API int32_t ripp_sipp_job_begin(ripp_sipp_job* j) { LOCK; ENGINE; if (!j) return RIPP_ERR_ARG; return job_begin(e, j); }
@@ -887,6 +940,7 @@ API int32_t ripp_sipp_job_prove(ripp_sipp_job* j, const ripp_gt* value, ripp_gt*
         Fp12 rows[2 * N_LINES];
         const double tr0 = now_ms();
         if ((rc = job_round_partials(e, j, rows))) return rc;
+        if (round == 0 && !j->seeded && (rc = job_precompute_round0(e, j))) return rc;      // asynchronous: overlaps the host work below and the hash
         const double t0 = now_ms();
         auto fut = host_pool().submit([&rows]() { return final_exponentiation(miller_combine(rows + N_LINES)); });
         const Fp12 zl = final_exponentiation(miller_combine(rows));

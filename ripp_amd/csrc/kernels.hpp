@@ -269,6 +269,66 @@ __global__ void __launch_bounds__(256) k_fold_g1_glv(const G1A* __restrict__ hi,
     out[i] = add_mixed(acc, lo[i]);
 }
 
+// ---- round-0 folds with a PRECOMPUTED second base ---------------------------------------------------------------------
+// In SIPP::prove the first challenge needs the Blake2s digest of the whole statement, which the host finishes ~90 ms after the GPU
+// has finished the first round's pairing products (n = 2^20).  That window is used to compute hi2[i] = 2^K * hi[i] for both
+// vectors (K = 64 on G1, K = 32 on G2): the fold scalar is then split at bit K, s = s_lo + 2^K s_hi, and
+//     out[i] = s_lo * hi[i] + s_hi * hi2[i] + lo[i]
+// needs K doublings instead of 2K -- the other K were done before the challenge was known.
+template <class F>
+__global__ void __launch_bounds__(256, 2) k_pow2_mul(const Affine<F>* __restrict__ in, uint32_t n, int k, Jac<F>* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Jac<F> acc = to_jac(in[i]);
+#pragma unroll 1
+    for (int t = 0; t < k; ++t) acc = dbl(acc);
+    out[i] = acc;
+}
+// G1: s_lo, s_hi are the 64-bit halves of the 128-bit challenge (sipp/src/lib.rs:85-91), NAF digit strings in dg.d1 / dg.d2
+__global__ void __launch_bounds__(256) k_fold_g1_two(const G1A* __restrict__ hi, const G1A* __restrict__ hi2, const G1A* __restrict__ lo, uint32_t half,
+                                                      GlvDigits dg, G1J* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= half) return;
+    const G1A p = hi[i], q = hi2[i];
+    G1J acc = jac_inf<Fp>();
+#pragma unroll 1
+    for (int pos = dg.len - 1; pos >= 0; --pos) {
+        acc = dbl(acc);
+        const int d1 = dg.d1[pos], d2 = dg.d2[pos];
+        if (d1 != 0) { G1A t = p; if (d1 < 0) t.y = neg(t.y); acc = add_mixed(acc, t); }
+        if (d2 != 0) { G1A t = q; if (d2 < 0) t.y = neg(t.y); acc = add_mixed(acc, t); }
+    }
+    out[i] = add_mixed(acc, lo[i]);
+}
+// G2: every base-u digit of the GLS decomposition is split at bit 32: eight digit strings of <= 33 NAF digits over the eight bases
+// psi^j(Q), psi^j(2^32 Q) (psi commutes with doubling): 33 doublings + ~88 additions instead of 65 + ~87.
+struct Gls8Digits { int8_t d[8][36]; int len; };
+__global__ void __launch_bounds__(64, RIPP_OCC) k_fold_g2_gls8(const G2A* __restrict__ hi, const G2A* __restrict__ hi2, const G2A* __restrict__ lo, uint32_t half,
+                                                      Gls8Digits dg, uint4* __restrict__ qtab, size_t stride, G2J* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= half) return;
+    {
+        const G2A q = hi[i], q2 = hi2[i];
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j) { store_chunks<G2A_CHUNKS>(qtab, j, stride, i, gls_image(q, j)); store_chunks<G2A_CHUNKS>(qtab, 4 + j, stride, i, gls_image(q2, j)); }
+    }
+    G2J acc = jac_inf<Fp2>();
+#pragma unroll 1
+    for (int pos = dg.len - 1; pos >= 0; --pos) {
+        acc = dbl(acc);
+#pragma unroll 1
+        for (int t = 0; t < 8; ++t) {
+            const int d = dg.d[t][pos];
+            if (d != 0) {
+                G2A q = load_chunks<G2A_CHUNKS, G2A>(qtab, t, stride, i);
+                if (d < 0) q.y = neg(q.y);
+                acc = add_mixed(acc, q);
+            }
+        }
+    }
+    out[i] = add_mixed(acc, lo[i]);
+}
+
 // ---- batch normalisation (CurveGroup::normalize_batch) ------------------------------------------------------
 // Lane t handles points t, t+T, ..., one inversion per lane (Montgomery's trick over its K points).  The running
 // prefix products are parked in out[i].x, so `in` and `out` must not alias.
