@@ -100,7 +100,7 @@ def test_sharded_prover_world2_gloo_matches_single_process(n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [4, 64])
+@pytest.mark.parametrize("n", [64])
 def test_sharded_prover_world2_real_engine(engine, n):
     """Two ranks, both driving cuda:0 through the C ABI's staged interface, gloo as the transport."""
     _run(2, n, use_gpu=True)
@@ -172,6 +172,6 @@ def test_sharded_inner_products_world2_gloo(n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [6, 1000])
+@pytest.mark.parametrize("n", [1000])
 def test_sharded_inner_products_world2_real_engine(engine, n):
     _run_ip(2, n, use_gpu=True)
