@@ -84,3 +84,23 @@ def test_fiat_shamir_step_matches_golden(hiplib, vectors):
         assert rc == 0
         import orclib
         assert hex(orclib.limbs_to_fr(x)) == v["challenges"][j]
+
+
+def _build_c_demo(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "c_abi_demo")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-std=c99", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_abi_demo.c"),
+                           "-L" + os.path.join(ROOT, "ripp_amd", "lib"), "-lripp_hip", "-Wl,-rpath," + os.path.join(ROOT, "ripp_amd", "lib"), "-o", exe])
+    return exe
+
+
+def test_header_is_plain_c_and_demo_fails_loudly_without_device(tmp_path):
+    """include/ripp_hip.h must be consumable from C99 (the drop-in boundary has no C++ in it); without a GPU the demo stops with the
+    'no CPU fallback' message instead of computing anything."""
+    import subprocess
+    exe = _build_c_demo(tmp_path)
+    from ripp_amd._lib import lib
+    if lib().ripp_device_count() > 0:
+        pytest.skip("a HIP device is present; the GPU variant of this test covers the run")
+    p = subprocess.run([exe, "4"], capture_output=True, text=True)
+    assert p.returncode == 2 and "no CPU fallback" in p.stderr

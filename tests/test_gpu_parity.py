@@ -307,3 +307,13 @@ def test_gipa_tipp_prove_vs_oracle(engine, orc, n):
         assert engine.GIPA_TIPP.verify(ck_a, ck_b, com, raw["round_order_steps"], proof["r_base"])
         assert not engine.GIPA_TIPP.verify(ck_a, ck_b, com, bad, proof["r_base"])
         assert not engine.GIPA_TIPP.verify(ck_a, ck_b, com, raw["round_order_steps"], (proof["r_base"][0], aux["ck_base"][0]))
+
+
+def test_c_abi_demo_program(engine, tmp_path):
+    """examples/c_abi_demo.c: a C99 program using only include/ripp_hip.h proves and verifies a 2^10 statement, rejects a tampered proof
+    and sees the reference's length error as a status code."""
+    import subprocess
+    from test_abi_cpu import _build_c_demo
+    p = subprocess.run([_build_c_demo(tmp_path), "10"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "verify accepts" in p.stdout and "tampered proof rejected" in p.stdout
