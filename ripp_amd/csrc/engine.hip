@@ -809,27 +809,57 @@ API int32_t ripp_sipp_verify(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr
     if (n < 2 || (n & (n - 1))) return RIPP_ERR_POW2;                     // asserts at :118-119
     size_t lg = 0; while (((size_t)1 << lg) < n) ++lg;
     if (proof_rounds != lg) return RIPP_ERR_ARG;                          // :122-123
+    LOCK; ENGINE;
+    // the bases do not depend on the challenges: their upload runs while the host hashes the statement (the verifier's serial floor too)
+    G1A* da; G2A* db; int32_t rc;
+    if ((rc = upload<G1A>(e, e->affG1, a, n, &da)) || (rc = upload<G2A>(e, e->affG2, b, n, &db))) return rc;
     uint8_t digest[32];
-    int32_t rc = ripp_sipp_seed_digest(a, b, r, n, claimed, digest); if (rc) return rc;      // :126-132
+    if ((rc = ripp_sipp_seed_digest(a, b, r, n, claimed, digest))) return rc;      // :126-132
     fs::FiatShamirRng rng; rng.from_digest(digest);
     const Fp12* pr = reinterpret_cast<const Fp12*>(proof);
     std::vector<Fp12> P(2 * lg); std::memcpy(P.data(), pr, 2 * lg * sizeof(Fp12));
     std::vector<Fr> xs(lg), xinv(lg);
     for (size_t j = 0; j < lg; ++j) { xs[j] = fs::sipp_challenge(rng, P[2 * j], P[2 * j + 1]); xinv[j] = inv(xs[j]); }   // :134-149
-    Fp12 zp; std::memcpy(&zp, claimed, sizeof zp);
+    // z' = z * prod z_l^x z_r^(x^-1)  (:151-158): 2 log n independent GT exponentiations on the host workers.  The proof's elements are
+    // untrusted Fp12 values, so this uses the plain square-and-multiply (gt_pow_host's cyclotomic squarings assume GT membership).
     auto gt_pow = [](const Fp12& x, const Fr& k) { const Fr c = from_mont(k); Fp12 acc = Fp12::one(); bool st = false;
         for (int i = 255; i >= 0; --i) { if (st) acc = sqr(acc); if ((c.l[i >> 5] >> (i & 31)) & 1u) { acc = st ? mul(acc, x) : x; st = true; } } return acc; };
-    for (size_t j = 0; j < lg; ++j) zp = mul(zp, mul(gt_pow(P[2 * j], xs[j]), gt_pow(P[2 * j + 1], xinv[j])));           // :151-158
-    // s_i = r_i * prod_{j : bit (lg-1-j) of i set} x_j ;  s_inv likewise (:160-172), built by doubling
+    std::vector<std::future<Fp12>> pw;
+    for (size_t j = 0; j < lg; ++j) {
+        pw.push_back(host_pool().submit([&, j]() { return gt_pow(P[2 * j], xs[j]); }));
+        pw.push_back(host_pool().submit([&, j]() { return gt_pow(P[2 * j + 1], xinv[j]); }));
+    }
+    // s_i = r_i * prod_{j : bit (lg-1-j) of i set} x_j ;  s_inv likewise (:160-172), built by doubling; long levels are split over the workers
     std::vector<Fr> s(n), si(n); s[0] = Fr::one(); si[0] = Fr::one();
-    for (size_t j = lg; j-- > 0;) { const size_t bit = (size_t)1 << (lg - 1 - j); for (size_t i = 0; i < bit; ++i) { s[i + bit] = mul(s[i], xs[j]); si[i + bit] = mul(si[i], xinv[j]); } }
-    std::vector<Fr> rr(n); std::memcpy(rr.data(), r, n * sizeof(Fr));
-    for (size_t i = 0; i < n; ++i) s[i] = mul(s[i], rr[i]);
-    ripp_g1j ap; ripp_g2j bp;
-    if ((rc = ripp_msm_g1_a(a, reinterpret_cast<const ripp_fr*>(s.data()), n, &ap))) return rc;                           // :174
-    if ((rc = ripp_msm_g2_a(b, reinterpret_cast<const ripp_fr*>(si.data()), n, &bp))) return rc;                          // :175
-    ripp_gt e12;
-    if ((rc = ripp_pairing_product_j(&ap, 1, &bp, 1, &e12))) return rc;                                                    // :177
+    const Fr* rr = reinterpret_cast<const Fr*>(r);
+    auto parallel_for = [](size_t count, const std::function<void(size_t, size_t)>& body) {
+        const size_t chunks = count >= ((size_t)1 << 14) ? 6 : 1, per = (count + chunks - 1) / chunks;
+        std::vector<std::future<void>> f;
+        for (size_t c = 1; c < chunks; ++c) { const size_t lo = c * per, hi = std::min(count, lo + per); if (lo < hi) f.push_back(host_pool().submit([&body, lo, hi]() { body(lo, hi); })); }
+        body(0, std::min(count, per));
+        for (auto& x : f) x.get();
+    };
+    for (size_t j = lg; j-- > 0;) {
+        const size_t bit = (size_t)1 << (lg - 1 - j); const Fr xj = xs[j], xij = xinv[j];
+        parallel_for(bit, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) { s[i + bit] = mul(s[i], xj); si[i + bit] = mul(si[i], xij); } });
+    }
+    const bool aligned = ((uintptr_t)r & 15u) == 0;
+    std::vector<Fr> rcopy; if (!aligned) { rcopy.resize(n); std::memcpy(rcopy.data(), r, n * sizeof(Fr)); rr = rcopy.data(); }
+    parallel_for(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) s[i] = mul(s[i], rr[i]); });
+    // the two MSMs (:174-175) side by side on two streams against the bases already resident
+    if ((rc = e->kzg_q[0].reserve(n * sizeof(Fr))) || (rc = e->kzg_q[1].reserve(n * sizeof(Fr)))) return rc;
+    HIPCHK(hipMemcpyAsync(e->kzg_q[0].p, s.data(), n * sizeof(Fr), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->kzg_q[1].p, si.data(), n * sizeof(Fr), hipMemcpyHostToDevice, e->stream));
+    if ((rc = e->sync())) return rc;
+    if ((rc = e->msm_launch<Fp>(e->msm_scratch[1], e->stream3, da, e->kzg_q[0].as<Fr>(), n))) return rc;
+    if ((rc = e->msm_launch<Fp2>(e->msm_scratch[0], e->stream, db, e->kzg_q[1].as<Fr>(), n))) return rc;
+    if ((rc = e->sync())) return rc; HIPCHK(hipStreamSynchronize(e->stream3));
+    const G1A apa = to_affine(*reinterpret_cast<const G1J*>(e->msm_scratch[1].host_out)); const G2A bpa = to_affine(*reinterpret_cast<const G2J*>(e->msm_scratch[0].host_out));
+    Fp12 zp; std::memcpy(&zp, claimed, sizeof zp);
+    for (auto& f : pw) zp = mul(zp, f.get());
+    G1A* d1; G2A* d2; ripp_gt e12;
+    if ((rc = upload<G1A>(e, e->tmpA, &apa, 1, &d1)) || (rc = upload<G2A>(e, e->tmpB, &bpa, 1, &d2))) return rc;
+    if ((rc = pairing_product_dev(e, d1, d2, 1, &e12))) return rc;                                                       // :177
     Fp12 ev; std::memcpy(&ev, &e12, sizeof ev);
     *accept = (ev == zp) ? 1 : 0;
     return RIPP_OK;
