@@ -561,7 +561,7 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true)
     if (use_vm) {
         if ((rc = e->qtab.reserve(std::max<size_t>(4 * G2A_CHUNKS * qstride * sizeof(uint4), 4 * half * sizeof(G2J)))) != RIPP_OK) return rc;
         hipLaunchKernelGGL(k_vm_fold_g2_split, dim3(nblk(half, 4 * VM_EPW), 4), dim3(256), 4 * VM_EPW * VM_G2_SLOTS * sizeof(Fp), e->stream, b + half, (uint32_t)half, gls_digits(x_inv), e->qtab.as<G2J>(), e->vm_flag.as<uint32_t>());
-        hipLaunchKernelGGL(k_fold_g2_combine, dim3(nblk(half, 64)), dim3(64), 0, e->stream, e->qtab.as<G2J>(), b, (uint32_t)half, j->jac2.as<G2J>());
+        hipLaunchKernelGGL(k_vm_combine_g2, dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VM_G2_SLOTS * sizeof(Fp), e->stream, e->qtab.as<G2J>(), b, (uint32_t)half, j->jac2.as<G2J>());
     } else
     if (half <= e->gls_split_max) {     // latency-bound round: 4 lanes per element
         if ((rc = e->qtab.reserve(std::max<size_t>(4 * G2A_CHUNKS * qstride * sizeof(uint4), 4 * half * sizeof(G2J)))) != RIPP_OK) return rc;

@@ -203,12 +203,49 @@ __global__ void __launch_bounds__(256) k_vm_fold_g2_split(const G2A* __restrict_
         }
     }
     if (active && lg == 0) {
-        G2J r = jac_inf<Fp2>();
-        if (any && !qinf) {
-            const Fp2 X = {ws[SX], ws[SX + 1]}, Y = {ws[SY], ws[SY + 1]}, Z = {ws[SZ], ws[SZ + 1]};
-            if (!Z.is_zero()) { r.x = mul(X, Z); r.y = mul(Y, sqr(Z)); r.z = Z; }      // (X/Z, Y/Z) -> Jacobian (XZ, YZ^2, Z)
-        }
+        // parts are left in HOMOGENEOUS projective form (X : Y : Z), the identity as (0 : 1 : 0): k_vm_combine_g2 adds them with the
+        // complete addition program, so no lone-lane conversion sits on the chain
+        G2J r; r.x = Fp2::zero(); r.y = Fp2::one(); r.z = Fp2::zero();
+        if (any && !qinf) { r.x = {ws[SX], ws[SX + 1]}; r.y = {ws[SY], ws[SY + 1]}; r.z = {ws[SZ], ws[SZ + 1]}; }
         parts[(size_t)j * half + i] = r;
+    }
+}
+
+// out[i] = parts[0][i] + parts[1][i] + parts[2][i] + parts[3][i] + lo[i]  (Jacobian out): four complete VM additions instead of the
+// lone-lane Jacobian additions of k_fold_g2_combine (0.35-0.43 ms on the fold chain of every small round)
+__global__ void __launch_bounds__(256) k_vm_combine_g2(const G2J* __restrict__ parts, const G2A* __restrict__ lo, uint32_t half, G2J* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char vm_smem[];
+    Fp* const lds = reinterpret_cast<Fp*>(vm_smem);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lg = lane & (VM_G - 1), grp = lane / VM_G;
+    const uint32_t i = (blockIdx.x * 4 + wave) * VM_EPW + grp;
+    Fp* const ws = lds + (size_t)(wave * VM_EPW + grp) * VM_G2_SLOTS;
+    const bool active = i < half;
+    namespace vp = vmprog;
+    enum { SX = vp::g2_cadd_g16_in_X0, SY = vp::g2_cadd_g16_in_Y0, SZ = vp::g2_cadd_g16_in_Z0, SQX = vp::g2_cadd_g16_in_qx0, SQY = vp::g2_cadd_g16_in_qy0, SQZ = vp::g2_cadd_g16_in_qz0 };
+    auto put = [&](int s, const Fp2& v) { ws[s] = v.c0; ws[s + 1] = v.c1; };
+    if (lg == 0) {
+        ws[0] = Fp::zero();
+        G2J p0; p0.x = Fp2::zero(); p0.y = Fp2::one(); p0.z = Fp2::zero();
+        if (active) p0 = parts[i];
+        put(SX, p0.x); put(SY, p0.y); put(SZ, p0.z);
+    }
+#pragma unroll 1
+    for (int j = 1; j <= 4; ++j) {
+        if (lg == 0) {
+            G2J q; q.x = Fp2::zero(); q.y = Fp2::one(); q.z = Fp2::zero();
+            if (active) {
+                if (j < 4) q = parts[(size_t)j * half + i];
+                else { const G2A l = lo[i]; if (!is_inf(l)) { q.x = l.x; q.y = l.y; q.z = Fp2::one(); } }
+            }
+            put(SQX, q.x); put(SQY, q.y); put(SQZ, q.z);
+        }
+        vm_run(ws, vp::g2_cadd_g16_kind, vp::g2_cadd_g16_ops, vp::g2_cadd_g16_nlayers, lg);
+    }
+    if (active && lg == 0) {
+        const Fp2 X = {ws[SX], ws[SX + 1]}, Y = {ws[SY], ws[SY + 1]}, Z = {ws[SZ], ws[SZ + 1]};
+        G2J r = jac_inf<Fp2>();
+        if (!Z.is_zero()) { r.x = mul(X, Z); r.y = mul(Y, sqr(Z)); r.z = Z; }          // (X/Z, Y/Z) -> Jacobian (XZ, YZ^2, Z)
+        out[i] = r;
     }
 }
 
