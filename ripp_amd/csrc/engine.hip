@@ -24,6 +24,7 @@
 #include "kernels.hpp"
 #include "msm.hpp"
 #include "vm.hpp"
+#include "vm_fold2.hpp"
 #include "host_fs.hpp"
 #include "wire.hpp"
 
@@ -404,6 +405,20 @@ Gls8Digits gls8_digits(const Fr& s_mont) {                        // base-u digi
     return g;
 }
 
+// digit strings for vm_fold2.hpp: the same splits as split64_digits / gls8_digits in the SplitDigits layout
+SplitDigits split_digits_g1(const Fr& s_mont) {
+    const GlvDigits g = split64_digits(s_mont);
+    SplitDigits d; std::memset(&d, 0, sizeof d);
+    for (int i = 0; i < g.len && i < 68; ++i) { d.d[0][i] = g.d1[i]; d.d[1][i] = g.d2[i]; }
+    d.len = g.len; return d;
+}
+SplitDigits split_digits_g2(const Fr& s_mont) {
+    const Gls8Digits g = gls8_digits(s_mont);
+    SplitDigits d; std::memset(&d, 0, sizeof d);
+    for (int t = 0; t < 8; ++t) for (int i = 0; i < g.len; ++i) d.d[t][i] = g.d[t][i];
+    d.len = g.len; return d;
+}
+
 template <class T> int32_t upload(Engine* e, DevBuf& buf, const void* host, size_t n, T** dev) {
     int32_t rc = buf.reserve(std::max<size_t>(n, 1) * sizeof(T)); if (rc != RIPP_OK) return rc;
     if (n) HIPCHK(hipMemcpyAsync(buf.p, host, n * sizeof(T), hipMemcpyHostToDevice, e->stream));
@@ -464,6 +479,7 @@ struct ripp_sipp_job {
     DevBuf a0, b0, r0;                    // resident statement shard
     DevBuf a, b, a_next, b_next, jac1, jac2;   // working vectors
     DevBuf a_pow, b_pow; bool pre_ready = false;   // 2^64 * a_r and 2^32 * b_r of round 0, prepared while the statement hash finishes
+    DevBuf a_pow_h, b_pow_h, parts1, parts2; bool pre_vm_ready = false;   // the same for the small rounds, on the field VM (vm_fold2.hpp)
     std::vector<G1A> ha; std::vector<G2A> hb; std::vector<Fr> hr;   // host copy of the statement (rank 0 hashes it)
     const G1A* ha_ext = nullptr; const G2A* hb_ext = nullptr; const Fr* hr_ext = nullptr;   // one-shot proofs hash the CALLER's buffers in place
     bool hash_prestarted = false;
@@ -515,6 +531,20 @@ int32_t job_round_partials(Engine* e, ripp_sipp_job* j, Fp12* rows /* [2][68] */
 // Round 0 only, single-GPU proofs: enqueue hi2 = 2^64 a_r and 2^32 b_r (normalised) behind the round's pairing products.  The GPU would
 // otherwise idle until the statement hash delivers the first challenge; the fold then needs half the doublings (k_fold_g1_two /
 // k_fold_g2_gls8).  Not worth it for small rounds (latency-bound) -- and skipped when the hash is already done.
+// Small rounds (VM regime), every round: the same second bases on the field VM, projective (no normalisation), enqueued behind the
+// round's pairing products so that they run during the host's final exponentiations.
+int32_t job_precompute_vm(Engine* e, ripp_sipp_job* j) {
+    const size_t half = j->len / 2;
+    if (half == 0 || half > e->vm_fold_max || std::getenv("RIPP_NO_VM") || std::getenv("RIPP_NO_PRECOMPUTE")) return RIPP_OK;
+    int32_t rc;
+    if ((rc = j->a_pow_h.reserve(half * sizeof(G1J))) || (rc = j->b_pow_h.reserve(half * sizeof(G2J))) || (rc = j->parts1.reserve(2 * half * sizeof(G1J))) || (rc = j->parts2.reserve(8 * half * sizeof(G2J)))) return rc;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_pow2<Fp>), dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VmCurve<Fp>::SLOTS * sizeof(Fp), e->stream2, j->a.as<G1A>() + half, (uint32_t)half, 64, j->a_pow_h.as<G1J>());
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_pow2<Fp2>), dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VmCurve<Fp2>::SLOTS * sizeof(Fp), e->stream, j->b.as<G2A>() + half, (uint32_t)half, 32, j->b_pow_h.as<G2J>());
+    HIPCHK(hipGetLastError());
+    j->pre_vm_ready = true;
+    return RIPP_OK;
+}
+
 int32_t job_precompute_round0(Engine* e, ripp_sipp_job* j) {
     const size_t half = j->len / 2;
     if (half < ((size_t)1 << 16) || j->digest_ready.load() || std::getenv("RIPP_NO_PRECOMPUTE")) return RIPP_OK;
@@ -543,10 +573,15 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true)
     const bool use_vm = allow_vm && half <= e->vm_fold_max && !std::getenv("RIPP_NO_VM");
     if (use_vm) { if ((rc = e->vm_flag.reserve(sizeof(uint32_t))) != RIPP_OK) return rc; HIPCHK(hipMemsetAsync(e->vm_flag.p, 0, sizeof(uint32_t), e->stream)); }
     const bool pre = j->pre_ready && fits_128(x); j->pre_ready = false;      // second bases prepared in the hash window (job_precompute_round0)
+    const bool pre_vm = j->pre_vm_ready && fits_128(x) && allow_vm; j->pre_vm_ready = false;   // ... or on the VM during this round's host phase
     HIPCHK(hipEventRecord(e->ev_fork, e->stream));
     HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
     if (pre)
         hipLaunchKernelGGL(k_fold_g1_two, dim3(nblk(half, 256)), dim3(256), 0, e->stream2, a + half, j->a_pow.as<G1A>(), a, (uint32_t)half, split64_digits(x), j->jac1.as<G1J>());
+    else if (pre_vm) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_fold_split2<Fp>), dim3(nblk(half, 4 * VM_EPW), 2), dim3(256), 4 * VM_EPW * VmCurve<Fp>::SLOTS * sizeof(Fp), e->stream2, a + half, j->a_pow_h.as<G1J>(), (uint32_t)half, split_digits_g1(x), 1, j->parts1.as<G1J>());
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_combine<Fp>), dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VmCurve<Fp>::SLOTS * sizeof(Fp), e->stream2, j->parts1.as<G1J>(), 2, a, (uint32_t)half, j->jac1.as<G1J>());
+    }
     else if (use_vm)
         hipLaunchKernelGGL(k_vm_fold_g1, dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VM_G1_SLOTS * sizeof(Fp), e->stream2, a + half, a, (uint32_t)half, naf_digits(x), j->jac1.as<G1J>(), e->vm_flag.as<uint32_t>());
     else
@@ -554,6 +589,10 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true)
     HIPCHK(hipGetLastError());
     if ((rc = e->normalize_dev<Fp>(j->jac1.as<G1J>(), half, j->a_next.as<G1A>(), e->stream2)) != RIPP_OK) return rc;
     HIPCHK(hipEventRecord(e->ev_join, e->stream2));
+    if (pre_vm) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_fold_split2<Fp2>), dim3(nblk(half, 4 * VM_EPW), 8), dim3(256), 4 * VM_EPW * VmCurve<Fp2>::SLOTS * sizeof(Fp), e->stream, b + half, j->b_pow_h.as<G2J>(), (uint32_t)half, split_digits_g2(x_inv), 4, j->parts2.as<G2J>());
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_combine<Fp2>), dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VmCurve<Fp2>::SLOTS * sizeof(Fp), e->stream, j->parts2.as<G2J>(), 8, b, (uint32_t)half, j->jac2.as<G2J>());
+    } else
     if (pre) {
         if ((rc = e->qtab.reserve(8 * G2A_CHUNKS * qstride * sizeof(uint4))) != RIPP_OK) return rc;
         hipLaunchKernelGGL(k_fold_g2_gls8, dim3(nblk(half, 64)), dim3(64), 0, e->stream, b + half, j->b_pow.as<G2A>(), b, (uint32_t)half, gls8_digits(x_inv), e->qtab.as<uint4>(), qstride, j->jac2.as<G2J>());
@@ -900,7 +939,7 @@ API int32_t ripp_sipp_job_create(const ripp_g1a* a, const ripp_g2a* b, const rip
 API void ripp_sipp_job_destroy(ripp_sipp_job* j) {
     if (!j) return; LOCK;
     if (j->hash_thread.joinable()) j->hash_thread.join();
-    for (DevBuf* b : {&j->a0, &j->b0, &j->r0, &j->a, &j->b, &j->a_next, &j->b_next, &j->jac1, &j->jac2, &j->a_pow, &j->b_pow}) b->release();
+    for (DevBuf* b : {&j->a0, &j->b0, &j->r0, &j->a, &j->b, &j->a_next, &j->b_next, &j->jac1, &j->jac2, &j->a_pow, &j->b_pow, &j->a_pow_h, &j->b_pow_h, &j->parts1, &j->parts2}) b->release();
     delete j;
 }
 API int32_t ripp_sipp_job_begin(ripp_sipp_job* j) { LOCK; ENGINE; if (!j) return RIPP_ERR_ARG; return job_begin(e, j); }
@@ -910,6 +949,7 @@ API int32_t ripp_sipp_job_round_partials(ripp_sipp_job* j, ripp_gt* partials) {
     if (j->len < 2) { set_err("shard exhausted: gather the remaining elements onto one rank"); return RIPP_ERR_ARG; }
     Fp12 rows[2 * N_LINES];
     int32_t rc = job_round_partials(e, j, rows); if (rc) return rc;
+    if ((rc = job_precompute_vm(e, j))) return rc;          // small rounds: second fold bases on the VM while the ranks exchange and finish the values
     auto fut = host_pool().submit([&rows]() { return miller_combine(rows + N_LINES); });
     const Fp12 ml = miller_combine(rows), mr = fut.get();
     std::memcpy(&partials[0], &ml, sizeof ml); std::memcpy(&partials[1], &mr, sizeof mr);
@@ -971,6 +1011,7 @@ API int32_t ripp_sipp_job_prove(ripp_sipp_job* j, const ripp_gt* value, ripp_gt*
         const double tr0 = now_ms();
         if ((rc = job_round_partials(e, j, rows))) return rc;
         if (round == 0 && !j->seeded && (rc = job_precompute_round0(e, j))) return rc;      // asynchronous: overlaps the host work below and the hash
+        if ((rc = job_precompute_vm(e, j))) return rc;                                       // small rounds: the same on the VM, during the host phase
         const double t0 = now_ms();
         auto fut = host_pool().submit([&rows]() { return final_exponentiation(miller_combine(rows + N_LINES)); });
         const Fp12 zl = final_exponentiation(miller_combine(rows));

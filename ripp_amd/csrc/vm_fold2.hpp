@@ -1,0 +1,118 @@
+// Latency form of the halving-round folds with a PRECOMPUTED SECOND BASE (small rounds of SIPP::prove, sipp/src/lib.rs:87-100).
+// Between a round's pairing products and its challenge the GPU idles for the host's final exponentiations (~0.8 ms); in that gap
+// k_vm_pow2 computes 2^K * hi[i] (K = 64 on G1, 32 on G2) on the field VM, left in homogeneous projective form -- the complete
+// addition program takes projective addends, so nothing is normalised.  Once the challenge is known the scalar is split at bit K and
+// every half runs on its own group of 16 lanes (k_vm_fold_split2: blockIdx.y = digit string), so the dependent chain of a fold is
+// K doublings + ~K/3 additions instead of 2K + 2K/3; k_vm_combine adds the partial sums and lo with complete additions.
+// Same group elements as the one-base forms, hence bit-identical proofs.
+#pragma once
+#include "msm.hpp"      // VmCurve<F>
+
+namespace ripp {
+
+struct SplitDigits { int8_t d[8][68]; int len; };     // NAF digit strings; G1: d[0] = low half, d[1] = high half; G2: d[j] low, d[4+j] high of GLS digit j
+
+__device__ __forceinline__ Jac<Fp> vm_image_h(const Jac<Fp>& p, int) { return p; }
+__device__ __forceinline__ Jac<Fp2> vm_image_h(const Jac<Fp2>& q, int j) {          // psi^j on homogeneous coordinates (x = X/Z, y = Y/Z)
+    if (j == 0) return q;
+    const G2A c = gls_image(G2A{Fp2::one(), Fp2::one()}, j);                          // (PSIj_CX, PSIj_CY): the image of (1, 1) is the constant pair
+    const bool odd = (j & 1) != 0;
+    return {mul(odd ? conj(q.x) : q.x, c.x), mul(odd ? conj(q.y) : q.y, c.y), odd ? conj(q.z) : q.z};
+}
+__device__ __forceinline__ G1A vm_image_a(const G1A& p, int) { return p; }
+__device__ __forceinline__ G2A vm_image_a(const G2A& q, int j) { return gls_image(q, j); }
+
+template <class F> __device__ __forceinline__ Jac<F> vm_identity_h() { return {F::zero(), F::one(), F::zero()}; }
+
+// out_h[i] = 2^k * in[i], homogeneous projective
+template <class F>
+__global__ void __launch_bounds__(256) k_vm_pow2(const Affine<F>* __restrict__ in, uint32_t n, int k, Jac<F>* __restrict__ out_h) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char vm_smem[];
+    using C = VmCurve<F>;
+    Fp* const lds = reinterpret_cast<Fp*>(vm_smem);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lg = lane & (VM_G - 1), grp = lane / VM_G;
+    const uint32_t i = (blockIdx.x * 4 + wave) * VM_EPW + grp;
+    Fp* const ws = lds + (size_t)(wave * VM_EPW + grp) * C::SLOTS;
+    const bool active = i < n;
+    if (lg == 0) {
+        ws[0] = Fp::zero();
+        Jac<F> t = vm_identity_h<F>();
+        if (active) { const Affine<F> p = in[i]; if (!is_inf(p)) t = {p.x, p.y, F::one()}; }
+        C::put(ws, C::SX, t.x); C::put(ws, C::SY, t.y); C::put(ws, C::SZ, t.z);
+    }
+#pragma unroll 1
+    for (int s = 0; s < k; ++s) C::dbl_(ws, lg);
+    if (active && lg == 0) out_h[i] = {C::get(ws, C::SX), C::get(ws, C::SY), C::get(ws, C::SZ)};
+}
+
+// parts_h[t][i] = (digit string t) * base_t(i);  base_t = image t of hi[i] for t < nimg, image t - nimg of hi2_h[i] otherwise
+template <class F>
+__global__ void __launch_bounds__(256) k_vm_fold_split2(const Affine<F>* __restrict__ hi, const Jac<F>* __restrict__ hi2_h, uint32_t half, SplitDigits dg, int nimg,
+                                                         Jac<F>* __restrict__ parts_h) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char vm_smem[];
+    using C = VmCurve<F>;
+    Fp* const lds = reinterpret_cast<Fp*>(vm_smem);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lg = lane & (VM_G - 1), grp = lane / VM_G;
+    const uint32_t i = (blockIdx.x * 4 + wave) * VM_EPW + grp;
+    const int t = blockIdx.y;
+    Fp* const ws = lds + (size_t)(wave * VM_EPW + grp) * C::SLOTS;
+    const bool active = i < half;
+    Jac<F> base = vm_identity_h<F>();                        // lane 0 of the group keeps the base (projective) in registers
+    if (lg == 0) {
+        ws[0] = Fp::zero();
+        if (active) {
+            if (t < nimg) { const Affine<F> p = vm_image_a(hi[i], t); if (!is_inf(p)) base = {p.x, p.y, F::one()}; }
+            else base = vm_image_h(hi2_h[i], t - nimg);
+        }
+        C::put(ws, C::SX, F::zero()); C::put(ws, C::SY, F::one()); C::put(ws, C::SZ, F::zero());       // T = identity
+    }
+    int pos = dg.len - 1;
+    while (pos >= 0 && dg.d[t][pos] == 0) --pos;             // uniform over the launch row: leading zeros cost nothing
+#pragma unroll 1
+    for (; pos >= 0; --pos) {
+        C::dbl_(ws, lg);
+        const int d = dg.d[t][pos];
+        if (d != 0) {
+            if (lg == 0) { C::put(ws, C::QX, base.x); C::put(ws, C::QY, d < 0 ? neg(base.y) : base.y); C::put(ws, C::QZ, base.z); }
+            C::add_(ws, lg);
+        }
+    }
+    if (active && lg == 0) parts_h[(size_t)t * half + i] = {C::get(ws, C::SX), C::get(ws, C::SY), C::get(ws, C::SZ)};
+}
+
+// out[i] (Jacobian) = sum_{t < nparts} parts_h[t][i] + lo[i]
+template <class F>
+__global__ void __launch_bounds__(256) k_vm_combine(const Jac<F>* __restrict__ parts_h, int nparts, const Affine<F>* __restrict__ lo, uint32_t half, Jac<F>* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char vm_smem[];
+    using C = VmCurve<F>;
+    Fp* const lds = reinterpret_cast<Fp*>(vm_smem);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lg = lane & (VM_G - 1), grp = lane / VM_G;
+    const uint32_t i = (blockIdx.x * 4 + wave) * VM_EPW + grp;
+    Fp* const ws = lds + (size_t)(wave * VM_EPW + grp) * C::SLOTS;
+    const bool active = i < half;
+    if (lg == 0) {
+        ws[0] = Fp::zero();
+        const Jac<F> p0 = active ? parts_h[i] : vm_identity_h<F>();
+        C::put(ws, C::SX, p0.x); C::put(ws, C::SY, p0.y); C::put(ws, C::SZ, p0.z);
+    }
+#pragma unroll 1
+    for (int t = 1; t <= nparts; ++t) {
+        if (lg == 0) {
+            Jac<F> q = vm_identity_h<F>();
+            if (active) {
+                if (t < nparts) q = parts_h[(size_t)t * half + i];
+                else { const Affine<F> l = lo[i]; if (!is_inf(l)) q = {l.x, l.y, F::one()}; }
+            }
+            C::put(ws, C::QX, q.x); C::put(ws, C::QY, q.y); C::put(ws, C::QZ, q.z);
+        }
+        C::add_(ws, lg);
+    }
+    if (active && lg == 0) {
+        const F X = C::get(ws, C::SX), Y = C::get(ws, C::SY), Z = C::get(ws, C::SZ);
+        Jac<F> r = jac_inf<F>();
+        if (!Z.is_zero()) { r.x = fmul(X, Z); r.y = fmul(Y, fsqr(Z)); r.z = Z; }              // (X/Z, Y/Z) -> Jacobian (XZ, YZ^2, Z)
+        out[i] = r;
+    }
+}
+
+}  // namespace ripp
