@@ -361,10 +361,10 @@ GlsDigits gls_digits(const Fr& s_mont) {
 }
 
 // s = s1 + s2 * lambda (lambda = u^2 - 1 ~ sqrt(r)) by binary long division of the canonical scalar; both halves NAF-recoded
-GlvDigits glv_digits(const Fr& s_mont) {
+void glv_split(const Fr& s_mont, uint32_t rem[9], uint32_t quo[8]) {       // s = rem + quo * lambda, both < 2^128
     const Fr c = from_mont(s_mont);
     const uint32_t lam[8] = RIPP_GLV_LAMBDA;
-    uint32_t rem[9] = {0}, quo[8] = {0};
+    for (int i = 0; i < 9; ++i) rem[i] = 0; for (int i = 0; i < 8; ++i) quo[i] = 0;
     for (int bit = 255; bit >= 0; --bit) {                      // rem = rem * 2 + bit;  if rem >= lambda: rem -= lambda, quotient bit = 1
         for (int i = 8; i > 0; --i) rem[i] = (rem[i] << 1) | (rem[i - 1] >> 31);
         rem[0] = (rem[0] << 1) | ((c.l[bit >> 5] >> (bit & 31)) & 1u);
@@ -372,6 +372,9 @@ GlvDigits glv_digits(const Fr& s_mont) {
         if (!ge) { ge = true; for (int i = 7; i >= 0; --i) { if (rem[i] != lam[i]) { ge = rem[i] > lam[i]; break; } } }
         if (ge) { uint32_t borrow = 0; for (int i = 0; i < 8; ++i) rem[i] = subb32(rem[i], lam[i], borrow); rem[8] -= borrow; quo[bit >> 5] |= 1u << (bit & 31); }
     }
+}
+GlvDigits glv_digits(const Fr& s_mont) {
+    uint32_t rem[9], quo[8]; glv_split(s_mont, rem, quo);
     GlvDigits g; std::memset(&g, 0, sizeof g);
     const int l1 = naf_recode(rem, 5, g.d1, 131), l2 = naf_recode(quo, 5, g.d2, 131);
     g.len = l1 > l2 ? l1 : l2;
@@ -417,6 +420,15 @@ SplitDigits split_digits_g2(const Fr& s_mont) {
     SplitDigits d; std::memset(&d, 0, sizeof d);
     for (int t = 0; t < 8; ++t) for (int i = 0; i < g.len; ++i) d.d[t][i] = g.d[t][i];
     d.len = g.len; return d;
+}
+
+// full-width G1 scalar for the second-base VM fold: GLV halves k1, k2 (< 2^128), each split at bit 64 ->
+// d[0] = k1_lo (P), d[1] = k2_lo (phi P), d[2] = k1_hi (2^64 P), d[3] = k2_hi (phi 2^64 P)
+SplitDigits split_digits_g1_glv(const Fr& s_mont) {
+    uint32_t rem[9], quo[8]; glv_split(s_mont, rem, quo);
+    SplitDigits d; std::memset(&d, 0, sizeof d);
+    const int l0 = naf_recode(&rem[0], 2, d.d[0], 67), l1 = naf_recode(&quo[0], 2, d.d[1], 67), l2 = naf_recode(&rem[2], 2, d.d[2], 67), l3 = naf_recode(&quo[2], 2, d.d[3], 67);
+    d.len = std::max(std::max(l0, l1), std::max(l2, l3)); return d;
 }
 
 template <class T> int32_t upload(Engine* e, DevBuf& buf, const void* host, size_t n, T** dev) {

@@ -12,14 +12,15 @@ namespace ripp {
 
 struct SplitDigits { int8_t d[8][68]; int len; };     // NAF digit strings; G1: d[0] = low half, d[1] = high half; G2: d[j] low, d[4+j] high of GLS digit j
 
-__device__ __forceinline__ Jac<Fp> vm_image_h(const Jac<Fp>& p, int) { return p; }
+// image t of a base: G1: t = 1 is the GLV endomorphism phi(x, y) = (beta x, y) (full-width GIPA scalars); G2: psi^t (GLS)
+__device__ __forceinline__ Jac<Fp> vm_image_h(const Jac<Fp>& p, int t) { return t == 0 ? p : Jac<Fp>{fmul(p.x, fp_const(RIPP_GLV_BETA)), p.y, p.z}; }
 __device__ __forceinline__ Jac<Fp2> vm_image_h(const Jac<Fp2>& q, int j) {          // psi^j on homogeneous coordinates (x = X/Z, y = Y/Z)
     if (j == 0) return q;
     const G2A c = gls_image(G2A{Fp2::one(), Fp2::one()}, j);                          // (PSIj_CX, PSIj_CY): the image of (1, 1) is the constant pair
     const bool odd = (j & 1) != 0;
     return {mul(odd ? conj(q.x) : q.x, c.x), mul(odd ? conj(q.y) : q.y, c.y), odd ? conj(q.z) : q.z};
 }
-__device__ __forceinline__ G1A vm_image_a(const G1A& p, int) { return p; }
+__device__ __forceinline__ G1A vm_image_a(const G1A& p, int t) { return t == 0 ? p : G1A{fmul(p.x, fp_const(RIPP_GLV_BETA)), p.y}; }
 __device__ __forceinline__ G2A vm_image_a(const G2A& q, int j) { return gls_image(q, j); }
 
 template <class F> __device__ __forceinline__ Jac<F> vm_identity_h() { return {F::zero(), F::one(), F::zero()}; }
