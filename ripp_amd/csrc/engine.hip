@@ -117,7 +117,7 @@ struct Engine {
     size_t vm_tree_max = (size_t)1 << 14;                                 // tree levels with <= this many products use the VM Fp12 multiplier
     size_t vm_fold_max = (size_t)1 << 11;                                 // folds with <= this many outputs use the VM scalar multiplications
     DevBuf vm_flag;
-    size_t vm_lines_max = (size_t)1 << 13;                                // launches with <= this many pairs use the 16-lanes-per-pair VM line kernel
+    size_t vm_lines_max = (size_t)1 << 15;                                // launches with <= this many pairs use the 16-lanes-per-pair VM line kernel (measured crossover)
     size_t gls_split_max = (size_t)1 << 14;                               // rounds with <= this many outputs use the 4-lane GLS fold
     size_t max_pairs_per_batch = (size_t)1 << 19;                        // lines buffer cap: 2^19 pairs * 19.6 KB = 10.3 GB
     ripp_stats stats{};
