@@ -247,9 +247,11 @@ def test_sipp_full_size_round_trip(engine):
     assert not engine.SIPP.verify(a, b, r, value, bad)
 
 
-def test_scalar_kernels_without_vm(engine, orc):
-    """The latency-form (lane-parallel VM) kernels serve small launches; RIPP_NO_VM=1 forces the scalar kernels so
-    both implementations of the same path stay pinned to the oracle."""
+@pytest.mark.parametrize("switch", ["RIPP_NO_VM", "RIPP_NO_PRECOMPUTE"])
+def test_scalar_kernels_without_vm(engine, orc, switch):
+    """The latency-form (lane-parallel VM) kernels serve small launches, and the folds use second bases precomputed in the host phase;
+    RIPP_NO_VM=1 forces the scalar kernels and RIPP_NO_PRECOMPUTE=1 the one-base folds, so every implementation of the same path
+    stays pinned to the oracle."""
     import os, subprocess, sys, textwrap
     code = textwrap.dedent("""
         import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)
@@ -263,7 +265,7 @@ def test_scalar_kernels_without_vm(engine, orc):
         assert rc == 0 and np.array_equal(proof, eproof)
         print("ok")
     """) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, RIPP_NO_VM="1")
+    env = dict(os.environ, **{switch: "1"})
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
 
