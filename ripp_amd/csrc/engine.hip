@@ -191,7 +191,10 @@ struct Engine {
     template <class F> int32_t msm_launch(MsmScratch& ms, hipStream_t st, const Affine<F>* bases, const Fr* scalars, size_t n) {
         if (!ms.host_out) HIPCHK(hipHostMalloc(&ms.host_out, sizeof(G2J), hipHostMallocDefault));
         if (n == 0) { *reinterpret_cast<Jac<F>*>(ms.host_out) = jac_inf<F>(); return RIPP_OK; }
-        const MsmPlan p = msm_plan(n);
+        static const bool no_glv = std::getenv("RIPP_NO_MSM_GLV") != nullptr;
+        const size_t nreal = n;
+        const MsmPlan p = msm_plan(nreal, no_glv ? 1 : std::is_same<F, Fp>::value ? 2 : 4);
+        n = p.n;                                                                  // terms (2 * nreal in the GLV form, 4 * nreal in the GLS form)
         const size_t nwb = (size_t)p.nwin * p.nb;
         const uint32_t max_slots = (uint32_t)(n / p.ch + std::min<size_t>(p.nb, n) + 1);
         uint32_t nseg = (p.nb + p.seg - 1) / p.seg;
@@ -203,7 +206,7 @@ struct Engine {
             (rc = ms.seg2.reserve((size_t)p.nwin * ((nseg + MSM_SEG_FAN - 1) / MSM_SEG_FAN) * sizeof(Jac<F>))) ||
             (rc = ms.win.reserve(64 * sizeof(Jac<F>))) || (rc = ms.out.reserve(sizeof(Jac<F>)))) return rc;
         HIPCHK(hipMemsetAsync(ms.hist.p, 0, nwb * 4, st));
-        hipLaunchKernelGGL(k_msm_digits, dim3(nblk(n, 256)), dim3(256), 0, st, scalars, p, ms.digits.as<uint16_t>(), ms.hist.as<uint32_t>());
+        hipLaunchKernelGGL(k_msm_digits, dim3(nblk(nreal, 256)), dim3(256), 0, st, scalars, p, ms.digits.as<uint16_t>(), ms.hist.as<uint32_t>());
         hipLaunchKernelGGL(k_msm_scan, dim3(p.nwin), dim3(1024), 0, st, ms.hist.as<uint32_t>(), p, ms.offs.as<uint32_t>(), ms.cursor.as<uint32_t>(), ms.slotoffs.as<uint32_t>(), ms.spw.as<uint32_t>());
         hipLaunchKernelGGL(k_msm_scatter, dim3(nblk(n, 256)), dim3(256), 0, st, ms.digits.as<uint16_t>(), p, ms.cursor.as<uint32_t>(), ms.sorted.as<uint32_t>());
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_slot_sum<F>), dim3(nblk(max_slots, 64), p.nwin), dim3(64), 0, st, bases, p, ms.hist.as<uint32_t>(), ms.offs.as<uint32_t>(),

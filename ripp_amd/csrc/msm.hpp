@@ -12,13 +12,13 @@
 //                     one bucket per window) cannot serialise the launch.
 //   k_msm_bucket_merge lane per bucket: sum of its slots
 //   k_msm_segments    lane per segment of `seg` buckets: running-sum reduction  sum_d d*B_d  of the segment
-//   k_msm_seg_reduce  lane per 16 segment sums (repeated until <= 16 per window remain)
+//   k_msm_seg_reduce  lane per 4 segment sums (repeated until <= 4 per window remain)
 //   k_msm_finish_vm   one workgroup: lane per window adds the remaining segment sums, then the Horner recurrence over the
 //                     windows (255 doublings + nwin additions, ONE dependent chain) runs on the lane-parallel field VM
 //                     (vm.hpp: 16 lanes per point, complete projective addition, depth-2 doubling) instead of one lane.
 // Every stage after the scatter is a chain of dependent group operations per lane (~30-60 us each for a lone wave), so the
-// chain lengths -- not the operation count -- set the time for n <= 2^16: slots of 32 terms and segments of <= 16 buckets
-// there; slots of 256 terms once the launch fills the chip.
+// chain lengths -- not the operation count -- set the time for n <= 2^16: slots of 4..32 terms (as many lanes as fill the chip),
+// segments of 4 buckets and 4-ary reductions there; slots of 64 terms once the launch is throughput bound.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdlib>
@@ -27,32 +27,90 @@
 
 namespace ripp {
 
-constexpr int MSM_SEG_FAN = 16;      // segment sums added per lane in k_msm_seg_reduce / in phase 1 of the finish
+constexpr int MSM_SEG_FAN = 4;       // segment sums added per lane in k_msm_seg_reduce / in phase 1 of the finish (short chains: every level is latency)
 
-struct MsmPlan { int c, nwin; uint32_t nb; uint32_t n; uint32_t ch, seg; };   // ch: max terms per slot, seg: buckets per segment lane
+// n: terms the pipeline sorts and adds; nreal: bases in HBM.  n == 2 * nreal is the GLV form of a G1 MSM: scalar k = k1 + lambda k2 with
+// k1, k2 < 2^128 (lambda = z^2 - 1, the eigenvalue of phi(x, y) = (beta x, y)), term i carries k1 on base i and term nreal + i carries k2
+// on phi(base i), which the slot sums form with one field product while they gather.  n == 4 * nreal is the GLS form of a G2 MSM:
+// k = d0 + d1 u + d2 u^2 + d3 u^3 in base u = |x| (64 bits), term j * nreal + i carries d_j on [u^j] base i = +-psi^j(base i)
+// (kernels.hpp::gls_image, two Fp2 products).  Same number of gathered additions, 1/2 resp. 1/4 of the windows and Horner doublings.
+struct MsmPlan { int c, nwin; uint32_t nb; uint32_t n; uint32_t ch, seg; uint32_t nreal; };   // ch: max terms per slot, seg: buckets per segment lane
 
-inline MsmPlan msm_plan(size_t n) {
+inline MsmPlan msm_plan(size_t nreal, int split = 1) {
+    const size_t n = (size_t)split * nreal;
     int lg = 0; while (((size_t)1 << (lg + 1)) <= n) ++lg;
-    int c = lg - 6; if (c < 4) c = 4; if (c > 13) c = 13;
-    MsmPlan p; p.c = c; p.nwin = (255 + c - 1) / c; p.nb = 1u << c; p.n = (uint32_t)n;
-    p.ch = n > ((size_t)1 << 20) ? 64u : 32u;   // measured crossover (tools/msm_sweep.py): slots of 32 fill the chip best up to 2^20 terms
+    int c0 = lg - 6; if (c0 < 4) c0 = 4; if (c0 > 13) c0 = 13;
+    // The top window holds only  nbits - (nwin - 1) c  bits, so its few buckets collect 2^deficit times the terms of a regular
+    // bucket and their slot chains set the latency: among c0 - 1 .. c0 + 1 take the width with the fullest top window.
+    const int nbits = split == 1 ? 255 : split == 2 ? 128 : 64;
+    int c = c0, best = 1 << 20;
+    for (int cc = c0 - 1; cc <= c0 + 1; ++cc) {
+        if (cc < 4 || cc > 13) continue;
+        const int nw = (nbits + cc - 1) / cc, deficit = nw * cc - nbits;
+        const int score = 2 * deficit + (cc == c0 ? 0 : 1);
+        if (score < best) { best = score; c = cc; }
+    }
+    if (const char* e = std::getenv("RIPP_MSM_C")) c = std::atoi(e);
+    MsmPlan p; p.c = c; p.nwin = (nbits + c - 1) / c; p.nb = 1u << c; p.n = (uint32_t)n; p.nreal = (uint32_t)nreal;
+    // slot length: the shortest chain that still gives every SIMD two waves (131072 lanes; a lone wave issues at half rate), between
+    // 4 and 32 terms; 64 once the launch is throughput bound (measured crossover, tools/msm_sweep.py)
+    const size_t adds = n * (size_t)p.nwin;
+    p.ch = 4; while (p.ch < 32 && (size_t)p.ch * 131072 < adds) p.ch *= 2;
+    if (n > ((size_t)1 << 20)) p.ch = 64;
     if (const char* e = std::getenv("RIPP_MSM_CH")) p.ch = (uint32_t)std::strtoul(e, nullptr, 10);
-    p.seg = p.nb / 4 < 16 ? p.nb / 4 : 16;
+    p.seg = 4;                                   // nb >= 16; chain of 2 * seg additions + the (lo - 1) multiple per lane
     return p;
 }
 
-__global__ void __launch_bounds__(256) k_msm_digits(const Fr* __restrict__ scalars, MsmPlan p, uint16_t* __restrict__ digits, uint32_t* __restrict__ hist) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.n) return;
-    const Fr k = from_mont(scalars[i]);
+__device__ __forceinline__ void msm_emit_digits(const uint32_t* k, int nlimb, uint32_t i, const MsmPlan& p, uint16_t* __restrict__ digits, uint32_t* __restrict__ hist) {
     for (int w = 0; w < p.nwin; ++w) {
         const int bit = w * p.c, limb = bit >> 5, sh = bit & 31;
-        uint64_t v = k.l[limb];
-        if (limb + 1 < 8) v |= (uint64_t)k.l[limb + 1] << 32;
+        uint64_t v = k[limb];
+        if (limb + 1 < nlimb) v |= (uint64_t)k[limb + 1] << 32;
         const uint32_t d = (uint32_t)(v >> sh) & (p.nb - 1);
         digits[(size_t)w * p.n + i] = (uint16_t)d;
         if (d) atomicAdd(&hist[(size_t)w * p.nb + d], 1u);
     }
+}
+
+// k[0..8) = q * m + rem by restoring division (255 steps); m has ML limbs, rem ML + 1; q overwrites k
+template <int ML> __device__ __forceinline__ void msm_divmod(uint32_t* k, const uint32_t* m, uint32_t* rem) {
+    for (int t = 0; t <= ML; ++t) rem[t] = 0;
+#pragma unroll 1
+    for (int b = 254; b >= 0; --b) {
+        for (int t = ML; t > 0; --t) rem[t] = (rem[t] << 1) | (rem[t - 1] >> 31);
+        rem[0] = (rem[0] << 1) | (k[7] >> 30 & 1u);                                 // bit 254 of k
+        uint32_t d[ML + 1]; uint64_t br = 0;
+        for (int t = 0; t <= ML; ++t) { const uint64_t x = (uint64_t)rem[t] - (t < ML ? m[t] : 0u) - br; d[t] = (uint32_t)x; br = (x >> 32) & 1u; }
+        const bool ge = br == 0;
+        for (int t = 0; t <= ML; ++t) rem[t] = ge ? d[t] : rem[t];
+        for (int t = 7; t > 0; --t) k[t] = (k[t] << 1) | (k[t - 1] >> 31);          // shift the dividend up, quotient bits enter at the bottom
+        k[0] = (k[0] << 1) | (ge ? 1u : 0u);
+        k[7] &= 0x7fffffffu;                                                         // keep 255 bits
+    }
+}
+
+__global__ void __launch_bounds__(256) k_msm_digits(const Fr* __restrict__ scalars, MsmPlan p, uint16_t* __restrict__ digits, uint32_t* __restrict__ hist) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.nreal) return;
+    Fr k = from_mont(scalars[i]);
+    if (p.n == p.nreal) { msm_emit_digits(k.l, 8, i, p, digits, hist); return; }
+    if (p.n == 2 * p.nreal) {                                                        // GLV (G1): k = q * lambda + rem, both < 2^128
+        const uint32_t lam[8] = RIPP_GLV_LAMBDA;
+        uint32_t rem[5];
+        msm_divmod<4>(k.l, lam, rem);
+        msm_emit_digits(rem, 5, i, p, digits, hist);
+        msm_emit_digits(k.l, 8, p.nreal + i, p, digits, hist);
+        return;
+    }
+    const uint32_t u[2] = {0x00010000u, 0xd2010000u};                                // GLS (G2): base-|x| digits
+#pragma unroll 1
+    for (int j = 0; j < 3; ++j) {
+        uint32_t rem[3];
+        msm_divmod<2>(k.l, u, rem);
+        msm_emit_digits(rem, 3, j * p.nreal + i, p, digits, hist);
+    }
+    msm_emit_digits(k.l, 8, 3 * p.nreal + i, p, digits, hist);                       // k < r < u^4: the last quotient is the top digit
 }
 
 // one block (1024 lanes) per window; nb <= 8192 -> <= 8 counters per lane
@@ -85,6 +143,17 @@ __global__ void __launch_bounds__(256) k_msm_scatter(const uint16_t* __restrict_
     }
 }
 
+// term -> base: terms >= nreal are the phi images of the GLV form (G1 only)
+__device__ __forceinline__ G1A msm_term_base(const G1A* __restrict__ bases, uint32_t t, uint32_t nreal) {
+    if (t < nreal) return bases[t];
+    G1A q = bases[t - nreal]; q.x = fmul(q.x, fp_const(RIPP_GLV_BETA)); return q;      // (0,0) stays the identity
+}
+__device__ __forceinline__ G2A msm_term_base(const G2A* __restrict__ bases, uint32_t t, uint32_t nreal) {
+    if (t < nreal) return bases[t];
+    const uint32_t j = t / nreal;
+    return gls_image(bases[t - j * nreal], (int)j);
+}
+
 // grid.y = window; lane = slot index within the window (max_slots lanes per window, surplus lanes exit)
 template <class F>
 __global__ void __launch_bounds__(64, 2) k_msm_slot_sum(const Affine<F>* __restrict__ bases, MsmPlan p, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offs,
@@ -106,7 +175,7 @@ __global__ void __launch_bounds__(64, 2) k_msm_slot_sum(const Affine<F>* __restr
     const uint32_t end = min(offs[(size_t)w * p.nb + d] + cnt, begin + p.ch);
     Jac<F> acc = jac_inf<F>();
 #pragma unroll 1
-    for (uint32_t k = begin; k < end; ++k) acc = add_mixed(acc, bases[sorted[(size_t)w * p.n + k]]);
+    for (uint32_t k = begin; k < end; ++k) acc = add_mixed(acc, msm_term_base(bases, sorted[(size_t)w * p.n + k], p.nreal));
     slot_sums[(size_t)w * max_slots + s] = acc;
 }
 

@@ -134,6 +134,27 @@ def test_msm_adversarial_scalars(engine, orc):
         assert np.array_equal(got, orc.g1_to_affine(orc.msm_g1_a(b1, s)).reshape(1, 12))
 
 
+def test_msm_endomorphism_edge_scalars(engine, orc):
+    """The device splits every scalar before the bucket sort (msm.hpp: G1 k = k1 + lambda k2, G2 base-|x| digits): scalars that sit on
+    the boundaries of those decompositions (multiples and neighbours of lambda and of u^j, all-ones halves, r - 1) must come out as the
+    oracle's plain 255-bit sums, one scalar at a time (n = 1) and all together."""
+    lam, u = 0xac45a4010001a40200000000ffffffff, 0xd201000000010000
+    vals = [0, 1, 2, orc.R - 1, orc.R - 2, lam - 1, lam, lam + 1, 2 * lam, orc.R - lam, lam * lam % orc.R, (lam - 1) * lam + lam - 1,
+            u - 1, u, u + 1, u * u - 1, u * u, u * u + 1, u ** 3 - 1, u ** 3, u ** 3 + u - 1, (u - 1) * (1 + u + u * u + u ** 3) % orc.R,
+            (1 << 64) - 1, 1 << 64, (1 << 128) - 1, 1 << 128, (1 << 254), (1 << 254) + (1 << 127)]
+    vals = [v % orc.R for v in vals]
+    n = len(vals)
+    s = orc.fr_array(vals); b1, b2 = orc.gen_g1(15, n), orc.gen_g2(16, n)
+    j1, j2 = orc.blind_g1(b1, 5), orc.blind_g2(b2, 6)
+    for i in range(n):
+        assert np.array_equal(engine.normalize_batch_g1(engine.MultiexponentiationInnerProductG1.inner_product(j1[i:i + 1], s[i:i + 1])),
+                              orc.g1_to_affine(orc.msm_g1_a(b1[i:i + 1], s[i:i + 1])).reshape(1, 12)), hex(vals[i])
+        assert np.array_equal(engine.normalize_batch_g2(engine.MultiexponentiationInnerProductG2.inner_product(j2[i:i + 1], s[i:i + 1])),
+                              orc.g2_to_affine(orc.msm_g2_a(b2[i:i + 1], s[i:i + 1])).reshape(1, 24)), hex(vals[i])
+    assert np.array_equal(engine.normalize_batch_g1(engine.MultiexponentiationInnerProductG1.inner_product(j1, s)), orc.g1_to_affine(orc.msm_g1_a(b1, s)).reshape(1, 12))
+    assert np.array_equal(engine.normalize_batch_g2(engine.MultiexponentiationInnerProductG2.inner_product(j2, s)), orc.g2_to_affine(orc.msm_g2_a(b2, s)).reshape(1, 24))
+
+
 @pytest.mark.parametrize("lg", [15, 17, 18])
 def test_msm_mid_sizes_vs_oracle(engine, orc, lg):
     """Sizes where the window width leaves a SHORT top window (c = lg - 6: 255 mod 9/11/12 = 3/2/3 bits, i.e. 7/3/7 buckets holding
@@ -247,11 +268,11 @@ def test_sipp_full_size_round_trip(engine):
     assert not engine.SIPP.verify(a, b, r, value, bad)
 
 
-@pytest.mark.parametrize("switch", ["RIPP_NO_VM", "RIPP_NO_PRECOMPUTE"])
+@pytest.mark.parametrize("switch", ["RIPP_NO_VM", "RIPP_NO_PRECOMPUTE", "RIPP_NO_MSM_GLV"])
 def test_scalar_kernels_without_vm(engine, orc, switch):
     """The latency-form (lane-parallel VM) kernels serve small launches, and the folds use second bases precomputed in the host phase;
-    RIPP_NO_VM=1 forces the scalar kernels and RIPP_NO_PRECOMPUTE=1 the one-base folds, so every implementation of the same path
-    stays pinned to the oracle."""
+    RIPP_NO_VM=1 forces the scalar kernels, RIPP_NO_PRECOMPUTE=1 the one-base folds and RIPP_NO_MSM_GLV=1 the plain 255-bit Pippenger
+    windows, so every implementation of the same path stays pinned to the oracle."""
     import os, subprocess, sys, textwrap
     code = textwrap.dedent("""
         import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)
@@ -263,6 +284,10 @@ def test_scalar_kernels_without_vm(engine, orc, switch):
         proof = R.SIPP.prove(a, b, r, v)
         rc, eproof, _ = o.sipp_prove(a, b, r, v)
         assert rc == 0 and np.array_equal(proof, eproof)
+        m = 1000
+        s, b1, b2 = o.gen_scalars(21, m), o.gen_g1(5, m), o.gen_g2(6, m)
+        assert np.array_equal(R.normalize_batch_g1(R.MultiexponentiationInnerProductG1.inner_product(o.blind_g1(b1, 9), s)), o.g1_to_affine(o.msm_g1_a(b1, s)).reshape(1, 12))
+        assert np.array_equal(R.normalize_batch_g2(R.MultiexponentiationInnerProductG2.inner_product(o.blind_g2(b2, 9), s)), o.g2_to_affine(o.msm_g2_a(b2, s)).reshape(1, 24))
         print("ok")
     """) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, **{switch: "1"})
