@@ -212,7 +212,7 @@ struct Engine {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_slot_sum<F>), dim3(nblk(max_slots, 64), p.nwin), dim3(64), 0, st, bases, p, ms.hist.as<uint32_t>(), ms.offs.as<uint32_t>(),
                            ms.slotoffs.as<uint32_t>(), ms.spw.as<uint32_t>(), ms.sorted.as<uint32_t>(), ms.slots.as<Jac<F>>(), max_slots);
         uint32_t passes = 0;                                                       // a bucket holds at most n / ch + 1 slots
-        for (uint32_t stride = 1; passes < (uint32_t)MSM_GROUP_PASSES && n / p.ch + 1 > (size_t)MSM_SLOT_GROUP * stride; stride *= MSM_SLOT_GROUP, ++passes)
+        for (uint32_t stride = 1; passes < (uint32_t)MSM_GROUP_PASSES && n / p.ch + 1 > (size_t)p.gmin * stride; stride *= MSM_SLOT_GROUP, ++passes)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_slot_group<F>), dim3(nblk(max_slots, 64), p.nwin), dim3(64), 0, st, p, ms.hist.as<uint32_t>(),
                                ms.slotoffs.as<uint32_t>(), ms.spw.as<uint32_t>(), ms.slots.as<Jac<F>>(), max_slots, stride);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_bucket_merge<F>), dim3(nblk(p.nb, 64), p.nwin), dim3(64), 0, st, p, ms.hist.as<uint32_t>(), ms.slotoffs.as<uint32_t>(),

@@ -34,7 +34,7 @@ constexpr int MSM_SEG_FAN = 4;       // segment sums added per lane in k_msm_seg
 // on phi(base i), which the slot sums form with one field product while they gather.  n == 4 * nreal is the GLS form of a G2 MSM:
 // k = d0 + d1 u + d2 u^2 + d3 u^3 in base u = |x| (64 bits), term j * nreal + i carries d_j on [u^j] base i = +-psi^j(base i)
 // (kernels.hpp::gls_image, two Fp2 products).  Same number of gathered additions, 1/2 resp. 1/4 of the windows and Horner doublings.
-struct MsmPlan { int c, nwin; uint32_t nb; uint32_t n; uint32_t ch, seg; uint32_t nreal; };   // ch: max terms per slot, seg: buckets per segment lane
+struct MsmPlan { int c, nwin; uint32_t nb; uint32_t n; uint32_t ch, seg; uint32_t nreal, gmin; };   // ch: max terms per slot, seg: buckets per segment lane
 
 inline MsmPlan msm_plan(size_t nreal, int split = 1) {
     const size_t n = (size_t)split * nreal;
@@ -58,6 +58,7 @@ inline MsmPlan msm_plan(size_t nreal, int split = 1) {
     p.ch = 4; while (p.ch < 32 && (size_t)p.ch * 131072 < adds) p.ch *= 2;
     if (n > ((size_t)1 << 20)) p.ch = 64;
     if (const char* e = std::getenv("RIPP_MSM_CH")) p.ch = (uint32_t)std::strtoul(e, nullptr, 10);
+    p.gmin = 16; if (const char* e = std::getenv("RIPP_MSM_GMIN")) p.gmin = (uint32_t)std::strtoul(e, nullptr, 10);   // buckets of <= gmin slots go straight to the merge
     p.seg = 4;                                   // nb >= 16; chain of 2 * seg additions + the (lo - 1) multiple per lane
     return p;
 }
@@ -73,21 +74,36 @@ __device__ __forceinline__ void msm_emit_digits(const uint32_t* k, int nlimb, ui
     }
 }
 
-// k[0..8) = q * m + rem by restoring division (255 steps); m has ML limbs, rem ML + 1; q overwrites k
-template <int ML> __device__ __forceinline__ void msm_divmod(uint32_t* k, const uint32_t* m, uint32_t* rem) {
-    for (int t = 0; t <= ML; ++t) rem[t] = 0;
-#pragma unroll 1
-    for (int b = 254; b >= 0; --b) {
-        for (int t = ML; t > 0; --t) rem[t] = (rem[t] << 1) | (rem[t - 1] >> 31);
-        rem[0] = (rem[0] << 1) | (k[7] >> 30 & 1u);                                 // bit 254 of k
-        uint32_t d[ML + 1]; uint64_t br = 0;
-        for (int t = 0; t <= ML; ++t) { const uint64_t x = (uint64_t)rem[t] - (t < ML ? m[t] : 0u) - br; d[t] = (uint32_t)x; br = (x >> 32) & 1u; }
-        const bool ge = br == 0;
-        for (int t = 0; t <= ML; ++t) rem[t] = ge ? d[t] : rem[t];
-        for (int t = 7; t > 0; --t) k[t] = (k[t] << 1) | (k[t - 1] >> 31);          // shift the dividend up, quotient bits enter at the bottom
-        k[0] = (k[0] << 1) | (ge ? 1u : 0u);
-        k[7] &= 0x7fffffffu;                                                         // keep 255 bits
+// k[0..8) (< 2^255) = q * d + rem by Barrett division: mu = floor(2^256 / d) (MM limbs), q^ = floor(k mu / 2^256) >= q - 2, then at most
+// two corrections.  d has ML limbs, rem ML + 1; q overwrites k.
+template <int ML, int MM> __device__ __forceinline__ void msm_divmod(uint32_t* k, const uint32_t* d, const uint32_t* mu, uint32_t* rem) {
+    uint32_t prod[8 + MM];
+    for (int t = 0; t < 8 + MM; ++t) prod[t] = 0;
+    for (int i = 0; i < 8; ++i) {
+        uint64_t carry = 0;
+        for (int j = 0; j < MM; ++j) { const uint64_t t = (uint64_t)k[i] * mu[j] + prod[i + j] + carry; prod[i + j] = (uint32_t)t; carry = t >> 32; }
+        prod[i + MM] = (uint32_t)carry;
     }
+    uint32_t q[8];
+    for (int t = 0; t < 8; ++t) q[t] = t < MM ? prod[8 + t] : 0u;
+    uint32_t qd[ML + 1];                                                             // q^ d mod 2^(32 (ML + 1))
+    for (int t = 0; t <= ML; ++t) qd[t] = 0;
+    for (int i = 0; i <= ML; ++i) {
+        uint64_t carry = 0;
+        for (int j = 0; j < ML && i + j <= ML; ++j) { const uint64_t t = (uint64_t)q[i] * d[j] + qd[i + j] + carry; qd[i + j] = (uint32_t)t; carry = t >> 32; }
+        if (i + ML <= ML) qd[i + ML] += (uint32_t)carry;
+    }
+    uint64_t br = 0;
+    for (int t = 0; t <= ML; ++t) { const uint64_t x = (uint64_t)k[t] - qd[t] - br; rem[t] = (uint32_t)x; br = (x >> 32) & 1u; }
+#pragma unroll 1
+    for (int it = 0; it < 3; ++it) {
+        uint32_t df[ML + 1]; br = 0;
+        for (int t = 0; t <= ML; ++t) { const uint64_t x = (uint64_t)rem[t] - (t < ML ? d[t] : 0u) - br; df[t] = (uint32_t)x; br = (x >> 32) & 1u; }
+        if (br) break;
+        for (int t = 0; t <= ML; ++t) rem[t] = df[t];
+        uint32_t c = 1; for (int t = 0; t < 8; ++t) { const uint32_t v = q[t] + c; c = (v < c) ? 1u : 0u; q[t] = v; }
+    }
+    for (int t = 0; t < 8; ++t) k[t] = q[t];
 }
 
 __global__ void __launch_bounds__(256) k_msm_digits(const Fr* __restrict__ scalars, MsmPlan p, uint16_t* __restrict__ digits, uint32_t* __restrict__ hist) {
@@ -97,17 +113,19 @@ __global__ void __launch_bounds__(256) k_msm_digits(const Fr* __restrict__ scala
     if (p.n == p.nreal) { msm_emit_digits(k.l, 8, i, p, digits, hist); return; }
     if (p.n == 2 * p.nreal) {                                                        // GLV (G1): k = q * lambda + rem, both < 2^128
         const uint32_t lam[8] = RIPP_GLV_LAMBDA;
+        const uint32_t lam_mu[5] = {0xf6cfee30u, 0x63f6e522u, 0xe01faaddu, 0x7c6becf1u, 0x00000001u};     // floor(2^256 / lambda)
         uint32_t rem[5];
-        msm_divmod<4>(k.l, lam, rem);
+        msm_divmod<4, 5>(k.l, lam, lam_mu, rem);
         msm_emit_digits(rem, 5, i, p, digits, hist);
         msm_emit_digits(k.l, 8, p.nreal + i, p, digits, hist);
         return;
     }
     const uint32_t u[2] = {0x00010000u, 0xd2010000u};                                // GLS (G2): base-|x| digits
+    const uint32_t u_mu[7] = {0x8573b29cu, 0x92078a5eu, 0x3e76ec28u, 0x33cfcc0du, 0x56cd56b5u, 0x381204cau, 0x00000001u};   // floor(2^256 / |x|)
 #pragma unroll 1
     for (int j = 0; j < 3; ++j) {
         uint32_t rem[3];
-        msm_divmod<2>(k.l, u, rem);
+        msm_divmod<2, 7>(k.l, u, u_mu, rem);
         msm_emit_digits(rem, 3, j * p.nreal + i, p, digits, hist);
     }
     msm_emit_digits(k.l, 8, 3 * p.nreal + i, p, digits, hist);                       // k < r < u^4: the last quotient is the top digit
@@ -197,7 +215,7 @@ __global__ void __launch_bounds__(64) k_msm_slot_group(MsmPlan p, const uint32_t
     uint32_t d = lo;
     while (d > 0 && (hist[(size_t)w * p.nb + d] + p.ch - 1) / p.ch + so[d] <= s) --d;
     const uint32_t ns = (hist[(size_t)w * p.nb + d] + p.ch - 1) / p.ch, k0 = s - so[d];
-    if (ns <= MSM_SLOT_GROUP * stride || (k0 % (MSM_SLOT_GROUP * stride)) != 0) return;
+    if (ns <= p.gmin * stride || (k0 % (MSM_SLOT_GROUP * stride)) != 0) return;
     Jac<F>* base = slot_sums + (size_t)w * max_slots + so[d];
     Jac<F> acc = base[k0];
 #pragma unroll 1
@@ -214,7 +232,7 @@ __global__ void __launch_bounds__(64) k_msm_bucket_merge(MsmPlan p, const uint32
     if (d >= p.nb) return;
     const uint32_t cnt = hist[(size_t)w * p.nb + d], ns = (cnt + p.ch - 1) / p.ch, s0 = slot_offs[(size_t)w * p.nb + d];
     uint32_t step = 1;
-    for (uint32_t j = 0; j < passes && ns > MSM_SLOT_GROUP * step; ++j) step *= MSM_SLOT_GROUP;
+    for (uint32_t j = 0; j < passes && ns > p.gmin * step; ++j) step *= MSM_SLOT_GROUP;
     Jac<F> acc = jac_inf<F>();
 #pragma unroll 1
     for (uint32_t k = 0; k < ns; k += step) { const Jac<F> t = slot_sums[(size_t)w * max_slots + s0 + k]; acc = (k == 0) ? t : add(acc, t); }
