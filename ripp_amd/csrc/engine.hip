@@ -111,6 +111,9 @@ struct Engine {
     hipStream_t stream3 = nullptr;        // second MSM of a pair
     hipStream_t stream4 = nullptr;        // unscaled twin of m_a in the implicit-shift TIPP core
     hipEvent_t ev_join4 = nullptr;
+    size_t msm_vm_merge_max = 16384;      // buckets (all windows) up to which the bucket merge runs on the field VM
+    hipStream_t stream5 = nullptr;        // second G2 fold of a small GIPA round (own scratch there, so it need not queue behind the first)
+    hipEvent_t ev_join5 = nullptr;
     Fp12* pinned_rows = nullptr;          // pinned host landing zone for per-step products
     size_t pinned_rows_cap = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_lines, ev_prod;   // per-launch event pairs of the two dominant kernels
@@ -131,10 +134,11 @@ struct Engine {
         HIPCHK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&stream3, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&stream4, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&ev_join4, hipEventDisableTiming));
+        HIPCHK(hipStreamCreateWithFlags(&stream5, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&ev_join5, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_join3, hipEventDisableTiming));
         { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n_simd = pr.multiProcessorCount * 4; }
         auto env_sz = [](const char* k, size_t& v) { if (const char* s = std::getenv(k)) v = (size_t)std::strtoull(s, nullptr, 10); };
-        env_sz("RIPP_VM_LINES_MAX", vm_lines_max); env_sz("RIPP_VM_FOLD_MAX", vm_fold_max); env_sz("RIPP_VM_TREE_MAX", vm_tree_max); env_sz("RIPP_GLS_SPLIT_MAX", gls_split_max);
+        env_sz("RIPP_VM_LINES_MAX", vm_lines_max); env_sz("RIPP_VM_FOLD_MAX", vm_fold_max); env_sz("RIPP_VM_TREE_MAX", vm_tree_max); env_sz("RIPP_GLS_SPLIT_MAX", gls_split_max); env_sz("RIPP_MSM_VM_MERGE_MAX", msm_vm_merge_max);
         device = dev;
         return RIPP_OK;
     }
@@ -143,6 +147,7 @@ struct Engine {
         msm_scratch[0].release(); msm_scratch[1].release(); kzg_q[0].release(); kzg_q[1].release();
         if (stream3) (void)hipStreamDestroy(stream3);
         if (stream4) (void)hipStreamDestroy(stream4); if (ev_join4) (void)hipEventDestroy(ev_join4);
+        if (stream5) (void)hipStreamDestroy(stream5); if (ev_join5) (void)hipEventDestroy(ev_join5);
         if (pinned_rows) (void)hipHostFree(pinned_rows);
         for (auto& e : ev_lines) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         for (auto& e : ev_prod) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -209,25 +214,40 @@ struct Engine {
         hipLaunchKernelGGL(k_msm_digits, dim3(nblk(nreal, 256)), dim3(256), 0, st, scalars, p, ms.digits.as<uint16_t>(), ms.hist.as<uint32_t>());
         hipLaunchKernelGGL(k_msm_scan, dim3(p.nwin), dim3(1024), 0, st, ms.hist.as<uint32_t>(), p, ms.offs.as<uint32_t>(), ms.cursor.as<uint32_t>(), ms.slotoffs.as<uint32_t>(), ms.spw.as<uint32_t>());
         hipLaunchKernelGGL(k_msm_scatter, dim3(nblk(n, 256)), dim3(256), 0, st, ms.digits.as<uint16_t>(), p, ms.cursor.as<uint32_t>(), ms.sorted.as<uint32_t>());
+        // RIPP_NO_VM keeps every stage on single lanes in Jacobian coordinates (the A/B and fallback form); otherwise the stages after
+        // the gather work on homogeneous coordinates and the ones with few points run on the field VM (msm.hpp)
+        static const bool hom = std::getenv("RIPP_NO_VM") == nullptr;
+        const size_t vm_lds = 4 * VM_EPW * VmCurve<F>::SLOTS * sizeof(Fp);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_slot_sum<F>), dim3(nblk(max_slots, 64), p.nwin), dim3(64), 0, st, bases, p, ms.hist.as<uint32_t>(), ms.offs.as<uint32_t>(),
-                           ms.slotoffs.as<uint32_t>(), ms.spw.as<uint32_t>(), ms.sorted.as<uint32_t>(), ms.slots.as<Jac<F>>(), max_slots);
+                           ms.slotoffs.as<uint32_t>(), ms.spw.as<uint32_t>(), ms.sorted.as<uint32_t>(), ms.slots.as<Jac<F>>(), max_slots, hom);
         uint32_t passes = 0;                                                       // a bucket holds at most n / ch + 1 slots
         for (uint32_t stride = 1; passes < (uint32_t)MSM_GROUP_PASSES && n / p.ch + 1 > (size_t)p.gmin * stride; stride *= MSM_SLOT_GROUP, ++passes)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_slot_group<F>), dim3(nblk(max_slots, 64), p.nwin), dim3(64), 0, st, p, ms.hist.as<uint32_t>(),
-                               ms.slotoffs.as<uint32_t>(), ms.spw.as<uint32_t>(), ms.slots.as<Jac<F>>(), max_slots, stride);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_bucket_merge<F>), dim3(nblk(p.nb, 64), p.nwin), dim3(64), 0, st, p, ms.hist.as<uint32_t>(), ms.slotoffs.as<uint32_t>(),
-                           ms.slots.as<Jac<F>>(), max_slots, ms.buckets.as<Jac<F>>(), passes);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_segments<F>), dim3(nblk(nseg, 64), p.nwin), dim3(64), 0, st, p, ms.buckets.as<Jac<F>>(), ms.seg.as<Jac<F>>(), nseg);
-        Jac<F>* cur = ms.seg.as<Jac<F>>(); Jac<F>* nxt = ms.seg2.as<Jac<F>>();
-        while (nseg > (uint32_t)MSM_SEG_FAN) {                 // tree over the segment sums: chains of <= 16 additions
-            const uint32_t nout = (nseg + MSM_SEG_FAN - 1) / MSM_SEG_FAN;
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_seg_reduce<F>), dim3(nblk(nout, 64), p.nwin), dim3(64), 0, st, cur, nseg, nxt, nout);
-            std::swap(cur, nxt); nseg = nout;
-        }
-        if (std::getenv("RIPP_NO_VM"))
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_finish<F>), dim3(1), dim3(64), 0, st, p, cur, nseg, ms.win.as<Jac<F>>(), ms.out.as<Jac<F>>());
+                               ms.slotoffs.as<uint32_t>(), ms.spw.as<uint32_t>(), ms.slots.as<Jac<F>>(), max_slots, stride, hom);
+        if (hom && nwb <= msm_vm_merge_max)                                        // few buckets: 16 lanes per bucket still fit the chip
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_vm_merge<F>), dim3(nblk(p.nb, 4 * VM_EPW), p.nwin), dim3(256), vm_lds, st, p, ms.hist.as<uint32_t>(), ms.slotoffs.as<uint32_t>(),
+                               ms.slots.as<Jac<F>>(), max_slots, ms.buckets.as<Jac<F>>(), passes);
         else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_finish_vm<F>), dim3(1), dim3(64), VM_EPW * VmCurve<F>::SLOTS * sizeof(Fp), st, p, cur, nseg, ms.win.as<Jac<F>>(), ms.out.as<Jac<F>>());
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_bucket_merge<F>), dim3(nblk(p.nb, 64), p.nwin), dim3(64), 0, st, p, ms.hist.as<uint32_t>(), ms.slotoffs.as<uint32_t>(),
+                               ms.slots.as<Jac<F>>(), max_slots, ms.buckets.as<Jac<F>>(), passes, hom);
+        Jac<F>* cur = ms.seg.as<Jac<F>>(); Jac<F>* nxt = ms.seg2.as<Jac<F>>();
+        if (hom) {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_vm_segments<F>), dim3(nblk(nseg, 4 * VM_EPW), p.nwin), dim3(256), vm_lds, st, p, ms.buckets.as<Jac<F>>(), cur, nseg);
+            while (nseg > 1) {                                                     // 4-ary tree down to one sum per window
+                const uint32_t nout = (nseg + MSM_SEG_FAN - 1) / MSM_SEG_FAN;
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_vm_reduce<F>), dim3(nblk(nout, 4 * VM_EPW), p.nwin), dim3(256), vm_lds, st, cur, nseg, nxt, nout);
+                std::swap(cur, nxt); nseg = nout;
+            }
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_finish_vm<F>), dim3(1), dim3(64), VM_EPW * VmCurve<F>::SLOTS * sizeof(Fp), st, p, cur, ms.win.as<Jac<F>>(), ms.out.as<Jac<F>>());
+        } else {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_segments<F>), dim3(nblk(nseg, 64), p.nwin), dim3(64), 0, st, p, ms.buckets.as<Jac<F>>(), cur, nseg);
+            while (nseg > (uint32_t)MSM_SEG_FAN) {                 // tree over the segment sums: chains of <= 4 additions
+                const uint32_t nout = (nseg + MSM_SEG_FAN - 1) / MSM_SEG_FAN;
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_seg_reduce<F>), dim3(nblk(nout, 64), p.nwin), dim3(64), 0, st, cur, nseg, nxt, nout);
+                std::swap(cur, nxt); nseg = nout;
+            }
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_finish<F>), dim3(1), dim3(64), 0, st, p, cur, nseg, ms.win.as<Jac<F>>(), ms.out.as<Jac<F>>());
+        }
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(ms.host_out, ms.out.p, sizeof(Jac<F>), hipMemcpyDeviceToHost, st));
         return RIPP_OK;

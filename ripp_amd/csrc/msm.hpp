@@ -10,15 +10,17 @@
 //   k_msm_slot_sum    lane per SLOT (<= CH terms of one bucket): mixed additions of affine bases gathered from HBM.
 //                     Slots bound the work of one lane, so skewed scalar sets (all-equal scalars put every term in
 //                     one bucket per window) cannot serialise the launch.
-//   k_msm_bucket_merge lane per bucket: sum of its slots
-//   k_msm_segments    lane per segment of `seg` buckets: running-sum reduction  sum_d d*B_d  of the segment
-//   k_msm_seg_reduce  lane per 4 segment sums (repeated until <= 4 per window remain)
-//   k_msm_finish_vm   one workgroup: lane per window adds the remaining segment sums, then the Horner recurrence over the
-//                     windows (255 doublings + nwin additions, ONE dependent chain) runs on the lane-parallel field VM
-//                     (vm.hpp: 16 lanes per point, complete projective addition, depth-2 doubling) instead of one lane.
-// Every stage after the scatter is a chain of dependent group operations per lane (~30-60 us each for a lone wave), so the
-// chain lengths -- not the operation count -- set the time for n <= 2^16: slots of 4..32 terms (as many lanes as fill the chip),
-// segments of 4 buckets and 4-ary reductions there; slots of 64 terms once the launch is throughput bound.
+//   k_msm_slot_group  leaders of 8 slots add them, hierarchically, for buckets with more than 16 slots (short top window, skew)
+//   k_msm_bucket_merge / k_msm_vm_merge   per bucket: sum of its slot (group) sums
+//   k_msm_vm_segments per segment of 4 buckets: sum_d d*B_d of the segment
+//   k_msm_vm_reduce   per 4 segment sums (repeated until one per window remains)
+//   k_msm_finish_vm   one workgroup: the Horner recurrence over the windows (nbits doublings + nwin additions, ONE dependent chain)
+// Scalars are split on the device before the sort (GLV on G1, GLS on G2: see MsmPlan), so nbits is 128 / 64 instead of 255.
+// Every stage after the scatter is a chain of dependent group operations per lane (~60-170 us each for a lone wave), so the chain
+// lengths -- not the operation count -- set the time for n <= 2^16: slots of 4..32 terms (as many lanes as fill the chip), and
+// everything from the bucket merge on runs on the lane-parallel field VM (vm.hpp: 16 lanes per point, complete projective addition,
+// ~8-19 us per operation) in homogeneous coordinates.  RIPP_NO_VM=1 selects the single-lane Jacobian forms of the same stages
+// (k_msm_segments, k_msm_seg_reduce, k_msm_finish), kept for A/B and covered by the switch-parametrised parity test.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdlib>
@@ -161,6 +163,33 @@ __global__ void __launch_bounds__(256) k_msm_scatter(const uint16_t* __restrict_
     }
 }
 
+// ---- homogeneous projective coordinates (x = X/Z, y = Y/Z; identity (0 : 1 : 0)) ---------------------------------------------------
+// Everything after the gathered mixed additions is kept in this form so that the latency-bound stages can use the field VM's complete
+// addition (vm.hpp, 16 lanes per point, ~8x shorter latency than one lane); add_h is the one-lane twin of that program
+// (Renes-Costello-Batina 2015, Alg. 7, a = 0: 12 products, no exceptional case), used where a stage has lanes to spare instead.
+__device__ __forceinline__ Fp msm_mul_b3(const Fp& t) { const Fp t4 = dbl(dbl(t)); return add(dbl(t4), t4); }                     // 3b = 12
+__device__ __forceinline__ Fp2 msm_mul_b3(const Fp2& t) { const Fp2 x = mul_xi(t), x4 = dbl(dbl(x)); return add(dbl(x4), x4); }     // 3b' = 12 (1 + u)
+template <class F> __device__ __forceinline__ Jac<F> msm_id_h() { return {F::zero(), F::one(), F::zero()}; }
+template <class F> __device__ __forceinline__ Jac<F> msm_jac_to_h(const Jac<F>& a) {                                                // (X/Z^2, Y/Z^3) -> (X Z : Y : Z^3)
+    if (a.z.is_zero()) return msm_id_h<F>();
+    return {fmul(a.x, a.z), a.y, fmul(fsqr(a.z), a.z)};
+}
+template <class F> __device__ __noinline__ Jac<F> add_h(const Jac<F>& p, const Jac<F>& q) {
+    F t0 = fmul(p.x, q.x), t1 = fmul(p.y, q.y), t2 = fmul(p.z, q.z);
+    const F t3 = sub(sub(fmul(add(p.x, p.y), add(q.x, q.y)), t0), t1);
+    const F t4 = sub(sub(fmul(add(p.y, p.z), add(q.y, q.z)), t1), t2);
+    F y3 = sub(sub(fmul(add(p.x, p.z), add(q.x, q.z)), t0), t2);
+    t0 = add(dbl(t0), t0);
+    t2 = msm_mul_b3(t2);
+    const F z3 = add(t1, t2); t1 = sub(t1, t2);
+    y3 = msm_mul_b3(y3);
+    Jac<F> r;
+    r.x = sub(fmul(t3, t1), fmul(t4, y3));
+    r.y = add(fmul(t1, z3), fmul(y3, t0));
+    r.z = add(fmul(z3, t4), fmul(t0, t3));
+    return r;
+}
+
 // term -> base: terms >= nreal are the phi images of the GLV form (G1 only)
 __device__ __forceinline__ G1A msm_term_base(const G1A* __restrict__ bases, uint32_t t, uint32_t nreal) {
     if (t < nreal) return bases[t];
@@ -176,7 +205,7 @@ __device__ __forceinline__ G2A msm_term_base(const G2A* __restrict__ bases, uint
 template <class F>
 __global__ void __launch_bounds__(64, 2) k_msm_slot_sum(const Affine<F>* __restrict__ bases, MsmPlan p, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offs,
                                                       const uint32_t* __restrict__ slot_offs, const uint32_t* __restrict__ slots_per_window,
-                                                      const uint32_t* __restrict__ sorted, Jac<F>* __restrict__ slot_sums, uint32_t max_slots) {
+                                                      const uint32_t* __restrict__ sorted, Jac<F>* __restrict__ slot_sums, uint32_t max_slots, bool hom) {
     const int w = blockIdx.y;
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= slots_per_window[w]) return;
@@ -194,7 +223,7 @@ __global__ void __launch_bounds__(64, 2) k_msm_slot_sum(const Affine<F>* __restr
     Jac<F> acc = jac_inf<F>();
 #pragma unroll 1
     for (uint32_t k = begin; k < end; ++k) acc = add_mixed(acc, msm_term_base(bases, sorted[(size_t)w * p.n + k], p.nreal));
-    slot_sums[(size_t)w * max_slots + s] = acc;
+    slot_sums[(size_t)w * max_slots + s] = hom ? msm_jac_to_h(acc) : acc;
 }
 
 // Buckets that collect many slots (the short TOP window puts n / 2^(255 mod c) terms into each of its few buckets; skewed scalar sets
@@ -205,7 +234,7 @@ constexpr uint32_t MSM_SLOT_GROUP = 8;
 constexpr int MSM_GROUP_PASSES = 3;
 template <class F>
 __global__ void __launch_bounds__(64) k_msm_slot_group(MsmPlan p, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ slot_offs,
-                                                        const uint32_t* __restrict__ slots_per_window, Jac<F>* __restrict__ slot_sums, uint32_t max_slots, uint32_t stride) {
+                                                        const uint32_t* __restrict__ slots_per_window, Jac<F>* __restrict__ slot_sums, uint32_t max_slots, uint32_t stride, bool hom) {
     const int w = blockIdx.y;
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;                     // slot index in the window; leaders are relative to their BUCKET's first slot
     if (s >= slots_per_window[w]) return;
@@ -219,23 +248,23 @@ __global__ void __launch_bounds__(64) k_msm_slot_group(MsmPlan p, const uint32_t
     Jac<F>* base = slot_sums + (size_t)w * max_slots + so[d];
     Jac<F> acc = base[k0];
 #pragma unroll 1
-    for (uint32_t k = k0 + stride; k < k0 + MSM_SLOT_GROUP * stride && k < ns; k += stride) acc = add(acc, base[k]);
+    for (uint32_t k = k0 + stride; k < k0 + MSM_SLOT_GROUP * stride && k < ns; k += stride) acc = hom ? add_h(acc, base[k]) : add(acc, base[k]);
     base[k0] = acc;
 }
 
 // lane per (window, bucket): bucket = sum of its slots (of its group sums when the bucket went through `passes` grouping passes)
 template <class F>
 __global__ void __launch_bounds__(64) k_msm_bucket_merge(MsmPlan p, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ slot_offs,
-                                                          const Jac<F>* __restrict__ slot_sums, uint32_t max_slots, Jac<F>* __restrict__ buckets, uint32_t passes) {
+                                                          const Jac<F>* __restrict__ slot_sums, uint32_t max_slots, Jac<F>* __restrict__ buckets, uint32_t passes, bool hom) {
     const int w = blockIdx.y;
     const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= p.nb) return;
     const uint32_t cnt = hist[(size_t)w * p.nb + d], ns = (cnt + p.ch - 1) / p.ch, s0 = slot_offs[(size_t)w * p.nb + d];
     uint32_t step = 1;
     for (uint32_t j = 0; j < passes && ns > p.gmin * step; ++j) step *= MSM_SLOT_GROUP;
-    Jac<F> acc = jac_inf<F>();
+    Jac<F> acc = hom ? msm_id_h<F>() : jac_inf<F>();
 #pragma unroll 1
-    for (uint32_t k = 0; k < ns; k += step) { const Jac<F> t = slot_sums[(size_t)w * max_slots + s0 + k]; acc = (k == 0) ? t : add(acc, t); }
+    for (uint32_t k = 0; k < ns; k += step) { const Jac<F> t = slot_sums[(size_t)w * max_slots + s0 + k]; acc = (k == 0) ? t : hom ? add_h(acc, t) : add(acc, t); }
     buckets[(size_t)w * p.nb + d] = acc;
 }
 
@@ -301,26 +330,17 @@ template <> struct VmCurve<Fp2> {
     __device__ static Fp2 get(const Fp* ws, int slot) { return {ws[slot], ws[slot + 1]}; }
 };
 
-// one block of 64 lanes.  Phase 1: lane w adds the <= MSM_SEG_FAN remaining segment sums of window w and rewrites the window sum as a
-// homogeneous projective point (X Z : Y : Z^3) -- (0 : 1 : 0) for the identity.  Phase 2: lanes 0..15 run
+// one block of 64 lanes: seg[w] is the homogeneous sum of window w (k_msm_vm_reduce ran down to one per window); lanes 0..15 run
 //     T <- W_top;  for w = top-1 .. 0:  T <- 2^c T (c VM doublings);  T <- T + W_w (complete VM addition)
-// and lane 0 converts T back to Jacobian.  The complete addition law has no exceptional case, so no fallback is needed.
+// and lane 0 converts T to Jacobian.  The complete addition law has no exceptional case, so no fallback is needed.
 template <class F>
-__global__ void __launch_bounds__(64) k_msm_finish_vm(MsmPlan p, const Jac<F>* __restrict__ seg, uint32_t nseg, Jac<F>* __restrict__ win_h, Jac<F>* __restrict__ out) {
+__global__ void __launch_bounds__(64) k_msm_finish_vm(MsmPlan p, const Jac<F>* __restrict__ seg, Jac<F>* __restrict__ win_h, Jac<F>* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char vm_smem[];
     using C = VmCurve<F>;
     Fp* const lds = reinterpret_cast<Fp*>(vm_smem);
     const int lane = threadIdx.x, lg = lane & (VM_G - 1), grp = lane / VM_G;
     Fp* const ws = lds + (size_t)grp * C::SLOTS;
-    if ((uint32_t)lane < (uint32_t)p.nwin) {
-        Jac<F> acc = seg[(size_t)lane * nseg];
-#pragma unroll 1
-        for (uint32_t j = 1; j < nseg; ++j) acc = add(acc, seg[(size_t)lane * nseg + j]);
-        Jac<F> h;
-        if (acc.z.is_zero()) { h.x = F::zero(); h.y = F::one(); h.z = F::zero(); }
-        else { h.x = fmul(acc.x, acc.z); h.y = acc.y; h.z = fmul(fsqr(acc.z), acc.z); }
-        win_h[lane] = h;
-    }
+    if ((uint32_t)lane < (uint32_t)p.nwin) win_h[lane] = seg[lane];
     __syncthreads();
     const bool lead = (lane == 0);
     if (lg == 0) ws[0] = Fp::zero();
@@ -339,6 +359,106 @@ __global__ void __launch_bounds__(64) k_msm_finish_vm(MsmPlan p, const Jac<F>* _
         if (!Z.is_zero()) { r.x = fmul(X, Z); r.y = fmul(Y, fsqr(Z)); r.z = Z; }
         out[0] = r;
     }
+}
+
+// ---- the latency-bound middle of the pipeline on the field VM ---------------------------------------------------------------------
+// One point per group of 16 lanes (4 per wave, 16 per block), homogeneous coordinates in and out.  A complete addition costs ~8 us
+// (G1) / ~19 us (G2) here against ~60 / ~170 us for a lone wave's single lane, and these stages have few points: buckets, segments,
+// segment sums.  Groups whose chain is shorter keep adding the identity (the addition law is complete), so a wave stays converged.
+template <class F> __device__ __forceinline__ void vm_put_t(Fp* ws, const Jac<F>& t) { using C = VmCurve<F>; C::put(ws, C::SX, t.x); C::put(ws, C::SY, t.y); C::put(ws, C::SZ, t.z); }
+template <class F> __device__ __forceinline__ void vm_put_q(Fp* ws, const Jac<F>& t) { using C = VmCurve<F>; C::put(ws, C::QX, t.x); C::put(ws, C::QY, t.y); C::put(ws, C::QZ, t.z); }
+template <class F> __device__ __forceinline__ Jac<F> vm_get_t(const Fp* ws) { using C = VmCurve<F>; return {C::get(ws, C::SX), C::get(ws, C::SY), C::get(ws, C::SZ)}; }
+
+// group per (window, bucket): bucket = sum of its slot sums (of its group sums after `passes` grouping passes)
+template <class F>
+__global__ void __launch_bounds__(256) k_msm_vm_merge(MsmPlan p, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ slot_offs,
+                                                       const Jac<F>* __restrict__ slot_sums, uint32_t max_slots, Jac<F>* __restrict__ buckets, uint32_t passes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char vm_smem[];
+    using C = VmCurve<F>;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lg = lane & (VM_G - 1), grp = lane / VM_G, w = blockIdx.y;
+    const uint32_t d = (blockIdx.x * 4 + wave) * VM_EPW + grp;
+    Fp* const ws = reinterpret_cast<Fp*>(vm_smem) + (size_t)(wave * VM_EPW + grp) * C::SLOTS;
+    uint32_t ns = 0, s0 = 0, step = 1;
+    if (d < p.nb) {
+        ns = (hist[(size_t)w * p.nb + d] + p.ch - 1) / p.ch; s0 = slot_offs[(size_t)w * p.nb + d];
+        for (uint32_t j = 0; j < passes && ns > p.gmin * step; ++j) step *= MSM_SLOT_GROUP;
+    }
+    const Jac<F>* src = slot_sums + (size_t)w * max_slots + s0;
+    if (lg == 0) { ws[0] = Fp::zero(); vm_put_t<F>(ws, ns ? src[0] : msm_id_h<F>()); }
+    uint32_t k = step;
+#pragma unroll 1
+    while (__any(k < ns)) {
+        if (lg == 0) vm_put_q<F>(ws, k < ns ? src[k] : msm_id_h<F>());
+        C::add_(ws, lg);
+        k += step;
+    }
+    if (d < p.nb && lg == 0) buckets[(size_t)w * p.nb + d] = vm_get_t<F>(ws);
+}
+
+// group per (window, segment of 4 buckets lo .. lo + 3, lo = 4 j):  sum_r (lo + r) B_r  =  4 j S + (B1 + 2 B2 + 3 B3),  S = B0 + B1 + B2 + B3.
+//   U = B2 + B3;  local = 2 U + B1 + B3;  S = U + B1 + B0;  T = j S by double-and-add over the bits of j (every group walks the same
+//   number of bits and adds S or the identity);  out = 4 T + local.
+template <class F>
+__global__ void __launch_bounds__(256) k_msm_vm_segments(MsmPlan p, const Jac<F>* __restrict__ buckets, Jac<F>* __restrict__ seg_out, uint32_t nseg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char vm_smem[];
+    using C = VmCurve<F>;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lg = lane & (VM_G - 1), grp = lane / VM_G, w = blockIdx.y;
+    const uint32_t j = (blockIdx.x * 4 + wave) * VM_EPW + grp;
+    Fp* const ws = reinterpret_cast<Fp*>(vm_smem) + (size_t)(wave * VM_EPW + grp) * C::SLOTS;
+    const bool active = j < nseg, lead = lg == 0;
+    const Jac<F>* b = buckets + (size_t)w * p.nb + (size_t)j * 4;
+    Jac<F> B0 = msm_id_h<F>(), B1 = B0, B3 = B0, S = B0, local = B0;
+    if (lead) {
+        ws[0] = Fp::zero();
+        if (active) { B0 = b[0]; B1 = b[1]; B3 = b[3]; }
+        vm_put_t<F>(ws, active ? b[2] : msm_id_h<F>()); vm_put_q<F>(ws, B3);
+    }
+    C::add_(ws, lg);                                                  // U
+    if (lead) S = vm_get_t<F>(ws);                                    // S holds U for the moment
+    C::dbl_(ws, lg);
+    if (lead) vm_put_q<F>(ws, B1);                                    // (the doubling program's scratch overlays the addend slots: write Q after it)
+    C::add_(ws, lg);                                                  // 2U + B1
+    if (lead) vm_put_q<F>(ws, B3);
+    C::add_(ws, lg);                                                  // local
+    if (lead) { local = vm_get_t<F>(ws); vm_put_t<F>(ws, S); vm_put_q<F>(ws, B1); }
+    C::add_(ws, lg);
+    if (lead) vm_put_q<F>(ws, B0);
+    C::add_(ws, lg);                                                  // S
+    if (lead) { S = vm_get_t<F>(ws); vm_put_t<F>(ws, msm_id_h<F>()); }
+    int top = 31 - __clz((int)(nseg > 1 ? nseg - 1 : 1));
+#pragma unroll 1
+    for (int bit = top; bit >= 0; --bit) {
+        C::dbl_(ws, lg);
+        const bool set = active && ((j >> bit) & 1u);
+        if (__any(set)) {
+            if (lead) vm_put_q<F>(ws, set ? S : msm_id_h<F>());
+            C::add_(ws, lg);
+        }
+    }
+    C::dbl_(ws, lg); C::dbl_(ws, lg);
+    if (lead) vm_put_q<F>(ws, local);
+    C::add_(ws, lg);
+    if (active && lead) seg_out[(size_t)w * nseg + j] = vm_get_t<F>(ws);
+}
+
+// group per (window, MSM_SEG_FAN consecutive sums)
+template <class F>
+__global__ void __launch_bounds__(256) k_msm_vm_reduce(const Jac<F>* __restrict__ in, uint32_t nin, Jac<F>* __restrict__ out, uint32_t nout) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char vm_smem[];
+    using C = VmCurve<F>;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lg = lane & (VM_G - 1), grp = lane / VM_G, w = blockIdx.y;
+    const uint32_t j = (blockIdx.x * 4 + wave) * VM_EPW + grp;
+    Fp* const ws = reinterpret_cast<Fp*>(vm_smem) + (size_t)(wave * VM_EPW + grp) * C::SLOTS;
+    const uint32_t lo = j * MSM_SEG_FAN, hi = j < nout ? min(lo + MSM_SEG_FAN, nin) : lo;
+    const Jac<F>* src = in + (size_t)w * nin;
+    if (lg == 0) { ws[0] = Fp::zero(); vm_put_t<F>(ws, lo < hi ? src[lo] : msm_id_h<F>()); }
+#pragma unroll 1
+    for (uint32_t k = 1; k < (uint32_t)MSM_SEG_FAN; ++k) {
+        if (!__any(lo + k < hi)) break;
+        if (lg == 0) vm_put_q<F>(ws, lo + k < hi ? src[lo + k] : msm_id_h<F>());
+        C::add_(ws, lg);
+    }
+    if (j < nout && lg == 0) out[(size_t)w * nout + j] = vm_get_t<F>(ws);
 }
 
 template <class F>
