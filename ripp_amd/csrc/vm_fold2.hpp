@@ -46,13 +46,32 @@ __global__ void __launch_bounds__(256) k_vm_pow2(const Affine<F>* __restrict__ i
     if (active && lg == 0) out_h[i] = {C::get(ws, C::SX), C::get(ws, C::SY), C::get(ws, C::SZ)};
 }
 
-// parts_h[t][i] = (digit string t) * base_t(i);  base_t = image t of hi[i] for t < nimg, image t - nimg of hi2_h[i] otherwise
+// batched k_vm_pow2 (grid.y = vector)
+template <class F> struct Pow2Batch { const Affine<F>* in[3]; Jac<F>* out_h[3]; };
 template <class F>
-__global__ void __launch_bounds__(256) k_vm_fold_split2(const Affine<F>* __restrict__ hi, const Jac<F>* __restrict__ hi2_h, uint32_t half, SplitDigits dg, int nimg,
-                                                         Jac<F>* __restrict__ parts_h) {
+__global__ void __launch_bounds__(256) k_vm_pow2_b(Pow2Batch<F> pb, uint32_t n, int k) {
     extern __shared__ __attribute__((aligned(16))) unsigned char vm_smem[];
     using C = VmCurve<F>;
-    Fp* const lds = reinterpret_cast<Fp*>(vm_smem);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lg = lane & (VM_G - 1), grp = lane / VM_G, v = blockIdx.y;
+    const uint32_t i = (blockIdx.x * 4 + wave) * VM_EPW + grp;
+    Fp* const ws = reinterpret_cast<Fp*>(vm_smem) + (size_t)(wave * VM_EPW + grp) * C::SLOTS;
+    const bool active = i < n;
+    if (lg == 0) {
+        ws[0] = Fp::zero();
+        Jac<F> t = vm_identity_h<F>();
+        if (active) { const Affine<F> p = pb.in[v][i]; if (!is_inf(p)) t = {p.x, p.y, F::one()}; }
+        C::put(ws, C::SX, t.x); C::put(ws, C::SY, t.y); C::put(ws, C::SZ, t.z);
+    }
+#pragma unroll 1
+    for (int s = 0; s < k; ++s) C::dbl_(ws, lg);
+    if (active && lg == 0) pb.out_h[v][i] = {C::get(ws, C::SX), C::get(ws, C::SY), C::get(ws, C::SZ)};
+}
+
+// parts_h[t][i] = (digit string t) * base_t(i);  base_t = image t of hi[i] for t < nimg, image t - nimg of hi2_h[i] otherwise
+template <class F>
+__device__ __forceinline__ void vm_fold_split2_body(Fp* lds, const Affine<F>* __restrict__ hi, const Jac<F>* __restrict__ hi2_h, uint32_t half, const SplitDigits& dg, int nimg,
+                                                    Jac<F>* __restrict__ parts_h) {
+    using C = VmCurve<F>;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lg = lane & (VM_G - 1), grp = lane / VM_G;
     const uint32_t i = (blockIdx.x * 4 + wave) * VM_EPW + grp;
     const int t = blockIdx.y;
@@ -80,17 +99,29 @@ __global__ void __launch_bounds__(256) k_vm_fold_split2(const Affine<F>* __restr
     }
     if (active && lg == 0) parts_h[(size_t)t * half + i] = {C::get(ws, C::SX), C::get(ws, C::SY), C::get(ws, C::SZ)};
 }
-
-// out[i] (Jacobian) = sum_{t < nparts} parts_h[t][i] + lo[i]
 template <class F>
-__global__ void __launch_bounds__(256) k_vm_combine(const Jac<F>* __restrict__ parts_h, int nparts, const Affine<F>* __restrict__ lo, uint32_t half, Jac<F>* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_vm_fold_split2(const Affine<F>* __restrict__ hi, const Jac<F>* __restrict__ hi2_h, uint32_t half, SplitDigits dg, int nimg,
+                                                         Jac<F>* __restrict__ parts_h) {
     extern __shared__ __attribute__((aligned(16))) unsigned char vm_smem[];
+    vm_fold_split2_body<F>(reinterpret_cast<Fp*>(vm_smem), hi, hi2_h, half, dg, nimg, parts_h);
+}
+
+// Several vectors folded by ONE launch (grid.z = vector): a GIPA round folds up to three G1 and two G2 vectors of the same length, each a
+// latency-bound chain, and streams beyond the hardware queues would run them one after the other.
+constexpr int FOLD_BATCH_MAX = 3;
+template <class F> struct FoldSet { const Affine<F>* hi; const Jac<F>* hi2_h; const Affine<F>* lo; Jac<F>* parts_h; Affine<F>* out; };
+template <class F> struct FoldBatch { FoldSet<F> s[FOLD_BATCH_MAX]; SplitDigits dg[FOLD_BATCH_MAX]; };
+template <class F>
+__global__ void __launch_bounds__(256) k_vm_fold_split2_b(FoldBatch<F> fb, uint32_t half, int nimg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char vm_smem[];
+    const int v = blockIdx.z;
+    vm_fold_split2_body<F>(reinterpret_cast<Fp*>(vm_smem), fb.s[v].hi, fb.s[v].hi2_h, half, fb.dg[v], nimg, fb.s[v].parts_h);
+}
+
+// T (in the group's VM workspace) = sum_{t < nparts} parts_h[t][i] + lo[i]
+template <class F>
+__device__ __forceinline__ void vm_combine_sum(Fp* ws, int lg, bool active, uint32_t i, const Jac<F>* __restrict__ parts_h, int nparts, const Affine<F>* __restrict__ lo, uint32_t half) {
     using C = VmCurve<F>;
-    Fp* const lds = reinterpret_cast<Fp*>(vm_smem);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lg = lane & (VM_G - 1), grp = lane / VM_G;
-    const uint32_t i = (blockIdx.x * 4 + wave) * VM_EPW + grp;
-    Fp* const ws = lds + (size_t)(wave * VM_EPW + grp) * C::SLOTS;
-    const bool active = i < half;
     if (lg == 0) {
         ws[0] = Fp::zero();
         const Jac<F> p0 = active ? parts_h[i] : vm_identity_h<F>();
@@ -108,11 +139,42 @@ __global__ void __launch_bounds__(256) k_vm_combine(const Jac<F>* __restrict__ p
         }
         C::add_(ws, lg);
     }
+}
+
+// out[i] (Jacobian) = sum_{t < nparts} parts_h[t][i] + lo[i]
+template <class F>
+__global__ void __launch_bounds__(256) k_vm_combine(const Jac<F>* __restrict__ parts_h, int nparts, const Affine<F>* __restrict__ lo, uint32_t half, Jac<F>* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char vm_smem[];
+    using C = VmCurve<F>;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lg = lane & (VM_G - 1), grp = lane / VM_G;
+    const uint32_t i = (blockIdx.x * 4 + wave) * VM_EPW + grp;
+    Fp* const ws = reinterpret_cast<Fp*>(vm_smem) + (size_t)(wave * VM_EPW + grp) * C::SLOTS;
+    const bool active = i < half;
+    vm_combine_sum<F>(ws, lg, active, i, parts_h, nparts, lo, half);
     if (active && lg == 0) {
         const F X = C::get(ws, C::SX), Y = C::get(ws, C::SY), Z = C::get(ws, C::SZ);
         Jac<F> r = jac_inf<F>();
         if (!Z.is_zero()) { r.x = fmul(X, Z); r.y = fmul(Y, fsqr(Z)); r.z = Z; }              // (X/Z, Y/Z) -> Jacobian (XZ, YZ^2, Z)
         out[i] = r;
+    }
+}
+
+// batched form (grid.y = vector) that also normalises: out[i] = affine(sum), one inversion per point on the group's first lane --
+// for these lengths the separate normalisation kernel would run one inversion per lane as well, after one more launch
+template <class F>
+__global__ void __launch_bounds__(256) k_vm_combine_aff_b(FoldBatch<F> fb, int nparts, uint32_t half) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char vm_smem[];
+    using C = VmCurve<F>;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lg = lane & (VM_G - 1), grp = lane / VM_G, v = blockIdx.y;
+    const uint32_t i = (blockIdx.x * 4 + wave) * VM_EPW + grp;
+    Fp* const ws = reinterpret_cast<Fp*>(vm_smem) + (size_t)(wave * VM_EPW + grp) * C::SLOTS;
+    const bool active = i < half;
+    vm_combine_sum<F>(ws, lg, active, i, fb.s[v].parts_h, nparts, fb.s[v].lo, half);
+    if (active && lg == 0) {
+        const F Z = C::get(ws, C::SZ);
+        Affine<F> r = aff_inf<F>();
+        if (!Z.is_zero()) { const F zi = finv(Z); r.x = fmul(C::get(ws, C::SX), zi); r.y = fmul(C::get(ws, C::SY), zi); }
+        fb.s[v].out[i] = r;
     }
 }
 
