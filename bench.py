@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log-n", type=int, default=20)
-    ap.add_argument("--cpu-log-n", type=int, default=15, help="log2 size of the CPU-baseline sample (0 disables)")
+    ap.add_argument("--cpu-log-n", type=int, default=18, help="log2 size of the CPU-baseline sample (0 disables)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
