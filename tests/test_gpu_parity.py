@@ -226,14 +226,21 @@ def test_sipp_degenerate_statement_vs_oracle(engine, orc, n):
 
 def test_sipp_prove_2p17_vs_oracle_with_precomputed_round0(engine, orc):
     """n = 2^17 is the smallest statement for which round 0 uses the fold with a precomputed second base (2^64 a_r, 2^32 b_r prepared
-    while the statement hash runs): the whole proof must still equal the oracle's byte for byte; RIPP_NO_PRECOMPUTE gives the same."""
-    import os, subprocess, sys
+    while the statement hash runs) and, by default, over tables of the odd multiples {1,3,5,7} of both bases with width-4 wNAF digit
+    strings: the whole proof must still equal the oracle's byte for byte, with the tables (default) and with RIPP_NO_FOLD_TABLES=1
+    (the two-base NAF kernels; the library reads the switch at every call)."""
+    import os
     n = 1 << 17
     a, b, r = engine.synth_g1(1000, n), engine.synth_g2(2000, n), engine.synth_fr(0, n)
     value = engine.product_of_pairings_with_coeffs(a, b, r)
-    proof = engine.SIPP.prove(a, b, r, value)
     rc, eproof, _ = orc.sipp_prove(a, b, r, value)
-    assert rc == 0 and np.array_equal(proof, eproof)
+    assert rc == 0
+    assert np.array_equal(engine.SIPP.prove(a, b, r, value), eproof)
+    os.environ["RIPP_NO_FOLD_TABLES"] = "1"
+    try:
+        assert np.array_equal(engine.SIPP.prove(a, b, r, value), eproof)
+    finally:
+        del os.environ["RIPP_NO_FOLD_TABLES"]
 
 
 def test_sipp_rejects_non_power_of_two(engine, orc):
