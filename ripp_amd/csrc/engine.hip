@@ -416,11 +416,10 @@ int wnaf4_recode(uint64_t v, int8_t* digits, int maxd) {
     }
     return len;
 }
-GlvDigits split64_wnaf(const Fr& s_mont) {                       // 128-bit challenge -> width-4 wNAF strings of its two 64-bit halves
+Wnaf4 split32_wnaf(const Fr& s_mont) {                          // 128-bit challenge -> width-4 wNAF strings of its four 32-bit words
     const Fr c = from_mont(s_mont);
-    GlvDigits g; std::memset(&g, 0, sizeof g);
-    const int l1 = wnaf4_recode((uint64_t)c.l[0] | ((uint64_t)c.l[1] << 32), g.d1, 131), l2 = wnaf4_recode((uint64_t)c.l[2] | ((uint64_t)c.l[3] << 32), g.d2, 131);
-    g.len = l1 > l2 ? l1 : l2;
+    Wnaf4 g; std::memset(&g, 0, sizeof g);
+    for (int t = 0; t < 4; ++t) g.len = std::max(g.len, wnaf4_recode(c.l[t], g.d[t], 35));
     return g;
 }
 GlvDigits split64_digits(const Fr& s_mont) {                     // 128-bit challenge -> its two 64-bit halves
@@ -449,20 +448,17 @@ Gls8Digits gls8_digits(const Fr& s_mont) {                        // base-u digi
     return g;
 }
 
-Gls8Digits gls8_wnaf(const Fr& s_mont) {                          // the same split with width-4 wNAF strings
+Wnaf16 gls16_wnaf(const Fr& s_mont) {                            // base-u digits, each cut into four 16-bit pieces, width-4 wNAF strings
     const Fr c = from_mont(s_mont);
     uint64_t v[4] = {(uint64_t)c.l[0] | ((uint64_t)c.l[1] << 32), (uint64_t)c.l[2] | ((uint64_t)c.l[3] << 32),
                      (uint64_t)c.l[4] | ((uint64_t)c.l[5] << 32), (uint64_t)c.l[6] | ((uint64_t)c.l[7] << 32)};
-    Gls8Digits g; std::memset(&g, 0, sizeof g);
-    int maxlen = 0;
+    Wnaf16 g; std::memset(&g, 0, sizeof g);
     for (int j = 0; j < 4; ++j) {
         unsigned __int128 rem = 0;
         for (int i = 3; i >= 0; --i) { const unsigned __int128 cur = (rem << 64) | v[i]; v[i] = (uint64_t)(cur / BLS_X_ABS); rem = cur % BLS_X_ABS; }
         const uint64_t dj = (uint64_t)rem;
-        const int l1 = wnaf4_recode(dj & 0xffffffffu, g.d[j], 35), l2 = wnaf4_recode(dj >> 32, g.d[4 + j], 35);
-        maxlen = std::max(maxlen, std::max(l1, l2));
+        for (int b = 0; b < 4; ++b) g.len = std::max(g.len, wnaf4_recode((dj >> (16 * b)) & 0xffffu, g.d[4 * b + j], 19));
     }
-    g.len = maxlen;
     return g;
 }
 
@@ -548,7 +544,7 @@ struct ripp_sipp_job {
     int rank = 0, world = 1, world0 = 1;  // world0: sharding of the resident statement; world drops to 1 after the tail import
     DevBuf a0, b0, r0;                    // resident statement shard
     DevBuf a, b, a_next, b_next, jac1, jac2;   // working vectors
-    DevBuf tab1, mult2, tab2; size_t tab2_stride = 0; bool tab_ready = false;   // odd multiples {1,3,5,7} of both round-0 bases (G1: [8][half] affine; G2: psi images, chunked)
+    DevBuf tab1, mult2, tab2; size_t tab2_stride = 0; bool tab_ready = false;   // odd multiples {1,3,5,7} of the four round-0 bases (G1: [16][half] affine; G2: psi images, chunked)
     DevBuf a_pow, b_pow; bool pre_ready = false;   // 2^64 * a_r and 2^32 * b_r of round 0, prepared while the statement hash finishes
     DevBuf a_pow_h, b_pow_h, parts1, parts2; bool pre_vm_ready = false;   // the same for the small rounds, on the field VM (vm_fold2.hpp)
     std::vector<G1A> ha; std::vector<G2A> hb; std::vector<Fr> hr;   // host copy of the statement (rank 0 hashes it)
@@ -623,32 +619,41 @@ int32_t job_precompute_round0(Engine* e, ripp_sipp_job* j) {
     const bool tables = std::getenv("RIPP_NO_FOLD_TABLES") == nullptr;
     const size_t qstride = (half + 63) & ~(size_t)63, nj = tables ? 3 * half : half;       // every buffer is sized BEFORE the first launch: reserve() may reallocate
     if ((rc = j->a_pow.reserve(half * sizeof(G1A))) || (rc = j->b_pow.reserve(half * sizeof(G2A))) || (rc = j->jac1.reserve(nj * sizeof(G1J))) || (rc = j->jac2.reserve(nj * sizeof(G2J)))) return rc;
-    if (tables && ((rc = j->tab1.reserve(8 * half * sizeof(G1A))) || (rc = j->mult2.reserve(8 * half * sizeof(G2A))) || (rc = j->tab2.reserve(32 * G2A_CHUNKS * qstride * sizeof(uint4))))) return rc;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pow2_mul<Fp>), dim3(nblk(half, 256)), dim3(256), 0, e->stream, j->a.as<G1A>() + half, (uint32_t)half, 64, j->jac1.as<G1J>());
-    HIPCHK(hipGetLastError());
-    if ((rc = e->normalize_dev<Fp>(j->jac1.as<G1J>(), half, j->a_pow.as<G1A>()))) return rc;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pow2_mul<Fp2>), dim3(nblk(half, 256)), dim3(256), 0, e->stream, j->b.as<G2A>() + half, (uint32_t)half, 32, j->jac2.as<G2J>());
-    HIPCHK(hipGetLastError());
-    if ((rc = e->normalize_dev<Fp2>(j->jac2.as<G2J>(), half, j->b_pow.as<G2A>()))) return rc;
-    j->pre_ready = true;
-    // odd multiples of both bases of both vectors (kernels.hpp: width-4 wNAF folds); jac1 / jac2 are free again after the normalisations
     j->tab_ready = false;
-    if (!tables) return RIPP_OK;
-    for (int b = 0; b < 2; ++b) {
-        const G1A* base1 = b ? j->a_pow.as<G1A>() : j->a.as<G1A>() + half;
-        G1A* t1 = j->tab1.as<G1A>() + (size_t)4 * b * half;
-        HIPCHK(hipMemcpyAsync(t1, base1, half * sizeof(G1A), hipMemcpyDeviceToDevice, e->stream));
+    if (!tables) {                                              // two-base form: 2^64 a_r, 2^32 b_r
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pow2_mul<Fp>), dim3(nblk(half, 256)), dim3(256), 0, e->stream, j->a.as<G1A>() + half, (uint32_t)half, 64, j->jac1.as<G1J>());
+        HIPCHK(hipGetLastError());
+        if ((rc = e->normalize_dev<Fp>(j->jac1.as<G1J>(), half, j->a_pow.as<G1A>()))) return rc;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pow2_mul<Fp2>), dim3(nblk(half, 256)), dim3(256), 0, e->stream, j->b.as<G2A>() + half, (uint32_t)half, 32, j->jac2.as<G2J>());
+        HIPCHK(hipGetLastError());
+        if ((rc = e->normalize_dev<Fp2>(j->jac2.as<G2J>(), half, j->b_pow.as<G2A>()))) return rc;
+        j->pre_ready = true;
+        return RIPP_OK;
+    }
+    // table form (kernels.hpp): bases 2^(32 b) a_r and 2^(16 b) b_r, b < 4, and the odd multiples {1, 3, 5, 7} of each.
+    // tab1 / mult2 hold [4 b + m][half]; row 4 b is base b itself, written by the doubling chain's normalisation.
+    if ((rc = j->tab1.reserve(16 * half * sizeof(G1A))) || (rc = j->mult2.reserve(16 * half * sizeof(G2A))) || (rc = j->tab2.reserve(64 * G2A_CHUNKS * qstride * sizeof(uint4)))) return rc;
+    G1A* t1 = j->tab1.as<G1A>(); G2A* t2 = j->mult2.as<G2A>();
+    HIPCHK(hipMemcpyAsync(t1, j->a.as<G1A>() + half, half * sizeof(G1A), hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(t2, j->b.as<G2A>() + half, half * sizeof(G2A), hipMemcpyDeviceToDevice, e->stream));
+    for (int b = 0; b < 4; ++b) {
+        G1A* base1 = t1 + (size_t)4 * b * half; G2A* base2 = t2 + (size_t)4 * b * half;
+        if (b > 0) {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pow2_mul<Fp>), dim3(nblk(half, 256)), dim3(256), 0, e->stream, base1 - 4 * half, (uint32_t)half, 32, j->jac1.as<G1J>());
+            HIPCHK(hipGetLastError());
+            if ((rc = e->normalize_dev<Fp>(j->jac1.as<G1J>(), half, base1))) return rc;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pow2_mul<Fp2>), dim3(nblk(half, 256)), dim3(256), 0, e->stream, base2 - 4 * half, (uint32_t)half, 16, j->jac2.as<G2J>());
+            HIPCHK(hipGetLastError());
+            if ((rc = e->normalize_dev<Fp2>(j->jac2.as<G2J>(), half, base2))) return rc;
+        }
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_odd_multiples<Fp>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, base1, (uint32_t)half, j->jac1.as<G1J>());
         HIPCHK(hipGetLastError());
-        if ((rc = e->normalize_dev<Fp>(j->jac1.as<G1J>(), 3 * half, t1 + half))) return rc;
-        const G2A* base2 = b ? j->b_pow.as<G2A>() : j->b.as<G2A>() + half;
-        G2A* t2 = j->mult2.as<G2A>() + (size_t)4 * b * half;
-        HIPCHK(hipMemcpyAsync(t2, base2, half * sizeof(G2A), hipMemcpyDeviceToDevice, e->stream));
+        if ((rc = e->normalize_dev<Fp>(j->jac1.as<G1J>(), 3 * half, base1 + half))) return rc;
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_odd_multiples<Fp2>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, base2, (uint32_t)half, j->jac2.as<G2J>());
         HIPCHK(hipGetLastError());
-        if ((rc = e->normalize_dev<Fp2>(j->jac2.as<G2J>(), 3 * half, t2 + half))) return rc;
+        if ((rc = e->normalize_dev<Fp2>(j->jac2.as<G2J>(), 3 * half, base2 + half))) return rc;
     }
-    hipLaunchKernelGGL(k_g2_tab_images, dim3(nblk(half, 64), 8), dim3(64), 0, e->stream, j->mult2.as<G2A>(), (uint32_t)half, j->tab2.as<uint4>(), qstride);
+    hipLaunchKernelGGL(k_g2_tab_images, dim3(nblk(half, 64), 16), dim3(64), 0, e->stream, j->mult2.as<G2A>(), (uint32_t)half, j->tab2.as<uint4>(), qstride);
     HIPCHK(hipGetLastError());
     j->tab2_stride = qstride; j->tab_ready = true;
     return RIPP_OK;
@@ -670,9 +675,9 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true)
     const bool pre_vm = j->pre_vm_ready && fits_128(x) && allow_vm; j->pre_vm_ready = false;   // ... or on the VM during this round's host phase
     HIPCHK(hipEventRecord(e->ev_fork, e->stream));
     HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
-    const bool tab = pre && j->tab_ready; j->tab_ready = false;
+    const bool tab = j->tab_ready && fits_128(x); j->tab_ready = false;        // ... with the odd-multiple tables of four bases
     if (tab)
-        hipLaunchKernelGGL(k_fold_g1_tab, dim3(nblk(half, 256)), dim3(256), 0, e->stream2, j->tab1.as<G1A>(), a, (uint32_t)half, split64_wnaf(x), j->jac1.as<G1J>());
+        hipLaunchKernelGGL(k_fold_g1_tab, dim3(nblk(half, 256)), dim3(256), 0, e->stream2, j->tab1.as<G1A>(), a, (uint32_t)half, split32_wnaf(x), j->jac1.as<G1J>());
     else if (pre)
         hipLaunchKernelGGL(k_fold_g1_two, dim3(nblk(half, 256)), dim3(256), 0, e->stream2, a + half, j->a_pow.as<G1A>(), a, (uint32_t)half, split64_digits(x), j->jac1.as<G1J>());
     else if (pre_vm) {
@@ -691,7 +696,7 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_combine<Fp2>), dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VmCurve<Fp2>::SLOTS * sizeof(Fp), e->stream, j->parts2.as<G2J>(), 8, b, (uint32_t)half, j->jac2.as<G2J>());
     } else
     if (tab) {
-        hipLaunchKernelGGL(k_fold_g2_tab, dim3(nblk(half, 64)), dim3(64), 0, e->stream, j->tab2.as<uint4>(), j->tab2_stride, b, (uint32_t)half, gls8_wnaf(x_inv), j->jac2.as<G2J>());
+        hipLaunchKernelGGL(k_fold_g2_tab, dim3(nblk(half, 64)), dim3(64), 0, e->stream, j->tab2.as<uint4>(), j->tab2_stride, b, (uint32_t)half, gls16_wnaf(x_inv), j->jac2.as<G2J>());
     } else
     if (pre) {
         if ((rc = e->qtab.reserve(8 * G2A_CHUNKS * qstride * sizeof(uint4))) != RIPP_OK) return rc;

@@ -330,10 +330,11 @@ __global__ void __launch_bounds__(64, RIPP_OCC) k_fold_g2_gls8(const G2A* __rest
 }
 
 // ---- round-0 folds over PRECOMPUTED odd multiples (width-4 wNAF) -----------------------------------------------------------------
-// The same hash window also fits tables of the odd multiples {1, 3, 5, 7} of both bases of every element (k_odd_multiples, then the
-// batch normalisation; for G2 the psi images of all of them, k_g2_tab_images), so the digit strings of the fold become width-4 wNAF
-// strings -- one addition per 5 digit positions instead of one per 3.  G1: 64 doublings + ~26 additions (was ~43); G2: 33 doublings +
-// ~53 additions (was ~88), and the additions are 4/5 of the G2 fold.  Same group elements, hence the same proof bytes.
+// The same hash window also fits two more bases per element and tables of the odd multiples {1, 3, 5, 7} of all four (k_odd_multiples,
+// then the batch normalisation; for G2 the psi images of all of them, k_g2_tab_images), so the digit strings of the fold become
+// width-4 wNAF strings of 32 (G1) / 16 (G2) bits -- one addition per 5 digit positions instead of one per 3, and half the doublings
+// again.  G1: 33 doublings + ~26 additions (two-base NAF form: 65 + ~43); G2: 17 doublings + ~54 additions (33 + ~88).
+// Same group elements, hence the same proof bytes.
 template <class F>
 __global__ void __launch_bounds__(64, 2) k_odd_multiples(const Affine<F>* __restrict__ base, uint32_t n, Jac<F>* __restrict__ out) {   // out[m][i] = (2m + 3) base[i], m < 3
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -345,17 +346,22 @@ __global__ void __launch_bounds__(64, 2) k_odd_multiples(const Affine<F>* __rest
     t = add(t, b2); out[(size_t)n + i] = t;
     t = add(t, b2); out[2 * (size_t)n + i] = t;
 }
-// tab[e][i], e = 4 b + m: (2m + 1) * (base b of element i);  s_lo on base 0, s_hi on base 1 (= 2^64 base 0)
-__global__ void __launch_bounds__(256) k_fold_g1_tab(const G1A* __restrict__ tab, const G1A* __restrict__ lo, uint32_t half, GlvDigits dg, G1J* __restrict__ out) {
+// Four bases per element (G1: 2^(32 b) hi[i], G2: 2^(16 b) hi[i], b < 4), so the chain has 32 / 16 doublings.
+struct Wnaf4 { int8_t d[4][36]; int len; };            // G1: string b = 32-bit word b of the 128-bit challenge
+struct Wnaf16 { int8_t d[16][20]; int len; };          // G2: string 4 b + j = 16-bit piece b of GLS digit j
+// tab[e][i], e = 4 b + m: (2m + 1) * (base b of element i)
+__global__ void __launch_bounds__(256) k_fold_g1_tab(const G1A* __restrict__ tab, const G1A* __restrict__ lo, uint32_t half, Wnaf4 dg, G1J* __restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= half) return;
     G1J acc = jac_inf<Fp>();
 #pragma unroll 1
     for (int pos = dg.len - 1; pos >= 0; --pos) {
         acc = dbl(acc);
-        const int d1 = dg.d1[pos], d2 = dg.d2[pos];
-        if (d1 != 0) { G1A t = tab[(size_t)((d1 < 0 ? -d1 : d1) >> 1) * half + i]; if (d1 < 0) t.y = neg(t.y); acc = add_mixed(acc, t); }
-        if (d2 != 0) { G1A t = tab[(size_t)(4 + ((d2 < 0 ? -d2 : d2) >> 1)) * half + i]; if (d2 < 0) t.y = neg(t.y); acc = add_mixed(acc, t); }
+#pragma unroll 1
+        for (int t = 0; t < 4; ++t) {
+            const int d = dg.d[t][pos];
+            if (d != 0) { G1A q = tab[(size_t)(4 * t + ((d < 0 ? -d : d) >> 1)) * half + i]; if (d < 0) q.y = neg(q.y); acc = add_mixed(acc, q); }
+        }
     }
     out[i] = add_mixed(acc, lo[i]);
 }
@@ -368,8 +374,7 @@ __global__ void __launch_bounds__(64, RIPP_OCC) k_g2_tab_images(const G2A* __res
 #pragma unroll 1
     for (int j = 0; j < 4; ++j) store_chunks<G2A_CHUNKS>(qtab, (size_t)(e >> 2) * 16 + j * 4 + (e & 3), stride, i, gls_image(q, j));
 }
-// digit string t < 4: low half of GLS digit t (base 0), t >= 4: high half of GLS digit t - 4 (base 1 = 2^32 base 0)
-__global__ void __launch_bounds__(64, RIPP_OCC) k_fold_g2_tab(const uint4* __restrict__ qtab, size_t stride, const G2A* __restrict__ lo, uint32_t half, Gls8Digits dg, G2J* __restrict__ out) {
+__global__ void __launch_bounds__(64, RIPP_OCC) k_fold_g2_tab(const uint4* __restrict__ qtab, size_t stride, const G2A* __restrict__ lo, uint32_t half, Wnaf16 dg, G2J* __restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= half) return;
     G2J acc = jac_inf<Fp2>();
@@ -377,7 +382,7 @@ __global__ void __launch_bounds__(64, RIPP_OCC) k_fold_g2_tab(const uint4* __res
     for (int pos = dg.len - 1; pos >= 0; --pos) {
         acc = dbl(acc);
 #pragma unroll 1
-        for (int t = 0; t < 8; ++t) {
+        for (int t = 0; t < 16; ++t) {
             const int d = dg.d[t][pos];
             if (d != 0) {
                 G2A q = load_chunks<G2A_CHUNKS, G2A>(qtab, (size_t)(t >> 2) * 16 + (t & 3) * 4 + ((d < 0 ? -d : d) >> 1), stride, i);
