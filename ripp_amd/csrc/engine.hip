@@ -405,12 +405,13 @@ GlvDigits glv_digits(const Fr& s_mont) {
 }
 
 // digit strings of the folds with a precomputed second base (kernels.hpp, "round-0 folds")
-// width-4 wNAF of a value < 2^64: odd digits in [-7, 7], at most one nonzero in any 4 consecutive positions
+// width-w wNAF (w = RIPP_FOLD_W) of a value < 2^64: odd digits of magnitude < 2^(w-1), at most one nonzero in any w consecutive positions
 int wnaf4_recode(uint64_t v, int8_t* digits, int maxd) {
+    constexpr int W = RIPP_FOLD_W;
     unsigned __int128 k = v; int len = 0;
     while (k != 0 && len < maxd) {
         int d = 0;
-        if ((uint64_t)k & 1u) { d = (int)((uint64_t)k & 15u); if (d >= 8) d -= 16; if (d >= 0) k -= (unsigned)d; else k += (unsigned)(-d); }
+        if ((uint64_t)k & 1u) { d = (int)((uint64_t)k & ((1u << W) - 1)); if (d >= (1 << (W - 1))) d -= 1 << W; if (d >= 0) k -= (unsigned)d; else k += (unsigned)(-d); }
         digits[len++] = (int8_t)d;
         k >>= 1;
     }
@@ -617,7 +618,7 @@ int32_t job_precompute_round0(Engine* e, ripp_sipp_job* j) {
     if (half < ((size_t)1 << 16) || j->digest_ready.load() || std::getenv("RIPP_NO_PRECOMPUTE")) return RIPP_OK;
     int32_t rc;
     const bool tables = std::getenv("RIPP_NO_FOLD_TABLES") == nullptr;
-    const size_t qstride = (half + 63) & ~(size_t)63, nj = tables ? 3 * half : half;       // every buffer is sized BEFORE the first launch: reserve() may reallocate
+    const size_t qstride = (half + 63) & ~(size_t)63, nj = tables ? (FOLD_TAB_M - 1) * half : half;       // every buffer is sized BEFORE the first launch: reserve() may reallocate
     if ((rc = j->a_pow.reserve(half * sizeof(G1A))) || (rc = j->b_pow.reserve(half * sizeof(G2A))) || (rc = j->jac1.reserve(nj * sizeof(G1J))) || (rc = j->jac2.reserve(nj * sizeof(G2J)))) return rc;
     j->tab_ready = false;
     if (!tables) {                                              // two-base form: 2^64 a_r, 2^32 b_r
@@ -630,30 +631,33 @@ int32_t job_precompute_round0(Engine* e, ripp_sipp_job* j) {
         j->pre_ready = true;
         return RIPP_OK;
     }
-    // table form (kernels.hpp): bases 2^(32 b) a_r and 2^(16 b) b_r, b < 4, and the odd multiples {1, 3, 5, 7} of each.
-    // tab1 / mult2 hold [4 b + m][half]; row 4 b is base b itself, written by the doubling chain's normalisation.
-    if ((rc = j->tab1.reserve(16 * half * sizeof(G1A))) || (rc = j->mult2.reserve(16 * half * sizeof(G2A))) || (rc = j->tab2.reserve(64 * G2A_CHUNKS * qstride * sizeof(uint4)))) return rc;
+    // table form (kernels.hpp): bases 2^(32 b) a_r and 2^(16 b) b_r, b < 4, and the odd multiples 1, 3, .., 2 M - 1 of each.
+    // tab1 / mult2 hold [M b + m][half]; row M b is base b itself, written by the doubling chain's normalisation.
+    constexpr size_t M = FOLD_TAB_M;
+    const size_t njt = (M - 1) * half;
+    if ((rc = j->tab1.reserve(4 * M * half * sizeof(G1A))) || (rc = j->mult2.reserve(4 * M * half * sizeof(G2A))) || (rc = j->tab2.reserve(16 * M * G2A_CHUNKS * qstride * sizeof(uint4))) ||
+        (rc = j->jac1.reserve(njt * sizeof(G1J))) || (rc = j->jac2.reserve(njt * sizeof(G2J)))) return rc;
     G1A* t1 = j->tab1.as<G1A>(); G2A* t2 = j->mult2.as<G2A>();
     HIPCHK(hipMemcpyAsync(t1, j->a.as<G1A>() + half, half * sizeof(G1A), hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(t2, j->b.as<G2A>() + half, half * sizeof(G2A), hipMemcpyDeviceToDevice, e->stream));
     for (int b = 0; b < 4; ++b) {
-        G1A* base1 = t1 + (size_t)4 * b * half; G2A* base2 = t2 + (size_t)4 * b * half;
+        G1A* base1 = t1 + M * b * half; G2A* base2 = t2 + M * b * half;
         if (b > 0) {
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pow2_mul<Fp>), dim3(nblk(half, 256)), dim3(256), 0, e->stream, base1 - 4 * half, (uint32_t)half, 32, j->jac1.as<G1J>());
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pow2_mul<Fp>), dim3(nblk(half, 256)), dim3(256), 0, e->stream, base1 - M * half, (uint32_t)half, 32, j->jac1.as<G1J>());
             HIPCHK(hipGetLastError());
             if ((rc = e->normalize_dev<Fp>(j->jac1.as<G1J>(), half, base1))) return rc;
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pow2_mul<Fp2>), dim3(nblk(half, 256)), dim3(256), 0, e->stream, base2 - 4 * half, (uint32_t)half, 16, j->jac2.as<G2J>());
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pow2_mul<Fp2>), dim3(nblk(half, 256)), dim3(256), 0, e->stream, base2 - M * half, (uint32_t)half, 16, j->jac2.as<G2J>());
             HIPCHK(hipGetLastError());
             if ((rc = e->normalize_dev<Fp2>(j->jac2.as<G2J>(), half, base2))) return rc;
         }
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_odd_multiples<Fp>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, base1, (uint32_t)half, j->jac1.as<G1J>());
         HIPCHK(hipGetLastError());
-        if ((rc = e->normalize_dev<Fp>(j->jac1.as<G1J>(), 3 * half, base1 + half))) return rc;
+        if ((rc = e->normalize_dev<Fp>(j->jac1.as<G1J>(), njt, base1 + half))) return rc;
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_odd_multiples<Fp2>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, base2, (uint32_t)half, j->jac2.as<G2J>());
         HIPCHK(hipGetLastError());
-        if ((rc = e->normalize_dev<Fp2>(j->jac2.as<G2J>(), 3 * half, base2 + half))) return rc;
+        if ((rc = e->normalize_dev<Fp2>(j->jac2.as<G2J>(), njt, base2 + half))) return rc;
     }
-    hipLaunchKernelGGL(k_g2_tab_images, dim3(nblk(half, 64), 16), dim3(64), 0, e->stream, j->mult2.as<G2A>(), (uint32_t)half, j->tab2.as<uint4>(), qstride);
+    hipLaunchKernelGGL(k_g2_tab_images, dim3(nblk(half, 64), 4 * M), dim3(64), 0, e->stream, j->mult2.as<G2A>(), (uint32_t)half, j->tab2.as<uint4>(), qstride);
     HIPCHK(hipGetLastError());
     j->tab2_stride = qstride; j->tab_ready = true;
     return RIPP_OK;
