@@ -232,6 +232,14 @@ def test_sipp_prove_2p17_vs_oracle_with_precomputed_round0(engine, orc):
     import os
     n = 1 << 17
     a, b, r = engine.synth_g1(1000, n), engine.synth_g2(2000, n), engine.synth_fr(0, n)
+    # degenerate table rows: identities in the right halves (every multiple is the identity), a zero coefficient, a right-half element equal
+    # to its left partner (x * P + P), a negated pair
+    h = n // 2
+    a[h + 3] = 0; b[h + 5] = 0; b[7] = 0; r[h + 9] = 0
+    a[h + 11] = a[11]; b[h + 11] = b[11]; r[h + 11] = r[11]
+    b[h + 13, :12] = b[13, :12]
+    for k in (12, 18):                                                     # b_(h+13) = -b_13
+        b[h + 13, k:k + 6] = orc.fp_to_limbs((orc.P - orc.limbs_to_fp(b[13, k:k + 6])) % orc.P)
     value = engine.product_of_pairings_with_coeffs(a, b, r)
     rc, eproof, _ = orc.sipp_prove(a, b, r, value)
     assert rc == 0
