@@ -111,6 +111,7 @@ struct Engine {
     hipStream_t stream3 = nullptr;        // second MSM of a pair
     hipStream_t stream4 = nullptr;        // unscaled twin of m_a in the implicit-shift TIPP core
     hipEvent_t ev_join4 = nullptr;
+    size_t fold_tab_min = 32768;          // G2 folds of at least this many elements build in-round odd-multiple tables
     size_t msm_vm_merge_max = 16384;      // buckets (all windows) up to which the bucket merge runs on the field VM
     hipStream_t stream5 = nullptr;        // second G2 fold of a small GIPA round (own scratch there, so it need not queue behind the first)
     hipEvent_t ev_join5 = nullptr;
@@ -138,7 +139,7 @@ struct Engine {
         HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_join3, hipEventDisableTiming));
         { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n_simd = pr.multiProcessorCount * 4; }
         auto env_sz = [](const char* k, size_t& v) { if (const char* s = std::getenv(k)) v = (size_t)std::strtoull(s, nullptr, 10); };
-        env_sz("RIPP_VM_LINES_MAX", vm_lines_max); env_sz("RIPP_VM_FOLD_MAX", vm_fold_max); env_sz("RIPP_VM_TREE_MAX", vm_tree_max); env_sz("RIPP_GLS_SPLIT_MAX", gls_split_max); env_sz("RIPP_MSM_VM_MERGE_MAX", msm_vm_merge_max);
+        env_sz("RIPP_VM_LINES_MAX", vm_lines_max); env_sz("RIPP_VM_FOLD_MAX", vm_fold_max); env_sz("RIPP_VM_TREE_MAX", vm_tree_max); env_sz("RIPP_GLS_SPLIT_MAX", gls_split_max); env_sz("RIPP_MSM_VM_MERGE_MAX", msm_vm_merge_max); env_sz("RIPP_FOLD_TAB_MIN", fold_tab_min);
         device = dev;
         return RIPP_OK;
     }
@@ -406,8 +407,7 @@ GlvDigits glv_digits(const Fr& s_mont) {
 
 // digit strings of the folds with a precomputed second base (kernels.hpp, "round-0 folds")
 // width-w wNAF (w = RIPP_FOLD_W) of a value < 2^64: odd digits of magnitude < 2^(w-1), at most one nonzero in any w consecutive positions
-int wnaf4_recode(uint64_t v, int8_t* digits, int maxd) {
-    constexpr int W = RIPP_FOLD_W;
+int wnaf4_recode(uint64_t v, int8_t* digits, int maxd, int W = RIPP_FOLD_W) {
     unsigned __int128 k = v; int len = 0;
     while (k != 0 && len < maxd) {
         int d = 0;
@@ -459,6 +459,19 @@ Wnaf16 gls16_wnaf(const Fr& s_mont) {                            // base-u digit
         for (int i = 3; i >= 0; --i) { const unsigned __int128 cur = (rem << 64) | v[i]; v[i] = (uint64_t)(cur / BLS_X_ABS); rem = cur % BLS_X_ABS; }
         const uint64_t dj = (uint64_t)rem;
         for (int b = 0; b < 4; ++b) g.len = std::max(g.len, wnaf4_recode((dj >> (16 * b)) & 0xffffu, g.d[4 * b + j], 19));
+    }
+    return g;
+}
+
+GlsDigits gls_wnaf(const Fr& s_mont, int W) {                     // base-u digits as width-W wNAF strings (one base, in-round tables)
+    const Fr c = from_mont(s_mont);
+    uint64_t v[4] = {(uint64_t)c.l[0] | ((uint64_t)c.l[1] << 32), (uint64_t)c.l[2] | ((uint64_t)c.l[3] << 32),
+                     (uint64_t)c.l[4] | ((uint64_t)c.l[5] << 32), (uint64_t)c.l[6] | ((uint64_t)c.l[7] << 32)};
+    GlsDigits g; std::memset(&g, 0, sizeof g);
+    for (int j = 0; j < 4; ++j) {
+        unsigned __int128 rem = 0;
+        for (int i = 3; i >= 0; --i) { const unsigned __int128 cur = (rem << 64) | v[i]; v[i] = (uint64_t)(cur / BLS_X_ABS); rem = cur % BLS_X_ABS; }
+        g.len = std::max(g.len, wnaf4_recode((uint64_t)rem, g.d[j], 66, W));
     }
     return g;
 }
@@ -650,14 +663,14 @@ int32_t job_precompute_round0(Engine* e, ripp_sipp_job* j) {
             HIPCHK(hipGetLastError());
             if ((rc = e->normalize_dev<Fp2>(j->jac2.as<G2J>(), half, base2))) return rc;
         }
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_odd_multiples<Fp>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, base1, (uint32_t)half, j->jac1.as<G1J>());
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_odd_multiples<Fp>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, base1, (uint32_t)half, (int)M, j->jac1.as<G1J>());
         HIPCHK(hipGetLastError());
         if ((rc = e->normalize_dev<Fp>(j->jac1.as<G1J>(), njt, base1 + half))) return rc;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_odd_multiples<Fp2>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, base2, (uint32_t)half, j->jac2.as<G2J>());
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_odd_multiples<Fp2>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, base2, (uint32_t)half, (int)M, j->jac2.as<G2J>());
         HIPCHK(hipGetLastError());
         if ((rc = e->normalize_dev<Fp2>(j->jac2.as<G2J>(), njt, base2 + half))) return rc;
     }
-    hipLaunchKernelGGL(k_g2_tab_images, dim3(nblk(half, 64), 4 * M), dim3(64), 0, e->stream, j->mult2.as<G2A>(), (uint32_t)half, j->tab2.as<uint4>(), qstride);
+    hipLaunchKernelGGL(k_g2_tab_images, dim3(nblk(half, 64), 4 * M), dim3(64), 0, e->stream, j->mult2.as<G2A>(), (uint32_t)half, (int)M, j->tab2.as<uint4>(), qstride);
     HIPCHK(hipGetLastError());
     j->tab2_stride = qstride; j->tab_ready = true;
     return RIPP_OK;
@@ -681,7 +694,7 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true)
     HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
     const bool tab = j->tab_ready && fits_128(x); j->tab_ready = false;        // ... with the odd-multiple tables of four bases
     if (tab)
-        hipLaunchKernelGGL(k_fold_g1_tab, dim3(nblk(half, 256)), dim3(256), 0, e->stream2, j->tab1.as<G1A>(), a, (uint32_t)half, split32_wnaf(x), j->jac1.as<G1J>());
+        hipLaunchKernelGGL(k_fold_g1_tab, dim3(nblk(half, 256)), dim3(256), 0, e->stream2, j->tab1.as<G1A>(), (int)FOLD_TAB_M, a, (uint32_t)half, split32_wnaf(x), j->jac1.as<G1J>());
     else if (pre)
         hipLaunchKernelGGL(k_fold_g1_two, dim3(nblk(half, 256)), dim3(256), 0, e->stream2, a + half, j->a_pow.as<G1A>(), a, (uint32_t)half, split64_digits(x), j->jac1.as<G1J>());
     else if (pre_vm) {
@@ -700,7 +713,7 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_combine<Fp2>), dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VmCurve<Fp2>::SLOTS * sizeof(Fp), e->stream, j->parts2.as<G2J>(), 8, b, (uint32_t)half, j->jac2.as<G2J>());
     } else
     if (tab) {
-        hipLaunchKernelGGL(k_fold_g2_tab, dim3(nblk(half, 64)), dim3(64), 0, e->stream, j->tab2.as<uint4>(), j->tab2_stride, b, (uint32_t)half, gls16_wnaf(x_inv), j->jac2.as<G2J>());
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab<Wnaf16, 16>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, j->tab2.as<uint4>(), j->tab2_stride, (int)FOLD_TAB_M, b, (uint32_t)half, gls16_wnaf(x_inv), j->jac2.as<G2J>());
     } else
     if (pre) {
         if ((rc = e->qtab.reserve(8 * G2A_CHUNKS * qstride * sizeof(uint4))) != RIPP_OK) return rc;
@@ -715,6 +728,19 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true)
         if ((rc = e->qtab.reserve(std::max<size_t>(4 * G2A_CHUNKS * qstride * sizeof(uint4), 4 * half * sizeof(G2J)))) != RIPP_OK) return rc;
         hipLaunchKernelGGL(k_fold_g2_gls_split, dim3(nblk(half, 64), 4), dim3(64), 0, e->stream, b + half, (uint32_t)half, gls_digits(x_inv), e->qtab.as<G2J>());
         hipLaunchKernelGGL(k_fold_g2_combine, dim3(nblk(half, 64)), dim3(64), 0, e->stream, e->qtab.as<G2J>(), b, (uint32_t)half, j->jac2.as<G2J>());
+    } else if (half >= e->fold_tab_min && !std::getenv("RIPP_NO_FOLD_TABLES")) {
+        // throughput rounds: odd multiples {1,3,5,7} of every hi element (batch-normalised: the inversion is shared by 16 points) and their
+        // psi images, then width-4 wNAF strings -- 65 doublings + ~52 additions instead of 65 + ~87 for ~350 Fp products of table work
+        constexpr int M = 4;
+        if ((rc = j->mult2.reserve((size_t)M * half * sizeof(G2A))) || (rc = j->tab2.reserve((size_t)4 * M * G2A_CHUNKS * qstride * sizeof(uint4))) ||
+            (rc = j->jac2.reserve((size_t)(M - 1) * half * sizeof(G2J)))) return rc;
+        G2A* mult = j->mult2.as<G2A>();
+        HIPCHK(hipMemcpyAsync(mult, b + half, half * sizeof(G2A), hipMemcpyDeviceToDevice, e->stream));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_odd_multiples<Fp2>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, b + half, (uint32_t)half, M, j->jac2.as<G2J>());
+        HIPCHK(hipGetLastError());
+        if ((rc = e->normalize_dev<Fp2>(j->jac2.as<G2J>(), (size_t)(M - 1) * half, mult + half)) != RIPP_OK) return rc;
+        hipLaunchKernelGGL(k_g2_tab_images, dim3(nblk(half, 64), M), dim3(64), 0, e->stream, mult, (uint32_t)half, M, j->tab2.as<uint4>(), qstride);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab<GlsDigits, 4>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, j->tab2.as<uint4>(), qstride, M, b, (uint32_t)half, gls_wnaf(x_inv, 4), j->jac2.as<G2J>());
     } else {
         hipLaunchKernelGGL(k_fold_g2_gls, dim3(nblk(half, 64)), dim3(64), 0, e->stream, b + half, b, (uint32_t)half, gls_digits(x_inv), e->qtab.as<uint4>(), qstride, j->jac2.as<G2J>());
     }

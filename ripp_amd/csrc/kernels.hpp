@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(64, RIPP_OCC) k_fold_g2_gls8(const G2A* __rest
 #endif
 constexpr int FOLD_TAB_M = 1 << (RIPP_FOLD_W - 2);      // odd multiples 1, 3, .., 2 M - 1 per base
 template <class F>
-__global__ void __launch_bounds__(64, 2) k_odd_multiples(const Affine<F>* __restrict__ base, uint32_t n, Jac<F>* __restrict__ out) {   // out[m][i] = (2m + 3) base[i], m < M - 1
+__global__ void __launch_bounds__(64, 2) k_odd_multiples(const Affine<F>* __restrict__ base, uint32_t n, int M, Jac<F>* __restrict__ out) {   // out[m][i] = (2m + 3) base[i], m < M - 1
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const Affine<F> b = base[i];
@@ -348,13 +348,13 @@ __global__ void __launch_bounds__(64, 2) k_odd_multiples(const Affine<F>* __rest
     Jac<F> t = add_mixed(b2, b);
     out[i] = t;
 #pragma unroll 1
-    for (int m = 1; m < FOLD_TAB_M - 1; ++m) { t = add(t, b2); out[(size_t)m * n + i] = t; }
+    for (int m = 1; m < M - 1; ++m) { t = add(t, b2); out[(size_t)m * n + i] = t; }
 }
 // Four bases per element (G1: 2^(32 b) hi[i], G2: 2^(16 b) hi[i], b < 4), so the chain has 32 / 16 doublings.
 struct Wnaf4 { int8_t d[4][36]; int len; };            // G1: string b = 32-bit word b of the 128-bit challenge
 struct Wnaf16 { int8_t d[16][20]; int len; };          // G2: string 4 b + j = 16-bit piece b of GLS digit j
 // tab[e][i], e = M b + m: (2m + 1) * (base b of element i)
-__global__ void __launch_bounds__(256) k_fold_g1_tab(const G1A* __restrict__ tab, const G1A* __restrict__ lo, uint32_t half, Wnaf4 dg, G1J* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_fold_g1_tab(const G1A* __restrict__ tab, int M, const G1A* __restrict__ lo, uint32_t half, Wnaf4 dg, G1J* __restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= half) return;
     G1J acc = jac_inf<Fp>();
@@ -364,21 +364,23 @@ __global__ void __launch_bounds__(256) k_fold_g1_tab(const G1A* __restrict__ tab
 #pragma unroll 1
         for (int t = 0; t < 4; ++t) {
             const int d = dg.d[t][pos];
-            if (d != 0) { G1A q = tab[(size_t)(FOLD_TAB_M * t + ((d < 0 ? -d : d) >> 1)) * half + i]; if (d < 0) q.y = neg(q.y); acc = add_mixed(acc, q); }
+            if (d != 0) { G1A q = tab[(size_t)(M * t + ((d < 0 ? -d : d) >> 1)) * half + i]; if (d < 0) q.y = neg(q.y); acc = add_mixed(acc, q); }
         }
     }
     out[i] = add_mixed(acc, lo[i]);
 }
 // qtab row (4 b + j) M + m = psi^j((2m + 1) * base b), chunked like the other G2 tables; mult[e][i], e = M b + m
-__global__ void __launch_bounds__(64, RIPP_OCC) k_g2_tab_images(const G2A* __restrict__ mult, uint32_t half, uint4* __restrict__ qtab, size_t stride) {
+__global__ void __launch_bounds__(64, RIPP_OCC) k_g2_tab_images(const G2A* __restrict__ mult, uint32_t half, int M, uint4* __restrict__ qtab, size_t stride) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= half) return;
-    const int e = blockIdx.y, b = e / FOLD_TAB_M, m = e % FOLD_TAB_M;
+    const int e = blockIdx.y, b = e / M, m = e % M;
     const G2A q = mult[(size_t)e * half + i];
 #pragma unroll 1
-    for (int j = 0; j < 4; ++j) store_chunks<G2A_CHUNKS>(qtab, (size_t)(4 * b + j) * FOLD_TAB_M + m, stride, i, gls_image(q, j));
+    for (int j = 0; j < 4; ++j) store_chunks<G2A_CHUNKS>(qtab, (size_t)(4 * b + j) * M + m, stride, i, gls_image(q, j));
 }
-__global__ void __launch_bounds__(64, RIPP_OCC) k_fold_g2_tab(const uint4* __restrict__ qtab, size_t stride, const G2A* __restrict__ lo, uint32_t half, Wnaf16 dg, G2J* __restrict__ out) {
+// NS digit strings; string t = 4 b + j works on table rows t M .. t M + M - 1
+template <class D, int NS>
+__global__ void __launch_bounds__(64, RIPP_OCC) k_fold_g2_tab(const uint4* __restrict__ qtab, size_t stride, int M, const G2A* __restrict__ lo, uint32_t half, D dg, G2J* __restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= half) return;
     G2J acc = jac_inf<Fp2>();
@@ -386,10 +388,10 @@ __global__ void __launch_bounds__(64, RIPP_OCC) k_fold_g2_tab(const uint4* __res
     for (int pos = dg.len - 1; pos >= 0; --pos) {
         acc = dbl(acc);
 #pragma unroll 1
-        for (int t = 0; t < 16; ++t) {
+        for (int t = 0; t < NS; ++t) {
             const int d = dg.d[t][pos];
             if (d != 0) {
-                G2A q = load_chunks<G2A_CHUNKS, G2A>(qtab, (size_t)t * FOLD_TAB_M + ((d < 0 ? -d : d) >> 1), stride, i);      // t = 4 b + j
+                G2A q = load_chunks<G2A_CHUNKS, G2A>(qtab, (size_t)t * M + ((d < 0 ? -d : d) >> 1), stride, i);
                 if (d < 0) q.y = neg(q.y);
                 acc = add_mixed(acc, q);
             }
