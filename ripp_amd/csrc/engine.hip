@@ -111,6 +111,7 @@ struct Engine {
     hipStream_t stream3 = nullptr;        // second MSM of a pair
     hipStream_t stream4 = nullptr;        // unscaled twin of m_a in the implicit-shift TIPP core
     hipEvent_t ev_join4 = nullptr;
+    DevBuf fold_mult, fold_tab;           // in-round fold tables of the GIPA cores (the SIPP job has its own)
     size_t fold_tab_min = 32768;          // G2 folds of at least this many elements build in-round odd-multiple tables
     size_t msm_vm_merge_max = 16384;      // buckets (all windows) up to which the bucket merge runs on the field VM
     hipStream_t stream5 = nullptr;        // second G2 fold of a small GIPA round (own scratch there, so it need not queue behind the first)
@@ -144,7 +145,7 @@ struct Engine {
         return RIPP_OK;
     }
     void destroy() {
-        for (DevBuf* b : {&lines, &partA, &partB, &jacG1, &jacG2, &tmpA, &tmpB, &tmpR, &affG1, &affG2, &qtab, &vm_flag}) b->release();
+        for (DevBuf* b : {&lines, &partA, &partB, &jacG1, &jacG2, &tmpA, &tmpB, &tmpR, &affG1, &affG2, &qtab, &vm_flag, &fold_mult, &fold_tab}) b->release();
         msm_scratch[0].release(); msm_scratch[1].release(); kzg_q[0].release(); kzg_q[1].release();
         if (stream3) (void)hipStreamDestroy(stream3);
         if (stream4) (void)hipStreamDestroy(stream4); if (ev_join4) (void)hipEventDestroy(ev_join4);
@@ -676,6 +677,27 @@ int32_t job_precompute_round0(Engine* e, ripp_sipp_job* j) {
     return RIPP_OK;
 }
 
+// G2 fold of a throughput-bound round over in-round tables: odd multiples {1,3,5,7} of every hi element (batch-normalised: the inversion
+// is shared by 16 points) and their psi images, then width-4 wNAF strings -- 65 doublings + ~52 additions instead of 65 + ~87 for
+// ~350 Fp products of table work per element.  Leaves the Jacobian result in jac (first `half` entries).
+bool fold_g2_table_pays(const Engine* e, size_t half) { return half >= e->fold_tab_min && half > e->gls_split_max && !std::getenv("RIPP_NO_FOLD_TABLES"); }
+int32_t fold_g2_table(Engine* e, hipStream_t st, const G2A* hi, const G2A* lo, size_t half, const Fr& s, DevBuf& jac, DevBuf& multbuf, DevBuf& tab) {
+    constexpr int M = 4;
+    const size_t qstride = (half + 63) & ~(size_t)63;
+    int32_t rc;
+    if ((rc = multbuf.reserve((size_t)M * half * sizeof(G2A))) || (rc = tab.reserve((size_t)4 * M * G2A_CHUNKS * qstride * sizeof(uint4))) ||
+        (rc = jac.reserve((size_t)(M - 1) * half * sizeof(G2J)))) return rc;
+    G2A* mult = multbuf.as<G2A>();
+    HIPCHK(hipMemcpyAsync(mult, hi, half * sizeof(G2A), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_odd_multiples<Fp2>), dim3(nblk(half, 64)), dim3(64), 0, st, hi, (uint32_t)half, M, jac.as<G2J>());
+    HIPCHK(hipGetLastError());
+    if ((rc = e->normalize_dev<Fp2>(jac.as<G2J>(), (size_t)(M - 1) * half, mult + half, st)) != RIPP_OK) return rc;
+    hipLaunchKernelGGL(k_g2_tab_images, dim3(nblk(half, 64), M), dim3(64), 0, st, mult, (uint32_t)half, M, tab.as<uint4>(), qstride);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab<GlsDigits, 4>), dim3(nblk(half, 64)), dim3(64), 0, st, tab.as<uint4>(), qstride, M, lo, (uint32_t)half, gls_wnaf(s, 4), jac.as<G2J>());
+    HIPCHK(hipGetLastError());
+    return RIPP_OK;
+}
+
 int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true) {
     const size_t half = j->len / 2;
     int32_t rc;
@@ -728,19 +750,8 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true)
         if ((rc = e->qtab.reserve(std::max<size_t>(4 * G2A_CHUNKS * qstride * sizeof(uint4), 4 * half * sizeof(G2J)))) != RIPP_OK) return rc;
         hipLaunchKernelGGL(k_fold_g2_gls_split, dim3(nblk(half, 64), 4), dim3(64), 0, e->stream, b + half, (uint32_t)half, gls_digits(x_inv), e->qtab.as<G2J>());
         hipLaunchKernelGGL(k_fold_g2_combine, dim3(nblk(half, 64)), dim3(64), 0, e->stream, e->qtab.as<G2J>(), b, (uint32_t)half, j->jac2.as<G2J>());
-    } else if (half >= e->fold_tab_min && !std::getenv("RIPP_NO_FOLD_TABLES")) {
-        // throughput rounds: odd multiples {1,3,5,7} of every hi element (batch-normalised: the inversion is shared by 16 points) and their
-        // psi images, then width-4 wNAF strings -- 65 doublings + ~52 additions instead of 65 + ~87 for ~350 Fp products of table work
-        constexpr int M = 4;
-        if ((rc = j->mult2.reserve((size_t)M * half * sizeof(G2A))) || (rc = j->tab2.reserve((size_t)4 * M * G2A_CHUNKS * qstride * sizeof(uint4))) ||
-            (rc = j->jac2.reserve((size_t)(M - 1) * half * sizeof(G2J)))) return rc;
-        G2A* mult = j->mult2.as<G2A>();
-        HIPCHK(hipMemcpyAsync(mult, b + half, half * sizeof(G2A), hipMemcpyDeviceToDevice, e->stream));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_odd_multiples<Fp2>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, b + half, (uint32_t)half, M, j->jac2.as<G2J>());
-        HIPCHK(hipGetLastError());
-        if ((rc = e->normalize_dev<Fp2>(j->jac2.as<G2J>(), (size_t)(M - 1) * half, mult + half)) != RIPP_OK) return rc;
-        hipLaunchKernelGGL(k_g2_tab_images, dim3(nblk(half, 64), M), dim3(64), 0, e->stream, mult, (uint32_t)half, M, j->tab2.as<uint4>(), qstride);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab<GlsDigits, 4>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, j->tab2.as<uint4>(), qstride, M, b, (uint32_t)half, gls_wnaf(x_inv, 4), j->jac2.as<G2J>());
+    } else if (fold_g2_table_pays(e, half)) {
+        if ((rc = fold_g2_table(e, e->stream, b + half, b, half, x_inv, j->jac2, j->mult2, j->tab2)) != RIPP_OK) return rc;
     } else {
         hipLaunchKernelGGL(k_fold_g2_gls, dim3(nblk(half, 64)), dim3(64), 0, e->stream, b + half, b, (uint32_t)half, gls_digits(x_inv), e->qtab.as<uint4>(), qstride, j->jac2.as<G2J>());
     }

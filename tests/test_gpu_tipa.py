@@ -198,3 +198,34 @@ def test_aggregate_proofs_config5_size(engine, orc):
     assert engine.TIPAWithSSM.verify_with_structured_scalar_message(vs, (got.field("com_c"), got.field("agg_c")), r, ssm)
     print("aggregate_proofs n=2^14:", {k: round(v, 1) for k, v in stats.items() if k.endswith("_ms") and v})
     srs.close()
+
+
+def test_aggregate_proofs_table_fold_size(engine, orc):
+    """n = 2^16: the first TIPP round folds 32768 G2 elements per vector, the size from which the folds build in-round odd-multiple
+    tables (width-4 wNAF; engine.hip::fold_g2_table).  The aggregate must be byte-identical with and without the tables
+    (RIPP_NO_FOLD_TABLES=1, read per call) and pass the oracle's TIPA verifier."""
+    import os
+    n = 1 << 16
+    alpha, beta = orc.fr_array([0xa1fa0001]), orc.fr_array([0xbe7a0001])
+    srs = engine.SRS.from_trapdoors(alpha[0], beta[0], n)
+    a, b, c = engine.synth_g1(101, n), engine.synth_g2(202, n), engine.synth_g1(303, n)
+    got, _ = engine.aggregate_proofs(srs, a, b, c)
+    os.environ["RIPP_NO_FOLD_TABLES"] = "1"
+    try:
+        ref, _ = engine.aggregate_proofs(srs, a, b, c)
+    finally:
+        del os.environ["RIPP_NO_FOLD_TABLES"]
+    def canon(x):                                   # group elements travel in Jacobian form; MSM outputs are not canonical there (atomic scatter order)
+        x = np.ascontiguousarray(x).reshape(-1, x.shape[-1])
+        return engine.normalize_batch_g1(x) if x.shape[1] == 18 else engine.normalize_batch_g2(x) if x.shape[1] == 36 else x
+    for name in got.FIXED:
+        assert np.array_equal(canon(got.field(name)), canon(ref.field(name))), name
+    for name in got.STEPS:
+        assert np.array_equal(canon(getattr(got, name)), canon(getattr(ref, name))), name
+    vs = srs.get_verifier_key(); g, hh, g_beta, h_alpha = vs["g"], vs["h"], vs["g_beta"], vs["h_alpha"]
+    r = got.field("r")
+    tipp = dict(steps=got.ab_com_steps, base_a=got.field("ab_base_a"), base_b=got.field("ab_base_b"), final_ck_a=got.field("ab_final_ck_a"),
+                final_ck_b=got.field("ab_final_ck_b"), opening_a=got.field("ab_opening_a"), opening_b=got.field("ab_opening_b"))
+    tipp = {k: np.ascontiguousarray(v) for k, v in tipp.items()}
+    assert orc.tipa_tipp_verify(g, hh, g_beta, h_alpha, [got.field("com_a"), got.field("com_b"), got.field("ip_ab")], tipp, np.ascontiguousarray(r)) == 1
+    srs.close()
