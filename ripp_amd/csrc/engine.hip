@@ -111,7 +111,11 @@ struct Engine {
     hipStream_t stream3 = nullptr;        // second MSM of a pair
     hipStream_t stream4 = nullptr;        // unscaled twin of m_a in the implicit-shift TIPP core
     hipEvent_t ev_join4 = nullptr;
-    DevBuf fold_mult, fold_tab;           // in-round fold tables of the GIPA cores (the SIPP job has its own)
+    // Fold tables (kernels.hpp: k_odd_multiples / k_fold_g*_tab) live in the ENGINE, not in jobs or per-call vectors: they are GB-sized at
+    // n = 2^20 and a hipMalloc of that size costs ~100 ms, which a one-shot ripp_sipp_prove would pay on every call.  tab_owner names the
+    // job whose round-0 tables they hold; a job that finds another owner falls back to the table-free fold.
+    DevBuf fold_tab1, fold_mult, fold_tab, fold_jac1, fold_jac2;
+    const void* tab_owner = nullptr;
     size_t fold_tab_min = 32768;          // G2 folds of at least this many elements build in-round odd-multiple tables
     size_t msm_vm_merge_max = 16384;      // buckets (all windows) up to which the bucket merge runs on the field VM
     hipStream_t stream5 = nullptr;        // second G2 fold of a small GIPA round (own scratch there, so it need not queue behind the first)
@@ -145,7 +149,7 @@ struct Engine {
         return RIPP_OK;
     }
     void destroy() {
-        for (DevBuf* b : {&lines, &partA, &partB, &jacG1, &jacG2, &tmpA, &tmpB, &tmpR, &affG1, &affG2, &qtab, &vm_flag, &fold_mult, &fold_tab}) b->release();
+        for (DevBuf* b : {&lines, &partA, &partB, &jacG1, &jacG2, &tmpA, &tmpB, &tmpR, &affG1, &affG2, &qtab, &vm_flag, &fold_tab1, &fold_mult, &fold_tab, &fold_jac1, &fold_jac2}) b->release();
         msm_scratch[0].release(); msm_scratch[1].release(); kzg_q[0].release(); kzg_q[1].release();
         if (stream3) (void)hipStreamDestroy(stream3);
         if (stream4) (void)hipStreamDestroy(stream4); if (ev_join4) (void)hipEventDestroy(ev_join4);
@@ -559,7 +563,7 @@ struct ripp_sipp_job {
     int rank = 0, world = 1, world0 = 1;  // world0: sharding of the resident statement; world drops to 1 after the tail import
     DevBuf a0, b0, r0;                    // resident statement shard
     DevBuf a, b, a_next, b_next, jac1, jac2;   // working vectors
-    DevBuf tab1, mult2, tab2; size_t tab2_stride = 0; bool tab_ready = false;   // odd multiples {1,3,5,7} of the four round-0 bases (G1: [16][half] affine; G2: psi images, chunked)
+    size_t tab2_stride = 0; bool tab_ready = false;   // round-0 tables (odd multiples of four bases) of this job are in the engine's fold_* buffers
     DevBuf a_pow, b_pow; bool pre_ready = false;   // 2^64 * a_r and 2^32 * b_r of round 0, prepared while the statement hash finishes
     DevBuf a_pow_h, b_pow_h, parts1, parts2; bool pre_vm_ready = false;   // the same for the small rounds, on the field VM (vm_fold2.hpp)
     std::vector<G1A> ha; std::vector<G2A> hb; std::vector<Fr> hr;   // host copy of the statement (rank 0 hashes it)
@@ -632,8 +636,8 @@ int32_t job_precompute_round0(Engine* e, ripp_sipp_job* j) {
     if (half < ((size_t)1 << 16) || j->digest_ready.load() || std::getenv("RIPP_NO_PRECOMPUTE")) return RIPP_OK;
     int32_t rc;
     const bool tables = std::getenv("RIPP_NO_FOLD_TABLES") == nullptr;
-    const size_t qstride = (half + 63) & ~(size_t)63, nj = tables ? (FOLD_TAB_M - 1) * half : half;       // every buffer is sized BEFORE the first launch: reserve() may reallocate
-    if ((rc = j->a_pow.reserve(half * sizeof(G1A))) || (rc = j->b_pow.reserve(half * sizeof(G2A))) || (rc = j->jac1.reserve(nj * sizeof(G1J))) || (rc = j->jac2.reserve(nj * sizeof(G2J)))) return rc;
+    const size_t qstride = (half + 63) & ~(size_t)63;
+    if ((rc = j->a_pow.reserve(half * sizeof(G1A))) || (rc = j->b_pow.reserve(half * sizeof(G2A))) || (rc = j->jac1.reserve(half * sizeof(G1J))) || (rc = j->jac2.reserve(half * sizeof(G2J)))) return rc;
     j->tab_ready = false;
     if (!tables) {                                              // two-base form: 2^64 a_r, 2^32 b_r
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pow2_mul<Fp>), dim3(nblk(half, 256)), dim3(256), 0, e->stream, j->a.as<G1A>() + half, (uint32_t)half, 64, j->jac1.as<G1J>());
@@ -649,29 +653,31 @@ int32_t job_precompute_round0(Engine* e, ripp_sipp_job* j) {
     // tab1 / mult2 hold [M b + m][half]; row M b is base b itself, written by the doubling chain's normalisation.
     constexpr size_t M = FOLD_TAB_M;
     const size_t njt = (M - 1) * half;
-    if ((rc = j->tab1.reserve(4 * M * half * sizeof(G1A))) || (rc = j->mult2.reserve(4 * M * half * sizeof(G2A))) || (rc = j->tab2.reserve(16 * M * G2A_CHUNKS * qstride * sizeof(uint4))) ||
-        (rc = j->jac1.reserve(njt * sizeof(G1J))) || (rc = j->jac2.reserve(njt * sizeof(G2J)))) return rc;
-    G1A* t1 = j->tab1.as<G1A>(); G2A* t2 = j->mult2.as<G2A>();
+    if ((rc = e->fold_tab1.reserve(4 * M * half * sizeof(G1A))) || (rc = e->fold_mult.reserve(4 * M * half * sizeof(G2A))) || (rc = e->fold_tab.reserve(16 * M * G2A_CHUNKS * qstride * sizeof(uint4))) ||
+        (rc = e->fold_jac1.reserve(njt * sizeof(G1J))) || (rc = e->fold_jac2.reserve(njt * sizeof(G2J)))) return rc;      // all sized BEFORE the first launch: reserve() may reallocate
+    e->tab_owner = j;
+    G1A* t1 = e->fold_tab1.as<G1A>(); G2A* t2 = e->fold_mult.as<G2A>();
+    G1J* sj1 = e->fold_jac1.as<G1J>(); G2J* sj2 = e->fold_jac2.as<G2J>();
     HIPCHK(hipMemcpyAsync(t1, j->a.as<G1A>() + half, half * sizeof(G1A), hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(t2, j->b.as<G2A>() + half, half * sizeof(G2A), hipMemcpyDeviceToDevice, e->stream));
     for (int b = 0; b < 4; ++b) {
         G1A* base1 = t1 + M * b * half; G2A* base2 = t2 + M * b * half;
         if (b > 0) {
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pow2_mul<Fp>), dim3(nblk(half, 256)), dim3(256), 0, e->stream, base1 - M * half, (uint32_t)half, 32, j->jac1.as<G1J>());
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pow2_mul<Fp>), dim3(nblk(half, 256)), dim3(256), 0, e->stream, base1 - M * half, (uint32_t)half, 32, sj1);
             HIPCHK(hipGetLastError());
-            if ((rc = e->normalize_dev<Fp>(j->jac1.as<G1J>(), half, base1))) return rc;
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pow2_mul<Fp2>), dim3(nblk(half, 256)), dim3(256), 0, e->stream, base2 - M * half, (uint32_t)half, 16, j->jac2.as<G2J>());
+            if ((rc = e->normalize_dev<Fp>(sj1, half, base1))) return rc;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pow2_mul<Fp2>), dim3(nblk(half, 256)), dim3(256), 0, e->stream, base2 - M * half, (uint32_t)half, 16, sj2);
             HIPCHK(hipGetLastError());
-            if ((rc = e->normalize_dev<Fp2>(j->jac2.as<G2J>(), half, base2))) return rc;
+            if ((rc = e->normalize_dev<Fp2>(sj2, half, base2))) return rc;
         }
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_odd_multiples<Fp>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, base1, (uint32_t)half, (int)M, j->jac1.as<G1J>());
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_odd_multiples<Fp>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, base1, (uint32_t)half, (int)M, sj1);
         HIPCHK(hipGetLastError());
-        if ((rc = e->normalize_dev<Fp>(j->jac1.as<G1J>(), njt, base1 + half))) return rc;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_odd_multiples<Fp2>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, base2, (uint32_t)half, (int)M, j->jac2.as<G2J>());
+        if ((rc = e->normalize_dev<Fp>(sj1, njt, base1 + half))) return rc;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_odd_multiples<Fp2>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, base2, (uint32_t)half, (int)M, sj2);
         HIPCHK(hipGetLastError());
-        if ((rc = e->normalize_dev<Fp2>(j->jac2.as<G2J>(), njt, base2 + half))) return rc;
+        if ((rc = e->normalize_dev<Fp2>(sj2, njt, base2 + half))) return rc;
     }
-    hipLaunchKernelGGL(k_g2_tab_images, dim3(nblk(half, 64), 4 * M), dim3(64), 0, e->stream, j->mult2.as<G2A>(), (uint32_t)half, (int)M, j->tab2.as<uint4>(), qstride);
+    hipLaunchKernelGGL(k_g2_tab_images, dim3(nblk(half, 64), 4 * M), dim3(64), 0, e->stream, e->fold_mult.as<G2A>(), (uint32_t)half, (int)M, e->fold_tab.as<uint4>(), qstride);
     HIPCHK(hipGetLastError());
     j->tab2_stride = qstride; j->tab_ready = true;
     return RIPP_OK;
@@ -681,19 +687,20 @@ int32_t job_precompute_round0(Engine* e, ripp_sipp_job* j) {
 // is shared by 16 points) and their psi images, then width-4 wNAF strings -- 65 doublings + ~52 additions instead of 65 + ~87 for
 // ~350 Fp products of table work per element.  Leaves the Jacobian result in jac (first `half` entries).
 bool fold_g2_table_pays(const Engine* e, size_t half) { return half >= e->fold_tab_min && half > e->gls_split_max && !std::getenv("RIPP_NO_FOLD_TABLES"); }
-int32_t fold_g2_table(Engine* e, hipStream_t st, const G2A* hi, const G2A* lo, size_t half, const Fr& s, DevBuf& jac, DevBuf& multbuf, DevBuf& tab) {
+int32_t fold_g2_table(Engine* e, hipStream_t st, const G2A* hi, const G2A* lo, size_t half, const Fr& s, DevBuf& jac) {
     constexpr int M = 4;
     const size_t qstride = (half + 63) & ~(size_t)63;
     int32_t rc;
-    if ((rc = multbuf.reserve((size_t)M * half * sizeof(G2A))) || (rc = tab.reserve((size_t)4 * M * G2A_CHUNKS * qstride * sizeof(uint4))) ||
-        (rc = jac.reserve((size_t)(M - 1) * half * sizeof(G2J)))) return rc;
-    G2A* mult = multbuf.as<G2A>();
+    if ((rc = e->fold_mult.reserve((size_t)M * half * sizeof(G2A))) || (rc = e->fold_tab.reserve((size_t)4 * M * G2A_CHUNKS * qstride * sizeof(uint4))) ||
+        (rc = e->fold_jac2.reserve((size_t)(M - 1) * half * sizeof(G2J))) || (rc = jac.reserve(half * sizeof(G2J)))) return rc;
+    e->tab_owner = nullptr;                                     // whatever round-0 tables were there are overwritten
+    G2A* mult = e->fold_mult.as<G2A>();
     HIPCHK(hipMemcpyAsync(mult, hi, half * sizeof(G2A), hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_odd_multiples<Fp2>), dim3(nblk(half, 64)), dim3(64), 0, st, hi, (uint32_t)half, M, jac.as<G2J>());
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_odd_multiples<Fp2>), dim3(nblk(half, 64)), dim3(64), 0, st, hi, (uint32_t)half, M, e->fold_jac2.as<G2J>());
     HIPCHK(hipGetLastError());
-    if ((rc = e->normalize_dev<Fp2>(jac.as<G2J>(), (size_t)(M - 1) * half, mult + half, st)) != RIPP_OK) return rc;
-    hipLaunchKernelGGL(k_g2_tab_images, dim3(nblk(half, 64), M), dim3(64), 0, st, mult, (uint32_t)half, M, tab.as<uint4>(), qstride);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab<GlsDigits, 4>), dim3(nblk(half, 64)), dim3(64), 0, st, tab.as<uint4>(), qstride, M, lo, (uint32_t)half, gls_wnaf(s, 4), jac.as<G2J>());
+    if ((rc = e->normalize_dev<Fp2>(e->fold_jac2.as<G2J>(), (size_t)(M - 1) * half, mult + half, st)) != RIPP_OK) return rc;
+    hipLaunchKernelGGL(k_g2_tab_images, dim3(nblk(half, 64), M), dim3(64), 0, st, mult, (uint32_t)half, M, e->fold_tab.as<uint4>(), qstride);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab<GlsDigits, 4>), dim3(nblk(half, 64)), dim3(64), 0, st, e->fold_tab.as<uint4>(), qstride, M, lo, (uint32_t)half, gls_wnaf(s, 4), jac.as<G2J>());
     HIPCHK(hipGetLastError());
     return RIPP_OK;
 }
@@ -714,9 +721,9 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true)
     const bool pre_vm = j->pre_vm_ready && fits_128(x) && allow_vm; j->pre_vm_ready = false;   // ... or on the VM during this round's host phase
     HIPCHK(hipEventRecord(e->ev_fork, e->stream));
     HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
-    const bool tab = j->tab_ready && fits_128(x); j->tab_ready = false;        // ... with the odd-multiple tables of four bases
+    const bool tab = j->tab_ready && e->tab_owner == j && fits_128(x); j->tab_ready = false;        // ... with the odd-multiple tables of four bases
     if (tab)
-        hipLaunchKernelGGL(k_fold_g1_tab, dim3(nblk(half, 256)), dim3(256), 0, e->stream2, j->tab1.as<G1A>(), (int)FOLD_TAB_M, a, (uint32_t)half, split32_wnaf(x), j->jac1.as<G1J>());
+        hipLaunchKernelGGL(k_fold_g1_tab, dim3(nblk(half, 256)), dim3(256), 0, e->stream2, e->fold_tab1.as<G1A>(), (int)FOLD_TAB_M, a, (uint32_t)half, split32_wnaf(x), j->jac1.as<G1J>());
     else if (pre)
         hipLaunchKernelGGL(k_fold_g1_two, dim3(nblk(half, 256)), dim3(256), 0, e->stream2, a + half, j->a_pow.as<G1A>(), a, (uint32_t)half, split64_digits(x), j->jac1.as<G1J>());
     else if (pre_vm) {
@@ -735,7 +742,7 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_combine<Fp2>), dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VmCurve<Fp2>::SLOTS * sizeof(Fp), e->stream, j->parts2.as<G2J>(), 8, b, (uint32_t)half, j->jac2.as<G2J>());
     } else
     if (tab) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab<Wnaf16, 16>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, j->tab2.as<uint4>(), j->tab2_stride, (int)FOLD_TAB_M, b, (uint32_t)half, gls16_wnaf(x_inv), j->jac2.as<G2J>());
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab<Wnaf16, 16>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, e->fold_tab.as<uint4>(), j->tab2_stride, (int)FOLD_TAB_M, b, (uint32_t)half, gls16_wnaf(x_inv), j->jac2.as<G2J>());
     } else
     if (pre) {
         if ((rc = e->qtab.reserve(8 * G2A_CHUNKS * qstride * sizeof(uint4))) != RIPP_OK) return rc;
@@ -751,7 +758,7 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true)
         hipLaunchKernelGGL(k_fold_g2_gls_split, dim3(nblk(half, 64), 4), dim3(64), 0, e->stream, b + half, (uint32_t)half, gls_digits(x_inv), e->qtab.as<G2J>());
         hipLaunchKernelGGL(k_fold_g2_combine, dim3(nblk(half, 64)), dim3(64), 0, e->stream, e->qtab.as<G2J>(), b, (uint32_t)half, j->jac2.as<G2J>());
     } else if (fold_g2_table_pays(e, half)) {
-        if ((rc = fold_g2_table(e, e->stream, b + half, b, half, x_inv, j->jac2, j->mult2, j->tab2)) != RIPP_OK) return rc;
+        if ((rc = fold_g2_table(e, e->stream, b + half, b, half, x_inv, j->jac2)) != RIPP_OK) return rc;
     } else {
         hipLaunchKernelGGL(k_fold_g2_gls, dim3(nblk(half, 64)), dim3(64), 0, e->stream, b + half, b, (uint32_t)half, gls_digits(x_inv), e->qtab.as<uint4>(), qstride, j->jac2.as<G2J>());
     }
@@ -1085,7 +1092,8 @@ API int32_t ripp_sipp_job_create(const ripp_g1a* a, const ripp_g2a* b, const rip
 API void ripp_sipp_job_destroy(ripp_sipp_job* j) {
     if (!j) return; LOCK;
     if (j->hash_thread.joinable()) j->hash_thread.join();
-    for (DevBuf* b : {&j->a0, &j->b0, &j->r0, &j->a, &j->b, &j->a_next, &j->b_next, &j->jac1, &j->jac2, &j->a_pow, &j->b_pow, &j->a_pow_h, &j->b_pow_h, &j->parts1, &j->parts2, &j->tab1, &j->mult2, &j->tab2}) b->release();
+    for (DevBuf* b : {&j->a0, &j->b0, &j->r0, &j->a, &j->b, &j->a_next, &j->b_next, &j->jac1, &j->jac2, &j->a_pow, &j->b_pow, &j->a_pow_h, &j->b_pow_h, &j->parts1, &j->parts2}) b->release();
+    if (g_engine && g_engine->tab_owner == j) g_engine->tab_owner = nullptr;
     delete j;
 }
 API int32_t ripp_sipp_job_begin(ripp_sipp_job* j) { LOCK; ENGINE; if (!j) return RIPP_ERR_ARG; return job_begin(e, j); }
