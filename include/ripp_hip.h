@@ -10,6 +10,12 @@
  *   `Fp384.0.0` / `Fp256.0.0`, so the shim copies limbs without arithmetic.
  *   affine infinity == (0, 0); Jacobian infinity == Z = 0.
  *
+ * Group elements are elements of G1 / G2 PROPER (the prime-order subgroups), which is what ark-ec's `G1Affine` / `G2Affine` values
+ * are after `deserialize_*` with validation or as outputs of group arithmetic.  The G2 folds, the MSMs and the table folds use the
+ * curve endomorphisms (GLV on G1, psi on G2), which equal the corresponding scalar multiples only on those subgroups; a point that is
+ * merely on the curve (`new_unchecked`) gives the reference's value only on SIPP's G1 side, which uses plain arithmetic throughout.
+ * The deserialisers of section "wire format" reject such points like arkworks does.
+ *
  * Status codes: 0 ok, 1 message length mismatch (InnerProductError::MessageLengthInvalid,
  * inner_products/src/lib.rs:65-70), 2 length not a power of two (the asserts at sipp/src/lib.rs:48-53),
  * 3 HIP runtime / no device, 4 bad argument.  Nothing throws or aborts.  There is NO CPU fallback: every compute
