@@ -13,7 +13,7 @@
  * Group elements are elements of G1 / G2 PROPER (the prime-order subgroups), which is what ark-ec's `G1Affine` / `G2Affine` values
  * are after `deserialize_*` with validation or as outputs of group arithmetic.  The G2 folds, the MSMs and the table folds use the
  * curve endomorphisms (GLV on G1, psi on G2), which equal the corresponding scalar multiples only on those subgroups; a point that is
- * merely on the curve (`new_unchecked`) gives the reference's value only on SIPP's G1 side, which uses plain arithmetic throughout.
+ * merely on the curve (`new_unchecked`) gives the reference's value only on the G1 side of the SIPP prover, which uses plain arithmetic throughout.
  * The deserialisers of section "wire format" reject such points like arkworks does.
  *
  * Status codes: 0 ok, 1 message length mismatch (InnerProductError::MessageLengthInvalid,
