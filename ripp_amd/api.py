@@ -175,7 +175,8 @@ def product_of_pairings(a, b):
 def product_of_pairings_with_coeffs(a, b, r):
     """sipp/src/lib.rs:184-217."""
     a, b, r = _c(a, 12), _c(b, 24), _c(r, 4)
-    assert len(a) == len(b) == len(r)
+    if not (len(a) == len(b) == len(r)):
+        raise AssertionError(f"slice lengths differ: {len(a)}, {len(b)}, {len(r)}")
     out = np.zeros(72, dtype=np.uint64)
     _check(lib().ripp_pairing_product_coeffs_a(_p(a), _p(b), _p(r), ctypes.c_size_t(len(a)), _p(out)))
     return out
@@ -295,7 +296,8 @@ class SIPP:
     @staticmethod
     def prove(a, b, r, value):
         a, b, r = _c(a, 12), _c(b, 24), _c(r, 4)
-        assert len(a) == len(b), "assert_eq!(a.len(), b.len())"
+        if not (len(a) == len(b) == len(r)):      # the C side reads n elements of each: never let a short slice through
+            raise AssertionError(f"assert_eq!(a.len(), b.len()) / r.len(): {len(a)}, {len(b)}, {len(r)}  (sipp/src/lib.rs:48-49)")
         n = len(a)
         if n == 0 or n & (n - 1):
             raise AssertionError("vector length must be a power of two (sipp/src/lib.rs:48-53)")
@@ -316,7 +318,11 @@ class SIPP:
     @staticmethod
     def verify(a, b, r, claimed_value, proof):
         a, b, r = _c(a, 12), _c(b, 24), _c(r, 4)
+        if not (len(a) == len(b) == len(r)):      # sipp/src/lib.rs:116-117; the C side reads len(a) elements of b and r
+            raise AssertionError(f"assert_eq!(a.len(), b.len()) / r.len(): {len(a)}, {len(b)}, {len(r)}")
         proof = np.ascontiguousarray(proof, dtype=np.uint64).reshape(-1, 72)
+        if len(proof) % 2:
+            raise ValueError("a SIPP proof is a list of (z_l, z_r) pairs: odd number of GT elements")
         claimed_value = np.ascontiguousarray(claimed_value, dtype=np.uint64).reshape(72)
         acc = ctypes.c_int32(0)
         _check(lib().ripp_sipp_verify(_p(a), _p(b), _p(r), ctypes.c_size_t(len(a)), _p(claimed_value), _p(proof), ctypes.c_size_t(len(proof) // 2), ctypes.byref(acc)))

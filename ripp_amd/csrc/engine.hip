@@ -102,6 +102,7 @@ struct Engine {
     int device = -1;
     hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: the G1 half of a fold runs beside the G2 half
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;         // phase stopwatch (scale / fold), reused by every call
     int n_simd = 1024;
     // scratch
     DevBuf lines, partA, partB, jacG1, jacG2, tmpA, tmpB, tmpR, affG1, affG2;
@@ -130,6 +131,12 @@ struct Engine {
     size_t gls_split_max = (size_t)1 << 14;                               // rounds with <= this many outputs use the 4-lane GLS fold
     size_t max_pairs_per_batch = (size_t)1 << 19;                        // lines buffer cap: 2^19 pairs * 19.6 KB = 10.3 GB
     ripp_stats stats{};
+    // run-time switches: read from the environment ONCE per C-ABI call (get_engine), never inside round loops
+    struct Switches { bool no_vm = false, no_precompute = false, no_fold_tables = false, no_msm_glv = false; } sw;
+    void refresh_switches() {
+        sw.no_vm = std::getenv("RIPP_NO_VM") != nullptr; sw.no_precompute = std::getenv("RIPP_NO_PRECOMPUTE") != nullptr;
+        sw.no_fold_tables = std::getenv("RIPP_NO_FOLD_TABLES") != nullptr; sw.no_msm_glv = std::getenv("RIPP_NO_MSM_GLV") != nullptr;
+    }
 
     int32_t init(int dev) {
         int n = 0;
@@ -142,6 +149,7 @@ struct Engine {
         HIPCHK(hipStreamCreateWithFlags(&stream4, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&ev_join4, hipEventDisableTiming));
         HIPCHK(hipStreamCreateWithFlags(&stream5, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&ev_join5, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_join3, hipEventDisableTiming));
+        HIPCHK(hipEventCreate(&ev_t0)); HIPCHK(hipEventCreate(&ev_t1));
         { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n_simd = pr.multiProcessorCount * 4; }
         auto env_sz = [](const char* k, size_t& v) { if (const char* s = std::getenv(k)) v = (size_t)std::strtoull(s, nullptr, 10); };
         env_sz("RIPP_VM_LINES_MAX", vm_lines_max); env_sz("RIPP_VM_FOLD_MAX", vm_fold_max); env_sz("RIPP_VM_TREE_MAX", vm_tree_max); env_sz("RIPP_GLS_SPLIT_MAX", gls_split_max); env_sz("RIPP_MSM_VM_MERGE_MAX", msm_vm_merge_max); env_sz("RIPP_FOLD_TAB_MIN", fold_tab_min);
@@ -160,6 +168,7 @@ struct Engine {
         if (stream) (void)hipStreamDestroy(stream);
         if (stream2) (void)hipStreamDestroy(stream2);
         if (ev_fork) (void)hipEventDestroy(ev_fork); if (ev_join) (void)hipEventDestroy(ev_join); if (ev_join3) (void)hipEventDestroy(ev_join3);
+        if (ev_t0) (void)hipEventDestroy(ev_t0); if (ev_t1) (void)hipEventDestroy(ev_t1);
     }
     int32_t ensure_pinned_rows(size_t rows) {
         if (rows <= pinned_rows_cap) return RIPP_OK;
@@ -202,7 +211,7 @@ struct Engine {
     template <class F> int32_t msm_launch(MsmScratch& ms, hipStream_t st, const Affine<F>* bases, const Fr* scalars, size_t n) {
         if (!ms.host_out) HIPCHK(hipHostMalloc(&ms.host_out, sizeof(G2J), hipHostMallocDefault));
         if (n == 0) { *reinterpret_cast<Jac<F>*>(ms.host_out) = jac_inf<F>(); return RIPP_OK; }
-        static const bool no_glv = std::getenv("RIPP_NO_MSM_GLV") != nullptr;
+        const bool no_glv = sw.no_msm_glv;
         const size_t nreal = n;
         const MsmPlan p = msm_plan(nreal, no_glv ? 1 : std::is_same<F, Fp>::value ? 2 : 4);
         n = p.n;                                                                  // terms (2 * nreal in the GLV form, 4 * nreal in the GLS form)
@@ -222,7 +231,7 @@ struct Engine {
         hipLaunchKernelGGL(k_msm_scatter, dim3(nblk(n, 256)), dim3(256), 0, st, ms.digits.as<uint16_t>(), p, ms.cursor.as<uint32_t>(), ms.sorted.as<uint32_t>());
         // RIPP_NO_VM keeps every stage on single lanes in Jacobian coordinates (the A/B and fallback form); otherwise the stages after
         // the gather work on homogeneous coordinates and the ones with few points run on the field VM (msm.hpp)
-        static const bool hom = std::getenv("RIPP_NO_VM") == nullptr;
+        const bool hom = !sw.no_vm;
         const size_t vm_lds = 4 * VM_EPW * VmCurve<F>::SLOTS * sizeof(Fp);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_slot_sum<F>), dim3(nblk(max_slots, 64), p.nwin), dim3(64), 0, st, bases, p, ms.hist.as<uint32_t>(), ms.offs.as<uint32_t>(),
                            ms.slotoffs.as<uint32_t>(), ms.spw.as<uint32_t>(), ms.sorted.as<uint32_t>(), ms.slots.as<Jac<F>>(), max_slots, hom);
@@ -283,7 +292,7 @@ struct Engine {
             {
                 PairSets ps{}; for (int p = 0; p < nprod; ++p) { ps.a[p] = a[p] + off; ps.b[p] = b[p] + off; }
                 if ((rc = mark(ev_lines, true)) != RIPP_OK) return rc;
-                if (m * nprod <= vm_lines_max && !std::getenv("RIPP_NO_VM"))
+                if (m * nprod <= vm_lines_max && !sw.no_vm)
                     hipLaunchKernelGGL(k_vm_miller_lines, dim3(nblk(m, 4 * VM_EPW), nprod), dim3(256), 4 * VM_EPW * VM_LINES_SLOTS * sizeof(Fp), stream, ps, (uint32_t)m, lines.as<uint4>(), stride);
                 else
                     hipLaunchKernelGGL(k_miller_lines, dim3(nblk(m, 256), nprod), dim3(256), 0, stream, ps, (uint32_t)m, lines.as<uint4>(), stride);
@@ -308,7 +317,7 @@ struct Engine {
                 // radix 4 while the level still fills the chip, radix 2 (one dependent Fp12 product per level) once it is latency-bound
                 const int R = ((size_t)T * nrows > (size_t)n_simd * 64) ? 4 : 2;
                 const uint32_t Tout = (T + R - 1) / R;
-                if (R == 2 && (size_t)Tout * nrows <= vm_tree_max && !std::getenv("RIPP_NO_VM"))
+                if (R == 2 && (size_t)Tout * nrows <= vm_tree_max && !sw.no_vm)
                     hipLaunchKernelGGL(k_vm_fp12_tree, dim3(nblk(Tout, 2 * VM_EPW), (unsigned)nrows), dim3(128), 2 * VM_EPW * VM_F12_SLOTS * sizeof(Fp), stream, cur, T, nxt, Tout);
                 else
                 hipLaunchKernelGGL(k_fp12_tree, dim3(nblk(Tout, 64), (unsigned)nrows), dim3(64), 0, stream, cur, T, nxt, Tout, R);
@@ -332,6 +341,7 @@ int32_t get_engine(Engine** out) {
         g_engine = e;
     }
     if (hipSetDevice(g_engine->device) != hipSuccess) { set_err("hipSetDevice failed"); return RIPP_ERR_DEVICE; }
+    g_engine->refresh_switches();
     *out = g_engine; return RIPP_OK;
 }
 
@@ -588,7 +598,7 @@ int32_t job_begin(Engine* e, ripp_sipp_job* j) {
     e->stats = ripp_stats{};
     j->t_begin = now_ms();
     // a_i <- r_i * a_i, normalised (sipp/src/lib.rs:61-66); b copied (:67)
-    hipEvent_t t0, t1; HIPCHK(hipEventCreate(&t0)); HIPCHK(hipEventCreate(&t1));
+    hipEvent_t t0 = e->ev_t0, t1 = e->ev_t1;
     HIPCHK(hipEventRecord(t0, e->stream));
     hipLaunchKernelGGL(k_scale_g1, dim3(nblk(n, 256)), dim3(256), 0, e->stream, j->a0.as<G1A>(), j->r0.as<Fr>(), (uint32_t)n, j->jac1.as<G1J>());
     HIPCHK(hipGetLastError());
@@ -597,7 +607,6 @@ int32_t job_begin(Engine* e, ripp_sipp_job* j) {
     HIPCHK(hipEventRecord(t1, e->stream));
     if ((rc = e->sync()) != RIPP_OK) return rc;
     float ms = 0; (void)hipEventElapsedTime(&ms, t0, t1); e->stats.scale_ms += ms;
-    (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
     j->len = n; j->seeded = false; j->world = j->world0;
     return RIPP_OK;
 }
@@ -621,7 +630,7 @@ int32_t job_round_partials(Engine* e, ripp_sipp_job* j, Fp12* rows /* [2][68] */
 // round's pairing products so that they run during the host's final exponentiations.
 int32_t job_precompute_vm(Engine* e, ripp_sipp_job* j) {
     const size_t half = j->len / 2;
-    if (half == 0 || half > e->vm_fold_max || std::getenv("RIPP_NO_VM") || std::getenv("RIPP_NO_PRECOMPUTE")) return RIPP_OK;
+    if (half == 0 || half > e->vm_fold_max || e->sw.no_vm || e->sw.no_precompute) return RIPP_OK;
     int32_t rc;
     if ((rc = j->a_pow_h.reserve(half * sizeof(G1J))) || (rc = j->b_pow_h.reserve(half * sizeof(G2J))) || (rc = j->parts1.reserve(2 * half * sizeof(G1J))) || (rc = j->parts2.reserve(8 * half * sizeof(G2J)))) return rc;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_pow2<Fp>), dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VmCurve<Fp>::SLOTS * sizeof(Fp), e->stream2, j->a.as<G1A>() + half, (uint32_t)half, 64, j->a_pow_h.as<G1J>());
@@ -633,9 +642,9 @@ int32_t job_precompute_vm(Engine* e, ripp_sipp_job* j) {
 
 int32_t job_precompute_round0(Engine* e, ripp_sipp_job* j) {
     const size_t half = j->len / 2;
-    if (half < ((size_t)1 << 16) || j->digest_ready.load() || std::getenv("RIPP_NO_PRECOMPUTE")) return RIPP_OK;
+    if (half < ((size_t)1 << 16) || j->digest_ready.load() || e->sw.no_precompute) return RIPP_OK;
     int32_t rc;
-    const bool tables = std::getenv("RIPP_NO_FOLD_TABLES") == nullptr;
+    const bool tables = !e->sw.no_fold_tables;
     const size_t qstride = (half + 63) & ~(size_t)63;
     if ((rc = j->a_pow.reserve(half * sizeof(G1A))) || (rc = j->b_pow.reserve(half * sizeof(G2A))) || (rc = j->jac1.reserve(half * sizeof(G1J))) || (rc = j->jac2.reserve(half * sizeof(G2J)))) return rc;
     j->tab_ready = false;
@@ -686,7 +695,7 @@ int32_t job_precompute_round0(Engine* e, ripp_sipp_job* j) {
 // G2 fold of a throughput-bound round over in-round tables: odd multiples {1,3,5,7} of every hi element (batch-normalised: the inversion
 // is shared by 16 points) and their psi images, then width-4 wNAF strings -- 65 doublings + ~52 additions instead of 65 + ~87 for
 // ~350 Fp products of table work per element.  Leaves the Jacobian result in jac (first `half` entries).
-bool fold_g2_table_pays(const Engine* e, size_t half) { return half >= e->fold_tab_min && half > e->gls_split_max && !std::getenv("RIPP_NO_FOLD_TABLES"); }
+bool fold_g2_table_pays(const Engine* e, size_t half) { return half >= e->fold_tab_min && half > e->gls_split_max && !e->sw.no_fold_tables; }
 int32_t fold_g2_table(Engine* e, hipStream_t st, const G2A* hi, const G2A* lo, size_t half, const Fr& s, DevBuf& jac) {
     constexpr int M = 4;
     const size_t qstride = (half + 63) & ~(size_t)63;
@@ -709,13 +718,13 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true)
     const size_t half = j->len / 2;
     int32_t rc;
     const Fr x_inv = inv(x);                                                        // sipp/src/lib.rs:94
-    hipEvent_t t0, t1; HIPCHK(hipEventCreate(&t0)); HIPCHK(hipEventCreate(&t1));
+    hipEvent_t t0 = e->ev_t0, t1 = e->ev_t1;
     HIPCHK(hipEventRecord(t0, e->stream));
     G1A* a = j->a.as<G1A>(); G2A* b = j->b.as<G2A>();
     const size_t qstride = (half + 63) & ~(size_t)63;
     if ((rc = e->qtab.reserve(4 * G2A_CHUNKS * qstride * sizeof(uint4))) != RIPP_OK) return rc;
     // G1 half on stream2, G2 half on the main stream (small rounds leave most of the chip idle otherwise)
-    const bool use_vm = allow_vm && half <= e->vm_fold_max && !std::getenv("RIPP_NO_VM");
+    const bool use_vm = allow_vm && half <= e->vm_fold_max && !e->sw.no_vm;
     if (use_vm) { if ((rc = e->vm_flag.reserve(sizeof(uint32_t))) != RIPP_OK) return rc; HIPCHK(hipMemsetAsync(e->vm_flag.p, 0, sizeof(uint32_t), e->stream)); }
     const bool pre = j->pre_ready && fits_128(x); j->pre_ready = false;      // second bases prepared in the hash window (job_precompute_round0)
     const bool pre_vm = j->pre_vm_ready && fits_128(x) && allow_vm; j->pre_vm_ready = false;   // ... or on the VM during this round's host phase
@@ -768,7 +777,6 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true)
     HIPCHK(hipEventRecord(t1, e->stream));
     if ((rc = e->sync()) != RIPP_OK) return rc;
     float ms = 0; (void)hipEventElapsedTime(&ms, t0, t1); e->stats.fold_ms += ms;
-    (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
     if (use_vm) {   // an addition met T = +-Q (lambda == 0): the VM formulas do not cover it -> redo with the scalar kernels
         uint32_t flag = 0; HIPCHK(hipMemcpy(&flag, e->vm_flag.p, sizeof flag, hipMemcpyDeviceToHost));
         if (flag) return job_fold(e, j, x, false);
@@ -1017,6 +1025,8 @@ API int32_t ripp_sipp_verify(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr
     auto gt_pow = [](const Fp12& x, const Fr& k) { const Fr c = from_mont(k); Fp12 acc = Fp12::one(); bool st = false;
         for (int i = 255; i >= 0; --i) { if (st) acc = sqr(acc); if ((c.l[i >> 5] >> (i & 31)) & 1u) { acc = st ? mul(acc, x) : x; st = true; } } return acc; };
     std::vector<std::future<Fp12>> pw;
+    // the tasks below read P / xs / xinv by reference: every exit path (the HIP error returns included) waits for them first
+    struct Drain { std::vector<std::future<Fp12>>& v; ~Drain() { for (auto& f : v) if (f.valid()) f.wait(); } } drain{pw};
     for (size_t j = 0; j < lg; ++j) {
         pw.push_back(host_pool().submit([&, j]() { return gt_pow(P[2 * j], xs[j]); }));
         pw.push_back(host_pool().submit([&, j]() { return gt_pow(P[2 * j + 1], xinv[j]); }));
@@ -1075,15 +1085,23 @@ static int32_t sipp_job_create_impl(const ripp_g1a* a, const ripp_g2a* b, const 
         job_start_hash(j, v); j->hash_prestarted = true;
     }
     int32_t rc;
-    if ((rc = j->a0.reserve(n_local * sizeof(G1A))) || (rc = j->b0.reserve(n_local * sizeof(G2A))) || (rc = j->r0.reserve(n_local * sizeof(Fr)))) { if (j->hash_thread.joinable()) j->hash_thread.join(); delete j; return rc; }
-    HIPCHK(hipMemcpyAsync(j->a0.p, a, n_local * sizeof(G1A), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(j->b0.p, b, n_local * sizeof(G2A), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(j->r0.p, r, n_local * sizeof(Fr), hipMemcpyHostToDevice, e->stream));
+    if ((rc = j->a0.reserve(n_local * sizeof(G1A))) || (rc = j->b0.reserve(n_local * sizeof(G2A))) || (rc = j->r0.reserve(n_local * sizeof(Fr)))) { if (j->hash_thread.joinable()) j->hash_thread.join(); for (DevBuf* d : {&j->a0, &j->b0, &j->r0}) d->release(); delete j; return rc; }
+    {   // on failure: join the hash thread (it reads the CALLER's buffers in borrow mode) and free the job before returning
+        hipError_t he = hipMemcpyAsync(j->a0.p, a, n_local * sizeof(G1A), hipMemcpyHostToDevice, e->stream);
+        if (he == hipSuccess) he = hipMemcpyAsync(j->b0.p, b, n_local * sizeof(G2A), hipMemcpyHostToDevice, e->stream);
+        if (he == hipSuccess) he = hipMemcpyAsync(j->r0.p, r, n_local * sizeof(Fr), hipMemcpyHostToDevice, e->stream);
+        if (he != hipSuccess) {
+            set_err(std::string("statement upload: ") + hipGetErrorString(he));
+            if (j->hash_thread.joinable()) j->hash_thread.join();
+            for (DevBuf* d : {&j->a0, &j->b0, &j->r0}) d->release();
+            delete j; return RIPP_ERR_DEVICE;
+        }
+    }
     if (world == 1 && !borrow) {   // single-GPU jobs hash their own statement; keep the host image
         j->ha.resize(n_local); j->hb.resize(n_local); j->hr.resize(n_local);
         std::memcpy(j->ha.data(), a, n_local * sizeof(G1A)); std::memcpy(j->hb.data(), b, n_local * sizeof(G2A)); std::memcpy(j->hr.data(), r, n_local * sizeof(Fr));
     }
-    if ((rc = e->sync())) { if (j->hash_thread.joinable()) j->hash_thread.join(); delete j; return rc; }
+    if ((rc = e->sync())) { if (j->hash_thread.joinable()) j->hash_thread.join(); for (DevBuf* d : {&j->a0, &j->b0, &j->r0}) d->release(); delete j; return rc; }
     *job = j; return RIPP_OK;
 }
 API int32_t ripp_sipp_job_create(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr* r, size_t n_local, int32_t rank, int32_t world, ripp_sipp_job** job) {

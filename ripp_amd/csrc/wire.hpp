@@ -59,10 +59,18 @@ inline bool get_fr(const uint8_t* in, Fr& out) {
     if (!borrow) return false;
     out = to_mont(c); return true;
 }
+// `PairingOutput<P>::check` (ark-ec 0.4 pairing.rs, Valid impl; [ark-mem]): `self.0.pow(P::ScalarField::characteristic()).is_one()` --
+// an Fq12 that is not in the order-r subgroup (zero included: 0^r = 0) is InvalidData.  Plain square-and-multiply: the value is untrusted,
+// so the cyclotomic squaring formulas do not apply.  ~0.5 ms per element on the host; arkworks pays the same exponentiation.
+inline bool gt_in_subgroup(const Fp12& f) {
+    Fp12 acc = f;                                                   // r has bit 254 set
+    for (int i = 253; i >= 0; --i) { acc = sqr(acc); if ((FrParams::mod(i >> 5) >> (i & 31)) & 1u) acc = mul(acc, f); }
+    return acc == Fp12::one();
+}
 inline bool get_gt(const uint8_t* in, Fp12& f) {
     Fp2* c[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
     for (int i = 0; i < 6; ++i) if (!get_fp_le(in + 96 * i, c[i]->c0) || !get_fp_le(in + 96 * i + 48, c[i]->c1)) return false;
-    return true;
+    return gt_in_subgroup(f);
 }
 // square roots (p = 3 mod 4)
 inline bool fp_sqrt(const Fp& a, Fp& r) {

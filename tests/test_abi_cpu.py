@@ -52,6 +52,25 @@ def test_length_error_is_reported_before_touching_the_device(hiplib):
         R.MultiexponentiationInnerProductG1.inner_product(np.zeros((3, 18), dtype=np.uint64), np.zeros((2, 4), dtype=np.uint64))
 
 
+def test_sipp_slice_length_mismatch_never_reaches_the_library(hiplib):
+    """SIPP.prove / SIPP.verify / product_of_pairings_with_coeffs check len(a) == len(b) == len(r) (and an even proof length) on the
+    Python side: the C entry points take ONE n and would read past a short slice (sipp/src/lib.rs:48-49, 116-117)."""
+    import ripp_amd as R
+    z = lambda n, c: np.zeros((n, c), dtype=np.uint64)
+    gt = np.zeros(72, dtype=np.uint64)
+    for na, nb, nr in ((4, 2, 4), (4, 4, 2), (2, 4, 4)):
+        with pytest.raises(AssertionError):
+            R.SIPP.prove(z(na, 12), z(nb, 24), z(nr, 4), gt)
+        with pytest.raises(AssertionError):
+            R.SIPP.verify(z(na, 12), z(nb, 24), z(nr, 4), gt, np.zeros((4, 72), dtype=np.uint64))
+        with pytest.raises(AssertionError):
+            R.product_of_pairings_with_coeffs(z(na, 12), z(nb, 24), z(nr, 4))
+    with pytest.raises(ValueError):
+        R.SIPP.verify(z(4, 12), z(4, 24), z(4, 4), gt, np.zeros((3, 72), dtype=np.uint64))
+    with pytest.raises(AssertionError):
+        R.SippJob(z(4, 12), z(4, 24), z(2, 4))
+
+
 def test_host_helpers_match_oracle(hiplib, orc, vectors):
     import ripp_amd as R
     a, b = orc.gen_g1(77, 3), orc.gen_g2(88, 3)
@@ -104,3 +123,15 @@ def test_header_is_plain_c_and_demo_fails_loudly_without_device(tmp_path):
         pytest.skip("a HIP device is present; the GPU variant of this test covers the run")
     p = subprocess.run([exe, "4"], capture_output=True, text=True)
     assert p.returncode == 2 and "no CPU fallback" in p.stderr
+
+
+def test_library_point_encoding_matches_public_literals(hiplib, orc):
+    """The library's own (host-side) serialisers against the published zcash / IETF images of the BLS12-381 generators -- literals, not
+    model output (tests/test_oracle_cpu.py holds the citations)."""
+    import ripp_amd as R
+    from test_oracle_cpu import G1_COMPRESSED, G2_COMPRESSED, G1_X, G1_Y, G2_X0, G2_X1, G2_Y0, G2_Y1
+    g1, g2 = orc.gen_g1(1, 1)[0], orc.gen_g2(1, 1)[0]
+    assert R.ser_g1_compressed(g1).hex() == G1_COMPRESSED and R.ser_g2_compressed(g2).hex() == G2_COMPRESSED
+    assert R.ser_g1(g1).hex() == "%096x%096x" % (G1_X, G1_Y)
+    assert R.ser_g2(g2).hex() == "%096x%096x%096x%096x" % (G2_X1, G2_X0, G2_Y1, G2_Y0)
+    assert R.ser_g1_compressed(np.zeros(12, dtype=np.uint64)).hex() == "c0" + "00" * 47      # infinity: compression + infinity bits

@@ -100,6 +100,11 @@ def test_deserialisers_reject_malformed_images(api, tipp_proof):
     bad(lambda b: b.__setitem__(off_base_a, b[off_base_a] & 0x7f))     # compression flag cleared
     bad(lambda b: b.__setitem__(slice(8, 56), b"\xff" * 48))          # Fp coefficient >= p inside a GT
     bad(lambda b: b.__setitem__(8 + 2 * 576, 2))                      # IdentityOutput length != 1
+    # PairingOutput::check (ark-ec 0.4): an Fq12 outside the order-r subgroup is rejected -- the constant 2, zero, and a
+    # cyclotomic-looking value that is just another step's coefficient vector permuted
+    bad(lambda b: b.__setitem__(slice(8, 8 + 576), (2).to_bytes(48, "little") + bytes(528)))
+    bad(lambda b: b.__setitem__(slice(8, 8 + 576), bytes(576)))
+    bad(lambda b: b.__setitem__(slice(8, 8 + 576), bytes(b[8 + 96:8 + 576]) + bytes(b[8:8 + 96])))
     # an x with no point on the curve / a point outside the prime-order subgroup
     x = 0
     while True:
