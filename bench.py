@@ -25,7 +25,47 @@ sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_PAIR = 288          # one affine G1 (96 B) + one affine G2 (192 B) read once
 HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-FP_MUL_PEAK_G = 59.6              # measured chip rate of the 381-bit Montgomery multiplier (G products/s, tools/ubench/fpbench.hip)
+# Integer-ALU roofs for the 381-bit Montgomery product (12 x 32-bit limbs: 288 v_mad_u64_u32 per product):
+#   "mad_issue": the hardware's measured v_mad_u64_u32 issue rate, 34.7 T lane-MAD/s (profiles/r01_ubench_valu_rates.txt) / 288
+#   "multiplier": the production multiplier's own measured chip rate (every MAD is followed by the v_addc_co_u32 that captures its
+#                 carry: 578 issue slots per product), profiles/r02_fpbench_production.txt
+MAD_ISSUE_PEAK_G = 34.72e3 / 288
+FP_MUL_PEAK_G = 59.6
+
+
+def csrc_sha256():
+    """Fingerprint of the kernel sources: a committed PMC profile is only quoted on the bench line when it was taken on THIS code."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "ripp_amd", "csrc")
+    for dirpath, _, files in sorted(os.walk(d)):
+        for f in sorted(files):
+            if f.endswith((".hip", ".hpp", ".inc")):
+                h.update(f.encode()); h.update(open(os.path.join(dirpath, f), "rb").read())
+    return h.hexdigest()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N FRESH rank processes through torch.distributed.run (this process has not
+    touched the GPU -- nothing is re-exec'd after HIP initialisation) and relay rank 0's JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--log-n", str(args.log_n), "--cpu-log-n", str(args.cpu_log_n)]
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0"); env.setdefault("OMP_NUM_THREADS", "1")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line:
+        print(line, flush=True)
+    sys.exit(p.returncode if p.returncode or line else 1)
 
 
 def cpu_baseline(log_n_sample):
@@ -56,8 +96,8 @@ def main():
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch N > 1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N")
+        if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+            self_launch(args)                                 # does not return
         args.gpus = world
     n = 1 << args.log_n
 
@@ -67,9 +107,12 @@ def main():
     from ripp_amd.sharded import ShardedSippProver, TorchComm, SingleComm
 
     # test hooks (used on 1-GPU boxes to exercise the N > 1 control flow): all ranks on device 0, gloo transport
-    if os.environ.get("RIPP_BENCH_SINGLE_DEVICE"):
+    single_dev = bool(os.environ.get("RIPP_BENCH_SINGLE_DEVICE"))
+    if single_dev:
         local_rank = 0
-    backend = os.environ.get("RIPP_BENCH_BACKEND", "nccl")
+    backend = os.environ.get("RIPP_BENCH_BACKEND", "gloo" if single_dev else "nccl")    # RCCL needs one device per rank
+    if world > 1 and not single_dev and torch.cuda.device_count() < world:
+        sys.exit(f"bench.py --gpus {world}: only {torch.cuda.device_count()} device(s) visible (RIPP_BENCH_SINGLE_DEVICE=1 runs all ranks on device 0 over gloo, for control-flow tests only)")
     torch.cuda.set_device(local_rank)
     R.init(local_rank)
     if world > 1:
@@ -136,13 +179,16 @@ def main():
         k_prod = (stats["kernel_line_products_ms_sum"], stats["kernel_line_products_launches"], stats["pairs_products"], "k_line_products")
         dom = max(k_lines, k_prod, key=lambda k: k[0])
         achieved = (dom[2] * ALG_BYTES_PER_PAIR) / (dom[0] * 1e-3) / 1e9 if dom[0] > 0 else 0.0
-        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE,
-        # separate passes, same workload) -- see profiles/r01_hbm_traffic_pmc.csv.  None when the profile is absent / n differs.
+        # HBM bytes per launch of that kernel from rocprofv3 PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE, separate passes, this
+        # workload; tools/pmc_traffic.py).  Quoted ONLY when the committed profile was taken on exactly these kernel sources
+        # (csrc_sha256 recorded in the profile); null otherwise -- it is a counter measurement, not something a timed run can see.
         traffic = None
         try:
             if args.log_n == 20 and world == 1:
-                tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"].get(dom[3])
-                traffic = tr["bytes_per_launch"] if tr else None
+                prof = json.load(open(os.path.join(ROOT, "profiles", "traffic_current.json")))
+                if prof.get("csrc_sha256") == csrc_sha256():
+                    tr = prof["kernels"].get(dom[3])
+                    traffic = tr["bytes_per_launch"] if tr else None
         except Exception:
             traffic = None
         out = {
@@ -159,8 +205,11 @@ def main():
                          # the roof that actually binds: 381-bit Montgomery products on the VALU.  Algorithmic Fp products per pair of the
                          # kernel (k_line_products: 68 sparse mul_by_014 of 13 Fp2 = 39 Fp products; k_miller_lines: 63 doubling steps of 25
                          # + 5 addition steps of 41) against the multiplier's measured chip rate (profiles/r01_fpbench_cios_baseline.txt).
-                         "int_alu": (lambda fpm: {"unit": "G Fp-mul/s", "achieved": dom[2] * fpm / (dom[0] * 1e-3) / 1e9 if dom[0] > 0 else 0.0, "peak": FP_MUL_PEAK_G,
-                                                  "frac": (dom[2] * fpm / (dom[0] * 1e-3) / 1e9 / FP_MUL_PEAK_G) if dom[0] > 0 else 0.0,
+                         "int_alu": (lambda fpm: {"unit": "G Fp-mul/s", "achieved": dom[2] * fpm / (dom[0] * 1e-3) / 1e9 if dom[0] > 0 else 0.0,
+                                                  "peak": MAD_ISSUE_PEAK_G, "peak_kind": "hardware v_mad_u64_u32 issue rate / 288 MADs per product",
+                                                  "frac": (dom[2] * fpm / (dom[0] * 1e-3) / 1e9 / MAD_ISSUE_PEAK_G) if dom[0] > 0 else 0.0,
+                                                  "multiplier_peak": FP_MUL_PEAK_G,
+                                                  "frac_of_multiplier": (dom[2] * fpm / (dom[0] * 1e-3) / 1e9 / FP_MUL_PEAK_G) if dom[0] > 0 else 0.0,
                                                   "fp_products_per_pair": fpm})(68 * 39 if dom[3] == "k_line_products" else 63 * 25 + 5 * 41),
                          "note": "integer-ALU bound (381-bit Montgomery arithmetic, ~5e3 Fp products per 288 input bytes); see DESIGN.md"},
             "phase_ms": {k: round(v, 3) for k, v in stats.items() if k.endswith("_ms")},

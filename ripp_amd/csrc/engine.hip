@@ -1121,6 +1121,9 @@ API int32_t ripp_sipp_job_round_partials(ripp_sipp_job* j, ripp_gt* partials) {
     if (j->len < 2) { set_err("shard exhausted: gather the remaining elements onto one rank"); return RIPP_ERR_ARG; }
     Fp12 rows[2 * N_LINES];
     int32_t rc = job_round_partials(e, j, rows); if (rc) return rc;
+    // round 0 of a staged (sharded) proof: the challenge needs the digest of the WHOLE statement, which rank 0 is still hashing -- build this
+    // shard's fold tables behind the products, exactly as ripp_sipp_job_prove does on one GPU
+    if (!j->seeded && j->len == j->n_local && (rc = job_precompute_round0(e, j))) return rc;
     if ((rc = job_precompute_vm(e, j))) return rc;          // small rounds: second fold bases on the VM while the ranks exchange and finish the values
     auto fut = host_pool().submit([&rows]() { return miller_combine(rows + N_LINES); });
     const Fp12 ml = miller_combine(rows), mr = fut.get();
