@@ -22,6 +22,7 @@
 #include <vector>
 #include "../../include/ripp_hip.h"
 #include "kernels.hpp"
+#include "line_products.hpp"
 #include "msm.hpp"
 #include "vm.hpp"
 #include "vm_fold2.hpp"
@@ -132,10 +133,11 @@ struct Engine {
     size_t max_pairs_per_batch = (size_t)1 << 19;                        // lines buffer cap: 2^19 pairs * 19.6 KB = 10.3 GB
     ripp_stats stats{};
     // run-time switches: read from the environment ONCE per C-ABI call (get_engine), never inside round loops
-    struct Switches { bool no_vm = false, no_precompute = false, no_fold_tables = false, no_msm_glv = false; } sw;
+    struct Switches { bool no_vm = false, no_precompute = false, no_fold_tables = false, no_msm_glv = false, lp_one_lane = false; } sw;
     void refresh_switches() {
         sw.no_vm = std::getenv("RIPP_NO_VM") != nullptr; sw.no_precompute = std::getenv("RIPP_NO_PRECOMPUTE") != nullptr;
         sw.no_fold_tables = std::getenv("RIPP_NO_FOLD_TABLES") != nullptr; sw.no_msm_glv = std::getenv("RIPP_NO_MSM_GLV") != nullptr;
+        sw.lp_one_lane = std::getenv("RIPP_LP_ONE_LANE") != nullptr;
     }
 
     int32_t init(int dev) {
@@ -302,12 +304,18 @@ struct Engine {
             }
             // stage 2a: T lanes per row
             // one resident batch: rows * T / 64 waves <= SIMDs * RIPP_OCC, so no partially filled second batch
-            uint32_t T = (uint32_t)std::max<size_t>(64, ((size_t)n_simd * RIPP_OCC_PROD / nrows) * 64);
+            // T accumulators per row.  Spill-free form (line_products.hpp): 3 lanes per accumulator, 21 accumulators per wave;
+            // RIPP_LP_ONE_LANE=1 selects the one-lane-per-accumulator kernel (A/B reference).
+            const uint32_t per_wave = sw.lp_one_lane ? 64 : LP_GROUPS_PER_WAVE;
+            uint32_t T = (uint32_t)std::max<size_t>(per_wave, ((size_t)n_simd * RIPP_OCC_PROD / nrows) * per_wave);
             if (T > m) T = (uint32_t)m;
             if ((rc = partA.reserve(nrows * FP12_CHUNKS * (size_t)T * sizeof(uint4))) != RIPP_OK) return rc;
             if ((rc = partB.reserve(nrows * FP12_CHUNKS * (size_t)((T + 1) / 2) * sizeof(uint4))) != RIPP_OK) return rc;
             if ((rc = mark(ev_prod, true)) != RIPP_OK) return rc;
-            hipLaunchKernelGGL(k_line_products, dim3(nblk(T, 64), (unsigned)nrows), dim3(64), 0, stream, lines.as<uint4>(), stride, (uint32_t)m, partA.as<uint4>(), T);
+            if (sw.lp_one_lane)
+                hipLaunchKernelGGL(k_line_products1, dim3(nblk(T, 64), (unsigned)nrows), dim3(64), 0, stream, lines.as<uint4>(), stride, (uint32_t)m, partA.as<uint4>(), T);
+            else
+                hipLaunchKernelGGL(k_line_products, dim3(nblk(T, LP_GROUPS_PER_WAVE), (unsigned)nrows), dim3(64), 0, stream, lines.as<uint4>(), stride, (uint32_t)m, partA.as<uint4>(), T);
             HIPCHK(hipGetLastError());
             if ((rc = mark(ev_prod, false)) != RIPP_OK) return rc;
             stats.pairs_products += m * nprod;

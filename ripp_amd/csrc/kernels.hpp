@@ -51,34 +51,96 @@ __device__ __forceinline__ T load_chunks(const uint4* buf, size_t row, size_t st
 // Pairs with a point at infinity emit the unit line.  Both pairing products of a SIPP round go in ONE launch.
 constexpr int MAX_PRODUCTS = 6;     // pairing products sharing one launch (2 per SIPP round, 6 per GIPA/TIPP round)
 struct PairSets { const G1A* a[MAX_PRODUCTS]; const G2A* b[MAX_PRODUCTS]; };
+// Register discipline of this kernel (it used to spill 273 dwords, ~35 GB of scratch traffic per launch): the steps below are written in
+// a LOW-LIVENESS order pinned with scheduling barriers -- every line coefficient is stored the moment it is complete, P and Q are
+// re-loaded from L2 where they are used instead of being held for 68 steps, and the addition step (5 of 68) parks Y and theta in LDS
+// while they are idle.  The doubling step then needs 249 registers and no scratch at all.
+#define SB() __builtin_amdgcn_sched_barrier(0)
+template <class T> __device__ __forceinline__ const T* opaque(const T* p) { asm volatile("" : "+v"(p)); return p; }   // defeats hoisting: operands are RE-LOADED where used
+// low-liveness order; lines are stored as soon as they are complete
+__device__ __forceinline__ void line_double_store(Fp2& X, Fp2& Y, Fp2& Z, const G1A* p, uint4* lines, size_t s, size_t stride, size_t i, bool skip) {
+    const Fp2 t1 = sqr(add(Y, Z)); SB();
+    const Fp2 c = sqr(Z); SB();
+    const Fp2 b = sqr(Y); SB();
+    const Fp2 h = sub(t1, add(b, c)); SB();
+    {
+        const Fp yP = opaque(p)->y; const Fp2 l2 = mul_fp(neg(h), yP);
+        store_chunks<6>(lines, s * 3 + 2, stride, i, skip ? Fp2::zero() : l2);
+    } SB();
+    const Fp2 e = mul_by_b_twist(add(dbl(c), c)); SB();
+    store_chunks<6>(lines, s * 3 + 0, stride, i, skip ? Fp2::one() : sub(e, b)); SB();
+    const Fp2 a = half(mul(X, Y)); SB();
+    {
+        const Fp2 j = sqr(X);
+        const Fp xP = opaque(p)->x; const Fp2 l1 = mul_fp(add(dbl(j), j), xP);
+        store_chunks<6>(lines, s * 3 + 1, stride, i, skip ? Fp2::zero() : l1);
+    } SB();
+    Z = mul(b, h); SB();
+    const Fp2 f = add(dbl(e), e);
+    X = mul(a, sub(b, f)); SB();
+    const Fp2 g = half(add(b, f));
+    const Fp2 e2 = sqr(e); SB();
+    Y = sub(sqr(g), add(dbl(e2), e2));
+}
+
+__device__ __forceinline__ void line_add_store(Fp2& X, Fp2& Y, Fp2& Z, const G2A* q, const G1A* p, uint4* lines, size_t s, size_t stride, size_t i, bool skip, uint4* park) {
+    Fp2 theta, lambda;
+    { const Fp2 qy = opaque(q)->y; theta = sub(Y, mul(qy, Z)); } SB();
+    { const uint4* src = reinterpret_cast<const uint4*>(&Y);          // Y is not needed again until the last product: park it in LDS
+#pragma unroll
+      for (int k = 0; k < 6; ++k) park[k * 256] = src[k]; } SB();
+    { const Fp2 qx = opaque(q)->x; lambda = sub(X, mul(qx, Z)); } SB();
+    { const Fp2 qx = opaque(q)->x; const Fp2 t = mul(theta, qx); SB(); const Fp2 qy = opaque(q)->y; const Fp2 j = sub(t, mul(lambda, qy));
+      store_chunks<6>(lines, s * 3 + 0, stride, i, skip ? Fp2::one() : j); } SB();
+    { const Fp xP = opaque(p)->x; store_chunks<6>(lines, s * 3 + 1, stride, i, skip ? Fp2::zero() : mul_fp(neg(theta), xP)); } SB();
+    { const Fp yP = opaque(p)->y; store_chunks<6>(lines, s * 3 + 2, stride, i, skip ? Fp2::zero() : mul_fp(lambda, yP)); } SB();
+    Fp2 f;
+    { const Fp2 c = sqr(theta); SB(); f = mul(Z, c); } SB();
+    { const uint4* src = reinterpret_cast<const uint4*>(&theta);      // theta rests in LDS until the last-but-one product
+#pragma unroll
+      for (int k = 0; k < 6; ++k) park[(6 + k) * 256] = src[k]; } SB();
+    Fp2 e, g;
+    { const Fp2 d = sqr(lambda); SB(); e = mul(lambda, d); SB(); g = mul(X, d); } SB();
+    const Fp2 h = sub(add(e, f), dbl(g)); SB();
+    X = mul(lambda, h); SB();
+    Z = mul(Z, e); SB();
+    Fp2 t;
+    { Fp2 th; uint4* dst = reinterpret_cast<uint4*>(&th);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) dst[k] = park[(6 + k) * 256];
+      t = mul(th, sub(g, h)); } SB();
+    { Fp2 y0; uint4* dst = reinterpret_cast<uint4*>(&y0);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) dst[k] = park[k * 256];
+      Y = sub(t, mul(e, y0)); }
+}
 __global__ void __launch_bounds__(256, RIPP_OCC) k_miller_lines(PairSets ps, uint32_t M, uint4* __restrict__ lines, size_t stride) {
+    __shared__ uint4 park[12 * 256];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
     const G1A* __restrict__ a = ps.a[blockIdx.y];
     const G2A* __restrict__ b = ps.b[blockIdx.y];
-    const G1A P = a[i];
     Fp2 X, Y, Z = Fp2::one();
     { const G2A Q = b[i]; X = Q.x; Y = Q.y; }
-    const bool skip = is_inf(P) || (X.is_zero() && Y.is_zero());
+    bool skip; { const G1A P = a[i]; skip = is_inf(P) || (X.is_zero() && Y.is_zero()); }
     const LineCoeffs unit = {Fp2::one(), Fp2::zero(), Fp2::zero()};
     size_t s = (size_t)blockIdx.y * N_LINES;
 #pragma unroll 1
     for (int bit = 62; bit >= 0; --bit) {
-        LineCoeffs l = line_double(X, Y, Z, P.x, P.y);
-        store_chunks<LINE_CHUNKS>(lines, s, stride, i, skip ? unit : l);
+        line_double_store(X, Y, Z, a + i, lines, s, stride, i, skip);
         ++s;
         if ((BLS_X_ABS >> bit) & 1ull) {
-            const G2A Q = b[i];
-            l = line_add(X, Y, Z, Q.x, Q.y, P.x, P.y);
-            store_chunks<LINE_CHUNKS>(lines, s, stride, i, skip ? unit : l);
+            line_add_store(X, Y, Z, b + i, a + i, lines, s, stride, i, skip, park + threadIdx.x);
             ++s;
         }
     }
 }
 
+#undef SB
+
 // ---- stage 2a: sparse accumulation -------------------------------------------------------------------------
 // grid = (T / block, rows).  Lane t of row r multiplies lines r[t], r[t+T], ... (< M) and writes one dense partial.
-__global__ void __launch_bounds__(64, RIPP_OCC_PROD) k_line_products(const uint4* __restrict__ lines, size_t stride, uint32_t M,
+__global__ void __launch_bounds__(64, RIPP_OCC_PROD) k_line_products1(const uint4* __restrict__ lines, size_t stride, uint32_t M,
                                                         uint4* __restrict__ partials, uint32_t T) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
