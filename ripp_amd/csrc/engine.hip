@@ -24,6 +24,7 @@
 #include "kernels.hpp"
 #include "line_products.hpp"
 #include "msm.hpp"
+#include "scale.hpp"
 #include "vm.hpp"
 #include "vm_fold2.hpp"
 #include "host_fs.hpp"
@@ -159,7 +160,7 @@ struct Engine {
         return RIPP_OK;
     }
     void destroy() {
-        for (DevBuf* b : {&lines, &partA, &partB, &jacG1, &jacG2, &tmpA, &tmpB, &tmpR, &affG1, &affG2, &qtab, &vm_flag, &fold_tab1, &fold_mult, &fold_tab, &fold_jac1, &fold_jac2}) b->release();
+        for (DevBuf* b : {&lines, &partA, &partB, &jacG1, &jacG2, &tmpA, &tmpB, &tmpR, &affG1, &affG2, &qtab, &vm_flag, &scale_tab, &fold_tab1, &fold_mult, &fold_tab, &fold_jac1, &fold_jac2}) b->release();
         msm_scratch[0].release(); msm_scratch[1].release(); kzg_q[0].release(); kzg_q[1].release();
         if (stream3) (void)hipStreamDestroy(stream3);
         if (stream4) (void)hipStreamDestroy(stream4); if (ev_join4) (void)hipEventDestroy(ev_join4);
@@ -192,6 +193,17 @@ struct Engine {
             v.clear(); };
         drain(ev_lines, stats.kernel_miller_lines_ms_sum, stats.kernel_miller_lines_launches);
         drain(ev_prod, stats.kernel_line_products_ms_sum, stats.kernel_line_products_launches);
+    }
+
+    // ---- per-element G1 scalar multiplication (GLV + signed windows, scale.hpp); out may not alias base -----------------
+    DevBuf scale_tab;
+    int32_t scale_g1_dev(const G1A* base, uint32_t base_stride, const Fr* k, size_t n, G1J* out, hipStream_t st = nullptr) {
+        if (n == 0) return RIPP_OK;
+        if (!st) st = stream;
+        int32_t rc = scale_tab.reserve((size_t)SCALE_TAB * G1J_CHUNKS * n * sizeof(uint4)); if (rc) return rc;
+        hipLaunchKernelGGL(k_scale_g1_glv, dim3(nblk(n, 256)), dim3(256), 0, st, base, base_stride, k, (uint32_t)n, scale_tab.as<uint4>(), out);
+        HIPCHK(hipGetLastError());
+        return RIPP_OK;
     }
 
     // ---- normalisation (device in, device out) ------------------------------------------------------------
@@ -608,8 +620,7 @@ int32_t job_begin(Engine* e, ripp_sipp_job* j) {
     // a_i <- r_i * a_i, normalised (sipp/src/lib.rs:61-66); b copied (:67)
     hipEvent_t t0 = e->ev_t0, t1 = e->ev_t1;
     HIPCHK(hipEventRecord(t0, e->stream));
-    hipLaunchKernelGGL(k_scale_g1, dim3(nblk(n, 256)), dim3(256), 0, e->stream, j->a0.as<G1A>(), j->r0.as<Fr>(), (uint32_t)n, j->jac1.as<G1J>());
-    HIPCHK(hipGetLastError());
+    if ((rc = e->scale_g1_dev(j->a0.as<G1A>(), 1u, j->r0.as<Fr>(), n, j->jac1.as<G1J>())) != RIPP_OK) return rc;
     if ((rc = e->normalize_dev<Fp>(j->jac1.as<G1J>(), n, j->a.as<G1A>())) != RIPP_OK) return rc;
     HIPCHK(hipMemcpyAsync(j->b.p, j->b0.p, n * sizeof(G2A), hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipEventRecord(t1, e->stream));
@@ -849,8 +860,7 @@ API int32_t ripp_scale_g1_a(const ripp_g1a* a, const ripp_fr* r, size_t n, ripp_
     if ((rc = upload<Fr>(e, e->tmpR, r, n, &dr))) return rc;
     if ((rc = e->jacG1.reserve(n * sizeof(G1J)))) return rc;
     if ((rc = e->affG1.reserve(n * sizeof(G1A)))) return rc;
-    hipLaunchKernelGGL(k_scale_g1, dim3(nblk(n, 256)), dim3(256), 0, e->stream, da, dr, (uint32_t)n, e->jacG1.as<G1J>());
-    HIPCHK(hipGetLastError());
+    if ((rc = e->scale_g1_dev(da, 1u, dr, n, e->jacG1.as<G1J>()))) return rc;
     if ((rc = e->normalize_dev<Fp>(e->jacG1.as<G1J>(), n, e->affG1.as<G1A>()))) return rc;
     HIPCHK(hipMemcpyAsync(out, e->affG1.p, n * sizeof(G1A), hipMemcpyDeviceToHost, e->stream));
     return e->sync();
@@ -955,8 +965,7 @@ API int32_t ripp_pairing_product_coeffs_a(const ripp_g1a* a, const ripp_g2a* b, 
     if ((rc = e->jacG1.reserve(std::max<size_t>(n, 1) * sizeof(G1J)))) return rc;
     if ((rc = e->affG1.reserve(std::max<size_t>(n, 1) * sizeof(G1A)))) return rc;
     if (n) {
-        hipLaunchKernelGGL(k_scale_g1, dim3(nblk(n, 256)), dim3(256), 0, e->stream, da, dr, (uint32_t)n, e->jacG1.as<G1J>());
-        HIPCHK(hipGetLastError());
+        if ((rc = e->scale_g1_dev(da, 1u, dr, n, e->jacG1.as<G1J>()))) return rc;
         if ((rc = e->normalize_dev<Fp>(e->jacG1.as<G1J>(), n, e->affG1.as<G1A>()))) return rc;
     }
     return pairing_product_dev(e, e->affG1.as<G1A>(), db, n, out);

@@ -1,0 +1,5 @@
+set -x
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_tipa.py -m gpu -x -q 2>&1 | tail -5
+RIPP_TRACE=1 timeout 300 python bench.py --steps 3 --warmup 1 --cpu-log-n 0 2>&1 | grep "ripp\]\|metric" | tail -24 | cut -c1-420
