@@ -4,7 +4,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <vector>
-#include "bls12_381/fp.hpp"
+#include "line_products.hpp"
 
 using namespace ripp;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 1; } } while (0)
@@ -50,6 +50,18 @@ __global__ void __launch_bounds__(256) k_mulni_chain(const Fp* in, Fp* out, int 
     out[tid] = x;
 }
 
+// the lazily reduced 6-product sum of line_products.hpp: 6 limb-product blocks + ONE Montgomery reduction per result
+__global__ void __launch_bounds__(256, 2) k_dot6_chain(const Fp* in, Fp* out, int iters) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    Fp x[6], y[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { x[c] = in[(tid + 7 * c) & 1023]; y[c] = in[(tid + 11 * c + 1) & 1023]; }
+    for (int i = 0; i < iters; ++i) { const Fp r = fp_dot<6>(x, y); x[i % 6 == 0 ? 0 : 1] = r; }
+    Fp acc = x[0];
+#pragma unroll
+    for (int c = 1; c < 6; ++c) acc = add(acc, x[c]);
+    out[tid] = acc;
+}
 __global__ void __launch_bounds__(256) k_add_chain(const Fp* in, Fp* out, int iters) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     Fp x = in[tid & 1023], y = in[(tid + 1) & 1023];
@@ -125,6 +137,7 @@ int main() {
     run("fp_mul noinline call x1", k_mulni_chain, 1, 1);
     run("fp_mul x2 chains", k_mul_chain<2>, 2, 2);
     run("fp_mul x4 chains", k_mul_chain<4>, 4, 4);
+    run("fp_dot<6> (6 products, 1 reduction)", k_dot6_chain, 1, 6);
     run("fp_add+fp_sub", k_add_chain, 1, 2);
     return 0;
 }
