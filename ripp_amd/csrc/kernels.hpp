@@ -440,11 +440,52 @@ __global__ void __launch_bounds__(64, RIPP_OCC) k_g2_tab_images(const G2A* __res
 #pragma unroll 1
     for (int j = 0; j < 4; ++j) store_chunks<G2A_CHUNKS>(qtab, (size_t)(4 * b + j) * M + m, stride, i, gls_image(q, j));
 }
-// NS digit strings; string t = 4 b + j works on table rows t M .. t M + M - 1
+// ---- low-register G2 group law for the fold kernels ----------------------------------------------------------------------------------
+// With Fp2 coordinates the textbook formulas keep ~9 temporaries (216 dwords) beside the accumulator: the fold kernels spilled 200-250
+// dwords.  These forms compute the same values in a LOW-LIVENESS order pinned with scheduling barriers (at most 5-6 Fp2 live), read the
+// table point where it is used and park Y1 in LDS while it is idle.  They do NOT handle the exceptional cases (accumulator at infinity,
+// T = +-Q, table point at infinity): they REPORT them, and the kernel recomputes such a lane with the complete formulas of curve.hpp.
+#define SB() __builtin_amdgcn_sched_barrier(0)
+__device__ __forceinline__ void jdbl_lo(Fp2& X, Fp2& Y, Fp2& Z) {          // dbl-2009-l
+    Z = dbl(fmul(Y, Z)); SB();
+    const Fp2 A = fsqr(X); SB();
+    const Fp2 B = fsqr(Y); SB();
+    const Fp2 t = fsqr(add(X, B)); SB();
+    const Fp2 C = fsqr(B); SB();
+    const Fp2 D = dbl(sub(sub(t, A), C)); SB();
+    const Fp2 E = add(dbl(A), A); SB();
+    X = sub(sub(fsqr(E), D), D); SB();
+    Y = sub(fmul(E, sub(D, X)), dbl(dbl(dbl(C))));
+}
+// madd-2007-bl; loadx / loady fetch the affine addend's coordinates; park: this lane's 6 x 16 B LDS column (stride 64 lanes).
+// Returns true when the result is NOT valid (H = 0, i.e. T = +-Q, or Q at infinity).
+template <class LOADX, class LOADY>
+__device__ __forceinline__ bool jmadd_lo(Fp2& X, Fp2& Y, Fp2& Z, LOADX loadx, LOADY loady, bool negy, uint4* park) {
+    const Fp2 Z1Z1 = fsqr(Z); SB();
+    Fp2 H; bool qinf; { const Fp2 x2 = loadx(); qinf = x2.is_zero(); H = sub(fmul(x2, Z1Z1), X); } SB();
+    Fp2 r; { Fp2 y2 = loady(); qinf = qinf && y2.is_zero(); if (negy) y2 = neg(y2); const Fp2 t = fmul(Z, Z1Z1); SB(); r = sub(fmul(y2, t), Y); } SB();
+    const bool special = H.is_zero() || qinf;
+    { const uint4* src = reinterpret_cast<const uint4*>(&Y);              // Y1 rests in LDS until the last product
+#pragma unroll
+      for (int k = 0; k < 6; ++k) park[k * 64] = src[k]; } SB();
+    r = dbl(r);
+    const Fp2 HH = fsqr(H); SB();
+    Z = sub(sub(fsqr(add(Z, H)), Z1Z1), HH); SB();
+    const Fp2 I = dbl(dbl(HH));
+    const Fp2 J = fmul(H, I); SB();
+    const Fp2 V = fmul(X, I); SB();
+    X = sub(sub(sub(fsqr(r), J), V), V); SB();
+    Fp2 t2; { Fp2 y1; uint4* dst = reinterpret_cast<uint4*>(&y1);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) dst[k] = park[k * 64];
+      t2 = fmul(y1, J); } SB();
+    Y = sub(fmul(r, sub(V, X)), dbl(t2));
+    return special;
+}
+#undef SB
+// NS digit strings; string t = 4 b + j works on table rows t M .. t M + M - 1.  Complete formulas: the reference form and the per-lane fallback.
 template <class D, int NS>
-__global__ void __launch_bounds__(64, RIPP_OCC) k_fold_g2_tab(const uint4* __restrict__ qtab, size_t stride, int M, const G2A* __restrict__ lo, uint32_t half, D dg, G2J* __restrict__ out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= half) return;
+__device__ __noinline__ void fold_g2_tab_complete(const uint4* __restrict__ qtab, size_t stride, int M, const G2A* __restrict__ lo, uint32_t i, const D& dg, G2J* __restrict__ out) {
     G2J acc = jac_inf<Fp2>();
 #pragma unroll 1
     for (int pos = dg.len - 1; pos >= 0; --pos) {
@@ -460,6 +501,42 @@ __global__ void __launch_bounds__(64, RIPP_OCC) k_fold_g2_tab(const uint4* __res
         }
     }
     out[i] = add_mixed(acc, lo[i]);
+}
+template <class D, int NS>
+__global__ void __launch_bounds__(64, RIPP_OCC) k_fold_g2_tab(const uint4* __restrict__ qtab, size_t stride, int M, const G2A* __restrict__ lo, uint32_t half, D dg, G2J* __restrict__ out) {
+    __shared__ uint4 park_[6 * 64];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= half) return;
+    uint4* park = park_ + threadIdx.x;
+    Fp2 X = Fp2::one(), Y = Fp2::one(), Z = Fp2::zero();
+    bool inf = true, bad = false;                                        // inf is wave-uniform: the digit strings are shared by the launch
+#pragma unroll 1
+    for (int pos = dg.len - 1; pos >= 0; --pos) {
+        if (!inf) jdbl_lo(X, Y, Z);
+#pragma unroll 1
+        for (int t = 0; t < NS; ++t) {
+            const int d = dg.d[t][pos];
+            if (d == 0) continue;
+            const uint4* base = qtab + ((size_t)t * M + ((d < 0 ? -d : d) >> 1)) * G2A_CHUNKS * stride + i;
+            auto loadx = [&]() { Fp2 v; uint4* dd = reinterpret_cast<uint4*>(&v);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) dd[q] = base[(size_t)q * stride]; return v; };
+            auto loady = [&]() { Fp2 v; uint4* dd = reinterpret_cast<uint4*>(&v);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) dd[q] = base[(size_t)(6 + q) * stride]; return v; };
+            if (inf) {                                                    // first addition: acc <- +-Q
+                X = loadx(); Y = loady(); if (d < 0) Y = neg(Y); Z = Fp2::one(); inf = false;
+                bad |= X.is_zero() && Y.is_zero();
+            } else bad |= jmadd_lo(X, Y, Z, loadx, loady, d < 0, park);
+        }
+    }
+    {
+        const G2A* lp = lo + i;
+        bool linf; { const G2A q = *lp; linf = is_inf(q); if (inf) { X = q.x; Y = q.y; Z = linf ? Fp2::zero() : Fp2::one(); } }
+        if (!inf && !linf) bad |= jmadd_lo(X, Y, Z, [&]() { return opaque(lp)->x; }, [&]() { return opaque(lp)->y; }, false, park);
+    }
+    if (bad) fold_g2_tab_complete<D, NS>(qtab, stride, M, lo, i, dg, out);
+    else out[i] = G2J{X, Y, Z};
 }
 
 // ---- batch normalisation (CurveGroup::normalize_batch) ------------------------------------------------------

@@ -62,6 +62,29 @@ __global__ void __launch_bounds__(256, 2) k_dot6_chain(const Fp* in, Fp* out, in
     for (int c = 1; c < 6; ++c) acc = add(acc, x[c]);
     out[tid] = acc;
 }
+// the group law's Fp2 product is two of these calls (48 dwords of arguments: 16 of them travel through the stack)
+__global__ void __launch_bounds__(256, 2) k_mul2call_chain(const Fp* in, Fp* out, int iters) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    Fp x = in[tid & 1023], y = in[(tid + 1) & 1023], z = in[(tid + 2) & 1023], w = in[(tid + 3) & 1023];
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (int i = 0; i < iters; ++i) { x = fmul2_add(x, y, z, w); z = fmul2_add(z, w, x, y); }
+#endif
+    out[tid] = add(x, z);
+}
+__global__ void __launch_bounds__(256, 2) k_mul2inl_chain(const Fp* in, Fp* out, int iters) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    Fp x = in[tid & 1023], y = in[(tid + 1) & 1023], z = in[(tid + 2) & 1023], w = in[(tid + 3) & 1023];
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (int i = 0; i < iters; ++i) { x = mul2_add(x, y, z, w); z = mul2_add(z, w, x, y); }
+#endif
+    out[tid] = add(x, z);
+}
+__global__ void __launch_bounds__(256, 2) k_mulcall_chain(const Fp* in, Fp* out, int iters) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    Fp x = in[tid & 1023], y = in[(tid + 1) & 1023];
+    for (int i = 0; i < iters; ++i) { x = fmul(x, y); y = fmul(y, x); }
+    out[tid] = add(x, y);
+}
 __global__ void __launch_bounds__(256) k_add_chain(const Fp* in, Fp* out, int iters) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     Fp x = in[tid & 1023], y = in[(tid + 1) & 1023];
@@ -138,6 +161,9 @@ int main() {
     run("fp_mul x2 chains", k_mul_chain<2>, 2, 2);
     run("fp_mul x4 chains", k_mul_chain<4>, 4, 4);
     run("fp_dot<6> (6 products, 1 reduction)", k_dot6_chain, 1, 6);
+    run("fmul (fp_mul_call, 24 reg args) x2", k_mulcall_chain, 1, 2);
+    run("fmul2_add call (48 args, 16 via stack) x2", k_mul2call_chain, 1, 4);
+    run("mul2_add inlined x2", k_mul2inl_chain, 1, 4);
     run("fp_add+fp_sub", k_add_chain, 1, 2);
     return 0;
 }
