@@ -18,7 +18,6 @@ import json
 import os
 import sys
 import time
-from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -104,7 +103,7 @@ def main():
     import numpy as np
     import torch
     import ripp_amd as R
-    from ripp_amd.sharded import ShardedSippProver, TorchComm, SingleComm
+    from ripp_amd.sharded import NativeComm, native_sipp_job_prove
 
     # test hooks (used on 1-GPU boxes to exercise the N > 1 control flow): all ranks on device 0, gloo transport
     single_dev = bool(os.environ.get("RIPP_BENCH_SINGLE_DEVICE"))
@@ -118,11 +117,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend, rank=rank, world_size=world)     # "nccl" IS RCCL on ROCm
-        comm = TorchComm(f"cuda:{local_rank}" if backend == "nccl" else "cpu")
+        dist.init_process_group(backend, rank=rank, world_size=world)     # rendezvous + barriers; "nccl" IS RCCL on ROCm
+        # the proof's collectives run INSIDE libripp_hip.so: its own RCCL communicator over xGMI (id handed over through torch.distributed),
+        # or -- single-device test mode -- an all-gather callback over gloo
+        comm = NativeComm("rccl" if backend == "nccl" else "callback")
     else:
         dist = None
-        comm = SingleComm()
+        comm = None
 
     # ---- synthetic statement: a_i = (1000+i) G1, b_i = (2000+i) G2, r_i from SplitMix64(0) ----
     # every rank generates its shard on its own GPU; rank 0 additionally holds the full statement on the host because
@@ -142,15 +143,14 @@ def main():
         dist.broadcast(t, src=0); value = t.cpu().numpy().view(np.uint64)
 
     job = R.SippJob(a, b, r, rank=rank, world=world)      # statement (shard) now resident in HBM
-    pool = ThreadPoolExecutor(max_workers=1)
 
     def one_step():
         if world == 1:
             proof, ch, st = job.prove(value)              # hashing overlaps the first kernels inside the engine
             return proof, st
-        fut = pool.submit(R.sipp_seed_digest, full[0], full[1], full[2], value) if rank == 0 else None
-        proof, ch = ShardedSippProver(job, comm).prove((lambda: fut.result()) if rank == 0 else (lambda: None))
-        return proof, job.stats()
+        # ripp_sipp_job_prove_sharded: rank 0 hashes the full statement on a host thread of the library while all ranks run round 0
+        proof, ch, st = native_sipp_job_prove(job, value, full=full if rank == 0 else None)
+        return proof, st
 
     def fence():
         if dist is not None:
@@ -219,7 +219,7 @@ def main():
         print(json.dumps(out), flush=True)
     job.close()
     if dist is not None:
-        dist.barrier(); dist.destroy_process_group()
+        dist.barrier(); comm.close(); dist.destroy_process_group()
 
 
 if __name__ == "__main__":

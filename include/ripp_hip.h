@@ -136,6 +136,32 @@ int32_t ripp_combine_partials(const ripp_gt* gathered /* [world][count] */, int3
 /* Blake2s digest of (a, b, r, value).serialize_uncompressed for a FULL statement held on the host (sipp/src/lib.rs:56-59) */
 int32_t ripp_sipp_seed_digest(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr* r, size_t n, const ripp_gt* value, uint8_t digest[32]);
 
+/* ---- multi-GPU: one process per GPU, collectives INSIDE the library ----------------------------------
+ * Transport "rccl": librccl.so is loaded on first use; rank 0 creates the 128-byte id, the HOST hands it to the other ranks (it owns
+ * the rendezvous: torch.distributed store, MPI, a file), every rank calls ripp_comm_init after ripp_init(its device).
+ * Transport "callback": the host supplies the all-gather (recv holds `world` blocks of `bytes` in rank order); returns 0 on success. */
+typedef int32_t (*ripp_allgather_fn)(void* user, const void* send, void* recv, size_t bytes);
+int32_t ripp_comm_unique_id(uint8_t id[128]);
+int32_t ripp_comm_init(const uint8_t id[128], int32_t rank, int32_t world);
+int32_t ripp_comm_init_callback(int32_t rank, int32_t world, ripp_allgather_fn allgather, void* user);
+void    ripp_comm_destroy(void);
+int32_t ripp_comm_rank(void);
+int32_t ripp_comm_world(void);
+int32_t ripp_comm_allgather(const void* send, void* recv, size_t bytes);     /* host buffers; recv: world x bytes */
+/* InnerProduct implementations over vectors sharded by index residue (element i on rank i mod world); every rank passes ITS shard
+ * and receives the full result.  Same status codes as the single-GPU forms (inner_products/src/lib.rs:61-73, 128-141). */
+int32_t ripp_pairing_product_sharded_j(const ripp_g1j* left, size_t nl, const ripp_g2j* right, size_t nr, ripp_gt* out);
+int32_t ripp_msm_g1_sharded_j(const ripp_g1j* bases, size_t nl, const ripp_fr* scalars, size_t nr, ripp_g1j* out);
+int32_t ripp_msm_g2_sharded_j(const ripp_g2j* bases, size_t nl, const ripp_fr* scalars, size_t nr, ripp_g2j* out);
+/* SIPP::prove (sipp/src/lib.rs:42-106) across the communicator: a, b, r = this rank's shard (local j <-> global j * world + rank).
+ * Rank 0 passes the full statement (hashed on a host thread while round 0 runs) or its precomputed digest; other ranks pass NULL. */
+int32_t ripp_sipp_prove_sharded(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr* r, size_t n_local, const ripp_gt* value,
+                                const ripp_g1a* full_a, const ripp_g2a* full_b, const ripp_fr* full_r, const uint8_t* seed_digest,
+                                ripp_gt* proof, ripp_fr* challenges, ripp_stats* stats);
+/* the same on a resident shard: job from ripp_sipp_job_create(shard, n_local, ripp_comm_rank(), ripp_comm_world()) */
+int32_t ripp_sipp_job_prove_sharded(ripp_sipp_job* job, const ripp_gt* value, const ripp_g1a* full_a, const ripp_g2a* full_b, const ripp_fr* full_r,
+                                    const uint8_t* seed_digest, ripp_gt* proof, ripp_fr* challenges, ripp_stats* stats);
+
 /* ---- GIPA prover, TIPP instantiation  -- GIPA::prove_with_aux / _prove, ip_proofs/src/gipa.rs:162-312 ------------
  * GIPA<PairingInnerProduct, AFGHOCommitmentG1, AFGHOCommitmentG2, IdentityCommitment<GT, Fr>, Blake2b> (the instantiation
  * of the reference's tests, gipa.rs:470-497, and of TIPA).  m_a, ck_b: G1 projective; m_b, ck_a: G2 projective.

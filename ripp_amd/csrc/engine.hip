@@ -1281,6 +1281,8 @@ API int32_t ripp_sipp_challenge(uint8_t seed[32], const ripp_gt* z_l, const ripp
 
 #include "wire_api.inc"      // CanonicalSerialize / CanonicalDeserialize images of the proof structs
 
+#include "comm_api.inc"      // RCCL / callback communicator, sharded inner products and the sharded SIPP prover
+
 // ---- synthetic inputs ---------------------------------------------------------------------------------------------------
 extern "C++" {
 template <class F> static int32_t synth_points(const Affine<F>& g, uint64_t start, size_t first, size_t stride, size_t n, void* out) {

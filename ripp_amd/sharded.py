@@ -144,3 +144,96 @@ class ShardedSippProver:
         if not proof:
             return np.zeros((0, 72), dtype=np.uint64), np.zeros((0, 4), dtype=np.uint64)
         return np.stack(proof), np.stack(challenges)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Native path: the round loop and the collective live INSIDE libripp_hip.so (comm_api.inc: ripp_comm_*, ripp_sipp_*_prove_sharded),
+# so that a non-Python host binds one call.  torch.distributed is used here only as the RENDEZVOUS (to hand rank 0's RCCL id to the
+# other ranks) or, with transport="callback", as the all-gather the library calls back into (gloo: CPU boxes / several ranks on one GPU).
+class NativeComm:
+    """Initialises the library's communicator for this process.  transport: "rccl" (one GPU per rank, xGMI) or "callback"."""
+
+    def __init__(self, transport=None):
+        import ctypes
+        import torch.distributed as dist
+        from ._lib import lib
+        from . import api
+        self.dist, self.rank, self.world = dist, dist.get_rank(), dist.get_world_size()
+        if transport is None:
+            transport = "rccl" if dist.get_backend() == "nccl" else "callback"
+        self.transport = transport
+        if transport == "rccl":
+            import torch
+            ident = np.zeros(128, dtype=np.uint8)
+            if self.rank == 0:
+                api._check(lib().ripp_comm_unique_id(api._p(ident)))
+            t = torch.from_numpy(ident)
+            if dist.get_backend() == "nccl":
+                t = t.cuda()
+            dist.broadcast(t, src=0)
+            ident = t.cpu().numpy().copy()
+            api._check(lib().ripp_comm_init(api._p(ident), ctypes.c_int32(self.rank), ctypes.c_int32(self.world)))
+        else:
+            import torch
+            FN = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
+
+            def allgather(_user, send, recv, nbytes):
+                try:
+                    src = np.ctypeslib.as_array(ctypes.cast(send, ctypes.POINTER(ctypes.c_uint8)), shape=(nbytes,))
+                    t = torch.from_numpy(src.copy())
+                    outs = [torch.empty_like(t) for _ in range(self.world)]
+                    dist.all_gather(outs, t)
+                    dst = np.ctypeslib.as_array(ctypes.cast(recv, ctypes.POINTER(ctypes.c_uint8)), shape=(nbytes * self.world,))
+                    dst[:] = torch.cat(outs).numpy()
+                    return 0
+                except Exception:          # never unwind through the C frames
+                    return 1
+            self._cb = FN(allgather)                 # keep the trampoline alive as long as the communicator
+            api._check(lib().ripp_comm_init_callback(ctypes.c_int32(self.rank), ctypes.c_int32(self.world), self._cb, None))
+
+    def close(self):
+        from ._lib import lib
+        lib().ripp_comm_destroy()
+
+
+def native_sipp_job_prove(job, value, full=None, seed_digest=None):
+    """ripp_sipp_job_prove_sharded: SIPP::prove (sipp/src/lib.rs:42-106) across the library's communicator on a resident shard.
+    job: api.SippJob created with this rank / world; rank 0 passes full = (a, b, r) of the whole statement or seed_digest.
+    Returns (proof (2*rounds,72), challenges (rounds,4), stats)."""
+    import ctypes
+    from ._lib import lib, RippStats
+    from . import api
+    world = int(lib().ripp_comm_world())
+    n = job.n_local * world; lg = n.bit_length() - 1
+    value = np.ascontiguousarray(value, dtype=np.uint64).reshape(72)
+    proof = np.zeros((2 * max(lg, 1), 72), dtype=np.uint64); ch = np.zeros((max(lg, 1), 4), dtype=np.uint64); st = RippStats()
+    z = ctypes.c_void_p(None)
+    fa = fb = fr = z
+    if full is not None:
+        fa_, fb_, fr_ = api._c(full[0], 12), api._c(full[1], 24), api._c(full[2], 4)
+        assert len(fa_) == len(fb_) == len(fr_) == n
+        fa, fb, fr = api._p(fa_), api._p(fb_), api._p(fr_)
+    dg = (ctypes.c_uint8 * 32).from_buffer_copy(seed_digest) if seed_digest is not None else z
+    api._check(lib().ripp_sipp_job_prove_sharded(job._h, api._p(value), fa, fb, fr, dg, api._p(proof), api._p(ch), ctypes.byref(st)))
+    return proof[: 2 * lg], ch[:lg], st.as_dict()
+
+
+def native_pairing_inner_product(left_shard, right_shard):
+    """PairingInnerProduct::inner_product over vectors sharded by index residue, collective inside the library."""
+    import ctypes
+    from ._lib import lib
+    from . import api
+    l, r = api._c(left_shard, 18), api._c(right_shard, 36); out = np.zeros(72, dtype=np.uint64)
+    api._check(lib().ripp_pairing_product_sharded_j(api._p(l), ctypes.c_size_t(len(l)), api._p(r), ctypes.c_size_t(len(r)), api._p(out)), len(l), len(r))
+    return out
+
+
+def native_msm(bases_shard, scalars_shard, group="g1"):
+    import ctypes
+    from ._lib import lib
+    from . import api
+    cols = 18 if group == "g1" else 36
+    b, s = api._c(bases_shard, cols), api._c(scalars_shard, 4); out = np.zeros(cols, dtype=np.uint64)
+    fn = lib().ripp_msm_g1_sharded_j if group == "g1" else lib().ripp_msm_g2_sharded_j
+    api._check(fn(api._p(b), ctypes.c_size_t(len(b)), api._p(s), ctypes.c_size_t(len(s)), api._p(out)), len(b), len(s))
+    return out

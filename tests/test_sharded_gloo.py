@@ -175,3 +175,92 @@ def test_sharded_inner_products_world2_gloo(n):
 @pytest.mark.parametrize("n", [1000])
 def test_sharded_inner_products_world2_real_engine(engine, n):
     _run_ip(2, n, use_gpu=True)
+
+
+# ---------------------------------------------------------------- native driver: round loop + collective inside libripp_hip.so
+def _native_worker(rank, world, port, n, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    for p in (os.path.dirname(HERE), HERE, os.path.join(HERE, "model")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import orclib as o
+    import ripp_amd as R
+    from ripp_amd.sharded import NativeComm, shard, native_sipp_job_prove, native_pairing_inner_product, native_msm
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        R.init(0)
+        comm = NativeComm("callback")                    # both ranks share cuda:0: RCCL needs one device per rank, gloo carries the all-gather
+        a, b, r = o.gen_g1(123, n), o.gen_g2(456, n), o.gen_scalars(7, n)
+        value = o.product_of_pairings_with_coeffs(a, b, r)
+        job = R.SippJob(shard(a, rank, world), shard(b, rank, world), shard(r, rank, world), rank=rank, world=world)
+        proof, ch, _ = native_sipp_job_prove(job, value, full=(a, b, r) if rank == 0 else None)
+        rc, eproof, ech = o.sipp_prove(a, b, r, value)
+        ok = rc == 0 and np.array_equal(proof, eproof) and np.array_equal(ch, ech)
+        # second proof on the same resident shard, digest precomputed by the host
+        proof2, _, _ = native_sipp_job_prove(job, value, seed_digest=R.sipp_seed_digest(a, b, r, value) if rank == 0 else None)
+        ok = ok and np.array_equal(proof2, eproof)
+        job.close()
+        aj, bj, s = o.blind_g1(a, 1), o.blind_g2(b, 2), o.gen_scalars(9, n)
+        ok = ok and np.array_equal(native_pairing_inner_product(shard(aj, rank, world), shard(bj, rank, world)), o.pairing_product_j(aj, bj)[1])
+        ok = ok and np.array_equal(o.g1_to_affine(native_msm(shard(aj, rank, world), shard(s, rank, world), "g1")), o.g1_to_affine(o.msm_g1_j(aj, s)[1]))
+        ok = ok and np.array_equal(o.g2_to_affine(native_msm(shard(bj, rank, world), shard(s, rank, world), "g2")), o.g2_to_affine(o.msm_g2_j(bj, s)[1]))
+        comm.close()
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 64, 1 << 12])
+def test_native_sharded_driver_world2_callback_transport(engine, n):
+    """ripp_sipp_job_prove_sharded / ripp_*_sharded_j: the library's own round loop and collectives, two ranks on cuda:0 with the
+    all-gather supplied by the host (gloo): proofs, pairing product and MSMs equal the oracle's on the unsharded vectors."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_native_worker, args=(2, _free_port(), n, ret), nprocs=2, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+_RCCL_SCRIPT = r"""
+import os, sys
+import numpy as np
+import torch, torch.distributed as dist            # torch FIRST: the order bench.py uses (the library then shares torch's HIP runtime)
+for p in sys.argv[1:4]:
+    sys.path.insert(0, p)
+torch.cuda.set_device(0)
+import ripp_amd as R
+R.init(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+import ctypes
+from ripp_amd._lib import lib
+from ripp_amd import api
+from ripp_amd.sharded import NativeComm, native_sipp_job_prove
+comm = NativeComm("rccl")                          # ripp_comm_unique_id -> (broadcast over torch.distributed) -> ripp_comm_init
+assert lib().ripp_comm_world() == 1 and lib().ripp_comm_rank() == 0
+send = np.arange(1152, dtype=np.uint8); recv = np.zeros(1152, dtype=np.uint8)
+api._check(lib().ripp_comm_allgather(api._p(send), api._p(recv), ctypes.c_size_t(1152)))       # ncclAllGather on the engine's stream
+assert np.array_equal(send, recv)
+import orclib as o
+n = 64
+a, b, r = o.gen_g1(123, n), o.gen_g2(456, n), o.gen_scalars(7, n)
+value = o.product_of_pairings_with_coeffs(a, b, r)
+job = R.SippJob(a, b, r)
+proof, ch, _ = native_sipp_job_prove(job, value, full=(a, b, r))
+job.close()
+rc, eproof, ech = o.sipp_prove(a, b, r, value)
+assert rc == 0 and np.array_equal(proof, eproof) and np.array_equal(ch, ech)
+comm.close(); dist.destroy_process_group()
+print("RCCL-TRANSPORT-OK")
+"""
+
+
+@pytest.mark.gpu
+def test_native_rccl_transport_single_rank(engine):
+    """The RCCL transport itself (librccl.so loaded by the library beside the HIP runtime in use, ncclCommInitRank / ncclAllGather on
+    the engine's stream) with one rank -- all a 1-GPU box can run; the multi-rank protocol is the callback test above.  Runs in a fresh
+    process in bench.py's import order (a process that has mixed two ROCm installations in the other order cannot initialise RCCL)."""
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT, os.path.dirname(HERE), HERE, os.path.join(HERE, "model")], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "RCCL-TRANSPORT-OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
