@@ -86,6 +86,8 @@ int32_t ripp_fold_g2_a(const ripp_g2a* hi, const ripp_g2a* lo, size_t half, cons
 /* GIPA form: projective in/out through `mul_helper`  -- ip_proofs/src/gipa.rs:262-290, ip_proofs/src/lib.rs:15-19 */
 int32_t ripp_fold_g1_j(const ripp_g1j* hi, const ripp_g1j* lo, size_t half, const ripp_fr* s, ripp_g1j* out);
 int32_t ripp_fold_g2_j(const ripp_g2j* hi, const ripp_g2j* lo, size_t half, const ripp_fr* s, ripp_g2j* out);
+/* the same fold on a scalar vector (GIPA with Message = Fr, e.g. Pedersen messages: gipa.rs:270-274) */
+int32_t ripp_fold_fr(const ripp_fr* hi, const ripp_fr* lo, size_t half, const ripp_fr* s, ripp_fr* out);
 /* a_i <- r_i * a_i with per-element scalars, normalised  -- sipp/src/lib.rs:61-66 */
 int32_t ripp_scale_g1_a(const ripp_g1a* a, const ripp_fr* r, size_t n, ripp_g1a* out);
 /* CurveGroup::normalize_batch  -- inner_products/src/lib.rs:80-81,140; sipp/src/lib.rs:66,92,100 */

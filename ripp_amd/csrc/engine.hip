@@ -910,6 +910,18 @@ API int32_t ripp_fold_g2_a(const ripp_g2a* hi, const ripp_g2a* lo, size_t half, 
 API int32_t ripp_fold_g1_j(const ripp_g1j* hi, const ripp_g1j* lo, size_t half, const ripp_fr* s, ripp_g1j* out) { return fold_impl<Fp, true, false>(hi, lo, half, s, out); }
 API int32_t ripp_fold_g2_j(const ripp_g2j* hi, const ripp_g2j* lo, size_t half, const ripp_fr* s, ripp_g2j* out) { return fold_impl<Fp2, true, false>(hi, lo, half, s, out); }
 
+// scalar-vector fold of GIPA (gipa.rs:270-274 with Message = Fr): out[i] = hi[i] * s + lo[i]
+API int32_t ripp_fold_fr(const ripp_fr* hi, const ripp_fr* lo, size_t half, const ripp_fr* s, ripp_fr* out) {
+    LOCK; ENGINE; if (half == 0) return RIPP_OK; if (!hi || !lo || !s || !out) return RIPP_ERR_ARG;
+    Fr sm; std::memcpy(&sm, s, sizeof sm);
+    Fr *dh, *dl; int32_t rc;
+    if ((rc = upload<Fr>(e, e->tmpA, hi, half, &dh)) || (rc = upload<Fr>(e, e->tmpB, lo, half, &dl)) || (rc = e->tmpR.reserve(half * sizeof(Fr)))) return rc;
+    hipLaunchKernelGGL(k_fold_fr, dim3(nblk(half, 256)), dim3(256), 0, e->stream, dh, dl, (uint32_t)half, sm, e->tmpR.as<Fr>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, e->tmpR.p, half * sizeof(Fr), hipMemcpyDeviceToHost, e->stream));
+    return e->sync();
+}
+
 // ---- pairing products ------------------------------------------------------------------------------------------
 static int32_t pairing_product_dev(Engine* e, const G1A* da, const G2A* db, size_t n, ripp_gt* out) {
     Fp12 rows[N_LINES];
