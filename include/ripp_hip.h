@@ -229,6 +229,17 @@ typedef struct {
 int32_t ripp_aggregate_proofs(const ripp_srs* srs, const ripp_g1a* a, const ripp_g2a* b, const ripp_g1a* c, size_t n,
                               ripp_aggregate_proof* out, ripp_stats* stats);
 
+/* the same across the communicator's ranks (ripp_comm_*): a, b, c = this rank's shard of the n_local * world proofs (local j <->
+ * global j * world + rank), srs created for the GLOBAL n on every rank (the SRS is resident in full, the work is split); per round
+ * the ranks all-gather their 6 (TIPP) resp. 2 + 2 (SSM) partial values, the KZG openings are per-rank MSMs over a residue class
+ * of the powers.  Every rank receives the whole AggregateProof. */
+int32_t ripp_aggregate_proofs_sharded(const ripp_srs* srs, const ripp_g1a* a, const ripp_g2a* b, const ripp_g1a* c, size_t n_local,
+                                      ripp_aggregate_proof* out, ripp_stats* stats);
+/* GIPA::prove_with_aux, TIPP instantiation, on sharded vectors (outputs as ripp_gipa_tipp_prove, replicated) */
+int32_t ripp_gipa_tipp_prove_sharded(const ripp_g1j* m_a, const ripp_g2j* m_b, const ripp_g2j* ck_a, const ripp_g1j* ck_b, size_t n_local,
+                                     ripp_gt* com_steps, ripp_fr* transcript, ripp_g1j* base_a, ripp_g2j* base_b,
+                                     ripp_g2j* ck_base_a, ripp_g1j* ck_base_b, ripp_stats* stats);
+
 /* ---- verifiers: O(log n) GT / group exponentiations on the host, pairings and MSMs on the device --
  * Every function writes *accept = 1 / 0 and returns RIPP_OK when the check itself ran. */
 /* VerifierSRS (tipa/mod.rs:104-110, get_verifier_key :120-127) */

@@ -15,7 +15,7 @@ from ._lib import lib, last_error, RippStats, AggregateProof, VerifierSRSStruct,
 
 __all__ = ["InnerProductError", "DeviceError", "PairingInnerProduct", "MultiexponentiationInnerProductG1",
            "MultiexponentiationInnerProductG2", "ScalarInnerProduct", "AFGHOCommitmentG1", "AFGHOCommitmentG2", "PedersenCommitmentG1",
-           "PedersenCommitmentG2", "SIPP", "SippJob", "GIPA_TIPP", "SRS", "TIPA_TIPP", "TIPAWithSSM", "aggregate_proofs", "verify_aggregate_proof", "AggregateProof", "ser_tipa_tipp_proof", "de_tipa_tipp_proof", "ser_tipa_ssm_proof", "de_tipa_ssm_proof", "ser_g1_compressed", "ser_g2_compressed", "product_of_pairings", "product_of_pairings_with_coeffs",
+           "PedersenCommitmentG2", "SIPP", "SippJob", "GIPA_TIPP", "SRS", "TIPA_TIPP", "TIPAWithSSM", "aggregate_proofs", "aggregate_proofs_sharded", "gipa_tipp_prove_sharded", "verify_aggregate_proof", "AggregateProof", "ser_tipa_tipp_proof", "de_tipa_tipp_proof", "ser_tipa_ssm_proof", "de_tipa_ssm_proof", "ser_g1_compressed", "ser_g2_compressed", "product_of_pairings", "product_of_pairings_with_coeffs",
            "normalize_batch_g1", "normalize_batch_g2", "fold_g1_affine", "fold_g2_affine", "fold_g1", "fold_g2",
            "scale_g1_affine", "synth_g1", "synth_g2", "synth_fr", "init", "device_count", "final_exponentiation",
            "ser_gt", "ser_g1", "ser_g2", "ser_fr", "sipp_seed_digest", "gt_mul"]
@@ -519,6 +519,31 @@ def aggregate_proofs(ip_srs, a, b, c):
     pf = AggregateProof(len(a)); st = RippStats()
     _check(lib().ripp_aggregate_proofs(ip_srs._h, _p(a), _p(b), _p(c), ctypes.c_size_t(len(a)), pf.ref(), ctypes.byref(st)))
     return pf, st.as_dict()
+
+
+def aggregate_proofs_sharded(ip_srs, a_shard, b_shard, c_shard):
+    """aggregate_proofs across the library's communicator (ripp_amd.sharded.NativeComm): this rank's shard of the proofs (global index
+    j * world + rank), ip_srs built for the GLOBAL n.  Returns (AggregateProof, stats), identical on every rank."""
+    a, b, c = _c(a_shard, 12), _c(b_shard, 24), _c(c_shard, 12)
+    assert len(a) == len(b) == len(c)
+    world = int(lib().ripp_comm_world())
+    pf = AggregateProof(len(a) * world); st = RippStats()
+    _check(lib().ripp_aggregate_proofs_sharded(ip_srs._h, _p(a), _p(b), _p(c), ctypes.c_size_t(len(a)), pf.ref(), ctypes.byref(st)))
+    return pf, st.as_dict()
+
+
+def gipa_tipp_prove_sharded(m_a, m_b, ck_a, ck_b):
+    """ripp_gipa_tipp_prove_sharded: every argument is this rank's shard.  Returns (round-order steps (rounds*6,72), transcript (rounds,4),
+    (base_a, base_b), (ck_base_a, ck_base_b)), identical on every rank."""
+    m_a, m_b, ck_a, ck_b = _c(m_a, 18), _c(m_b, 36), _c(ck_a, 36), _c(ck_b, 18)
+    nl = len(m_a); world = int(lib().ripp_comm_world()); n = nl * world
+    rounds = max(n.bit_length() - 1, 1)
+    steps = np.zeros((rounds * 6, 72), dtype=np.uint64); tr = np.zeros((rounds, 4), dtype=np.uint64)
+    ba = np.zeros(18, dtype=np.uint64); bb = np.zeros(36, dtype=np.uint64); ka = np.zeros(36, dtype=np.uint64); kb = np.zeros(18, dtype=np.uint64)
+    st = RippStats()
+    _check(lib().ripp_gipa_tipp_prove_sharded(_p(m_a), _p(m_b), _p(ck_a), _p(ck_b), ctypes.c_size_t(nl), _p(steps), _p(tr), _p(ba), _p(bb), _p(ka), _p(kb), ctypes.byref(st)))
+    r = n.bit_length() - 1
+    return steps[: 6 * r], tr[:r], (ba, bb), (ka, kb)
 
 
 # ------------------------------------------------------------------ wire format (CanonicalSerialize images of the proof structs)

@@ -111,6 +111,7 @@ struct Engine {
     DevBuf qtab;                          // [u^j]Q table of the GLS G2 fold
     MsmScratch msm_scratch[2];
     DevBuf kzg_q[2];                      // quotient-polynomial coefficients of the (up to two concurrent) KZG openings
+    DevBuf kzg_bases[2];                  // sharded openings: this rank's residue class of the SRS powers, gathered contiguously
     hipStream_t stream3 = nullptr;        // second MSM of a pair
     hipStream_t stream4 = nullptr;        // unscaled twin of m_a in the implicit-shift TIPP core
     hipEvent_t ev_join4 = nullptr;
@@ -161,7 +162,7 @@ struct Engine {
     }
     void destroy() {
         for (DevBuf* b : {&lines, &partA, &partB, &jacG1, &jacG2, &tmpA, &tmpB, &tmpR, &affG1, &affG2, &qtab, &vm_flag, &scale_tab, &fold_tab1, &fold_mult, &fold_tab, &fold_jac1, &fold_jac2}) b->release();
-        msm_scratch[0].release(); msm_scratch[1].release(); kzg_q[0].release(); kzg_q[1].release();
+        msm_scratch[0].release(); msm_scratch[1].release(); kzg_q[0].release(); kzg_q[1].release(); kzg_bases[0].release(); kzg_bases[1].release();
         if (stream3) (void)hipStreamDestroy(stream3);
         if (stream4) (void)hipStreamDestroy(stream4); if (ev_join4) (void)hipEventDestroy(ev_join4);
         if (stream5) (void)hipStreamDestroy(stream5); if (ev_join5) (void)hipEventDestroy(ev_join5);
@@ -1097,6 +1098,7 @@ API int32_t ripp_sipp_verify(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr
 }
 
 
+#include "comm_core.inc"     // RCCL / callback communicator (ripp_comm_*), used by the sharded provers below
 #include "tipa_api.inc"      // GIPA / TIPA / TIPAWithSSM provers, aggregate_proofs, verifiers
 
 // ---- SIPP ----------------------------------------------------------------------------------------------------------
