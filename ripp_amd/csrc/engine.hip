@@ -596,6 +596,8 @@ struct ripp_sipp_job {
     DevBuf a, b, a_next, b_next, jac1, jac2;   // working vectors
     size_t tab2_stride = 0; bool tab_ready = false;   // round-0 tables (odd multiples of four bases) of this job are in the engine's fold_* buffers
     DevBuf a_pow, b_pow; bool pre_ready = false;   // 2^64 * a_r and 2^32 * b_r of round 0, prepared while the statement hash finishes
+    // round 1's z_l pre-evaluated in the hash window through bilinearity (see job_preevaluate_round1): the four quarter products
+    Fp12 pre_zl[4]; bool pre_zl_ready = false;
     DevBuf a_pow_h, b_pow_h, parts1, parts2; bool pre_vm_ready = false;   // the same for the small rounds, on the field VM (vm_fold2.hpp)
     std::vector<G1A> ha; std::vector<G2A> hb; std::vector<Fr> hr;   // host copy of the statement (rank 0 hashes it)
     const G1A* ha_ext = nullptr; const G2A* hb_ext = nullptr; const Fr* hr_ext = nullptr;   // one-shot proofs hash the CALLER's buffers in place
@@ -803,6 +805,32 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true)
     }
     std::swap(j->a, j->a_next); std::swap(j->b, j->b_next);
     j->len = half;
+    return RIPP_OK;
+}
+
+// Round 1's z_l BEFORE the first challenge is known.  With the quarters a = [a0|a1|a2|a3], b = [b0|b1|b2|b3] of round 0, the folded
+// vectors are a' = [a0 + x a2 | a1 + x a3], b' = [b0 + x^-1 b2 | b1 + x^-1 b3], so round 1's
+//     z_l = prod e(a'_r, b'_l) = prod e(a1 + x a3, b0 + x^-1 b2) = E(a1,b0) * E(a1,b2)^(x^-1) * E(a3,b0)^x * E(a3,b2)
+// with E(u, v) = prod_i e(u_i, v_i) over n/4 pairs -- four products that need NO challenge.  On one GPU the statement hash (sequential
+// Blake2s, ~0.31 s at n = 2^20) ends ~110 ms after the GPU has finished round 0 and the fold tables: the four products (n pairs, ~97 ms)
+// run in that window; once x is known z_l costs two GT powers on host threads, and round 1 evaluates only z_r on the device.
+// Same group element, hence the same proof bytes.  (z_r as well would need another n pairs: the window is not that long.)
+int32_t job_preevaluate_round1(Engine* e, ripp_sipp_job* j) {
+    j->pre_zl_ready = false;
+    const size_t q = j->len / 4;
+    if (q < ((size_t)1 << 15) || j->digest_ready.load() || e->sw.no_precompute) return RIPP_OK;      // small statements: the hash is done long before
+    const G1A* a = j->a.as<G1A>(); const G2A* b = j->b.as<G2A>();
+    const G1A* as[4] = {a + q, a + q, a + 3 * q, a + 3 * q};
+    const G2A* bs[4] = {b, b + 2 * q, b, b + 2 * q};
+    std::vector<Fp12> rows(4 * N_LINES);
+    const double t0 = now_ms();
+    int32_t rc = e->step_products(as, bs, 4, q, rows.data()); if (rc) return rc;
+    std::vector<std::future<Fp12>> f;
+    for (int k = 1; k < 4; ++k) f.push_back(host_pool().submit([&rows, k]() { return final_exponentiation(miller_combine(rows.data() + (size_t)k * N_LINES)); }));
+    j->pre_zl[0] = final_exponentiation(miller_combine(rows.data()));
+    for (int k = 1; k < 4; ++k) j->pre_zl[k] = f[k - 1].get();
+    j->pre_zl_ready = true;
+    if (trace_on()) fprintf(stderr, "[ripp] round-1 z_l pre-evaluated in the hash window: %.1f ms (hash %s)\n", now_ms() - t0, j->digest_ready.load() ? "already done" : "still running");
     return RIPP_OK;
 }
 
@@ -1212,16 +1240,33 @@ API int32_t ripp_sipp_job_prove(ripp_sipp_job* j, const ripp_gt* value, ripp_gt*
     int32_t rc = job_begin(e, j); if (rc) return rc;
     if (trace_on()) fprintf(stderr, "[ripp] scale+normalize done at t=%.1f ms\n", now_ms() - t_start);
     size_t round = 0;
+    Fr x_prev = Fr::zero();
+    j->pre_zl_ready = false;
     while (j->len > 1) {
         Fp12 rows[2 * N_LINES];
         const double tr0 = now_ms();
-        if ((rc = job_round_partials(e, j, rows))) return rc;
+        const bool have_zl = round == 1 && j->pre_zl_ready;                                  // z_l of round 1 was evaluated in the hash window
+        j->pre_zl_ready = false;
+        if (have_zl) {                                                                       // only z_r = prod e(a_l, b_r) on the device
+            const size_t half = j->len / 2;
+            const G1A* as[1] = {j->a.as<G1A>()}; const G2A* bs[1] = {j->b.as<G2A>() + half};
+            const double tp = now_ms();
+            if ((rc = e->step_products(as, bs, 1, half, rows + N_LINES))) return rc;
+            e->stats.miller_products_ms += now_ms() - tp;
+        } else if ((rc = job_round_partials(e, j, rows))) return rc;
         if (round == 0 && !j->seeded && (rc = job_precompute_round0(e, j))) return rc;      // asynchronous: overlaps the host work below and the hash
         if ((rc = job_precompute_vm(e, j))) return rc;                                       // small rounds: the same on the VM, during the host phase
         const double t0 = now_ms();
         auto fut = host_pool().submit([&rows]() { return final_exponentiation(miller_combine(rows + N_LINES)); });
-        const Fp12 zl = final_exponentiation(miller_combine(rows));
+        Fp12 zl;
+        if (have_zl) {          // E(a1,b0) * E(a1,b2)^(1/x) * E(a3,b0)^x * E(a3,b2): two GT powers on host threads (values of GT proper)
+            const Fr xi = inv(x_prev);
+            auto p1 = host_pool().submit([j, xi]() { return gt_pow_gls(j->pre_zl[1], xi); });
+            const Fp12 p2 = gt_pow_gls(j->pre_zl[2], x_prev);
+            zl = mul(mul(j->pre_zl[0], p1.get()), mul(p2, j->pre_zl[3]));
+        } else zl = final_exponentiation(miller_combine(rows));
         const Fp12 zr = fut.get();
+        if (round == 0 && !j->seeded && (rc = job_preevaluate_round1(e, j))) return rc;      // blocks on the GPU while the hash thread is still busy
         if (!j->seeded) {
             const double th = now_ms();
             if (j->hash_thread.joinable()) j->hash_thread.join();
@@ -1229,6 +1274,7 @@ API int32_t ripp_sipp_job_prove(ripp_sipp_job* j, const ripp_gt* value, ripp_gt*
             j->rng.from_digest(j->digest); j->seeded = true;
         }
         const Fr x = fs::sipp_challenge(j->rng, zl, zr);
+        x_prev = x;
         e->stats.host_ms += now_ms() - t0;
         std::memcpy(&proof[2 * round], &zl, sizeof(Fp12)); std::memcpy(&proof[2 * round + 1], &zr, sizeof(Fp12));
         if (challenges) std::memcpy(&challenges[round], &x, sizeof(Fr));
