@@ -12,7 +12,13 @@
 #define RIPP_ORACLE_FIELD_H
 #include <stdint.h>
 #include <string.h>
+#ifdef ORC_BLS12_377
+/* BLS12-377 build (liboracle for the curve of the reference's own SIPP test, sipp/src/lib.rs:229): Fp2 = Fp[u]/(u^2+5),
+ * Fp6 = Fp2[v]/(v^3-u), Fp12 = Fp6[w]/(w^2-v)  (ark-bls12-377 0.4) -- only fp2_mul / fp2_sqr / fp2_inv / fp2_mul_xi differ. */
+#include "params_377.h"
+#else
 #include "params.h"
+#endif
 
 typedef unsigned __int128 u128;
 typedef struct { uint64_t l[6]; } fp_t;
@@ -101,6 +107,20 @@ ORC_INLINE int fp2_is_zero(const fp2_t *a) { return fp_is_zero(&a->c0) && fp_is_
 ORC_INLINE int fp2_eq(const fp2_t *a, const fp2_t *b) { return fp_eq(&a->c0, &b->c0) && fp_eq(&a->c1, &b->c1); }
 ORC_INLINE fp2_t fp2_zero(void) { fp2_t r; r.c0 = fp_zero(); r.c1 = fp_zero(); return r; }
 ORC_INLINE fp2_t fp2_one(void) { fp2_t r; r.c0 = fp_one(); r.c1 = fp_zero(); return r; }
+#ifdef ORC_BLS12_377
+ORC_INLINE void fp_mul5(fp_t *r, const fp_t *a) { fp_t t; fp_dbl(&t, a); fp_dbl(&t, &t); fp_add(r, &t, a); }
+ORC_INLINE void fp2_mul(fp2_t *r, const fp2_t *a, const fp2_t *b) {      /* u^2 = -5: c0 = a0 b0 - 5 a1 b1 */
+    fp_t t0, t1, s0, s1, m, t5;
+    fp_mul(&t0, &a->c0, &b->c0); fp_mul(&t1, &a->c1, &b->c1);
+    fp_add(&s0, &a->c0, &a->c1); fp_add(&s1, &b->c0, &b->c1); fp_mul(&m, &s0, &s1);
+    fp_mul5(&t5, &t1); fp_sub(&r->c0, &t0, &t5); fp_sub(&m, &m, &t0); fp_sub(&r->c1, &m, &t1);
+}
+ORC_INLINE void fp2_sqr(fp2_t *r, const fp2_t *a) {                       /* c0 = a0^2 - 5 a1^2 = (a0+a1)(a0-5a1) + 4 a0 a1 */
+    fp_t s, d, m, a5, m4;
+    fp_mul5(&a5, &a->c1); fp_add(&s, &a->c0, &a->c1); fp_sub(&d, &a->c0, &a5); fp_mul(&m, &a->c0, &a->c1);
+    fp_mul(&s, &s, &d); fp_dbl(&m4, &m); fp_dbl(&m4, &m4); fp_add(&r->c0, &s, &m4); fp_dbl(&r->c1, &m);
+}
+#else
 ORC_INLINE void fp2_mul(fp2_t *r, const fp2_t *a, const fp2_t *b) {
     fp_t t0, t1, s0, s1, m;
     fp_mul(&t0, &a->c0, &b->c0); fp_mul(&t1, &a->c1, &b->c1);
@@ -112,13 +132,23 @@ ORC_INLINE void fp2_sqr(fp2_t *r, const fp2_t *a) {
     fp_add(&s, &a->c0, &a->c1); fp_sub(&d, &a->c0, &a->c1); fp_mul(&m, &a->c0, &a->c1);
     fp_mul(&r->c0, &s, &d); fp_dbl(&r->c1, &m);
 }
+#endif
 ORC_INLINE void fp2_mul_fp(fp2_t *r, const fp2_t *a, const fp_t *s) { fp_mul(&r->c0, &a->c0, s); fp_mul(&r->c1, &a->c1, s); }
+#ifdef ORC_BLS12_377
+/* multiply by the Fp6 non-residue xi = u:  (a0 + a1 u) u = -5 a1 + a0 u */
+ORC_INLINE void fp2_mul_xi(fp2_t *r, const fp2_t *a) { fp_t t0, t1; fp_mul5(&t0, &a->c1); fp_neg(&t0, &t0); t1 = a->c0; r->c0 = t0; r->c1 = t1; }
+static void fp2_inv(fp2_t *r, const fp2_t *a) {                            /* norm = a0^2 + 5 a1^2 */
+    fp_t n, t; fp_sqr(&n, &a->c0); fp_sqr(&t, &a->c1); fp_mul5(&t, &t); fp_add(&n, &n, &t); fp_inv(&n, &n);
+    fp_mul(&r->c0, &a->c0, &n); fp_mul(&t, &a->c1, &n); fp_neg(&r->c1, &t);
+}
+#else
 /* multiply by the Fp6 non-residue xi = 1 + u */
 ORC_INLINE void fp2_mul_xi(fp2_t *r, const fp2_t *a) { fp_t t0, t1; fp_sub(&t0, &a->c0, &a->c1); fp_add(&t1, &a->c0, &a->c1); r->c0 = t0; r->c1 = t1; }
 static void fp2_inv(fp2_t *r, const fp2_t *a) {
     fp_t n, t; fp_sqr(&n, &a->c0); fp_sqr(&t, &a->c1); fp_add(&n, &n, &t); fp_inv(&n, &n);
     fp_mul(&r->c0, &a->c0, &n); fp_mul(&t, &a->c1, &n); fp_neg(&r->c1, &t);
 }
+#endif
 
 /* ------------------------------------------------------------------ Fp6 */
 ORC_INLINE void fp6_add(fp6_t *r, const fp6_t *a, const fp6_t *b) { fp2_add(&r->c0, &a->c0, &b->c0); fp2_add(&r->c1, &a->c1, &b->c1); fp2_add(&r->c2, &a->c2, &b->c2); }
@@ -192,6 +222,17 @@ static void fp12_mul_by_014(fp12_t *f, const fp2_t *c0, const fp2_t *c1, const f
     fp2_add(&o, c1, c4);
     fp6_add(&s, &f->c1, &f->c0); fp6_mul_by_01(&s, &s, c0, &o); fp6_sub(&s, &s, &aa); fp6_sub(&s, &s, &bb);
     fp6_mul_v(&t, &bb); fp6_add(&f->c0, &t, &aa); f->c1 = s;
+}
+/* f * (c0 + (d0 + d1 v) w)  -- ark-ff Fp12::mul_by_034, used by the D-twist line (ark-ec bls12 `ell`, TwistType::D) */
+static void fp12_mul_by_034(fp12_t *f, const fp2_t *c0, const fp2_t *d0, const fp2_t *d1) {
+    fp6_t a, b, e, t; fp2_t c0d0;
+    a.c0 = f->c0.c0; a.c1 = f->c0.c1; a.c2 = f->c0.c2;
+    fp2_mul(&a.c0, &f->c0.c0, c0); fp2_mul(&a.c1, &f->c0.c1, c0); fp2_mul(&a.c2, &f->c0.c2, c0);     /* a = f.c0 * c0 */
+    fp6_mul_by_01(&b, &f->c1, d0, d1);                                                                /* b = f.c1 * (d0 + d1 v) */
+    fp2_add(&c0d0, c0, d0);
+    fp6_add(&e, &f->c0, &f->c1); fp6_mul_by_01(&e, &e, &c0d0, d1);                                   /* e = (f.c0 + f.c1)(c0 + d0 + d1 v) */
+    fp6_sub(&e, &e, &a); fp6_sub(&e, &e, &b);
+    fp6_mul_v(&t, &b); fp6_add(&f->c0, &a, &t); f->c1 = e;
 }
 static void fp12_inv(fp12_t *r, const fp12_t *a) {
     fp6_t t0, t1; fp6_sqr(&t0, &a->c0); fp6_sqr(&t1, &a->c1); fp6_mul_v(&t1, &t1); fp6_sub(&t0, &t0, &t1); fp6_inv(&t0, &t0);

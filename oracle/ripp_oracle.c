@@ -46,6 +46,30 @@ static void ser_fp_be(uint8_t *out, const fp_t *a) {    /* canonical big-endian,
 }
 static void ser_fp_le(uint8_t *out, const fp_t *a) { fp_t c; fp_from_mont(&c, a); memcpy(out, c.l, 48); }
 ORC_API size_t orc_ser_fr(const fr_t *a, uint8_t out[32]) { fr_t c; fr_from_mont(&c, a); memcpy(out, c.l, 32); return 32; }
+#ifdef ORC_BLS12_377
+/* ark-bls12-377 has no zcash-style override: the GENERIC ark-ec 0.4 short-Weierstrass encoding applies [ark-mem] -- x then y,
+ * little-endian canonical, SWFlags in the two top bits of the LAST byte: bit 7 = YIsNegative (y > -y as integers; Fq2 compares c1 first),
+ * bit 6 = PointAtInfinity (x = y = 0 written).  serialize_with_mode writes the flags in the uncompressed form too. */
+static int fp_canon_gt(const fp_t *a, const fp_t *b) {                      /* canonical integers: a > b */
+    fp_t x, y; fp_from_mont(&x, a); fp_from_mont(&y, b);
+    for (int i = 5; i >= 0; --i) if (x.l[i] != y.l[i]) return x.l[i] > y.l[i];
+    return 0;
+}
+ORC_API size_t orc_ser_g1(const g1a_t *p, uint8_t out[96]) {
+    if (g1a_is_inf(p)) { memset(out, 0, 96); out[95] = 0x40; return 96; }
+    ser_fp_le(out, &p->x); ser_fp_le(out + 48, &p->y);
+    fp_t ny; fp_neg(&ny, &p->y); if (fp_canon_gt(&p->y, &ny)) out[95] |= 0x80;
+    return 96;
+}
+ORC_API size_t orc_ser_g2(const g2a_t *p, uint8_t out[192]) {
+    if (g2a_is_inf(p)) { memset(out, 0, 192); out[191] = 0x40; return 192; }
+    ser_fp_le(out, &p->x.c0); ser_fp_le(out + 48, &p->x.c1); ser_fp_le(out + 96, &p->y.c0); ser_fp_le(out + 144, &p->y.c1);
+    fp2_t ny; fp2_neg(&ny, &p->y);
+    const int neg = fp_is_zero(&p->y.c1) ? fp_canon_gt(&p->y.c0, &ny.c0) : fp_canon_gt(&p->y.c1, &ny.c1);
+    if (neg) out[191] |= 0x80;
+    return 192;
+}
+#else
 ORC_API size_t orc_ser_g1(const g1a_t *p, uint8_t out[96]) {
     if (g1a_is_inf(p)) { memset(out, 0, 96); out[0] = 0x40; return 96; }
     ser_fp_be(out, &p->x); ser_fp_be(out + 48, &p->y); return 96;
@@ -54,6 +78,7 @@ ORC_API size_t orc_ser_g2(const g2a_t *p, uint8_t out[192]) {
     if (g2a_is_inf(p)) { memset(out, 0, 192); out[0] = 0x40; return 192; }
     ser_fp_be(out, &p->x.c1); ser_fp_be(out + 48, &p->x.c0); ser_fp_be(out + 96, &p->y.c1); ser_fp_be(out + 144, &p->y.c0); return 192;
 }
+#endif
 ORC_API size_t orc_ser_gt(const fp12_t *f, uint8_t out[576]) {
     const fp2_t *c[6] = { &f->c0.c0, &f->c0.c1, &f->c0.c2, &f->c1.c0, &f->c1.c1, &f->c1.c2 };
     for (int i = 0; i < 6; ++i) { ser_fp_le(out + 96 * i, &c[i]->c0); ser_fp_le(out + 96 * i + 48, &c[i]->c1); }
@@ -478,4 +503,6 @@ ORC_API int orc_gipa_tipp_verify(const g2j_t *ck_a, const g1j_t *ck_b, size_t n,
     return ok;
 }
 
-#include "tipa.h"
+#ifndef ORC_BLS12_377
+#include "tipa.h"       /* TIPA / aggregation restatements: BLS12-381 only (Fr::from_random_bytes masks, GLS-free but 381-tested) */
+#endif
