@@ -85,12 +85,16 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  ripp_amd has no CPU fallback.")
-        L = ctypes.CDLL(LIB_PATH)
-        L.ripp_last_error.restype = ctypes.c_char_p
-        for name in ("ripp_ser_gt", "ripp_ser_g1", "ripp_ser_g2", "ripp_ser_fr", "ripp_sipp_job_rounds_left", "ripp_sipp_job_local_len"):
-            getattr(L, name).restype = ctypes.c_size_t
-        _lib = L
+        _lib = load_library(LIB_PATH)
     return _lib
+
+
+def load_library(path):
+    L = ctypes.CDLL(path)
+    L.ripp_last_error.restype = ctypes.c_char_p
+    for name in ("ripp_ser_gt", "ripp_ser_g1", "ripp_ser_g2", "ripp_ser_fr", "ripp_sipp_job_rounds_left", "ripp_sipp_job_local_len"):
+        getattr(L, name).restype = ctypes.c_size_t
+    return L
 
 
 def last_error():

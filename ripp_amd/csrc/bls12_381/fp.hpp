@@ -10,7 +10,14 @@
 // and add-with-carry chains (`v_add_co_u32` / `v_addc_co_u32`) for the rest.
 #pragma once
 #include <stdint.h>
+#if defined(RIPP_BLS12_377)
+// BLS12-377 build (libripp_hip_377.so; the curve of the reference's own SIPP test, sipp/src/lib.rs:229): the same 12 x u32 / 8 x u32 limb
+// layouts and code, other constants.  Endomorphism-accelerated paths and the field VM are disabled in that build (engine.hip).
+#include "../bls12_377/params.hpp"
+#include "../bls12_377/endo_stub.hpp"
+#else
 #include "params.hpp"
+#endif
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -63,7 +70,11 @@ struct FpParams {
     RIPP_HD static constexpr uint32_t one(int i)  { constexpr uint32_t v[12] = RIPP_FP_R1; return v[i]; }
     RIPP_HD static constexpr uint32_t r2(int i)   { constexpr uint32_t v[12] = RIPP_FP_R2; return v[i]; }
     RIPP_HD static constexpr uint32_t pm2(int i)  { constexpr uint32_t v[12] = RIPP_FP_P_MINUS_2; return v[i]; }
+#if defined(RIPP_BLS12_377)
+    static constexpr int BITS = 377;
+#else
     static constexpr int BITS = 381;
+#endif
 };
 struct FrParams {
     static constexpr int N = 8;
@@ -72,7 +83,11 @@ struct FrParams {
     RIPP_HD static constexpr uint32_t one(int i)  { constexpr uint32_t v[8] = RIPP_FR_R1; return v[i]; }
     RIPP_HD static constexpr uint32_t r2(int i)   { constexpr uint32_t v[8] = RIPP_FR_R2; return v[i]; }
     RIPP_HD static constexpr uint32_t pm2(int i)  { constexpr uint32_t v[8] = RIPP_FR_R_MINUS_2; return v[i]; }
+#if defined(RIPP_BLS12_377)
+    static constexpr int BITS = 253;
+#else
     static constexpr int BITS = 255;
+#endif
 };
 
 // ---------------------------------------------------------------- generic Montgomery field

@@ -12,7 +12,11 @@
 namespace ripp {
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
 __device__ const uint32_t KALISKI_FIX[769][12] = {
+#if defined(RIPP_BLS12_377)
+#include "../bls12_377/inv_table.inc"
+#else
 #include "inv_table.inc"
+#endif
 };
 
 __device__ __noinline__ inline Fp fp_inv_kaliski(const Fp& a) {

@@ -15,8 +15,15 @@
 
 namespace ripp {
 
+#if defined(RIPP_BLS12_377)
+constexpr uint64_t BLS_X_ABS = 0x8508c00000000001ull;   // x > 0 (no conjugations)
+constexpr bool BLS_X_NEG = false;
+constexpr int N_LINES = 69;                              // 63 doubling + 6 addition steps
+#else
 constexpr uint64_t BLS_X_ABS = 0xd201000000010000ull;   // |x|, x < 0
+constexpr bool BLS_X_NEG = true;
 constexpr int N_LINES = 68;                              // 63 doubling + 5 addition steps
+#endif
 
 // a / 2 mod p without a multiplication: (a + (a odd ? p : 0)) >> 1
 RIPP_HD Fp half(const Fp& a) {
@@ -34,8 +41,13 @@ RIPP_HD Fp2 half(const Fp2& a) { return {half(a.c0), half(a.c1)}; }
 
 struct LineCoeffs { Fp2 c0, c1, c2; };   // line element c0 + c1 v + c2 v w  (indices 0,1,4 of mul_by_014)
 
+#if defined(RIPP_BLS12_377)
+// b' = 1/u = (0, -1/5):  (a0 + a1 u) * b' = a1 + (a0 * (-1/5)) u   -- one Fp product by a constant
+RIPP_MID Fp2 mul_by_b_twist(const Fp2& a) { return {a.c1, fmul(a.c0, fp_const(RIPP_FP_TWIST_B1))}; }
+#else
 // 4(1+u) * a  -- multiplication by the twist coefficient b' with additions only
 RIPP_HD Fp2 mul_by_b_twist(const Fp2& a) { return mul_xi(dbl(dbl(a))); }
+#endif
 
 // Doubling step in homogeneous projective coordinates (the formulas ark-ec 0.4 bls12::g2 `double_in_place` uses,
 // with the two multiplications by 1/2 replaced by shifts): T <- 2T, returns the tangent line at T scaled for P.
@@ -52,7 +64,11 @@ RIPP_MID LineCoeffs line_double(Fp2& X, Fp2& Y, Fp2& Z, const Fp& xP, const Fp& 
     X = mul(a, sub(b, f));
     Y = sub(sqr(g), add(dbl(e2), e2));
     Z = mul(b, h);
+#if defined(RIPP_BLS12_377)
+    return {mul_fp(neg(h), yP), mul_fp(add(dbl(j), j), xP), i};            // TwistType::D: (-h yP, 3j xP, i) at w^0, w^1, w^3
+#else
     return {i, mul_fp(add(dbl(j), j), xP), mul_fp(neg(h), yP)};
+#endif
 }
 // Addition step T <- T + Q (Q affine), returns the chord line scaled for P.
 RIPP_MID LineCoeffs line_add(Fp2& X, Fp2& Y, Fp2& Z, const Fp2& qx, const Fp2& qy, const Fp& xP, const Fp& yP) {
@@ -65,7 +81,11 @@ RIPP_MID LineCoeffs line_add(Fp2& X, Fp2& Y, Fp2& Z, const Fp2& qx, const Fp2& q
     Y = sub(mul(theta, sub(g, h)), mul(e, Y));
     Z = mul(Z, e);
     const Fp2 j = sub(mul(theta, qx), mul(lambda, qy));
+#if defined(RIPP_BLS12_377)
+    return {mul_fp(lambda, yP), mul_fp(neg(theta), xP), j};
+#else
     return {j, mul_fp(neg(theta), xP), mul_fp(lambda, yP)};
+#endif
 }
 
 // Stage (3): fold the per-step products L[0..67] into the Miller-loop value (conjugated because x < 0).
@@ -76,14 +96,14 @@ RIPP_FN Fp12 miller_combine(const Fp12* L) {
         f = mul(sqr(f), L[s++]);
         if ((BLS_X_ABS >> b) & 1) f = mul(f, L[s++]);
     }
-    return conj(f);
+    return BLS_X_NEG ? conj(f) : f;
 }
 
 // f^|x| then conjugate (x < 0), on cyclotomic-subgroup elements
 RIPP_FN Fp12 exp_by_x(const Fp12& a) {
     Fp12 acc = a;
     for (int i = 62; i >= 0; --i) { acc = cyclotomic_sqr(acc); if ((BLS_X_ABS >> i) & 1) acc = mul(acc, a); }
-    return conj(acc);
+    return BLS_X_NEG ? conj(acc) : acc;
 }
 
 // Final exponentiation with the exponent (p^6-1)(p^2+1) * ((x-1)^2 (x+p)(x^2+p^2-1) + 3): the value arkworks'

@@ -22,6 +22,25 @@ RIPP_HD Fp2 sub(const Fp2& a, const Fp2& b) { return {sub(a.c0, b.c0), sub(a.c1,
 RIPP_HD Fp2 neg(const Fp2& a) { return {neg(a.c0), neg(a.c1)}; }
 RIPP_HD Fp2 dbl(const Fp2& a) { return {dbl(a.c0), dbl(a.c1)}; }
 RIPP_HD Fp2 conj(const Fp2& a) { return {a.c0, neg(a.c1)}; }
+#if defined(RIPP_BLS12_377)
+// BLS12-377: Fp2 = Fp[u]/(u^2 + 5), Fp6 non-residue xi = u  (ark-bls12-377 0.4)
+RIPP_HD Fp mul5(const Fp& a) { const Fp t = dbl(dbl(a)); return add(t, a); }
+RIPP_MID Fp2 mul(const Fp2& a, const Fp2& b) {           // Karatsuba: c0 = a0 b0 - 5 a1 b1
+    const Fp t0 = fmul(a.c0, b.c0), t1 = fmul(a.c1, b.c1);
+    const Fp m = fmul(add(a.c0, a.c1), add(b.c0, b.c1));
+    return {sub(t0, mul5(t1)), sub(sub(m, t0), t1)};
+}
+RIPP_MID Fp2 sqr(const Fp2& a) {                          // a0^2 - 5 a1^2 = (a0 + a1)(a0 - 5 a1) + 4 a0 a1
+    const Fp m = fmul(a.c0, a.c1);
+    return {add(fmul(add(a.c0, a.c1), sub(a.c0, mul5(a.c1))), dbl(dbl(m))), dbl(m)};
+}
+RIPP_MID Fp2 mul_fp(const Fp2& a, const Fp& s) { return {fmul(a.c0, s), fmul(a.c1, s)}; }
+RIPP_HD Fp2 mul_xi(const Fp2& a) { return {neg(mul5(a.c1)), a.c0}; }                 // * u
+RIPP_MID Fp2 inv(const Fp2& a) {                          // norm a0^2 + 5 a1^2
+    const Fp n = finv(add(fsqr(a.c0), mul5(fsqr(a.c1))));
+    return {fmul(a.c0, n), neg(fmul(a.c1, n))};
+}
+#else
 RIPP_MID Fp2 mul(const Fp2& a, const Fp2& b) {           // Karatsuba: 3 Fp products
     const Fp t0 = fmul(a.c0, b.c0), t1 = fmul(a.c1, b.c1);
     const Fp m = fmul(add(a.c0, a.c1), add(b.c0, b.c1));
@@ -37,13 +56,16 @@ RIPP_MID Fp2 inv(const Fp2& a) {
     const Fp n = finv(add(fsqr(a.c0), fsqr(a.c1)));
     return {fmul(a.c0, n), neg(fmul(a.c1, n))};
 }
+#endif
 
 RIPP_HD Fp2 finv(const Fp2& a) { return inv(a); }
 // fmul is what the group law (curve.hpp) and the MSM / fold kernels call.  On the device it is two sum-of-two-products with one
 // Montgomery reduction each (fp.hpp::mul2_add): the same limb products as Karatsuba's three multiplications, none of its five
 // additions and two calls instead of three -- measured 4-5 % on the G2 folds and MSM.  The pairing tower above keeps Karatsuba
 // (`mul`): its kernels are register bound and the 48-register call makes k_line_products 5 % slower.
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(RIPP_NO_FP2_LAZY)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RIPP_NO_FP2_LAZY) && defined(RIPP_BLS12_377)
+RIPP_MID Fp2 fmul(const Fp2& a, const Fp2& b) { return {fmul2_add(a.c0, b.c0, neg(mul5(a.c1)), b.c1), fmul2_add(a.c0, b.c1, a.c1, b.c0)}; }   // a0 b0 + (-5 a1) b1
+#elif defined(__HIP_DEVICE_COMPILE__) && !defined(RIPP_NO_FP2_LAZY)
 RIPP_MID Fp2 fmul(const Fp2& a, const Fp2& b) { return {fmul2_add(a.c0, b.c0, neg(a.c1), b.c1), fmul2_add(a.c0, b.c1, a.c1, b.c0)}; }
 #else
 RIPP_HD Fp2 fmul(const Fp2& a, const Fp2& b) { return mul(a, b); }
@@ -109,6 +131,13 @@ RIPP_MID Fp12 mul_by_014(const Fp12& f, const Fp2& c0, const Fp2& c1, const Fp2&
     const Fp6 bb = mul_by_1(f.c1, c4);
     const Fp6 s = sub(sub(mul_by_01(add(f.c1, f.c0), c0, add(c1, c4)), aa), bb);
     return {add(mul_v(bb), aa), s};
+}
+// f * (c0 + (d0 + d1 v) w): the D-twist line element (ark-ff Fp12::mul_by_034)
+RIPP_MID Fp12 mul_by_034(const Fp12& f, const Fp2& c0, const Fp2& d0, const Fp2& d1) {
+    const Fp6 a = {mul(f.c0.c0, c0), mul(f.c0.c1, c0), mul(f.c0.c2, c0)};
+    const Fp6 b = mul_by_01(f.c1, d0, d1);
+    const Fp6 e = sub(sub(mul_by_01(add(f.c0, f.c1), add(c0, d0), d1), a), b);
+    return {add(a, mul_v(b)), e};
 }
 RIPP_FN Fp12 inv(const Fp12& a) {
     const Fp6 t = inv(sub(mul(a.c0, a.c0), mul_v(mul(a.c1, a.c1))));

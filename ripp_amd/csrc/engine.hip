@@ -135,11 +135,16 @@ struct Engine {
     size_t max_pairs_per_batch = (size_t)1 << 19;                        // lines buffer cap: 2^19 pairs * 19.6 KB = 10.3 GB
     ripp_stats stats{};
     // run-time switches: read from the environment ONCE per C-ABI call (get_engine), never inside round loops
-    struct Switches { bool no_vm = false, no_precompute = false, no_fold_tables = false, no_msm_glv = false, lp_one_lane = false; } sw;
+    struct Switches { bool no_vm = false, no_precompute = false, no_fold_tables = false, no_msm_glv = false, lp_one_lane = false, no_endo = false; } sw;
     void refresh_switches() {
         sw.no_vm = std::getenv("RIPP_NO_VM") != nullptr; sw.no_precompute = std::getenv("RIPP_NO_PRECOMPUTE") != nullptr;
         sw.no_fold_tables = std::getenv("RIPP_NO_FOLD_TABLES") != nullptr; sw.no_msm_glv = std::getenv("RIPP_NO_MSM_GLV") != nullptr;
         sw.lp_one_lane = std::getenv("RIPP_LP_ONE_LANE") != nullptr;
+        sw.no_endo = std::getenv("RIPP_NO_ENDO") != nullptr;            // plain scalar multiplications in the folds / scaling (no GLV, no psi)
+#if defined(RIPP_BLS12_377)
+        // this build carries no endomorphism constants and no VM programs for its tower: plain paths only
+        sw.no_vm = sw.no_precompute = sw.no_fold_tables = sw.no_msm_glv = sw.no_endo = true; sw.lp_one_lane = false;
+#endif
     }
 
     int32_t init(int dev) {
@@ -201,6 +206,11 @@ struct Engine {
     int32_t scale_g1_dev(const G1A* base, uint32_t base_stride, const Fr* k, size_t n, G1J* out, hipStream_t st = nullptr) {
         if (n == 0) return RIPP_OK;
         if (!st) st = stream;
+        if (sw.no_endo) {                                     // 255-bit double-and-add (the reference's `a.mul(r)`, sipp/src/lib.rs:61-65)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scale_pts<Fp>), dim3(nblk(n, 256)), dim3(256), 0, st, base, base_stride, k, (uint32_t)n, out);
+            HIPCHK(hipGetLastError());
+            return RIPP_OK;
+        }
         int32_t rc = scale_tab.reserve((size_t)SCALE_TAB * G1J_CHUNKS * n * sizeof(uint4)); if (rc) return rc;
         hipLaunchKernelGGL(k_scale_g1_glv, dim3(nblk(n, 256)), dim3(256), 0, st, base, base_stride, k, (uint32_t)n, scale_tab.as<uint4>(), out);
         HIPCHK(hipGetLastError());
@@ -325,9 +335,11 @@ struct Engine {
             if ((rc = partA.reserve(nrows * FP12_CHUNKS * (size_t)T * sizeof(uint4))) != RIPP_OK) return rc;
             if ((rc = partB.reserve(nrows * FP12_CHUNKS * (size_t)((T + 1) / 2) * sizeof(uint4))) != RIPP_OK) return rc;
             if ((rc = mark(ev_prod, true)) != RIPP_OK) return rc;
+#if !defined(RIPP_BLS12_377)
             if (sw.lp_one_lane)
                 hipLaunchKernelGGL(k_line_products1, dim3(nblk(T, 64), (unsigned)nrows), dim3(64), 0, stream, lines.as<uint4>(), stride, (uint32_t)m, partA.as<uint4>(), T);
             else
+#endif
                 hipLaunchKernelGGL(k_line_products, dim3(nblk(T, LP_GROUPS_PER_WAVE), (unsigned)nrows), dim3(64), 0, stream, lines.as<uint4>(), stride, (uint32_t)m, partA.as<uint4>(), T);
             HIPCHK(hipGetLastError());
             if ((rc = mark(ev_prod, false)) != RIPP_OK) return rc;
@@ -784,6 +796,9 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true)
         hipLaunchKernelGGL(k_vm_fold_g2_split, dim3(nblk(half, 4 * VM_EPW), 4), dim3(256), 4 * VM_EPW * VM_G2_SLOTS * sizeof(Fp), e->stream, b + half, (uint32_t)half, gls_digits(x_inv), e->qtab.as<G2J>(), e->vm_flag.as<uint32_t>());
         hipLaunchKernelGGL(k_vm_combine_g2, dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VM_G2_SLOTS * sizeof(Fp), e->stream, e->qtab.as<G2J>(), b, (uint32_t)half, j->jac2.as<G2J>());
     } else
+    if (e->sw.no_endo) {               // no psi on this build / switch: the 255-bit NAF fold (x^-1 is full width)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_affine_naf<Fp2>), dim3(nblk(half, 256)), dim3(256), 0, e->stream, b + half, b, (uint32_t)half, naf_digits(x_inv), j->jac2.as<G2J>());
+    } else
     if (half <= e->gls_split_max) {     // latency-bound round: 4 lanes per element
         if ((rc = e->qtab.reserve(std::max<size_t>(4 * G2A_CHUNKS * qstride * sizeof(uint4), 4 * half * sizeof(G2J)))) != RIPP_OK) return rc;
         hipLaunchKernelGGL(k_fold_g2_gls_split, dim3(nblk(half, 64), 4), dim3(64), 0, e->stream, b + half, (uint32_t)half, gls_digits(x_inv), e->qtab.as<G2J>());
@@ -914,7 +929,7 @@ static int32_t fold_impl(const IN* hi, const IN* lo, size_t half, const ripp_fr*
         Affine<F>*dh, *dl;
         if ((rc = upload<Affine<F>>(e, e->tmpA, hi, half, &dh))) return rc;
         if ((rc = upload<Affine<F>>(e, e->tmpB, lo, half, &dl))) return rc;
-        if (std::is_same<F, Fp2>::value) {
+        if (std::is_same<F, Fp2>::value && !e->sw.no_endo) {
             const size_t qstride = (half + 63) & ~(size_t)63;
             if ((rc = e->qtab.reserve(4 * G2A_CHUNKS * qstride * sizeof(uint4)))) return rc;
             hipLaunchKernelGGL(k_fold_g2_gls, dim3(nblk(half, 64)), dim3(64), 0, e->stream, reinterpret_cast<const G2A*>(dh), reinterpret_cast<const G2A*>(dl), (uint32_t)half,

@@ -173,6 +173,23 @@ inline void ser_fp_be(const Fp& a, uint8_t* out) {
     for (int i = 0; i < 12; ++i) { const uint32_t w = c.l[i]; out[47 - 4 * i] = (uint8_t)w; out[46 - 4 * i] = (uint8_t)(w >> 8); out[45 - 4 * i] = (uint8_t)(w >> 16); out[44 - 4 * i] = (uint8_t)(w >> 24); }
 }
 inline void ser_fr(const Fr& a, uint8_t* out) { const Fr c = from_mont(a); std::memcpy(out, c.l, 32); }
+#if defined(RIPP_BLS12_377)
+// ark-bls12-377 keeps the GENERIC ark-ec 0.4 short-Weierstrass encoding [ark-mem]: x then y, little-endian canonical, SWFlags in the two
+// top bits of the LAST byte -- bit 7 YIsNegative (y > -y as integers; Fq2 compares c1 first, then c0), bit 6 PointAtInfinity -- also in
+// the uncompressed form (SWCurveConfig::serialize_with_mode writes y.serialize_with_flags).
+inline bool canon_gt(const Fp& a, const Fp& b) { const Fp x = from_mont(a), y = from_mont(b); for (int i = 11; i >= 0; --i) if (x.l[i] != y.l[i]) return x.l[i] > y.l[i]; return false; }
+inline void ser_g1(const G1A& p, uint8_t* out) {
+    if (is_inf(p)) { std::memset(out, 0, 96); out[95] = 0x40; return; }
+    ser_fp_le(p.x, out); ser_fp_le(p.y, out + 48);
+    if (canon_gt(p.y, neg(p.y))) out[95] |= 0x80;
+}
+inline void ser_g2(const G2A& p, uint8_t* out) {
+    if (is_inf(p)) { std::memset(out, 0, 192); out[191] = 0x40; return; }
+    ser_fp_le(p.x.c0, out); ser_fp_le(p.x.c1, out + 48); ser_fp_le(p.y.c0, out + 96); ser_fp_le(p.y.c1, out + 144);
+    const bool ng = p.y.c1.is_zero() ? canon_gt(p.y.c0, neg(p.y.c0)) : canon_gt(p.y.c1, neg(p.y.c1));
+    if (ng) out[191] |= 0x80;
+}
+#else
 inline void ser_g1(const G1A& p, uint8_t* out) {
     if (is_inf(p)) { std::memset(out, 0, 96); out[0] = 0x40; return; }
     ser_fp_be(p.x, out); ser_fp_be(p.y, out + 48);
@@ -181,6 +198,7 @@ inline void ser_g2(const G2A& p, uint8_t* out) {
     if (is_inf(p)) { std::memset(out, 0, 192); out[0] = 0x40; return; }
     ser_fp_be(p.x.c1, out); ser_fp_be(p.x.c0, out + 48); ser_fp_be(p.y.c1, out + 96); ser_fp_be(p.y.c0, out + 144);
 }
+#endif
 inline void ser_gt(const Fp12& f, uint8_t* out) {
     const Fp2* c[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
     for (int i = 0; i < 6; ++i) { ser_fp_le(c[i]->c0, out + 96 * i); ser_fp_le(c[i]->c1, out + 96 * i + 48); }

@@ -55,6 +55,21 @@ struct PairSets { const G1A* a[MAX_PRODUCTS]; const G2A* b[MAX_PRODUCTS]; };
 // a LOW-LIVENESS order pinned with scheduling barriers -- every line coefficient is stored the moment it is complete, P and Q are
 // re-loaded from L2 where they are used instead of being held for 68 steps, and the addition step (5 of 68) parks Y and theta in LDS
 // while they are idle.  The doubling step then needs 249 registers and no scratch at all.
+// Slots of the stored sparse line (c[0], c[1], c[2]) and where they sit in Fp12 (line_products.hpp):
+//   M-type twist (BLS12-381, ark-ec `ell` -> mul_by_014): (free, xP-scaled, yP-scaled) at w^0, w^2, w^3
+//   D-type twist (BLS12-377,               -> mul_by_034): (yP-scaled, xP-scaled, free) at w^0, w^1, w^3
+// The unit line (pairs with a point at infinity) is 1 at w^0 in both.
+#if defined(RIPP_BLS12_377)
+#define LINE_SLOT_YP 0
+#define LINE_SLOT_FREE 2
+#define LINE_UNIT_YP Fp2::one()
+#define LINE_UNIT_FREE Fp2::zero()
+#else
+#define LINE_SLOT_YP 2
+#define LINE_SLOT_FREE 0
+#define LINE_UNIT_YP Fp2::zero()
+#define LINE_UNIT_FREE Fp2::one()
+#endif
 #define SB() __builtin_amdgcn_sched_barrier(0)
 template <class T> __device__ __forceinline__ const T* opaque(const T* p) { asm volatile("" : "+v"(p)); return p; }   // defeats hoisting: operands are RE-LOADED where used
 // low-liveness order; lines are stored as soon as they are complete
@@ -65,10 +80,10 @@ __device__ __forceinline__ void line_double_store(Fp2& X, Fp2& Y, Fp2& Z, const 
     const Fp2 h = sub(t1, add(b, c)); SB();
     {
         const Fp yP = opaque(p)->y; const Fp2 l2 = mul_fp(neg(h), yP);
-        store_chunks<6>(lines, s * 3 + 2, stride, i, skip ? Fp2::zero() : l2);
+        store_chunks<6>(lines, s * 3 + LINE_SLOT_YP, stride, i, skip ? LINE_UNIT_YP : l2);
     } SB();
     const Fp2 e = mul_by_b_twist(add(dbl(c), c)); SB();
-    store_chunks<6>(lines, s * 3 + 0, stride, i, skip ? Fp2::one() : sub(e, b)); SB();
+    store_chunks<6>(lines, s * 3 + LINE_SLOT_FREE, stride, i, skip ? LINE_UNIT_FREE : sub(e, b)); SB();
     const Fp2 a = half(mul(X, Y)); SB();
     {
         const Fp2 j = sqr(X);
@@ -91,9 +106,9 @@ __device__ __forceinline__ void line_add_store(Fp2& X, Fp2& Y, Fp2& Z, const G2A
       for (int k = 0; k < 6; ++k) park[k * 256] = src[k]; } SB();
     { const Fp2 qx = opaque(q)->x; lambda = sub(X, mul(qx, Z)); } SB();
     { const Fp2 qx = opaque(q)->x; const Fp2 t = mul(theta, qx); SB(); const Fp2 qy = opaque(q)->y; const Fp2 j = sub(t, mul(lambda, qy));
-      store_chunks<6>(lines, s * 3 + 0, stride, i, skip ? Fp2::one() : j); } SB();
+      store_chunks<6>(lines, s * 3 + LINE_SLOT_FREE, stride, i, skip ? LINE_UNIT_FREE : j); } SB();
     { const Fp xP = opaque(p)->x; store_chunks<6>(lines, s * 3 + 1, stride, i, skip ? Fp2::zero() : mul_fp(neg(theta), xP)); } SB();
-    { const Fp yP = opaque(p)->y; store_chunks<6>(lines, s * 3 + 2, stride, i, skip ? Fp2::zero() : mul_fp(lambda, yP)); } SB();
+    { const Fp yP = opaque(p)->y; store_chunks<6>(lines, s * 3 + LINE_SLOT_YP, stride, i, skip ? LINE_UNIT_YP : mul_fp(lambda, yP)); } SB();
     Fp2 f;
     { const Fp2 c = sqr(theta); SB(); f = mul(Z, c); } SB();
     { const uint4* src = reinterpret_cast<const uint4*>(&theta);      // theta rests in LDS until the last-but-one product
@@ -140,6 +155,7 @@ __global__ void __launch_bounds__(256, RIPP_OCC) k_miller_lines(PairSets ps, uin
 
 // ---- stage 2a: sparse accumulation -------------------------------------------------------------------------
 // grid = (T / block, rows).  Lane t of row r multiplies lines r[t], r[t+T], ... (< M) and writes one dense partial.
+#if !defined(RIPP_BLS12_377)       // A/B reference form (mul_by_014): BLS12-381 build only
 __global__ void __launch_bounds__(64, RIPP_OCC_PROD) k_line_products1(const uint4* __restrict__ lines, size_t stride, uint32_t M,
                                                         uint4* __restrict__ partials, uint32_t T) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -157,6 +173,7 @@ __global__ void __launch_bounds__(64, RIPP_OCC_PROD) k_line_products1(const uint
     }
     store_chunks<FP12_CHUNKS>(partials, row, T, t, acc);
 }
+#endif
 
 // ---- stage 2b: dense product tree --------------------------------------------------------------------------
 // in: [rows][36][Tin] -> out: [rows][36][Tout];  out[j] = prod_{k<R} in[j + k*Tout]

@@ -94,8 +94,15 @@ __global__ void __launch_bounds__(64, 2) k_line_products(const uint4* __restrict
     __syncthreads();
     // operand slots of this lane's two outputs k = j and k = j + 3:  (f_k, [xi] f_(k-2), [xi] f_(k-3));  xi f_i sits in slot i + 3
     //   k = 0: f0, xi f4, xi f3     k = 1: f1, xi f5, xi f4     k = 2: f2, f0, xi f5     k = 3: f3, f1, f0     k = 4: f4, f2, f1     k = 5: f5, f3, f2
+#if defined(RIPP_BLS12_377)
+    // D-type twist: line = l0 + l1 w + l2 w^3  =>  out_k = f_k l0 + [xi] f_(k-1) l1 + [xi] f_(k-3) l2
+    //   k = 0: f0, xi f5, xi f3     k = 1: f1, f0, xi f4     k = 2: f2, f1, xi f5     k = 3: f3, f2, f0     k = 4: f4, f3, f1     k = 5: f5, f4, f2
+    const int s1a = j == 0 ? 8 : (int)j - 1, s2a = j == 0 ? 6 : j == 1 ? 7 : 8;          // output j
+    const int s0b = j + 3, s1b = j + 2, s2b = j;                                          // output j + 3
+#else
     const int s1a = j == 0 ? 7 : j == 1 ? 8 : 0, s2a = j == 0 ? 6 : j == 1 ? 7 : 8;      // output j
     const int s0b = j + 3, s1b = j + 1, s2b = j;                                          // output j + 3
+#endif
     const uint32_t st = (uint32_t)stride;                                   // rows are < 2^32 chunks apart (<= 18 * 2^19 * ... per row block)
     const uint4* __restrict__ lrow = lines + row * 18 * stride;
     const uint32_t iters = (M + T - 1) / T;                                 // uniform trip count (the barriers below are reached by every lane);
@@ -124,7 +131,11 @@ __global__ void __launch_bounds__(64, 2) k_line_products(const uint4* __restrict
             const Fp im = fp_dot<6>(xs, ys);
             // real part: sum x.c0 y.c0 + (-x.c1) y.c1 -- the negation goes to x, which is reloaded for every output anyway, so that
             // y stays as loaded for the second output of the line (p - x.c1 <= p is a valid lazy operand)
+#if defined(RIPP_BLS12_377)
+            xs[1] = neg(mul5(xs[1])); xs[3] = neg(mul5(xs[3])); xs[5] = neg(mul5(xs[5]));          // u^2 = -5
+#else
             xs[1] = neg(xs[1]); xs[3] = neg(xs[3]); xs[5] = neg(xs[5]);
+#endif
             ys[0] = y[0].c0; ys[1] = y[0].c1; ys[2] = y[1].c0; ys[3] = y[1].c1; ys[4] = y[2].c0; ys[5] = y[2].c1;
             const Fp re = fp_dot<6>(xs, ys);
             if (h == 0) { out0.c0 = re; out0.c1 = im; } else { out1.c0 = re; out1.c1 = im; }

@@ -1,0 +1,123 @@
+"""GPU parity (-m gpu), BLS12-377 build of the engine (ripp_amd.bls12_377 -> libripp_hip_377.so) against the BLS12-377 build of the oracle
+on identical inputs, bit-exact: pairing products (incl. infinities), MSMs, folds, the SIPP prover and verifier -- the reference's own SIPP
+test (sipp/src/lib.rs:232-254) and its scaling-ipp harness run on THIS curve."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def E(engine):
+    import ripp_amd.bls12_377 as R377
+    R377.init(0)
+    return R377
+
+
+@pytest.fixture(scope="module")
+def o():
+    import orclib377
+    orclib377.lib()
+    return orclib377
+
+
+@pytest.fixture(scope="module")
+def v():
+    return json.load(open(os.path.join(HERE, "golden", "bls12_377_vectors.json")))
+
+
+def _g1(o, pts): return o.g1_array([None if p is None else (int(p[0], 16), int(p[1], 16)) for p in pts])
+def _g2(o, pts): return o.g2_array([None if q is None else ((int(q[0][0], 16), int(q[0][1], 16)), (int(q[1][0], 16), int(q[1][1], 16))) for q in pts])
+
+
+def test_golden_vectors(E, o, v):
+    g = v["generators"]
+    g1, g2 = _g1(o, [g["g1"]]), _g2(o, [g["g2"]])
+    assert np.array_equal(E.synth_g1(1, 1), g1) and np.array_equal(E.synth_g2(1, 1), g2)
+    assert E.ser_g1(g1[0]).hex() == g["ser_g1"] and E.ser_g2(g2[0]).hex() == g["ser_g2"]
+    assert E.ser_g1(np.zeros(12, dtype=np.uint64)).hex() == g["ser_g1_inf"]
+    assert E.ser_gt(E.product_of_pairings(g1, g2)).hex() == v["pairing_generators"]["gt"]
+    p8 = v["product8"]
+    assert E.ser_gt(E.product_of_pairings(_g1(o, p8["a"]), _g2(o, p8["b"]))).hex() == p8["gt"]
+    s4 = v["sipp4"]
+    a, b, r = _g1(o, s4["a"]), _g2(o, s4["b"]), o.fr_array([int(x, 16) for x in s4["r"]])
+    value = E.product_of_pairings_with_coeffs(a, b, r)
+    assert E.ser_gt(value).hex() == s4["value"] and E.sipp_seed_digest(a, b, r, value).hex() == s4["seed_digest"]
+    proof = E.SIPP.prove(a, b, r, value)
+    assert [[E.ser_gt(proof[2 * j]).hex(), E.ser_gt(proof[2 * j + 1]).hex()] for j in range(2)] == s4["proof"]
+    assert E.SIPP.verify(a, b, r, value, proof)
+
+
+def test_synthetic_inputs_match_oracle(E, o):
+    n = 257
+    assert np.array_equal(E.synth_g1(1000, n), o.gen_g1(1000, n)) and np.array_equal(E.synth_g2(2000, n), o.gen_g2(2000, n))
+    assert np.array_equal(E.synth_fr(3, n), o.gen_scalars(3, n))
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 33, 64, 1000, 1 << 13])
+def test_pairing_inner_product_vs_oracle(E, o, n):
+    a, b = o.gen_g1(50, n), o.gen_g2(60, n)
+    if n > 5:
+        a[2] = 0; b[4] = 0
+    aj, bj = o.blind_g1(a, 1), o.blind_g2(b, 2)
+    rc, exp = o.pairing_product_j(aj, bj)
+    assert rc == 0 and np.array_equal(E.PairingInnerProduct.inner_product(aj, bj), exp)
+    assert np.array_equal(E.product_of_pairings(a, b), o.pairing_product_a(a, b))
+    if n == 3:
+        with pytest.raises(E.InnerProductError):
+            E.PairingInnerProduct.inner_product(aj, bj[:2])
+
+
+@pytest.mark.parametrize("n", [1, 2, 33, 1 << 10, (1 << 14) + 5])
+def test_msm_and_folds_vs_oracle(E, o, n):
+    a, b, s = o.gen_g1(31, n), o.gen_g2(41, n), o.gen_scalars(9, n)
+    assert np.array_equal(E.normalize_batch_g1(E.MultiexponentiationInnerProductG1.inner_product(o.to_jac_g1(a), s)), o.g1_to_affine(o.msm_g1_a(a, s)).reshape(1, 12))
+    assert np.array_equal(E.normalize_batch_g2(E.MultiexponentiationInnerProductG2.inner_product(o.to_jac_g2(b), s)), o.g2_to_affine(o.msm_g2_a(b, s)).reshape(1, 24))
+    if n >= 2:
+        h = n // 2
+        for sc in (s[0], o.fr_array([2**128 - 1])[0], o.fr_array([0])[0]):
+            assert np.array_equal(E.fold_g1_affine(a[h:2 * h], a[:h], sc), o.fold_g1_a(a[h:2 * h], a[:h], sc))
+            assert np.array_equal(E.fold_g2_affine(b[h:2 * h], b[:h], sc), o.fold_g2_a(b[h:2 * h], b[:h], sc))
+        assert np.array_equal(E.scale_g1_affine(a, s), o.scale_g1_a(a, s))
+
+
+@pytest.mark.parametrize("n", [1, 2, 32, 1 << 10, 1 << 14])
+def test_sipp_prove_vs_oracle(E, o, n):
+    """n = 32 is the reference's own test size (prove_and_verify_base_case), 2^10 the scaling-ipp plumbing config."""
+    a, b, r = o.gen_g1(123, n), o.gen_g2(456, n), o.gen_scalars(7, n)
+    value = o.product_of_pairings_with_coeffs(a, b, r)
+    assert np.array_equal(E.product_of_pairings_with_coeffs(a, b, r), value)
+    proof, ch, _ = E.SIPP.prove_with_stats(a, b, r, value)
+    rc, eproof, ech = o.sipp_prove(a, b, r, value)
+    assert rc == 0 and np.array_equal(proof, eproof) and np.array_equal(ch, ech)
+    if n >= 2:
+        assert E.SIPP.verify(a, b, r, value, proof) and o.sipp_verify(a, b, r, value, proof) == 1
+        bad = proof.copy(); bad[1] = proof[0]
+        assert not E.SIPP.verify(a, b, r, value, bad)
+
+
+def test_sipp_degenerate_statement_vs_oracle(E, o):
+    n = 64
+    a, b, r = o.gen_g1(70, n), o.gen_g2(80, n), o.gen_scalars(9, n)
+    r[1] = 0; a[2] = 0; b[3] = 0; a[n - 1] = 0; b[n - 1] = 0
+    a[5] = a[4]; b[5] = b[4]; r[5] = r[4]
+    q = 4 + n // 2
+    a[q] = a[4]; b[q] = b[4]; r[q] = r[4]
+    value = E.product_of_pairings_with_coeffs(a, b, r)
+    assert np.array_equal(value, o.product_of_pairings_with_coeffs(a, b, r))
+    proof = E.SIPP.prove(a, b, r, value)
+    rc, eproof, _ = o.sipp_prove(a, b, r, value)
+    assert rc == 0 and np.array_equal(proof, eproof) and E.SIPP.verify(a, b, r, value, proof)
+
+
+def test_both_curves_side_by_side(E, engine, orc, o):
+    """the two builds are separate libraries with separate engines: BLS12-381 results are unaffected by the 377 engine being live"""
+    n = 64
+    a, b = orc.gen_g1(5, n), orc.gen_g2(6, n)
+    assert np.array_equal(engine.product_of_pairings(a, b), orc.pairing_product_a(a, b))
+    a7, b7 = o.gen_g1(5, n), o.gen_g2(6, n)
+    assert np.array_equal(E.product_of_pairings(a7, b7), o.pairing_product_a(a7, b7))

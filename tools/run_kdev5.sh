@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_sharded_gloo.py tests/test_gpu_tipa.py -m gpu -x -q 2>&1 | tail -30
+timeout 900 python -m pytest tests/test_gpu_bls12_377.py -m gpu -x -q 2>&1 | tail -30
