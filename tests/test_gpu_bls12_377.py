@@ -121,3 +121,15 @@ def test_both_curves_side_by_side(E, engine, orc, o):
     assert np.array_equal(engine.product_of_pairings(a, b), orc.pairing_product_a(a, b))
     a7, b7 = o.gen_g1(5, n), o.gen_g2(6, n)
     assert np.array_equal(E.product_of_pairings(a7, b7), o.pairing_product_a(a7, b7))
+
+
+@pytest.mark.parametrize("n", [32, 1 << 10])
+def test_scaling_ipp_inputs_verbatim(E, o, n):
+    """sipp/examples/scaling-ipp.rs:41-51 verbatim: ONE point 2g / 2h and ONE scalar repeated n times, on the example's own curve.
+    Every fold then adds equal operands (x P + P): the exceptional cases of the group law; proofs must still equal the oracle's."""
+    a, b, r = np.repeat(o.gen_g1(2, 1), n, axis=0), np.repeat(o.gen_g2(2, 1), n, axis=0), np.repeat(o.gen_scalars(0, 1), n, axis=0)
+    value = E.product_of_pairings_with_coeffs(a, b, r)
+    assert np.array_equal(value, o.product_of_pairings_with_coeffs(a, b, r))
+    proof = E.SIPP.prove(a, b, r, value)
+    rc, eproof, _ = o.sipp_prove(a, b, r, value)
+    assert rc == 0 and np.array_equal(proof, eproof) and E.SIPP.verify(a, b, r, value, proof)

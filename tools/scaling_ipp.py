@@ -5,8 +5,9 @@ for each log-size in [log_min, log_max] time the direct product, the prover and 
 
   python tools/scaling_ipp.py <log_min> <log_max> <out_dir> [--cpu-max LOG]   (CPU oracle rows only up to --cpu-max)
 
-Differences from the reference, on purpose: BLS12-381 instead of BLS12-377, and distinct
-points a_i = (1000+i)G1, b_i = (2000+i)G2, r_i = SplitMix64(0) instead of one repeated point/scalar."""
+Defaults differ from the reference on purpose: BLS12-381 (BASELINE's curve) and distinct points
+a_i = (1000+i)G1, b_i = (2000+i)G2, r_i = SplitMix64(0).  `--curve 377 --repeated` is the reference example verbatim: its own curve and
+ONE repeated point / scalar (every fold then meets x P + P with equal operands: the exceptional-case paths)."""
 import argparse, csv, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -24,8 +25,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("log_min", type=int); ap.add_argument("log_max", type=int); ap.add_argument("out_dir")
     ap.add_argument("--cpu-max", type=int, default=14)
+    ap.add_argument("--curve", choices=["381", "377"], default="381", help="377 = the reference example's own curve (scaling-ipp.rs:2,10)")
+    ap.add_argument("--repeated", action="store_true", help="the reference's inputs: ONE point 2g / 2h and ONE scalar repeated n times (scaling-ipp.rs:41-51)")
     args = ap.parse_args()
-    import numpy as np, orclib as o, ripp_amd as R
+    import numpy as np
+    if args.curve == "377":
+        import orclib377 as o, ripp_amd.bls12_377 as R
+    else:
+        import orclib as o, ripp_amd as R
     R.init(0)
     os.makedirs(args.out_dir, exist_ok=True)
     rows_gpu, rows_cpu = [], []
@@ -33,6 +40,8 @@ def main():
         n = 1 << lg
         reps = 5 if lg <= 14 else (3 if lg <= 18 else 2)         # scaling-ipp.rs:57-62 scales repetitions with size too
         a, b, r = R.synth_g1(1000, n), R.synth_g2(2000, n), R.synth_fr(0, n)
+        if args.repeated:
+            a, b, r = np.repeat(R.synth_g1(2, 1), n, axis=0), np.repeat(R.synth_g2(2, 1), n, axis=0), np.repeat(R.synth_fr(0, 1), n, axis=0)
         td, z = timed(lambda: R.product_of_pairings_with_coeffs(a, b, r), reps)
         tp, proof = timed(lambda: R.SIPP.prove(a, b, r, z), reps)
         tv, ok = timed(lambda: R.SIPP.verify(a, b, r, z, proof), reps)
@@ -46,7 +55,8 @@ def main():
             assert rc == 0 and cok == 1 and np.array_equal(cproof, proof) and np.array_equal(cz, z)
             rows_cpu.append(dict(size=n, direct=cd * 1e3, prover=cp * 1e3, verifier=cv * 1e3, backend="cpu-oracle", threads=o.lib().orc_num_threads()))
             print(f"      cpu direct {cd*1e3:.1f} ms, prover {cp*1e3:.1f} ms, verifier {cv*1e3:.1f} ms  (proofs identical)", flush=True)
-    for name, rows in (("ipp-mi355x-hip.csv", rows_gpu), ("ipp-cpu-oracle.csv", rows_cpu)):
+    tag = ("-bls12_377" if args.curve == "377" else "") + ("-repeated" if args.repeated else "")
+    for name, rows in (("ipp-mi355x-hip%s.csv" % tag, rows_gpu), ("ipp-cpu-oracle%s.csv" % tag, rows_cpu)):
         with open(os.path.join(args.out_dir, name), "w", newline="") as f:
             w = csv.DictWriter(f, fieldnames=["size", "direct", "prover", "verifier", "backend", "threads"]); w.writeheader(); w.writerows(rows)
 
