@@ -54,6 +54,10 @@ typedef struct {
 int32_t ripp_init(int32_t device_ordinal);
 void    ripp_shutdown(void);
 int32_t ripp_device_count(void);
+/* ripp_init(other_ordinal) while job / SRS handles of the current device are alive returns RIPP_ERR_ARG (it would free their streams).
+ * ripp_release_scratch frees the engine's grow-only scratch (line buffer, fold tables, MSM scratch: ~19 GB after an n = 2^20 proof);
+ * the next call re-allocates what it needs. */
+int32_t ripp_release_scratch(void);
 const char* ripp_last_error(void);   /* message of the calling thread's last failed call (thread-local, errno-style) */
 
 /* ---- L1 trait surface on host slices ------------------------------------------------------------------ */

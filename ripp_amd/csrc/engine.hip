@@ -67,6 +67,7 @@ private:
 HostPool& host_pool() { static HostPool pool(6); return pool; }
 struct Engine;
 Engine* g_engine = nullptr;
+std::atomic<int> g_live_handles{0};       // ripp_sipp_job / ripp_srs objects holding device memory of the current engine
 
 #define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_err(std::string(#expr) + ": " + hipGetErrorString(e_)); return RIPP_ERR_DEVICE; } } while (0)
 void set_err(const std::string& s) { g_err = s; }
@@ -873,12 +874,28 @@ API void ripp_debug_digest_times(double* hash_ms, double* wait_ms) { *hash_ms = 
 API int32_t ripp_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 API int32_t ripp_init(int32_t dev) {
     LOCK;
-    if (g_engine) { if (g_engine->device == dev) return RIPP_OK; g_engine->destroy(); delete g_engine; g_engine = nullptr; }
+    if (g_engine) {
+        if (g_engine->device == dev) return RIPP_OK;
+        // re-binding to another device would free the engine's streams under live job / SRS handles: refuse instead
+        if (g_live_handles.load() > 0) { set_err("ripp_init: " + std::to_string(g_live_handles.load()) + " job / SRS handle(s) are alive on device " + std::to_string(g_engine->device) + "; destroy them before re-binding the engine"); return RIPP_ERR_ARG; }
+        g_engine->destroy(); delete g_engine; g_engine = nullptr;
+    }
     Engine* e = new Engine(); int32_t rc = e->init(dev);
     if (rc != RIPP_OK) { delete e; return rc; }
     g_engine = e; return RIPP_OK;
 }
 API void ripp_shutdown(void) { LOCK; if (g_engine) { g_engine->destroy(); delete g_engine; g_engine = nullptr; } }
+// frees the engine's grow-only scratch (line buffer, fold tables -- ~19 GB after an n = 2^20 proof --, MSM scratch): the next call re-allocates
+// what it needs.  Job and SRS handles keep their own buffers.
+API int32_t ripp_release_scratch(void) {
+    LOCK; if (!g_engine) return RIPP_OK;
+    Engine* e = g_engine;
+    if (hipSetDevice(e->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { set_err("ripp_release_scratch: device synchronisation failed"); return RIPP_ERR_DEVICE; }
+    for (DevBuf* b : {&e->lines, &e->partA, &e->partB, &e->jacG1, &e->jacG2, &e->tmpA, &e->tmpB, &e->tmpR, &e->affG1, &e->affG2, &e->qtab, &e->scale_tab, &e->fold_tab1, &e->fold_mult, &e->fold_tab, &e->fold_jac1, &e->fold_jac2}) b->release();
+    e->msm_scratch[0].release(); e->msm_scratch[1].release(); e->kzg_q[0].release(); e->kzg_q[1].release(); e->kzg_bases[0].release(); e->kzg_bases[1].release();
+    e->tab_owner = nullptr;
+    return RIPP_OK;
+}
 
 // ---- normalisation / scaling / folds on host slices ---------------------------------------------------------
 API int32_t ripp_normalize_g1(const ripp_g1j* in, size_t n, ripp_g1a* out) {
@@ -1151,6 +1168,7 @@ static int32_t sipp_job_create_impl(const ripp_g1a* a, const ripp_g2a* b, const 
     LOCK; ENGINE; if (!a || !b || !r || !job || n_local == 0 || world < 1 || rank < 0 || rank >= world) return RIPP_ERR_ARG;
     if (n_local & (n_local - 1)) return RIPP_ERR_POW2;
     ripp_sipp_job* j = new ripp_sipp_job();
+    struct Live { bool keep = false; Live() { ++g_live_handles; } ~Live() { if (!keep) --g_live_handles; } } live;
     j->n_local = n_local; j->rank = rank; j->world = world; j->world0 = world;
     const bool borrow = borrow_value && world == 1 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)r) & 15u) == 0;
     if (borrow) {
@@ -1176,6 +1194,7 @@ static int32_t sipp_job_create_impl(const ripp_g1a* a, const ripp_g2a* b, const 
         std::memcpy(j->ha.data(), a, n_local * sizeof(G1A)); std::memcpy(j->hb.data(), b, n_local * sizeof(G2A)); std::memcpy(j->hr.data(), r, n_local * sizeof(Fr));
     }
     if ((rc = e->sync())) { if (j->hash_thread.joinable()) j->hash_thread.join(); for (DevBuf* d : {&j->a0, &j->b0, &j->r0}) d->release(); delete j; return rc; }
+    live.keep = true;
     *job = j; return RIPP_OK;
 }
 API int32_t ripp_sipp_job_create(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr* r, size_t n_local, int32_t rank, int32_t world, ripp_sipp_job** job) {
@@ -1186,7 +1205,7 @@ API void ripp_sipp_job_destroy(ripp_sipp_job* j) {
     if (j->hash_thread.joinable()) j->hash_thread.join();
     for (DevBuf* b : {&j->a0, &j->b0, &j->r0, &j->a, &j->b, &j->a_next, &j->b_next, &j->jac1, &j->jac2, &j->a_pow, &j->b_pow, &j->a_pow_h, &j->b_pow_h, &j->parts1, &j->parts2}) b->release();
     if (g_engine && g_engine->tab_owner == j) g_engine->tab_owner = nullptr;
-    delete j;
+    delete j; --g_live_handles;
 }
 API int32_t ripp_sipp_job_begin(ripp_sipp_job* j) { LOCK; ENGINE; if (!j) return RIPP_ERR_ARG; return job_begin(e, j); }
 API size_t ripp_sipp_job_rounds_left(const ripp_sipp_job* j) { if (!j) return 0; size_t total = j->len * (size_t)j->world, r = 0; while (total > 1) { total >>= 1; ++r; } return r; }

@@ -96,6 +96,28 @@ def test_pedersen_commitment(engine, orc):
     assert C.verify(keys, msg, com) and not C.verify(keys, wrong, com)
     with pytest.raises(engine.InnerProductError):
         C.verify(keys, orc.gen_scalars(5, n + 1), com)
+    # the committed VALUE against the oracle (pedersen/mod.rs:24-26 = MultiexponentiationInnerProduct::inner_product(k, m)), both groups
+    rc, exp = orc.msm_g1_j(keys, msg); assert rc == 0
+    assert np.array_equal(engine.normalize_batch_g1(com), orc.normalize_g1(exp.reshape(1, 18)))
+    keys2 = orc.blind_g2(orc.gen_g2(41, n), 5)
+    rc, exp2 = orc.msm_g2_j(keys2, msg); assert rc == 0
+    assert np.array_equal(engine.normalize_batch_g2(engine.PedersenCommitmentG2.commit(keys2, msg)), orc.normalize_g2(exp2.reshape(1, 36)))
+
+
+def test_engine_lifecycle_guards(engine, orc):
+    """ripp_init on another ordinal is refused while handles are alive; ripp_release_scratch frees the grow-only buffers and the next call
+    simply re-allocates (same results)."""
+    import ctypes
+    from ripp_amd._lib import lib
+    n = 64
+    a, b, r = orc.gen_g1(5, n), orc.gen_g2(6, n), orc.gen_scalars(7, n)
+    before = engine.product_of_pairings(a, b)
+    job = engine.SippJob(a, b, r)
+    assert lib().ripp_init(ctypes.c_int32(1)) == 4                     # RIPP_ERR_ARG: a live job pins the engine to its device
+    job.close()
+    assert lib().ripp_release_scratch() == 0
+    assert np.array_equal(engine.product_of_pairings(a, b), before)
+    assert lib().ripp_init(ctypes.c_int32(0)) == 0
 
 
 @pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 1 << 10, (1 << 12) + 5])
