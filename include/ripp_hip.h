@@ -98,6 +98,33 @@ int32_t ripp_scale_g1_a(const ripp_g1a* a, const ripp_fr* r, size_t n, ripp_g1a*
 int32_t ripp_normalize_g1(const ripp_g1j* in, size_t n, ripp_g1a* out);
 int32_t ripp_normalize_g2(const ripp_g2j* in, size_t n, ripp_g2a* out);
 
+/* ---- device-resident vectors ---------------------------------------------------
+ * The entry points above take host slices, as the reference's traits do (inner_products/src/lib.rs:45-48): each call uploads and
+ * normalises its inputs.  A ripp_vec keeps a vector in HBM across calls -- group elements affine (normalised once), scalars in
+ * Montgomery form -- so that a caller running the reference's generic GIPA loop (ip_proofs/src/gipa.rs:196-297) uploads each
+ * vector once and then works on views: `ripp_vec_halves` is the split of a halving round, `ripp_vec_fold` its fold
+ * (gipa.rs:262-291), and the three inner products read the views in place.  Views share the storage; every handle (vector or view)
+ * is freed with ripp_vec_free, the storage goes with the last one.  Length mismatches return RIPP_ERR_LENGTH like the slice forms. */
+typedef struct ripp_vec ripp_vec;
+enum { RIPP_VEC_G1 = 1, RIPP_VEC_G2 = 2, RIPP_VEC_FR = 3 };
+int32_t ripp_vec_upload_g1a(const ripp_g1a* p, size_t n, ripp_vec** out);
+int32_t ripp_vec_upload_g2a(const ripp_g2a* p, size_t n, ripp_vec** out);
+int32_t ripp_vec_upload_g1j(const ripp_g1j* p, size_t n, ripp_vec** out);     /* normalised on the device */
+int32_t ripp_vec_upload_g2j(const ripp_g2j* p, size_t n, ripp_vec** out);
+int32_t ripp_vec_upload_fr(const ripp_fr* p, size_t n, ripp_vec** out);
+size_t  ripp_vec_len(const ripp_vec* v);
+int32_t ripp_vec_kind(const ripp_vec* v);
+int32_t ripp_vec_slice(const ripp_vec* v, size_t off, size_t len, ripp_vec** view);
+int32_t ripp_vec_halves(const ripp_vec* v, ripp_vec** lo, ripp_vec** hi);      /* (v[..len/2], v[len/2..]) */
+int32_t ripp_vec_download(const ripp_vec* v, void* out);                       /* ripp_g1a / ripp_g2a / ripp_fr elements by kind */
+void    ripp_vec_free(ripp_vec* v);
+/* PairingInnerProduct / MultiexponentiationInnerProduct / ScalarInnerProduct on resident vectors (inner_products/src/lib.rs:61-166) */
+int32_t ripp_vec_pairing_product(const ripp_vec* left_g1, const ripp_vec* right_g2, ripp_gt* out);
+int32_t ripp_vec_msm(const ripp_vec* bases, const ripp_vec* scalars, void* out /* ripp_g1j or ripp_g2j by the bases' kind */);
+int32_t ripp_vec_scalar_inner_product(const ripp_vec* left, const ripp_vec* right, ripp_fr* out);
+/* out[i] = s * hi[i] + lo[i], a new resident vector (hi and lo of one kind and length; typically the two halves of one vector) */
+int32_t ripp_vec_fold(const ripp_vec* hi, const ripp_vec* lo, const ripp_fr* s, ripp_vec** out);
+
 /* ---- SIPP prover  -- SIPP::<Bls12_381, Blake2s>::prove, sipp/src/lib.rs:42-106 ---------------------------- */
 /* proof: 2*log2(n) GT elements, (z_l, z_r) per round in round order (Proof::gt_elems, sipp/src/lib.rs:32-34).
  * challenges (optional, may be NULL): log2(n) Fr values x of sipp/src/lib.rs:85. */

@@ -92,8 +92,9 @@ def lib():
 def load_library(path):
     L = ctypes.CDLL(path)
     L.ripp_last_error.restype = ctypes.c_char_p
-    for name in ("ripp_ser_gt", "ripp_ser_g1", "ripp_ser_g2", "ripp_ser_fr", "ripp_sipp_job_rounds_left", "ripp_sipp_job_local_len"):
+    for name in ("ripp_ser_gt", "ripp_ser_g1", "ripp_ser_g2", "ripp_ser_fr", "ripp_sipp_job_rounds_left", "ripp_sipp_job_local_len", "ripp_vec_len"):
         getattr(L, name).restype = ctypes.c_size_t
+    L.ripp_vec_free.restype = None; L.ripp_vec_free.argtypes = [ctypes.c_void_p]
     return L
 
 

@@ -13,7 +13,7 @@ import ctypes
 import numpy as np
 from ._lib import lib, last_error, RippStats, AggregateProof, VerifierSRSStruct, Groth16VKStruct, RIPP_OK, RIPP_ERR_LENGTH, RIPP_ERR_POW2, RIPP_ERR_DEVICE
 
-__all__ = ["InnerProductError", "DeviceError", "PairingInnerProduct", "MultiexponentiationInnerProductG1",
+__all__ = ["InnerProductError", "DeviceError", "Vec", "PairingInnerProduct", "MultiexponentiationInnerProductG1",
            "MultiexponentiationInnerProductG2", "ScalarInnerProduct", "AFGHOCommitmentG1", "AFGHOCommitmentG2", "PedersenCommitmentG1",
            "PedersenCommitmentG2", "SIPP", "SippJob", "GIPA_TIPP", "SRS", "TIPA_TIPP", "TIPAWithSSM", "aggregate_proofs", "aggregate_proofs_sharded", "gipa_tipp_prove_sharded", "verify_aggregate_proof", "AggregateProof", "ser_tipa_tipp_proof", "de_tipa_tipp_proof", "ser_tipa_ssm_proof", "de_tipa_ssm_proof", "ser_g1_compressed", "ser_g2_compressed", "product_of_pairings", "product_of_pairings_with_coeffs",
            "normalize_batch_g1", "normalize_batch_g2", "fold_g1_affine", "fold_g2_affine", "fold_g1", "fold_g2",
@@ -69,11 +69,101 @@ def device_count():
 
 
 # ------------------------------------------------------------------ InnerProduct implementations
+# ------------------------------------------------------------------ device-resident vectors (ripp_vec_*)
+_FP_ONE = None
+
+
+def _fp_one():
+    """Fp::one() in Montgomery form, read off the library's own generator table (Z of the first SRS power) -- curve-agnostic."""
+    global _FP_ONE
+    if _FP_ONE is None:
+        g = np.zeros((1, 18), dtype=np.uint64)
+        _check(lib().ripp_srs_powers_g1(_p(FR_ONE), ctypes.c_size_t(1), _p(g)))
+        a = normalize_batch_g1(g)
+        # (x, y, Z) with Z = 1: Z is recovered as the Jacobian Z of an already-affine point, i.e. the one the library wrote when Z == 1
+        _FP_ONE = g[0, 12:18].copy() if np.array_equal(g[0, :12], a[0]) else None
+        if _FP_ONE is None:
+            raise RuntimeError("generator came back with Z != 1")
+    return _FP_ONE
+
+
+class Vec:
+    """A vector kept in HBM across calls (include/ripp_hip.h: ripp_vec).  kind: "G1" | "G2" | "Fr".  Group elements are stored affine
+    (normalised on upload / after a fold).  Slicing with a contiguous range gives a VIEW sharing the storage -- `v[:s]`, `v[s:]` are the
+    halves of a GIPA round; `v[i]` downloads one element (projective layout for groups, like the host-slice API)."""
+    KINDS = {"G1": 1, "G2": 2, "Fr": 3}
+    COLS = {1: 12, 2: 24, 3: 4}
+
+    def __init__(self, handle, kind, n):
+        self._h, self.kind, self._n = handle, kind, n
+
+    @staticmethod
+    def upload(kind, array):
+        """array: G1 (n,12) affine or (n,18) projective; G2 (n,24) or (n,36); Fr (n,4)."""
+        k = Vec.KINDS[kind]
+        a = np.ascontiguousarray(array, dtype=np.uint64)
+        if a.ndim == 1: a = a.reshape(1, -1)
+        fn = {(1, 12): "ripp_vec_upload_g1a", (1, 18): "ripp_vec_upload_g1j", (2, 24): "ripp_vec_upload_g2a", (2, 36): "ripp_vec_upload_g2j", (3, 4): "ripp_vec_upload_fr"}.get((k, a.shape[1]))
+        if fn is None:
+            raise ValueError(f"no {kind} layout with {a.shape[1]} limbs per element")
+        h = ctypes.c_void_p()
+        _check(getattr(lib(), fn)(_p(a), ctypes.c_size_t(len(a)), ctypes.byref(h)))
+        return Vec(h, k, len(a))
+
+    def __len__(self): return self._n
+
+    def __getitem__(self, key):
+        if isinstance(key, slice):
+            start, stop, step = key.indices(self._n)
+            if step != 1: raise IndexError("device vectors slice by contiguous ranges only")
+            h = ctypes.c_void_p()
+            _check(lib().ripp_vec_slice(self._h, ctypes.c_size_t(start), ctypes.c_size_t(max(stop - start, 0)), ctypes.byref(h)))
+            return Vec(h, self.kind, max(stop - start, 0))
+        i = key + self._n if key < 0 else key
+        if not 0 <= i < self._n: raise IndexError(key)
+        return self[i:i + 1].to_host()[0]
+
+    def download(self):
+        """the stored elements: G1 (n,12) / G2 (n,24) affine, Fr (n,4)"""
+        out = np.zeros((self._n, Vec.COLS[self.kind]), dtype=np.uint64)
+        _check(lib().ripp_vec_download(self._h, _p(out))); return out
+
+    def to_host(self):
+        """the host-slice layouts of the trait-level API: projective (Z = 1, or Z = 0 for the point at infinity) for groups"""
+        a = self.download()
+        if self.kind == 3: return a
+        half = a.shape[1] // 2                                     # limbs of one coordinate
+        out = np.zeros((self._n, 3 * half), dtype=np.uint64); out[:, :2 * half] = a
+        inf = ~a.any(axis=1)
+        out[~inf, 2 * half:2 * half + 6] = _fp_one()
+        out[inf, 0:6] = _fp_one(); out[inf, half:half + 6] = _fp_one()     # (1, 1, 0), arkworks' zero()
+        return out
+
+    def fold(self, lo, s):
+        """self * s + lo, element-wise (gipa.rs:262-291) -> a new resident vector"""
+        h = ctypes.c_void_p()
+        _check(lib().ripp_vec_fold(self._h, lo._h, _p(np.ascontiguousarray(s, dtype=np.uint64).reshape(4)), ctypes.byref(h)), len(self), len(lo))
+        return Vec(h, self.kind, self._n)
+
+    def close(self):
+        if self._h:
+            lib().ripp_vec_free(self._h); self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class PairingInnerProduct:
     """inner_products/src/lib.rs:52-75.  left: G1 projective (n,18); right: G2 projective (n,36) -> GT (72,)."""
 
     @staticmethod
     def inner_product(left, right):
+        if isinstance(left, Vec) or isinstance(right, Vec):
+            out = np.zeros(72, dtype=np.uint64)
+            _check(lib().ripp_vec_pairing_product(left._h, right._h, _p(out)), len(left), len(right)); return out
         l, r = _c(left, 18), _c(right, 36)
         out = np.zeros(72, dtype=np.uint64)
         _check(lib().ripp_pairing_product_j(_p(l), ctypes.c_size_t(len(l)), _p(r), ctypes.c_size_t(len(r)), _p(out)), len(l), len(r))
@@ -85,6 +175,9 @@ class MultiexponentiationInnerProductG1:
 
     @staticmethod
     def inner_product(left, right):
+        if isinstance(left, Vec) or isinstance(right, Vec):
+            out = np.zeros(18, dtype=np.uint64)
+            _check(lib().ripp_vec_msm(left._h, right._h, _p(out)), len(left), len(right)); return out
         l, r = _c(left, 18), _c(right, 4)
         out = np.zeros(18, dtype=np.uint64)
         _check(lib().ripp_msm_g1_j(_p(l), ctypes.c_size_t(len(l)), _p(r), ctypes.c_size_t(len(r)), _p(out)), len(l), len(r))
@@ -94,6 +187,9 @@ class MultiexponentiationInnerProductG1:
 class MultiexponentiationInnerProductG2:
     @staticmethod
     def inner_product(left, right):
+        if isinstance(left, Vec) or isinstance(right, Vec):
+            out = np.zeros(36, dtype=np.uint64)
+            _check(lib().ripp_vec_msm(left._h, right._h, _p(out)), len(left), len(right)); return out
         l, r = _c(left, 36), _c(right, 4)
         out = np.zeros(36, dtype=np.uint64)
         _check(lib().ripp_msm_g2_j(_p(l), ctypes.c_size_t(len(l)), _p(r), ctypes.c_size_t(len(r)), _p(out)), len(l), len(r))
@@ -105,6 +201,9 @@ class ScalarInnerProduct:
 
     @staticmethod
     def inner_product(left, right):
+        if isinstance(left, Vec) or isinstance(right, Vec):
+            out = np.zeros(4, dtype=np.uint64)
+            _check(lib().ripp_vec_scalar_inner_product(left._h, right._h, _p(out)), len(left), len(right)); return out
         l, r = _c(left, 4), _c(right, 4)
         out = np.zeros(4, dtype=np.uint64)
         _check(lib().ripp_scalar_inner_product(_p(l), ctypes.c_size_t(len(l)), _p(r), ctypes.c_size_t(len(r)), _p(out)), len(l), len(r))

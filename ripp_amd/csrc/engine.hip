@@ -1373,6 +1373,8 @@ API int32_t ripp_sipp_challenge(uint8_t seed[32], const ripp_gt* z_l, const ripp
     const Fr c = fs::sipp_challenge(rng, a, b); std::memcpy(seed, rng.seed, 32); std::memcpy(x, &c, sizeof c); return RIPP_OK;
 }
 
+#include "vec_api.inc"       // device-resident vectors (ripp_vec_*)
+
 #include "wire_api.inc"      // CanonicalSerialize / CanonicalDeserialize images of the proof structs
 
 #include "comm_api.inc"      // RCCL / callback communicator, sharded inner products and the sharded SIPP prover

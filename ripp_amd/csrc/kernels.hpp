@@ -105,6 +105,9 @@ __device__ __forceinline__ void line_add_store(Fp2& X, Fp2& Y, Fp2& Z, const G2A
 #pragma unroll
       for (int k = 0; k < 6; ++k) park[k * 256] = src[k]; } SB();
     { const Fp2 qx = opaque(q)->x; lambda = sub(X, mul(qx, Z)); } SB();
+    { const uint4* src = reinterpret_cast<const uint4*>(&X);          // X idles until g = X lambda^2
+#pragma unroll
+      for (int k = 0; k < 6; ++k) park[(12 + k) * 256] = src[k]; } SB();
     { const Fp2 qx = opaque(q)->x; const Fp2 t = mul(theta, qx); SB(); const Fp2 qy = opaque(q)->y; const Fp2 j = sub(t, mul(lambda, qy));
       store_chunks<6>(lines, s * 3 + LINE_SLOT_FREE, stride, i, skip ? LINE_UNIT_FREE : j); } SB();
     { const Fp xP = opaque(p)->x; store_chunks<6>(lines, s * 3 + 1, stride, i, skip ? Fp2::zero() : mul_fp(neg(theta), xP)); } SB();
@@ -115,7 +118,11 @@ __device__ __forceinline__ void line_add_store(Fp2& X, Fp2& Y, Fp2& Z, const G2A
 #pragma unroll
       for (int k = 0; k < 6; ++k) park[(6 + k) * 256] = src[k]; } SB();
     Fp2 e, g;
-    { const Fp2 d = sqr(lambda); SB(); e = mul(lambda, d); SB(); g = mul(X, d); } SB();
+    { const Fp2 d = sqr(lambda); SB(); e = mul(lambda, d); SB();
+      Fp2 x0; uint4* dst = reinterpret_cast<uint4*>(&x0);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) dst[k] = park[(12 + k) * 256];
+      g = mul(x0, d); } SB();
     const Fp2 h = sub(add(e, f), dbl(g)); SB();
     X = mul(lambda, h); SB();
     Z = mul(Z, e); SB();
@@ -130,7 +137,7 @@ __device__ __forceinline__ void line_add_store(Fp2& X, Fp2& Y, Fp2& Z, const G2A
       Y = sub(t, mul(e, y0)); }
 }
 __global__ void __launch_bounds__(256, RIPP_OCC) k_miller_lines(PairSets ps, uint32_t M, uint4* __restrict__ lines, size_t stride) {
-    __shared__ uint4 park[12 * 256];
+    __shared__ uint4 park[18 * 256];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
     const G1A* __restrict__ a = ps.a[blockIdx.y];

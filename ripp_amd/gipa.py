@@ -37,11 +37,11 @@ def fr_from_int(v):
 
 # ---------------------------------------------------------------- value kinds: what `Add`, `MulAssign<Scalar>`, `CanonicalSerialize` do
 class G1:
-    cols = 18
+    cols = 18; vec_kind = "G1"
     @staticmethod
     def ser(v): return api.ser_g1(api.normalize_batch_g1(np.asarray(v, dtype=np.uint64).reshape(1, 18))[0])     # projective serialises as affine
     @staticmethod
-    def fold(hi, lo, s): return api.fold_g1(hi, lo, s)
+    def fold(hi, lo, s): return hi.fold(lo, s) if isinstance(hi, api.Vec) else api.fold_g1(hi, lo, s)
     @staticmethod
     def zero(): z = np.zeros(18, dtype=np.uint64); return z                                                      # Z = 0
     @staticmethod
@@ -53,11 +53,11 @@ class G1:
 
 
 class G2:
-    cols = 36
+    cols = 36; vec_kind = "G2"
     @staticmethod
     def ser(v): return api.ser_g2(api.normalize_batch_g2(np.asarray(v, dtype=np.uint64).reshape(1, 36))[0])
     @staticmethod
-    def fold(hi, lo, s): return api.fold_g2(hi, lo, s)
+    def fold(hi, lo, s): return hi.fold(lo, s) if isinstance(hi, api.Vec) else api.fold_g2(hi, lo, s)
     @staticmethod
     def zero(): return np.zeros(36, dtype=np.uint64)
     @staticmethod
@@ -69,11 +69,12 @@ class G2:
 
 
 class Fr:
-    cols = 4
+    cols = 4; vec_kind = "Fr"
     @staticmethod
     def ser(v): return api.ser_fr(v)
     @staticmethod
     def fold(hi, lo, s):
+        if isinstance(hi, api.Vec): return hi.fold(lo, s)
         hi, lo = api._c(hi, 4), api._c(lo, 4); out = np.zeros_like(hi)
         api._check(lib().ripp_fold_fr(api._p(hi), api._p(lo), ctypes.c_size_t(len(hi)), api._p(np.ascontiguousarray(s, dtype=np.uint64).reshape(4)), api._p(out)))
         return out
@@ -172,8 +173,15 @@ ScalarIP = _IP(api.ScalarInnerProduct.inner_product, Fr, Fr, Fr)
 class GIPA:
     """GIPA<IP, LMC, RMC, IPC, Blake2b>.  Vectors are numpy arrays of the kinds' layouts (placeholder keys: any list of the right length)."""
 
-    def __init__(self, ip, lmc, rmc, ipc):
+    def __init__(self, ip, lmc, rmc, ipc, resident=True):
         self.ip, self.lmc, self.rmc, self.ipc = ip, lmc, rmc, ipc
+        self.resident = resident         # prover vectors live in HBM (api.Vec) between rounds; False = the host-slice calls of round 1
+
+    @staticmethod
+    def _to_device(kind, v):
+        """upload a message / key vector once (include/ripp_hip.h: ripp_vec_*); placeholders and already-resident vectors pass through"""
+        if isinstance(v, api.Vec) or not hasattr(kind, "vec_kind") or len(v) < 2: return v
+        return api.Vec.upload(kind.vec_kind, np.asarray(v, dtype=np.uint64).reshape(len(v), -1))
 
     # ---- Fiat-Shamir challenge (gipa.rs:233-258 and :331-356): returns (c, c_inv) AFTER the reference's swap
     def _challenge(self, prev, com_1, com_2):
@@ -194,6 +202,8 @@ class GIPA:
         n = len(m_a)
         assert n & (n - 1) == 0 and n > 0, "assert!(m_a.len().is_power_of_two())  (gipa.rs:195)"
         L, Rk, KA, KB = self.lmc.message, self.rmc.message, self.lmc.key, self.rmc.key
+        if self.resident:
+            m_a, m_b, ck_a, ck_b = self._to_device(L, m_a), self._to_device(Rk, m_b), self._to_device(KA, ck_a), self._to_device(KB, ck_b)
         steps, transcript = [], []
         while len(m_a) > 1:
             split = len(m_a) // 2

@@ -50,6 +50,22 @@ extern "C" {
     pub fn ripp_fold_g2_a(hi: *const RippG2A, lo: *const RippG2A, half: usize, s: *const RippFr, out: *mut RippG2A) -> i32;
     pub fn ripp_normalize_g1(p: *const RippG1J, n: usize, out: *mut RippG1A) -> i32;
     pub fn ripp_normalize_g2(p: *const RippG2J, n: usize, out: *mut RippG2A) -> i32;
+    // device-resident vectors: upload once, split / fold / take inner products on views (include/ripp_hip.h, "device-resident vectors")
+    pub fn ripp_vec_upload_g1a(p: *const RippG1A, n: usize, out: *mut *mut c_void) -> i32;
+    pub fn ripp_vec_upload_g2a(p: *const RippG2A, n: usize, out: *mut *mut c_void) -> i32;
+    pub fn ripp_vec_upload_g1j(p: *const RippG1J, n: usize, out: *mut *mut c_void) -> i32;
+    pub fn ripp_vec_upload_g2j(p: *const RippG2J, n: usize, out: *mut *mut c_void) -> i32;
+    pub fn ripp_vec_upload_fr(p: *const RippFr, n: usize, out: *mut *mut c_void) -> i32;
+    pub fn ripp_vec_len(v: *const c_void) -> usize;
+    pub fn ripp_vec_kind(v: *const c_void) -> i32;
+    pub fn ripp_vec_slice(v: *const c_void, off: usize, len: usize, view: *mut *mut c_void) -> i32;
+    pub fn ripp_vec_halves(v: *const c_void, lo: *mut *mut c_void, hi: *mut *mut c_void) -> i32;
+    pub fn ripp_vec_download(v: *const c_void, out: *mut c_void) -> i32;
+    pub fn ripp_vec_free(v: *mut c_void);
+    pub fn ripp_vec_pairing_product(left_g1: *const c_void, right_g2: *const c_void, out: *mut RippGt) -> i32;
+    pub fn ripp_vec_msm(bases: *const c_void, scalars: *const c_void, out: *mut c_void) -> i32;
+    pub fn ripp_vec_scalar_inner_product(l: *const c_void, r: *const c_void, out: *mut RippFr) -> i32;
+    pub fn ripp_vec_fold(hi: *const c_void, lo: *const c_void, s: *const RippFr, out: *mut *mut c_void) -> i32;
     // SIPP
     pub fn ripp_sipp_prove(a: *const RippG1A, b: *const RippG2A, r: *const RippFr, n: usize, value: *const RippGt,
                            proof: *mut RippGt, challenges: *mut RippFr, stats: *mut RippStats) -> i32;
