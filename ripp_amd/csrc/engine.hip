@@ -258,7 +258,7 @@ struct Engine {
         // RIPP_NO_VM keeps every stage on single lanes in Jacobian coordinates (the A/B and fallback form); otherwise the stages after
         // the gather work on homogeneous coordinates and the ones with few points run on the field VM (msm.hpp)
         const bool hom = !sw.no_vm;
-        const size_t vm_lds = 4 * VM_EPW * VmCurve<F>::SLOTS * sizeof(Fp);
+        const size_t vm_lds = 4 * VM_EPW * VmCurve<F>::SLOTS * sizeof(VmSlot);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_slot_sum<F>), dim3(nblk(max_slots, 64), p.nwin), dim3(64), 0, st, bases, p, ms.hist.as<uint32_t>(), ms.offs.as<uint32_t>(),
                            ms.slotoffs.as<uint32_t>(), ms.spw.as<uint32_t>(), ms.sorted.as<uint32_t>(), ms.slots.as<Jac<F>>(), max_slots, hom);
         uint32_t passes = 0;                                                       // a bucket holds at most n / ch + 1 slots
@@ -279,7 +279,7 @@ struct Engine {
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_vm_reduce<F>), dim3(nblk(nout, 4 * VM_EPW), p.nwin), dim3(256), vm_lds, st, cur, nseg, nxt, nout);
                 std::swap(cur, nxt); nseg = nout;
             }
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_finish_vm<F>), dim3(1), dim3(64), VM_EPW * VmCurve<F>::SLOTS * sizeof(Fp), st, p, cur, ms.win.as<Jac<F>>(), ms.out.as<Jac<F>>());
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_finish_vm<F>), dim3(1), dim3(64), VM_EPW * VmCurve<F>::SLOTS * sizeof(VmSlot), st, p, cur, ms.win.as<Jac<F>>(), ms.out.as<Jac<F>>());
         } else {
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_segments<F>), dim3(nblk(nseg, 64), p.nwin), dim3(64), 0, st, p, ms.buckets.as<Jac<F>>(), cur, nseg);
             while (nseg > (uint32_t)MSM_SEG_FAN) {                 // tree over the segment sums: chains of <= 4 additions
@@ -319,7 +319,7 @@ struct Engine {
                 PairSets ps{}; for (int p = 0; p < nprod; ++p) { ps.a[p] = a[p] + off; ps.b[p] = b[p] + off; }
                 if ((rc = mark(ev_lines, true)) != RIPP_OK) return rc;
                 if (m * nprod <= vm_lines_max && !sw.no_vm)
-                    hipLaunchKernelGGL(k_vm_miller_lines, dim3(nblk(m, 4 * VM_EPW), nprod), dim3(256), 4 * VM_EPW * VM_LINES_SLOTS * sizeof(Fp), stream, ps, (uint32_t)m, lines.as<uint4>(), stride);
+                    hipLaunchKernelGGL(k_vm_miller_lines, dim3(nblk(m, 4 * VM_EPW), nprod), dim3(256), 4 * VM_EPW * VM_LINES_SLOTS * sizeof(VmSlot), stream, ps, (uint32_t)m, lines.as<uint4>(), stride);
                 else
                     hipLaunchKernelGGL(k_miller_lines, dim3(nblk(m, 256), nprod), dim3(256), 0, stream, ps, (uint32_t)m, lines.as<uint4>(), stride);
                 HIPCHK(hipGetLastError());
@@ -352,7 +352,7 @@ struct Engine {
                 const int R = ((size_t)T * nrows > (size_t)n_simd * 64) ? 4 : 2;
                 const uint32_t Tout = (T + R - 1) / R;
                 if (R == 2 && (size_t)Tout * nrows <= vm_tree_max && !sw.no_vm)
-                    hipLaunchKernelGGL(k_vm_fp12_tree, dim3(nblk(Tout, 2 * VM_EPW), (unsigned)nrows), dim3(128), 2 * VM_EPW * VM_F12_SLOTS * sizeof(Fp), stream, cur, T, nxt, Tout);
+                    hipLaunchKernelGGL(k_vm_fp12_tree, dim3(nblk(Tout, 2 * VM_EPW), (unsigned)nrows), dim3(128), 2 * VM_EPW * VM_F12_SLOTS * sizeof(VmSlot), stream, cur, T, nxt, Tout);
                 else
                 hipLaunchKernelGGL(k_fp12_tree, dim3(nblk(Tout, 64), (unsigned)nrows), dim3(64), 0, stream, cur, T, nxt, Tout, R);
                 HIPCHK(hipGetLastError());
@@ -668,8 +668,8 @@ int32_t job_precompute_vm(Engine* e, ripp_sipp_job* j) {
     if (half == 0 || half > e->vm_fold_max || e->sw.no_vm || e->sw.no_precompute) return RIPP_OK;
     int32_t rc;
     if ((rc = j->a_pow_h.reserve(half * sizeof(G1J))) || (rc = j->b_pow_h.reserve(half * sizeof(G2J))) || (rc = j->parts1.reserve(2 * half * sizeof(G1J))) || (rc = j->parts2.reserve(8 * half * sizeof(G2J)))) return rc;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_pow2<Fp>), dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VmCurve<Fp>::SLOTS * sizeof(Fp), e->stream2, j->a.as<G1A>() + half, (uint32_t)half, 64, j->a_pow_h.as<G1J>());
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_pow2<Fp2>), dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VmCurve<Fp2>::SLOTS * sizeof(Fp), e->stream, j->b.as<G2A>() + half, (uint32_t)half, 32, j->b_pow_h.as<G2J>());
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_pow2<Fp>), dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VmCurve<Fp>::SLOTS * sizeof(VmSlot), e->stream2, j->a.as<G1A>() + half, (uint32_t)half, 64, j->a_pow_h.as<G1J>());
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_pow2<Fp2>), dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VmCurve<Fp2>::SLOTS * sizeof(VmSlot), e->stream, j->b.as<G2A>() + half, (uint32_t)half, 32, j->b_pow_h.as<G2J>());
     HIPCHK(hipGetLastError());
     j->pre_vm_ready = true;
     return RIPP_OK;
@@ -771,19 +771,19 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true)
     else if (pre)
         hipLaunchKernelGGL(k_fold_g1_two, dim3(nblk(half, 256)), dim3(256), 0, e->stream2, a + half, j->a_pow.as<G1A>(), a, (uint32_t)half, split64_digits(x), j->jac1.as<G1J>());
     else if (pre_vm) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_fold_split2<Fp>), dim3(nblk(half, 4 * VM_EPW), 2), dim3(256), 4 * VM_EPW * VmCurve<Fp>::SLOTS * sizeof(Fp), e->stream2, a + half, j->a_pow_h.as<G1J>(), (uint32_t)half, split_digits_g1(x), 1, j->parts1.as<G1J>());
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_combine<Fp>), dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VmCurve<Fp>::SLOTS * sizeof(Fp), e->stream2, j->parts1.as<G1J>(), 2, a, (uint32_t)half, j->jac1.as<G1J>());
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_fold_split2<Fp>), dim3(nblk(half, 4 * VM_EPW), 2), dim3(256), 4 * VM_EPW * VmCurve<Fp>::SLOTS * sizeof(VmSlot), e->stream2, a + half, j->a_pow_h.as<G1J>(), (uint32_t)half, split_digits_g1(x), 1, j->parts1.as<G1J>());
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_combine<Fp>), dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VmCurve<Fp>::SLOTS * sizeof(VmSlot), e->stream2, j->parts1.as<G1J>(), 2, a, (uint32_t)half, j->jac1.as<G1J>());
     }
     else if (use_vm)
-        hipLaunchKernelGGL(k_vm_fold_g1, dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VM_G1_SLOTS * sizeof(Fp), e->stream2, a + half, a, (uint32_t)half, naf_digits(x), j->jac1.as<G1J>(), e->vm_flag.as<uint32_t>());
+        hipLaunchKernelGGL(k_vm_fold_g1, dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VM_G1_SLOTS * sizeof(VmSlot), e->stream2, a + half, a, (uint32_t)half, naf_digits(x), j->jac1.as<G1J>(), e->vm_flag.as<uint32_t>());
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_affine_naf<Fp>), dim3(nblk(half, 256)), dim3(256), 0, e->stream2, a + half, a, (uint32_t)half, naf_digits(x), j->jac1.as<G1J>());
     HIPCHK(hipGetLastError());
     if ((rc = e->normalize_dev<Fp>(j->jac1.as<G1J>(), half, j->a_next.as<G1A>(), e->stream2)) != RIPP_OK) return rc;
     HIPCHK(hipEventRecord(e->ev_join, e->stream2));
     if (pre_vm) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_fold_split2<Fp2>), dim3(nblk(half, 4 * VM_EPW), 8), dim3(256), 4 * VM_EPW * VmCurve<Fp2>::SLOTS * sizeof(Fp), e->stream, b + half, j->b_pow_h.as<G2J>(), (uint32_t)half, split_digits_g2(x_inv), 4, j->parts2.as<G2J>());
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_combine<Fp2>), dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VmCurve<Fp2>::SLOTS * sizeof(Fp), e->stream, j->parts2.as<G2J>(), 8, b, (uint32_t)half, j->jac2.as<G2J>());
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_fold_split2<Fp2>), dim3(nblk(half, 4 * VM_EPW), 8), dim3(256), 4 * VM_EPW * VmCurve<Fp2>::SLOTS * sizeof(VmSlot), e->stream, b + half, j->b_pow_h.as<G2J>(), (uint32_t)half, split_digits_g2(x_inv), 4, j->parts2.as<G2J>());
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_combine<Fp2>), dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VmCurve<Fp2>::SLOTS * sizeof(VmSlot), e->stream, j->parts2.as<G2J>(), 8, b, (uint32_t)half, j->jac2.as<G2J>());
     } else
     if (tab) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab<Wnaf16, 16>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, e->fold_tab.as<uint4>(), j->tab2_stride, (int)FOLD_TAB_M, b, (uint32_t)half, gls16_wnaf(x_inv), j->jac2.as<G2J>());
@@ -794,8 +794,8 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true)
     } else
     if (use_vm) {
         if ((rc = e->qtab.reserve(std::max<size_t>(4 * G2A_CHUNKS * qstride * sizeof(uint4), 4 * half * sizeof(G2J)))) != RIPP_OK) return rc;
-        hipLaunchKernelGGL(k_vm_fold_g2_split, dim3(nblk(half, 4 * VM_EPW), 4), dim3(256), 4 * VM_EPW * VM_G2_SLOTS * sizeof(Fp), e->stream, b + half, (uint32_t)half, gls_digits(x_inv), e->qtab.as<G2J>(), e->vm_flag.as<uint32_t>());
-        hipLaunchKernelGGL(k_vm_combine_g2, dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VM_G2_SLOTS * sizeof(Fp), e->stream, e->qtab.as<G2J>(), b, (uint32_t)half, j->jac2.as<G2J>());
+        hipLaunchKernelGGL(k_vm_fold_g2_split, dim3(nblk(half, 4 * VM_EPW), 4), dim3(256), 4 * VM_EPW * VM_G2_SLOTS * sizeof(VmSlot), e->stream, b + half, (uint32_t)half, gls_digits(x_inv), e->qtab.as<G2J>(), e->vm_flag.as<uint32_t>());
+        hipLaunchKernelGGL(k_vm_combine_g2, dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VM_G2_SLOTS * sizeof(VmSlot), e->stream, e->qtab.as<G2J>(), b, (uint32_t)half, j->jac2.as<G2J>());
     } else
     if (e->sw.no_endo) {               // no psi on this build / switch: the 255-bit NAF fold (x^-1 is full width)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_affine_naf<Fp2>), dim3(nblk(half, 256)), dim3(256), 0, e->stream, b + half, b, (uint32_t)half, naf_digits(x_inv), j->jac2.as<G2J>());

@@ -311,10 +311,10 @@ template <> struct VmCurve<Fp> {
     static constexpr int QX = vmprog::g1_cadd_g16_in_qx0, QY = vmprog::g1_cadd_g16_in_qy0, QZ = vmprog::g1_cadd_g16_in_qz0;
     static_assert(vmprog::g1_hdbl_g16_in_X0 == SX && vmprog::g1_hdbl_g16_in_Y0 == SY && vmprog::g1_hdbl_g16_in_Z0 == SZ, "accumulator slots");
     static_assert(vmprog::g1_cadd_g16_out_X0 == SX && vmprog::g1_cadd_g16_out_Y0 == SY && vmprog::g1_cadd_g16_out_Z0 == SZ, "accumulator slots");
-    __device__ static void dbl_(Fp* ws, int lg) { vm_run(ws, vmprog::g1_hdbl_g16_kind, vmprog::g1_hdbl_g16_ops, vmprog::g1_hdbl_g16_nlayers, lg); }
-    __device__ static void add_(Fp* ws, int lg) { vm_run(ws, vmprog::g1_cadd_g16_kind, vmprog::g1_cadd_g16_ops, vmprog::g1_cadd_g16_nlayers, lg); }
-    __device__ static void put(Fp* ws, int slot, const Fp& v) { ws[slot] = v; }
-    __device__ static Fp get(const Fp* ws, int slot) { return ws[slot]; }
+    __device__ static void dbl_(VmSlot* ws, int lg) { vm_run(ws, vmprog::g1_hdbl_g16_kind, vmprog::g1_hdbl_g16_ops, vmprog::g1_hdbl_g16_nlayers, lg); }
+    __device__ static void add_(VmSlot* ws, int lg) { vm_run(ws, vmprog::g1_cadd_g16_kind, vmprog::g1_cadd_g16_ops, vmprog::g1_cadd_g16_nlayers, lg); }
+    __device__ static void put(VmSlot* ws, int slot, const Fp& v) { vm_put(ws, slot, v); }
+    __device__ static Fp get(const VmSlot* ws, int slot) { return vm_get(ws, slot); }
 };
 template <> struct VmCurve<Fp2> {
     static constexpr int NF = 2;
@@ -324,10 +324,10 @@ template <> struct VmCurve<Fp2> {
     static_assert(vmprog::g2_hdbl_g16_in_X0 == SX && vmprog::g2_hdbl_g16_in_Y0 == SY && vmprog::g2_hdbl_g16_in_Z0 == SZ, "accumulator slots");
     static_assert(vmprog::g2_cadd_g16_out_X0 == SX && vmprog::g2_cadd_g16_out_Y0 == SY && vmprog::g2_cadd_g16_out_Z0 == SZ, "accumulator slots");
     static_assert(vmprog::g2_cadd_g16_in_X1 == SX + 1 && vmprog::g2_cadd_g16_in_qz1 == QZ + 1 && vmprog::g2_hdbl_g16_in_Z1 == SZ + 1, "c0/c1 adjacent");
-    __device__ static void dbl_(Fp* ws, int lg) { vm_run(ws, vmprog::g2_hdbl_g16_kind, vmprog::g2_hdbl_g16_ops, vmprog::g2_hdbl_g16_nlayers, lg); }
-    __device__ static void add_(Fp* ws, int lg) { vm_run(ws, vmprog::g2_cadd_g16_kind, vmprog::g2_cadd_g16_ops, vmprog::g2_cadd_g16_nlayers, lg); }
-    __device__ static void put(Fp* ws, int slot, const Fp2& v) { ws[slot] = v.c0; ws[slot + 1] = v.c1; }
-    __device__ static Fp2 get(const Fp* ws, int slot) { return {ws[slot], ws[slot + 1]}; }
+    __device__ static void dbl_(VmSlot* ws, int lg) { vm_run(ws, vmprog::g2_hdbl_g16_kind, vmprog::g2_hdbl_g16_ops, vmprog::g2_hdbl_g16_nlayers, lg); }
+    __device__ static void add_(VmSlot* ws, int lg) { vm_run(ws, vmprog::g2_cadd_g16_kind, vmprog::g2_cadd_g16_ops, vmprog::g2_cadd_g16_nlayers, lg); }
+    __device__ static void put(VmSlot* ws, int slot, const Fp2& v) { vm_put(ws, slot, v.c0); vm_put(ws, slot + 1, v.c1); }
+    __device__ static Fp2 get(const VmSlot* ws, int slot) { return {vm_get(ws, slot), vm_get(ws, slot + 1)}; }
 };
 
 // one block of 64 lanes: seg[w] is the homogeneous sum of window w (k_msm_vm_reduce ran down to one per window); lanes 0..15 run
@@ -337,13 +337,13 @@ template <class F>
 __global__ void __launch_bounds__(64) k_msm_finish_vm(MsmPlan p, const Jac<F>* __restrict__ seg, Jac<F>* __restrict__ win_h, Jac<F>* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char vm_smem[];
     using C = VmCurve<F>;
-    Fp* const lds = reinterpret_cast<Fp*>(vm_smem);
+    VmSlot* const lds = reinterpret_cast<VmSlot*>(vm_smem);
     const int lane = threadIdx.x, lg = lane & (VM_G - 1), grp = lane / VM_G;
-    Fp* const ws = lds + (size_t)grp * C::SLOTS;
+    VmSlot* const ws = lds + (size_t)grp * C::SLOTS;
     if ((uint32_t)lane < (uint32_t)p.nwin) win_h[lane] = seg[lane];
     __syncthreads();
     const bool lead = (lane == 0);
-    if (lg == 0) ws[0] = Fp::zero();
+    if (lg == 0) vm_zero(ws);
     if (lead) { const Jac<F> t = win_h[p.nwin - 1]; C::put(ws, C::SX, t.x); C::put(ws, C::SY, t.y); C::put(ws, C::SZ, t.z); }
     else if (lg == 0) { C::put(ws, C::SX, F::zero()); C::put(ws, C::SY, F::one()); C::put(ws, C::SZ, F::zero()); }   // idle groups: a valid point
 #pragma unroll 1
@@ -365,9 +365,9 @@ __global__ void __launch_bounds__(64) k_msm_finish_vm(MsmPlan p, const Jac<F>* _
 // One point per group of 16 lanes (4 per wave, 16 per block), homogeneous coordinates in and out.  A complete addition costs ~8 us
 // (G1) / ~19 us (G2) here against ~60 / ~170 us for a lone wave's single lane, and these stages have few points: buckets, segments,
 // segment sums.  Groups whose chain is shorter keep adding the identity (the addition law is complete), so a wave stays converged.
-template <class F> __device__ __forceinline__ void vm_put_t(Fp* ws, const Jac<F>& t) { using C = VmCurve<F>; C::put(ws, C::SX, t.x); C::put(ws, C::SY, t.y); C::put(ws, C::SZ, t.z); }
-template <class F> __device__ __forceinline__ void vm_put_q(Fp* ws, const Jac<F>& t) { using C = VmCurve<F>; C::put(ws, C::QX, t.x); C::put(ws, C::QY, t.y); C::put(ws, C::QZ, t.z); }
-template <class F> __device__ __forceinline__ Jac<F> vm_get_t(const Fp* ws) { using C = VmCurve<F>; return {C::get(ws, C::SX), C::get(ws, C::SY), C::get(ws, C::SZ)}; }
+template <class F> __device__ __forceinline__ void vm_put_t(VmSlot* ws, const Jac<F>& t) { using C = VmCurve<F>; C::put(ws, C::SX, t.x); C::put(ws, C::SY, t.y); C::put(ws, C::SZ, t.z); }
+template <class F> __device__ __forceinline__ void vm_put_q(VmSlot* ws, const Jac<F>& t) { using C = VmCurve<F>; C::put(ws, C::QX, t.x); C::put(ws, C::QY, t.y); C::put(ws, C::QZ, t.z); }
+template <class F> __device__ __forceinline__ Jac<F> vm_get_t(const VmSlot* ws) { using C = VmCurve<F>; return {C::get(ws, C::SX), C::get(ws, C::SY), C::get(ws, C::SZ)}; }
 
 // group per (window, bucket): bucket = sum of its slot sums (of its group sums after `passes` grouping passes)
 template <class F>
@@ -377,14 +377,14 @@ __global__ void __launch_bounds__(256) k_msm_vm_merge(MsmPlan p, const uint32_t*
     using C = VmCurve<F>;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lg = lane & (VM_G - 1), grp = lane / VM_G, w = blockIdx.y;
     const uint32_t d = (blockIdx.x * 4 + wave) * VM_EPW + grp;
-    Fp* const ws = reinterpret_cast<Fp*>(vm_smem) + (size_t)(wave * VM_EPW + grp) * C::SLOTS;
+    VmSlot* const ws = reinterpret_cast<VmSlot*>(vm_smem) + (size_t)(wave * VM_EPW + grp) * C::SLOTS;
     uint32_t ns = 0, s0 = 0, step = 1;
     if (d < p.nb) {
         ns = (hist[(size_t)w * p.nb + d] + p.ch - 1) / p.ch; s0 = slot_offs[(size_t)w * p.nb + d];
         for (uint32_t j = 0; j < passes && ns > p.gmin * step; ++j) step *= MSM_SLOT_GROUP;
     }
     const Jac<F>* src = slot_sums + (size_t)w * max_slots + s0;
-    if (lg == 0) { ws[0] = Fp::zero(); vm_put_t<F>(ws, ns ? src[0] : msm_id_h<F>()); }
+    if (lg == 0) { vm_zero(ws); vm_put_t<F>(ws, ns ? src[0] : msm_id_h<F>()); }
     uint32_t k = step;
 #pragma unroll 1
     while (__any(k < ns)) {
@@ -404,12 +404,12 @@ __global__ void __launch_bounds__(256) k_msm_vm_segments(MsmPlan p, const Jac<F>
     using C = VmCurve<F>;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lg = lane & (VM_G - 1), grp = lane / VM_G, w = blockIdx.y;
     const uint32_t j = (blockIdx.x * 4 + wave) * VM_EPW + grp;
-    Fp* const ws = reinterpret_cast<Fp*>(vm_smem) + (size_t)(wave * VM_EPW + grp) * C::SLOTS;
+    VmSlot* const ws = reinterpret_cast<VmSlot*>(vm_smem) + (size_t)(wave * VM_EPW + grp) * C::SLOTS;
     const bool active = j < nseg, lead = lg == 0;
     const Jac<F>* b = buckets + (size_t)w * p.nb + (size_t)j * 4;
     Jac<F> B0 = msm_id_h<F>(), B1 = B0, B3 = B0, S = B0, local = B0;
     if (lead) {
-        ws[0] = Fp::zero();
+        vm_zero(ws);
         if (active) { B0 = b[0]; B1 = b[1]; B3 = b[3]; }
         vm_put_t<F>(ws, active ? b[2] : msm_id_h<F>()); vm_put_q<F>(ws, B3);
     }
@@ -448,10 +448,10 @@ __global__ void __launch_bounds__(256) k_msm_vm_reduce(const Jac<F>* __restrict_
     using C = VmCurve<F>;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lg = lane & (VM_G - 1), grp = lane / VM_G, w = blockIdx.y;
     const uint32_t j = (blockIdx.x * 4 + wave) * VM_EPW + grp;
-    Fp* const ws = reinterpret_cast<Fp*>(vm_smem) + (size_t)(wave * VM_EPW + grp) * C::SLOTS;
+    VmSlot* const ws = reinterpret_cast<VmSlot*>(vm_smem) + (size_t)(wave * VM_EPW + grp) * C::SLOTS;
     const uint32_t lo = j * MSM_SEG_FAN, hi = j < nout ? min(lo + MSM_SEG_FAN, nin) : lo;
     const Jac<F>* src = in + (size_t)w * nin;
-    if (lg == 0) { ws[0] = Fp::zero(); vm_put_t<F>(ws, lo < hi ? src[lo] : msm_id_h<F>()); }
+    if (lg == 0) { vm_zero(ws); vm_put_t<F>(ws, lo < hi ? src[lo] : msm_id_h<F>()); }
 #pragma unroll 1
     for (uint32_t k = 1; k < (uint32_t)MSM_SEG_FAN; ++k) {
         if (!__any(lo + k < hi)) break;

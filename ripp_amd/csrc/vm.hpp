@@ -2,97 +2,209 @@
 // per-element LDS workspace; a program is a list of homogeneous LAYERS (tables generated and verified offline by
 // tools/vmgen.py) in which each lane performs one
 //     MUL  ws[dst] = (+-ws[a0] +-ws[a1]) * (+-ws[a2] +-ws[a3])
-//     LIN  ws[dst] = ((+-ws[a0] +-ws[a1] +-ws[a2] +-ws[a3]) << sh) [/ 2]
+//     LIN  ws[dst] = sum_t c[t] * ws[s[t]]              (<= 16 terms, small signed integer coefficients)
 // Why: the scalar kernels (one lane per element) keep ~400 dwords of live state per lane, so they run one wave per
 // SIMD and, in the small late rounds of a proof, one lone lane pays ~2.4 us per DEPENDENT Fp product.  Here the
-// state sits in LDS (160 KB/CU), each lane needs ~60 VGPRs, the multiplier is inlined once (no calls), and the
+// state sits in LDS (160 KB/CU), each lane needs ~60-100 VGPRs, the multiplier is inlined once (no calls), and the
 // 25-54 independent products of a step run side by side: a Miller doubling step is 2 product layers instead of 25
 // dependent products.  Used for the latency-bound part of the pipeline; the scalar kernels remain the throughput
-// path (and the fallback if an exceptional group-law case is flagged).
+// path.
+//
+// Second form (build round 2): the workspace holds values in the CARRY-FREE radix of fq28.hpp (14 limbs of 28 bits, Montgomery
+// R' = 2^392).  A lone wave issues one instruction per ~8 cycles whatever it is, so latency == instruction count: the product is
+// ~530 instructions instead of ~1 100 (the 12 x 32-bit form pays a carry instruction and a hazard nop per limb product), and a
+// linear combination with ARBITRARY small coefficients is one pass of signed multiply-adds into 64-bit columns, so the chains of
+// +-1 additions / doublings / halvings between two product layers collapse into ONE layer (Miller doubling step: 9 -> 4 layers).
+//
+// Values cross the kernel boundary WITHOUT a Montgomery conversion: the 12 x u32 words of an engine value a R (R = 2^384) are simply
+// re-sliced into limbs, i.e. read as the R'-form of a * 2^-8.  Every program that runs on such inputs is HOMOGENEOUS in them
+// (projective group law in and out, bilinear Fp12 product), so the constant 2^-8 only rescales a projective representative resp.
+// multiplies an Fp12 value by an element of Fp, which the final exponentiation removes.  The one inhomogeneous program (the mixed
+// addition step of the Miller loop) gets its affine point properly converted, once per pair.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "bls12_381/pairing.hpp"
 #include "kernels.hpp"
+#include "fq28.hpp"
 
 namespace ripp {
 
-struct VmOp { unsigned char dst, a0, a1, a2, a3, flags; };
+struct VmOp { unsigned char dst, flags; unsigned short nbias; unsigned char s[16]; signed char c[16]; };   // 36 bytes
+struct alignas(16) VmSlot { uint32_t l[16]; };          // 14 limbs + padding: four 16-byte LDS accesses
 }  // namespace ripp
 #include "vm_programs.inc"
 namespace ripp {
 
 constexpr int VM_G = 16;                 // lanes per element
 constexpr int VM_EPW = 64 / VM_G;        // elements per wave
+constexpr int VM_SLOT_VB = 16;           // every workspace value is < 16 p with normalised limbs (vmgen.py: LIGHT_MAX)
+constexpr int VM_NEG_K = 17;             // a negated MUL operand term is K17 - x, K17 = 17 p (vmgen.py: NEG_K)
 
-__device__ __forceinline__ Fp vm_cneg(const Fp& x, bool f) {
-    const Fp n = neg(x);
-    Fp r;
+#if defined(__HIP_DEVICE_COMPILE__)
+using VmVal = Fq<FQ_LN, VM_SLOT_VB>;
+namespace fq28 {
+// 17 p with every limb >= the corresponding limb of any workspace value: n_k + 2^28 [k < 13] - [k > 0]; the top limb of a workspace
+// value is bounded by its value (< 16 p)
+constexpr Limbs neg_bias() { Limbs n = times_p(VM_NEG_K), r{}; for (int k = 0; k < NL; ++k) r.l[k] = n.l[k] + (k < NL - 1 ? (1u << W) : 0u) - (k > 0 ? 1u : 0u); return r; }
+constexpr Limbs K17 = neg_bias();
+static_assert((uint64_t)K17.l[NL - 1] >= (uint64_t)VM_SLOT_VB * (P_TOP + 1), "K17's top limb must dominate a workspace value's");
+constexpr float INV_PTOP = (1.0f - 1.0f / 1048576.0f) / (float)(P_TOP + 1);     // quotient estimate of a heavy LIN: never above the true quotient
+}  // namespace fq28
+
+__device__ __forceinline__ VmVal vm_ld(const VmSlot* ws, unsigned s) {
+    VmVal r; uint4 q[4];
+    const uint4* p = reinterpret_cast<const uint4*>(ws[s].l);
 #pragma unroll
-    for (int i = 0; i < 12; ++i) r.l[i] = f ? n.l[i] : x.l[i];
+    for (int i = 0; i < 4; ++i) q[i] = p[i];
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(q);
+#pragma unroll
+    for (int i = 0; i < fq28::NL; ++i) r.l[i] = w[i];
     return r;
+}
+template <uint64_t LM, int VB>
+__device__ __forceinline__ void vm_st(VmSlot* ws, unsigned s, const Fq<LM, VB>& v) {
+    static_assert(LM <= FQ_LN && VB <= VM_SLOT_VB, "workspace values are normalised and < 16 p");
+    uint4 q[4]; uint32_t* w = reinterpret_cast<uint32_t*>(q);
+#pragma unroll
+    for (int i = 0; i < fq28::NL; ++i) w[i] = v.l[i];
+    w[14] = 0; w[15] = 0;
+    uint4* p = reinterpret_cast<uint4*>(ws[s].l);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p[i] = q[i];
+}
+// kernel-side access to the workspace: engine values are RE-SLICED, not converted (see the header note)
+__device__ __forceinline__ void vm_put(VmSlot* ws, int slot, const Fp& v) { vm_st(ws, slot, fq_unpack(v.l)); }
+__device__ __forceinline__ void vm_put_converted(VmSlot* ws, int slot, const Fp& v) { vm_st(ws, slot, fq_from_fp(v)); }
+__device__ __forceinline__ void vm_put_raw(VmSlot* ws, int slot, const Fqn& v) { vm_st(ws, slot, v); }
+__device__ __forceinline__ void vm_zero(VmSlot* ws) { vm_st(ws, 0, fq_zero()); }
+// program outputs are < 2p (vmgen.py reduces them): canonical representative, packed
+__device__ __forceinline__ Fp vm_get(const VmSlot* ws, int slot) {
+    const VmVal t = vm_ld(ws, slot);
+    Fqn u;
+#pragma unroll
+    for (int i = 0; i < fq28::NL; ++i) u.l[i] = t.l[i];
+    const Fqn c = fq_canon(u);
+    Fp r; fq_pack(c, r.l); return r;
+}
+
+// one operand of a MUL: (+-ws[s0]) (+-ws[s1]); "second term absent" == slot index 0 (which holds zero)
+__device__ __forceinline__ Fq<((uint64_t)1 << 30), 2 * VM_NEG_K> vm_operand(const VmSlot* ws, unsigned s0, unsigned s1, bool n0, bool n1) {
+    using namespace fq28;
+    Fq<((uint64_t)1 << 30), 2 * VM_NEG_K> r;
+    const VmVal x = vm_ld(ws, s0);
+    if (__any(n0)) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) r.l[i] = n0 ? K17.l[i] - x.l[i] : x.l[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) r.l[i] = x.l[i];
+    }
+    if (__any(s1 != 0u)) {
+        const VmVal y = vm_ld(ws, s1);
+        if (__any(n1)) {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) r.l[i] += n1 ? K17.l[i] - y.l[i] : y.l[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) r.l[i] += y.l[i];
+        }
+    }
+    return r;
+}
+// signed carry pass over 64-bit columns whose total is >= 0: limbs < 2^28, the top limb keeps the rest
+__device__ __forceinline__ void vm_carry(const int64_t (&col)[fq28::NL], uint32_t (&r)[fq28::NL]) {
+    int64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < fq28::NL - 1; ++i) { const int64_t t = col[i] + carry; r[i] = (uint32_t)t & fq28::MASK; carry = t >> fq28::W; }
+    r[fq28::NL - 1] = (uint32_t)(col[fq28::NL - 1] + carry);
 }
 
 // Run one program on this lane's element.  `ws` = LDS workspace of the element, `lg` = lane index within the group.
-// A lone wave issues one VALU instruction per ~8 cycles, so every instruction of a layer is latency: the operand preparation
-// (conditional negations, the second term of each operand, shifts, halving) is skipped whenever NO lane of the wave needs it -- the
-// test is wave-uniform (`__any`), so there is no divergence.  Slot 0 holds zero, hence "second term absent" == slot index 0.
-__device__ __forceinline__ Fp vm_operand(const Fp* ws, unsigned s0, unsigned s1, bool n0, bool n1) {
-    Fp x = ws[s0];
-    if (__any(n0)) x = vm_cneg(x, n0);
-    if (__any(s1 != 0u)) { Fp y = ws[s1]; if (__any(n1)) y = vm_cneg(y, n1); x = add(x, y); }
-    return x;
-}
-__device__ __forceinline__ void vm_run(Fp* ws, const unsigned char* __restrict__ kind, const VmOp* __restrict__ ops, int nlayers, int lg) {
+// Every instruction of a layer is latency, so the operand preparation a layer does not need (negations, second terms, the reduction of
+// a LIN whose bound is small) is skipped by WAVE-UNIFORM tests -- no divergence.
+__device__ __forceinline__ void vm_run(VmSlot* ws, const unsigned char* __restrict__ kind, const VmOp* __restrict__ ops, int nlayers, int lg) {
+    using namespace fq28;
 #pragma unroll 1
     for (int l = 0; l < nlayers; ++l) {
-        const VmOp op = ops[l * VM_G + lg];
-        const unsigned f = op.flags;
-        Fp r;
-        if (kind[l] == 0) {                                    // MUL layer (uniform over the wave)
-            const Fp A = vm_operand(ws, op.a0, op.a1, f & 1u, f & 2u);
-            const Fp B = vm_operand(ws, op.a2, op.a3, f & 4u, f & 8u);
-            r = mul(A, B);
-        } else {                                                // LIN layer
-            r = vm_operand(ws, op.a0, op.a1, f & 1u, f & 2u);
-            if (__any((op.a2 | op.a3) != 0u)) r = add(r, vm_operand(ws, op.a2, op.a3, f & 4u, f & 8u));
-            const unsigned sh = (f >> 5) & 3u;
-            if (__any(sh != 0u)) {
+        const VmOp* __restrict__ opp = ops + (l * VM_G + lg);
+        const unsigned k = kind[l];
+        const unsigned dst = opp->dst;
+        if (k == 0) {                                          // MUL layer (uniform over the wave)
+            const unsigned f = opp->flags;
+            const auto A = vm_operand(ws, opp->s[0], opp->s[1], f & 1u, f & 2u);
+            const auto B = vm_operand(ws, opp->s[2], opp->s[3], f & 4u, f & 8u);
+            const Fqn r = fq_mul(A, B);
+            vm_st(ws, dst, r);     // all lanes of the wave have issued their reads of this layer before any write (lockstep, in-order LDS)
+        } else {                                                // LIN layer: k & 31 terms, bit 6 = reduce the results below 2p
+            const int nt = (int)(k & 31u);
+            int64_t col[NL];
+#pragma unroll
+            for (int i = 0; i < NL; ++i) col[i] = 0;
 #pragma unroll 1
-                for (unsigned k = 0; k < 3; ++k) { if (!__any(k < sh)) break; const Fp d = dbl(r); const bool t = k < sh;
+            for (int t = 0; t < nt; ++t) {
+                const int c = opp->c[t];
+                const VmVal x = vm_ld(ws, opp->s[t]);
 #pragma unroll
-                    for (int i = 0; i < 12; ++i) r.l[i] = t ? d.l[i] : r.l[i]; }
+                for (int i = 0; i < NL; ++i) col[i] += (int64_t)c * (int32_t)x.l[i];
             }
-            if (__any((f & 16u) != 0u)) { const Fp h = half(r); const bool t = (f & 16u) != 0u;
+            const int nb = opp->nbias;                          // + nb p: covers the negative terms, so the total is >= 0
 #pragma unroll
-                for (int i = 0; i < 12; ++i) r.l[i] = t ? h.l[i] : r.l[i]; }
+            for (int i = 0; i < NL; ++i) col[i] += (int64_t)nb * (int32_t)P28.l[i];
+            uint32_t r[NL];
+            vm_carry(col, r);
+            if (k & 64u) {                                      // value < ~1000 p: subtract q p, q = the estimate from the top limb (never too large, at most one too small)
+                const int q = (int)((float)r[NL - 1] * INV_PTOP);
+#pragma unroll
+                for (int i = 0; i < NL; ++i) col[i] = (int64_t)r[i] - (int64_t)q * (int32_t)P28.l[i];
+                vm_carry(col, r);
+            }
+            Fq<FQ_LN, VM_SLOT_VB> o;
+#pragma unroll
+            for (int i = 0; i < NL; ++i) o.l[i] = r[i];
+            vm_st(ws, dst, o);
         }
-        ws[op.dst] = r;     // all lanes of the wave have issued their reads of this layer before any write (lockstep, in-order LDS)
     }
 }
+#else
+struct VmValHost {};
+__device__ void vm_run(VmSlot* ws, const unsigned char* kind, const VmOp* ops, int nlayers, int lg);
+__device__ void vm_put(VmSlot* ws, int slot, const Fp& v);
+__device__ void vm_put_converted(VmSlot* ws, int slot, const Fp& v);
+__device__ void vm_zero(VmSlot* ws);
+__device__ Fp vm_get(const VmSlot* ws, int slot);
+#endif
 
 // ---- stage 1 of the pairing product in latency form: VM_G lanes per (P,Q) pair ---------------------------------
 // grid.x covers ceil(M / (4 * VM_EPW)) blocks of 256 threads, grid.y = product; same line buffer layout as k_miller_lines.
 constexpr int VM_LINES_SLOTS = (vmprog::line_double_g16_nslots > vmprog::line_add_g16_nslots) ? vmprog::line_double_g16_nslots : vmprog::line_add_g16_nslots;
 __global__ void __launch_bounds__(256) k_vm_miller_lines(PairSets ps, uint32_t M, uint4* __restrict__ lines, size_t stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char vm_smem[];
-    Fp* const lds = reinterpret_cast<Fp*>(vm_smem);
+    VmSlot* const lds = reinterpret_cast<VmSlot*>(vm_smem);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lg = lane & (VM_G - 1), grp = lane / VM_G;
     const uint32_t i = (blockIdx.x * 4 + wave) * VM_EPW + grp;       // pair index handled by this group
-    Fp* const ws = lds + (size_t)(wave * VM_EPW + grp) * VM_LINES_SLOTS;
+    VmSlot* const ws = lds + (size_t)(wave * VM_EPW + grp) * VM_LINES_SLOTS;
     const bool active = i < M;
     const G1A* __restrict__ a = ps.a[blockIdx.y];
     const G2A* __restrict__ b = ps.b[blockIdx.y];
     namespace vp = vmprog;
     bool skip = false;
+    // This program set is NOT homogeneous in its inputs (mixed addition with an affine Q; the line's free coefficient against the ones scaled
+    // by xP, yP), so the six input coordinates are properly converted to the workspace's Montgomery form -- one product each, on six
+    // lanes side by side, once per pair.  Lanes 0..3 keep their coordinate of Q in registers for the five addition steps.
+#if defined(__HIP_DEVICE_COMPILE__)
+    Fqn qc = fq_zero();
     if (active) {
-        // lanes 0..7 of the group load the 8 input Fp's; everyone learns whether the pair contributes the unit line
         const G1A P = a[i]; const G2A Q = b[i];
         skip = is_inf(P) || is_inf(Q);
-        if (lg == 0) { ws[0] = Fp::zero(); ws[vp::line_double_g16_in_X0] = Q.x.c0; ws[vp::line_double_g16_in_X1] = Q.x.c1; }
-        if (lg == 1) { ws[vp::line_double_g16_in_Y0] = Q.y.c0; ws[vp::line_double_g16_in_Y1] = Q.y.c1; }
-        if (lg == 2) { ws[vp::line_double_g16_in_Z0] = Fp::one(); ws[vp::line_double_g16_in_Z1] = Fp::zero(); }
-        if (lg == 3) { ws[vp::line_double_g16_in_xP] = P.x; ws[vp::line_double_g16_in_yP] = P.y; }
+        if (lg < 4) {
+            qc = fq_from_fp(lg == 0 ? Q.x.c0 : lg == 1 ? Q.x.c1 : lg == 2 ? Q.y.c0 : Q.y.c1);
+            vm_put_raw(ws, lg == 0 ? vp::line_double_g16_in_X0 : lg == 1 ? vp::line_double_g16_in_X1 : lg == 2 ? vp::line_double_g16_in_Y0 : vp::line_double_g16_in_Y1, qc);
+        }
+        if (lg == 4) { vm_zero(ws); vm_put_raw(ws, vp::line_double_g16_in_Z0, fq_one()); vm_put_raw(ws, vp::line_double_g16_in_Z1, fq_zero()); }
+        if (lg == 5) vm_put_converted(ws, vp::line_double_g16_in_xP, P.x);
+        if (lg == 6) vm_put_converted(ws, vp::line_double_g16_in_yP, P.y);
     }
+#endif
     const size_t row0 = (size_t)blockIdx.y * N_LINES;
     int s = 0;
 #pragma unroll 1
@@ -103,7 +215,7 @@ __global__ void __launch_bounds__(256) k_vm_miller_lines(PairSets ps, uint32_t M
             int src = OUT[0];
 #pragma unroll
             for (int k = 1; k < 6; ++k) src = (lg == k) ? OUT[k] : src;
-            Fp v = ws[src];
+            Fp v = vm_get(ws, src);
             if (skip) v = (lg == 0) ? Fp::one() : Fp::zero();
             const uint4* pv = reinterpret_cast<const uint4*>(&v);
 #pragma unroll
@@ -111,14 +223,16 @@ __global__ void __launch_bounds__(256) k_vm_miller_lines(PairSets ps, uint32_t M
         }
         ++s;
         if ((BLS_X_ABS >> bit) & 1ull) {
-            if (active && lg == 4) { const G2A Q = b[i]; ws[vp::line_add_g16_in_qx0] = Q.x.c0; ws[vp::line_add_g16_in_qx1] = Q.x.c1; ws[vp::line_add_g16_in_qy0] = Q.y.c0; ws[vp::line_add_g16_in_qy1] = Q.y.c1; }
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (active && lg < 4) vm_put_raw(ws, lg == 0 ? vp::line_add_g16_in_qx0 : lg == 1 ? vp::line_add_g16_in_qx1 : lg == 2 ? vp::line_add_g16_in_qy0 : vp::line_add_g16_in_qy1, qc);
+#endif
             vm_run(ws, vp::line_add_g16_kind, vp::line_add_g16_ops, vp::line_add_g16_nlayers, lg);
             if (active && lg < 6) {
                 constexpr int OUT[6] = {vp::line_add_g16_out_L00, vp::line_add_g16_out_L01, vp::line_add_g16_out_L10, vp::line_add_g16_out_L11, vp::line_add_g16_out_L20, vp::line_add_g16_out_L21};
                 int src = OUT[0];
 #pragma unroll
                 for (int k = 1; k < 6; ++k) src = (lg == k) ? OUT[k] : src;
-                Fp v = ws[src];
+                Fp v = vm_get(ws, src);
                 if (skip) v = (lg == 0) ? Fp::one() : Fp::zero();
                 const uint4* pv = reinterpret_cast<const uint4*>(&v);
 #pragma unroll
@@ -133,30 +247,30 @@ __global__ void __launch_bounds__(256) k_vm_miller_lines(PairSets ps, uint32_t M
 constexpr int VM_F12_SLOTS = vmprog::fp12_mul_g16_nslots;
 __global__ void __launch_bounds__(128) k_vm_fp12_tree(const uint4* __restrict__ in, uint32_t Tin, uint4* __restrict__ out, uint32_t Tout) {
     extern __shared__ __attribute__((aligned(16))) unsigned char vm_smem[];
-    Fp* const lds = reinterpret_cast<Fp*>(vm_smem);
+    VmSlot* const lds = reinterpret_cast<VmSlot*>(vm_smem);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lg = lane & (VM_G - 1), grp = lane / VM_G;
     const uint32_t j = (blockIdx.x * (blockDim.x >> 6) + wave) * VM_EPW + grp;
     const size_t row = blockIdx.y;
-    Fp* const ws = lds + (size_t)(wave * VM_EPW + grp) * VM_F12_SLOTS;
+    VmSlot* const ws = lds + (size_t)(wave * VM_EPW + grp) * VM_F12_SLOTS;
     const bool active = j < Tout, pair = active && (j + Tout < Tin);
     namespace vp = vmprog;
     if (active && lg < 12) {      // Fp k of an Fp12 = chunks 3k..3k+2; f -> slots 2.., g -> slots 14..
         Fp f; uint4* pf = reinterpret_cast<uint4*>(&f);
 #pragma unroll
         for (int c = 0; c < 3; ++c) pf[c] = in[(row * FP12_CHUNKS + 3 * lg + c) * Tin + j];
-        ws[vp::fp12_mul_g16_in[0] + lg] = f;
+        vm_put(ws, vp::fp12_mul_g16_in[0] + lg, f);
         if (pair) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) pf[c] = in[(row * FP12_CHUNKS + 3 * lg + c) * Tin + j + Tout];
-            ws[vp::fp12_mul_g16_in[12] + lg] = f;
+            vm_put(ws, vp::fp12_mul_g16_in[12] + lg, f);
         }
-        if (lg == 0) ws[0] = Fp::zero();
+        if (lg == 0) vm_zero(ws);
     }
     // groups without a partner (odd tail) just copy; the program still runs wave-uniformly on harmless data
     vm_run(ws, vp::fp12_mul_g16_kind, vp::fp12_mul_g16_ops, vp::fp12_mul_g16_nlayers, lg);
     if (active && lg < 12) {
         Fp f;
-        if (pair) f = ws[vp::fp12_mul_g16_out[0] + lg];
+        if (pair) f = vm_get(ws, vp::fp12_mul_g16_out[0] + lg);
         else { uint4* pf = reinterpret_cast<uint4*>(&f);
 #pragma unroll
             for (int c = 0; c < 3; ++c) pf[c] = in[(row * FP12_CHUNKS + 3 * lg + c) * Tin + j]; }
@@ -172,23 +286,23 @@ __global__ void __launch_bounds__(128) k_vm_fp12_tree(const uint4* __restrict__ 
 constexpr int VM_G2_SLOTS = (vmprog::g2_hdbl_g16_nslots > vmprog::g2_cadd_g16_nslots) ? vmprog::g2_hdbl_g16_nslots : vmprog::g2_cadd_g16_nslots;
 __global__ void __launch_bounds__(256) k_vm_fold_g2_split(const G2A* __restrict__ hi, uint32_t half, GlsDigits dg, G2J* __restrict__ parts, uint32_t* __restrict__ flag) {
     extern __shared__ __attribute__((aligned(16))) unsigned char vm_smem[];
-    Fp* const lds = reinterpret_cast<Fp*>(vm_smem);
+    VmSlot* const lds = reinterpret_cast<VmSlot*>(vm_smem);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lg = lane & (VM_G - 1), grp = lane / VM_G;
     const uint32_t i = (blockIdx.x * 4 + wave) * VM_EPW + grp;
     const int j = blockIdx.y;
-    Fp* const ws = lds + (size_t)(wave * VM_EPW + grp) * VM_G2_SLOTS;
+    VmSlot* const ws = lds + (size_t)(wave * VM_EPW + grp) * VM_G2_SLOTS;
     const bool active = i < half;
     namespace vp = vmprog;
     enum { SX = vp::g2_cadd_g16_in_X0, SY = vp::g2_cadd_g16_in_Y0, SZ = vp::g2_cadd_g16_in_Z0, SQX = vp::g2_cadd_g16_in_qx0, SQY = vp::g2_cadd_g16_in_qy0, SQZ = vp::g2_cadd_g16_in_qz0 };
     static_assert(vp::g2_hdbl_g16_in_X0 == SX && vp::g2_hdbl_g16_in_Y0 == SY && vp::g2_hdbl_g16_in_Z0 == SZ, "accumulator slots shared by the two programs");
     G2A q = aff_inf<Fp2>(); bool qinf = true;
-    if (active && lg == 0) { q = gls_image(hi[i], j); qinf = is_inf(q); ws[0] = Fp::zero(); }
+    if (active && lg == 0) { q = gls_image(hi[i], j); qinf = is_inf(q); vm_zero(ws); }
     int pos = dg.len - 1;
     while (pos >= 0 && dg.d[j][pos] == 0) --pos;               // uniform: digits are shared by the whole launch
     const bool any = pos >= 0;
     if (any && active && lg == 0) {
         const Fp2 y0 = dg.d[j][pos] < 0 ? neg(q.y) : q.y;
-        ws[SX] = q.x.c0; ws[SX + 1] = q.x.c1; ws[SY] = y0.c0; ws[SY + 1] = y0.c1; ws[SZ] = Fp::one(); ws[SZ + 1] = Fp::zero();
+        vm_put(ws, SX, q.x.c0); vm_put(ws, SX + 1, q.x.c1); vm_put(ws, SY, y0.c0); vm_put(ws, SY + 1, y0.c1); vm_put(ws, SZ, Fp::one()); vm_put(ws, SZ + 1, Fp::zero());
     }
     // additions use the COMPLETE projective law (g2_cadd: depth 2, no exceptional case), the addend (q.x : +-q.y : 1) is rewritten
     // before each one because the doubling program may use those slots as temporaries
@@ -198,7 +312,7 @@ __global__ void __launch_bounds__(256) k_vm_fold_g2_split(const G2A* __restrict_
         vm_run(ws, vp::g2_hdbl_g16_kind, vp::g2_hdbl_g16_ops, vp::g2_hdbl_g16_nlayers, lg);
         const int d = dg.d[j][pos];
         if (d != 0) {
-            if (active && lg == 0) { const Fp2 y = d < 0 ? neg(q.y) : q.y; ws[SQX] = q.x.c0; ws[SQX + 1] = q.x.c1; ws[SQY] = y.c0; ws[SQY + 1] = y.c1; ws[SQZ] = Fp::one(); ws[SQZ + 1] = Fp::zero(); }
+            if (active && lg == 0) { const Fp2 y = d < 0 ? neg(q.y) : q.y; vm_put(ws, SQX, q.x.c0); vm_put(ws, SQX + 1, q.x.c1); vm_put(ws, SQY, y.c0); vm_put(ws, SQY + 1, y.c1); vm_put(ws, SQZ, Fp::one()); vm_put(ws, SQZ + 1, Fp::zero()); }
             vm_run(ws, vp::g2_cadd_g16_kind, vp::g2_cadd_g16_ops, vp::g2_cadd_g16_nlayers, lg);
         }
     }
@@ -206,7 +320,7 @@ __global__ void __launch_bounds__(256) k_vm_fold_g2_split(const G2A* __restrict_
         // parts are left in HOMOGENEOUS projective form (X : Y : Z), the identity as (0 : 1 : 0): k_vm_combine_g2 adds them with the
         // complete addition program, so no lone-lane conversion sits on the chain
         G2J r; r.x = Fp2::zero(); r.y = Fp2::one(); r.z = Fp2::zero();
-        if (any && !qinf) { r.x = {ws[SX], ws[SX + 1]}; r.y = {ws[SY], ws[SY + 1]}; r.z = {ws[SZ], ws[SZ + 1]}; }
+        if (any && !qinf) { r.x = {vm_get(ws, SX), vm_get(ws, SX + 1)}; r.y = {vm_get(ws, SY), vm_get(ws, SY + 1)}; r.z = {vm_get(ws, SZ), vm_get(ws, SZ + 1)}; }
         parts[(size_t)j * half + i] = r;
     }
 }
@@ -215,16 +329,16 @@ __global__ void __launch_bounds__(256) k_vm_fold_g2_split(const G2A* __restrict_
 // lone-lane Jacobian additions of k_fold_g2_combine (0.35-0.43 ms on the fold chain of every small round)
 __global__ void __launch_bounds__(256) k_vm_combine_g2(const G2J* __restrict__ parts, const G2A* __restrict__ lo, uint32_t half, G2J* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char vm_smem[];
-    Fp* const lds = reinterpret_cast<Fp*>(vm_smem);
+    VmSlot* const lds = reinterpret_cast<VmSlot*>(vm_smem);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lg = lane & (VM_G - 1), grp = lane / VM_G;
     const uint32_t i = (blockIdx.x * 4 + wave) * VM_EPW + grp;
-    Fp* const ws = lds + (size_t)(wave * VM_EPW + grp) * VM_G2_SLOTS;
+    VmSlot* const ws = lds + (size_t)(wave * VM_EPW + grp) * VM_G2_SLOTS;
     const bool active = i < half;
     namespace vp = vmprog;
     enum { SX = vp::g2_cadd_g16_in_X0, SY = vp::g2_cadd_g16_in_Y0, SZ = vp::g2_cadd_g16_in_Z0, SQX = vp::g2_cadd_g16_in_qx0, SQY = vp::g2_cadd_g16_in_qy0, SQZ = vp::g2_cadd_g16_in_qz0 };
-    auto put = [&](int s, const Fp2& v) { ws[s] = v.c0; ws[s + 1] = v.c1; };
+    auto put = [&](int s, const Fp2& v) { vm_put(ws, s, v.c0); vm_put(ws, s + 1, v.c1); };
     if (lg == 0) {
-        ws[0] = Fp::zero();
+        vm_zero(ws);
         G2J p0; p0.x = Fp2::zero(); p0.y = Fp2::one(); p0.z = Fp2::zero();
         if (active) p0 = parts[i];
         put(SX, p0.x); put(SY, p0.y); put(SZ, p0.z);
@@ -242,7 +356,7 @@ __global__ void __launch_bounds__(256) k_vm_combine_g2(const G2J* __restrict__ p
         vm_run(ws, vp::g2_cadd_g16_kind, vp::g2_cadd_g16_ops, vp::g2_cadd_g16_nlayers, lg);
     }
     if (active && lg == 0) {
-        const Fp2 X = {ws[SX], ws[SX + 1]}, Y = {ws[SY], ws[SY + 1]}, Z = {ws[SZ], ws[SZ + 1]};
+        const Fp2 X = {vm_get(ws, SX), vm_get(ws, SX + 1)}, Y = {vm_get(ws, SY), vm_get(ws, SY + 1)}, Z = {vm_get(ws, SZ), vm_get(ws, SZ + 1)};
         G2J r = jac_inf<Fp2>();
         if (!Z.is_zero()) { r.x = mul(X, Z); r.y = mul(Y, sqr(Z)); r.z = Z; }          // (X/Z, Y/Z) -> Jacobian (XZ, YZ^2, Z)
         out[i] = r;
@@ -253,34 +367,34 @@ __global__ void __launch_bounds__(256) k_vm_combine_g2(const G2J* __restrict__ p
 constexpr int VM_G1_SLOTS = (vmprog::g1_hdbl_g16_nslots > vmprog::g1_cadd_g16_nslots) ? vmprog::g1_hdbl_g16_nslots : vmprog::g1_cadd_g16_nslots;
 __global__ void __launch_bounds__(256) k_vm_fold_g1(const G1A* __restrict__ hi, const G1A* __restrict__ lo, uint32_t half, NafDigits dg, G1J* __restrict__ out, uint32_t* __restrict__ flag) {
     extern __shared__ __attribute__((aligned(16))) unsigned char vm_smem[];
-    Fp* const lds = reinterpret_cast<Fp*>(vm_smem);
+    VmSlot* const lds = reinterpret_cast<VmSlot*>(vm_smem);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lg = lane & (VM_G - 1), grp = lane / VM_G;
     const uint32_t i = (blockIdx.x * 4 + wave) * VM_EPW + grp;
-    Fp* const ws = lds + (size_t)(wave * VM_EPW + grp) * VM_G1_SLOTS;
+    VmSlot* const ws = lds + (size_t)(wave * VM_EPW + grp) * VM_G1_SLOTS;
     const bool active = i < half;
     namespace vp = vmprog;
     enum { SX = vp::g1_cadd_g16_in_X0, SY = vp::g1_cadd_g16_in_Y0, SZ = vp::g1_cadd_g16_in_Z0, SQX = vp::g1_cadd_g16_in_qx0, SQY = vp::g1_cadd_g16_in_qy0, SQZ = vp::g1_cadd_g16_in_qz0 };
     static_assert(vp::g1_hdbl_g16_in_X0 == SX && vp::g1_hdbl_g16_in_Y0 == SY && vp::g1_hdbl_g16_in_Z0 == SZ, "accumulator slots shared by the two programs");
     G1A q = aff_inf<Fp>(); bool qinf = true;
-    if (active && lg == 0) { q = hi[i]; qinf = is_inf(q); ws[0] = Fp::zero(); }
+    if (active && lg == 0) { q = hi[i]; qinf = is_inf(q); vm_zero(ws); }
     int pos = dg.len - 1;
     while (pos >= 0 && dg.d[pos] == 0) --pos;
     const bool any = pos >= 0;
-    if (any && active && lg == 0) { ws[SX] = q.x; ws[SY] = dg.d[pos] < 0 ? neg(q.y) : q.y; ws[SZ] = Fp::one(); }
+    if (any && active && lg == 0) { vm_put(ws, SX, q.x); vm_put(ws, SY, dg.d[pos] < 0 ? neg(q.y) : q.y); vm_put(ws, SZ, Fp::one()); }
     (void)flag;                                                 // complete addition (g1_cadd): nothing to report
 #pragma unroll 1
     for (--pos; pos >= 0; --pos) {
         vm_run(ws, vp::g1_hdbl_g16_kind, vp::g1_hdbl_g16_ops, vp::g1_hdbl_g16_nlayers, lg);
         const int d = dg.d[pos];
         if (d != 0) {
-            if (active && lg == 0) { ws[SQX] = q.x; ws[SQY] = d < 0 ? neg(q.y) : q.y; ws[SQZ] = Fp::one(); }
+            if (active && lg == 0) { vm_put(ws, SQX, q.x); vm_put(ws, SQY, d < 0 ? neg(q.y) : q.y); vm_put(ws, SQZ, Fp::one()); }
             vm_run(ws, vp::g1_cadd_g16_kind, vp::g1_cadd_g16_ops, vp::g1_cadd_g16_nlayers, lg);
         }
     }
     if (active && lg == 0) {
         G1J r = jac_inf<Fp>();
         if (any && !qinf) {
-            const Fp X = ws[SX], Y = ws[SY], Z = ws[SZ];
+            const Fp X = vm_get(ws, SX), Y = vm_get(ws, SY), Z = vm_get(ws, SZ);
             if (!Z.is_zero()) { r.x = fmul(X, Z); r.y = fmul(Y, fsqr(Z)); r.z = Z; }
         }
         out[i] = add_mixed(r, lo[i]);
@@ -291,32 +405,32 @@ __global__ void __launch_bounds__(256) k_vm_fold_g1(const G1A* __restrict__ hi, 
 // (128 VM doublings, complete additions of +-P and +-phi(P)).
 __global__ void __launch_bounds__(256) k_vm_fold_g1_glv(const G1A* __restrict__ hi, const G1A* __restrict__ lo, uint32_t half, GlvDigits dg, G1J* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char vm_smem[];
-    Fp* const lds = reinterpret_cast<Fp*>(vm_smem);
+    VmSlot* const lds = reinterpret_cast<VmSlot*>(vm_smem);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lg = lane & (VM_G - 1), grp = lane / VM_G;
     const uint32_t i = (blockIdx.x * 4 + wave) * VM_EPW + grp;
-    Fp* const ws = lds + (size_t)(wave * VM_EPW + grp) * VM_G1_SLOTS;
+    VmSlot* const ws = lds + (size_t)(wave * VM_EPW + grp) * VM_G1_SLOTS;
     const bool active = i < half;
     namespace vp = vmprog;
     enum { SX = vp::g1_cadd_g16_in_X0, SY = vp::g1_cadd_g16_in_Y0, SZ = vp::g1_cadd_g16_in_Z0, SQX = vp::g1_cadd_g16_in_qx0, SQY = vp::g1_cadd_g16_in_qy0, SQZ = vp::g1_cadd_g16_in_qz0 };
     G1A q = aff_inf<Fp>(); Fp bx = Fp::zero(); bool qinf = true;
-    if (active && lg == 0) { q = hi[i]; qinf = is_inf(q); bx = fmul(q.x, fp_const(RIPP_GLV_BETA)); ws[0] = Fp::zero(); ws[SX] = Fp::zero(); ws[SY] = Fp::one(); ws[SZ] = Fp::zero(); }   // T = identity (0:1:0)
+    if (active && lg == 0) { q = hi[i]; qinf = is_inf(q); bx = fmul(q.x, fp_const(RIPP_GLV_BETA)); vm_zero(ws); vm_put(ws, SX, Fp::zero()); vm_put(ws, SY, Fp::one()); vm_put(ws, SZ, Fp::zero()); }   // T = identity (0:1:0)
 #pragma unroll 1
     for (int pos = dg.len - 1; pos >= 0; --pos) {
         vm_run(ws, vp::g1_hdbl_g16_kind, vp::g1_hdbl_g16_ops, vp::g1_hdbl_g16_nlayers, lg);
         const int d1 = dg.d1[pos], d2 = dg.d2[pos];
         if (d1 != 0) {
-            if (active && lg == 0) { ws[SQX] = q.x; ws[SQY] = d1 < 0 ? neg(q.y) : q.y; ws[SQZ] = Fp::one(); }
+            if (active && lg == 0) { vm_put(ws, SQX, q.x); vm_put(ws, SQY, d1 < 0 ? neg(q.y) : q.y); vm_put(ws, SQZ, Fp::one()); }
             vm_run(ws, vp::g1_cadd_g16_kind, vp::g1_cadd_g16_ops, vp::g1_cadd_g16_nlayers, lg);
         }
         if (d2 != 0) {
-            if (active && lg == 0) { ws[SQX] = bx; ws[SQY] = d2 < 0 ? neg(q.y) : q.y; ws[SQZ] = Fp::one(); }
+            if (active && lg == 0) { vm_put(ws, SQX, bx); vm_put(ws, SQY, d2 < 0 ? neg(q.y) : q.y); vm_put(ws, SQZ, Fp::one()); }
             vm_run(ws, vp::g1_cadd_g16_kind, vp::g1_cadd_g16_ops, vp::g1_cadd_g16_nlayers, lg);
         }
     }
     if (active && lg == 0) {
         G1J r = jac_inf<Fp>();
         if (!qinf) {
-            const Fp X = ws[SX], Y = ws[SY], Z = ws[SZ];
+            const Fp X = vm_get(ws, SX), Y = vm_get(ws, SY), Z = vm_get(ws, SZ);
             if (!Z.is_zero()) { r.x = fmul(X, Z); r.y = fmul(Y, fsqr(Z)); r.z = Z; }
         }
         out[i] = add_mixed(r, lo[i]);

@@ -30,13 +30,13 @@ template <class F>
 __global__ void __launch_bounds__(256) k_vm_pow2(const Affine<F>* __restrict__ in, uint32_t n, int k, Jac<F>* __restrict__ out_h) {
     extern __shared__ __attribute__((aligned(16))) unsigned char vm_smem[];
     using C = VmCurve<F>;
-    Fp* const lds = reinterpret_cast<Fp*>(vm_smem);
+    VmSlot* const lds = reinterpret_cast<VmSlot*>(vm_smem);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lg = lane & (VM_G - 1), grp = lane / VM_G;
     const uint32_t i = (blockIdx.x * 4 + wave) * VM_EPW + grp;
-    Fp* const ws = lds + (size_t)(wave * VM_EPW + grp) * C::SLOTS;
+    VmSlot* const ws = lds + (size_t)(wave * VM_EPW + grp) * C::SLOTS;
     const bool active = i < n;
     if (lg == 0) {
-        ws[0] = Fp::zero();
+        vm_zero(ws);
         Jac<F> t = vm_identity_h<F>();
         if (active) { const Affine<F> p = in[i]; if (!is_inf(p)) t = {p.x, p.y, F::one()}; }
         C::put(ws, C::SX, t.x); C::put(ws, C::SY, t.y); C::put(ws, C::SZ, t.z);
@@ -54,10 +54,10 @@ __global__ void __launch_bounds__(256) k_vm_pow2_b(Pow2Batch<F> pb, uint32_t n, 
     using C = VmCurve<F>;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lg = lane & (VM_G - 1), grp = lane / VM_G, v = blockIdx.y;
     const uint32_t i = (blockIdx.x * 4 + wave) * VM_EPW + grp;
-    Fp* const ws = reinterpret_cast<Fp*>(vm_smem) + (size_t)(wave * VM_EPW + grp) * C::SLOTS;
+    VmSlot* const ws = reinterpret_cast<VmSlot*>(vm_smem) + (size_t)(wave * VM_EPW + grp) * C::SLOTS;
     const bool active = i < n;
     if (lg == 0) {
-        ws[0] = Fp::zero();
+        vm_zero(ws);
         Jac<F> t = vm_identity_h<F>();
         if (active) { const Affine<F> p = pb.in[v][i]; if (!is_inf(p)) t = {p.x, p.y, F::one()}; }
         C::put(ws, C::SX, t.x); C::put(ws, C::SY, t.y); C::put(ws, C::SZ, t.z);
@@ -69,17 +69,17 @@ __global__ void __launch_bounds__(256) k_vm_pow2_b(Pow2Batch<F> pb, uint32_t n, 
 
 // parts_h[t][i] = (digit string t) * base_t(i);  base_t = image t of hi[i] for t < nimg, image t - nimg of hi2_h[i] otherwise
 template <class F>
-__device__ __forceinline__ void vm_fold_split2_body(Fp* lds, const Affine<F>* __restrict__ hi, const Jac<F>* __restrict__ hi2_h, uint32_t half, const SplitDigits& dg, int nimg,
+__device__ __forceinline__ void vm_fold_split2_body(VmSlot* lds, const Affine<F>* __restrict__ hi, const Jac<F>* __restrict__ hi2_h, uint32_t half, const SplitDigits& dg, int nimg,
                                                     Jac<F>* __restrict__ parts_h) {
     using C = VmCurve<F>;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lg = lane & (VM_G - 1), grp = lane / VM_G;
     const uint32_t i = (blockIdx.x * 4 + wave) * VM_EPW + grp;
     const int t = blockIdx.y;
-    Fp* const ws = lds + (size_t)(wave * VM_EPW + grp) * C::SLOTS;
+    VmSlot* const ws = lds + (size_t)(wave * VM_EPW + grp) * C::SLOTS;
     const bool active = i < half;
     Jac<F> base = vm_identity_h<F>();                        // lane 0 of the group keeps the base (projective) in registers
     if (lg == 0) {
-        ws[0] = Fp::zero();
+        vm_zero(ws);
         if (active) {
             if (t < nimg) { const Affine<F> p = vm_image_a(hi[i], t); if (!is_inf(p)) base = {p.x, p.y, F::one()}; }
             else base = vm_image_h(hi2_h[i], t - nimg);
@@ -103,7 +103,7 @@ template <class F>
 __global__ void __launch_bounds__(256) k_vm_fold_split2(const Affine<F>* __restrict__ hi, const Jac<F>* __restrict__ hi2_h, uint32_t half, SplitDigits dg, int nimg,
                                                          Jac<F>* __restrict__ parts_h) {
     extern __shared__ __attribute__((aligned(16))) unsigned char vm_smem[];
-    vm_fold_split2_body<F>(reinterpret_cast<Fp*>(vm_smem), hi, hi2_h, half, dg, nimg, parts_h);
+    vm_fold_split2_body<F>(reinterpret_cast<VmSlot*>(vm_smem), hi, hi2_h, half, dg, nimg, parts_h);
 }
 
 // Several vectors folded by ONE launch (grid.z = vector): a GIPA round folds up to three G1 and two G2 vectors of the same length, each a
@@ -115,15 +115,15 @@ template <class F>
 __global__ void __launch_bounds__(256) k_vm_fold_split2_b(FoldBatch<F> fb, uint32_t half, int nimg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char vm_smem[];
     const int v = blockIdx.z;
-    vm_fold_split2_body<F>(reinterpret_cast<Fp*>(vm_smem), fb.s[v].hi, fb.s[v].hi2_h, half, fb.dg[v], nimg, fb.s[v].parts_h);
+    vm_fold_split2_body<F>(reinterpret_cast<VmSlot*>(vm_smem), fb.s[v].hi, fb.s[v].hi2_h, half, fb.dg[v], nimg, fb.s[v].parts_h);
 }
 
 // T (in the group's VM workspace) = sum_{t < nparts} parts_h[t][i] + lo[i]
 template <class F>
-__device__ __forceinline__ void vm_combine_sum(Fp* ws, int lg, bool active, uint32_t i, const Jac<F>* __restrict__ parts_h, int nparts, const Affine<F>* __restrict__ lo, uint32_t half) {
+__device__ __forceinline__ void vm_combine_sum(VmSlot* ws, int lg, bool active, uint32_t i, const Jac<F>* __restrict__ parts_h, int nparts, const Affine<F>* __restrict__ lo, uint32_t half) {
     using C = VmCurve<F>;
     if (lg == 0) {
-        ws[0] = Fp::zero();
+        vm_zero(ws);
         const Jac<F> p0 = active ? parts_h[i] : vm_identity_h<F>();
         C::put(ws, C::SX, p0.x); C::put(ws, C::SY, p0.y); C::put(ws, C::SZ, p0.z);
     }
@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(256) k_vm_combine(const Jac<F>* __restrict__ p
     using C = VmCurve<F>;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lg = lane & (VM_G - 1), grp = lane / VM_G;
     const uint32_t i = (blockIdx.x * 4 + wave) * VM_EPW + grp;
-    Fp* const ws = reinterpret_cast<Fp*>(vm_smem) + (size_t)(wave * VM_EPW + grp) * C::SLOTS;
+    VmSlot* const ws = reinterpret_cast<VmSlot*>(vm_smem) + (size_t)(wave * VM_EPW + grp) * C::SLOTS;
     const bool active = i < half;
     vm_combine_sum<F>(ws, lg, active, i, parts_h, nparts, lo, half);
     if (active && lg == 0) {
@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(256) k_vm_combine_aff_b(FoldBatch<F> fb, int n
     using C = VmCurve<F>;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lg = lane & (VM_G - 1), grp = lane / VM_G, v = blockIdx.y;
     const uint32_t i = (blockIdx.x * 4 + wave) * VM_EPW + grp;
-    Fp* const ws = reinterpret_cast<Fp*>(vm_smem) + (size_t)(wave * VM_EPW + grp) * C::SLOTS;
+    VmSlot* const ws = reinterpret_cast<VmSlot*>(vm_smem) + (size_t)(wave * VM_EPW + grp) * C::SLOTS;
     const bool active = i < half;
     vm_combine_sum<F>(ws, lg, active, i, fb.s[v].parts_h, nparts, fb.s[v].lo, half);
     if (active && lg == 0) {

@@ -1,0 +1,149 @@
+// Fq28 (14 x 28-bit carry-free limbs) against the 12 x 32-bit multiplier: agreement with the host field + throughput (gfx950).
+// Build: hipcc --offload-arch=gfx950 -O3 -I../../ripp_amd/csrc -o build/fqbench fqbench.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+#include "line_products.hpp"
+#include "fq28.hpp"
+
+using namespace ripp;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 1; } } while (0)
+
+
+__global__ void k_check(const Fp* a, const Fp* b, Fp* prod, Fp* sum, Fp* dif, Fp* dot, Fp* rt, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const Fqn x = fq_from_fp(a[i]), y = fq_from_fp(b[i]);
+    prod[i] = fq_to_fp(fq_mul(x, y));
+    rt[i] = fq_to_fp(x);
+    const auto s = fq_add(x, y);                 // lazy: <29, 4>
+    sum[i] = fq_to_fp(fq_mul(s, fq_one()));
+    const auto d = fq_sub(x, y);
+    dif[i] = fq_to_fp(fq_mul(d, fq_one()));
+    // (x+y)(x-y) + x*y + y*y  == x^2 + xy  as a lazy 3-product sum with lazy operands
+    const decltype(fq_add(x, y)) A[3] = {s, fq_add(x, fq_zero()), fq_add(y, fq_zero())};
+    const auto dn = fq_norm(d);
+    const decltype(dn) B[3] = {dn, fq_widen<FQ_LN, 5>(y), fq_widen<FQ_LN, 5>(y)};
+    dot[i] = fq_to_fp(fq_dot<3>(A, B));
+#endif
+}
+
+__global__ void __launch_bounds__(256) k_fq_mul_chain(const Fp* in, Fp* out, int iters) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+#if defined(__HIP_DEVICE_COMPILE__)
+    Fqn x = fq_unpack(in[tid & 1023].l), y = fq_unpack(in[(tid + 1) & 1023].l);
+    for (int i = 0; i < iters; ++i) x = fq_mul(x, y);
+    Fp r; fq_pack(x, r.l); out[tid] = r;
+#endif
+}
+__global__ void __launch_bounds__(256, 2) k_fq_dot6_chain(const Fp* in, Fp* out, int iters) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+#if defined(__HIP_DEVICE_COMPILE__)
+    Fqn x[6], y[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { x[c] = fq_unpack(in[(tid + 7 * c) & 1023].l); y[c] = fq_unpack(in[(tid + 11 * c + 1) & 1023].l); }
+    for (int i = 0; i < iters; ++i) { const Fqn r = fq_dot<6>(x, y); x[i % 6 == 0 ? 0 : 1] = r; }
+    Fqn acc = x[0];
+#pragma unroll
+    for (int c = 1; c < 6; ++c) { const auto w = fq_norm(fq_add(acc, x[c])); for (int q = 0; q < 14; ++q) acc.l[q] = w.l[q]; acc.l[13] &= 0xfffff; }
+    Fp r; fq_pack(acc, r.l); out[tid] = r;
+#endif
+}
+// group-law shaped mix: 2 lazy adds + 1 lazy sub per product
+__global__ void __launch_bounds__(256) k_fq_mix_chain(const Fp* in, Fp* out, int iters) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+#if defined(__HIP_DEVICE_COMPILE__)
+    Fqn x = fq_unpack(in[tid & 1023].l), y = fq_unpack(in[(tid + 1) & 1023].l), z = fq_unpack(in[(tid + 2) & 1023].l);
+    for (int i = 0; i < iters; ++i) { const Fqn t = fq_mul(fq_add(x, y), fq_sub(z, x)); x = y; y = z; z = t; }
+    Fp r; fq_pack(z, r.l); out[tid] = r;
+#endif
+}
+__global__ void __launch_bounds__(256) k_fp_mix_chain(const Fp* in, Fp* out, int iters) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    Fp x = in[tid & 1023], y = in[(tid + 1) & 1023], z = in[(tid + 2) & 1023];
+    for (int i = 0; i < iters; ++i) { const Fp t = mul(add(x, y), sub(z, x)); x = y; y = z; z = t; }
+    out[tid] = z;
+}
+__global__ void __launch_bounds__(256) k_fp_mul_chain(const Fp* in, Fp* out, int iters) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    Fp x = in[tid & 1023], y = in[(tid + 1) & 1023];
+    for (int i = 0; i < iters; ++i) x = mul(x, y);
+    out[tid] = x;
+}
+__global__ void __launch_bounds__(256, 2) k_fp_dot6_chain(const Fp* in, Fp* out, int iters) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    Fp x[6], y[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { x[c] = in[(tid + 7 * c) & 1023]; y[c] = in[(tid + 11 * c + 1) & 1023]; }
+    for (int i = 0; i < iters; ++i) { const Fp r = fp_dot<6>(x, y); x[i % 6 == 0 ? 0 : 1] = r; }
+    Fp acc = x[0];
+#pragma unroll
+    for (int c = 1; c < 6; ++c) acc = add(acc, x[c]);
+    out[tid] = acc;
+}
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static uint64_t splitmix() { uint64_t z = (rng_state += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+
+int main() {
+    hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+    printf("device: %s CUs=%d\n", prop.name, prop.multiProcessorCount);
+    const int n = 1024;
+    std::vector<Fp> ha(n), hb(n);
+    for (int i = 0; i < n; ++i) {
+        for (int j = 0; j < 12; j += 2) { uint64_t v = splitmix(); ha[i].l[j] = (uint32_t)v; ha[i].l[j + 1] = (uint32_t)(v >> 32); v = splitmix(); hb[i].l[j] = (uint32_t)v; hb[i].l[j + 1] = (uint32_t)(v >> 32); }
+        ha[i].l[11] &= 0x0fffffffu; hb[i].l[11] &= 0x0fffffffu;   // < 2^380 < p
+    }
+    // edge values: 0, 1, p-1, all-ones-ish
+    ha[0] = Fp::zero(); hb[0] = Fp::one(); ha[1] = neg(Fp::one()); hb[1] = neg(Fp::one()); ha[2] = neg(Fp::one()); hb[2] = Fp::zero(); ha[3] = Fp::one(); hb[3] = neg(Fp::one());
+    Fp *da, *db, *dp, *ds, *dd, *dt, *dr, *dout;
+    CK(hipMalloc(&da, n * sizeof(Fp))); CK(hipMalloc(&db, n * sizeof(Fp))); CK(hipMalloc(&dp, n * sizeof(Fp)));
+    CK(hipMalloc(&ds, n * sizeof(Fp))); CK(hipMalloc(&dd, n * sizeof(Fp))); CK(hipMalloc(&dt, n * sizeof(Fp))); CK(hipMalloc(&dr, n * sizeof(Fp)));
+    CK(hipMemcpy(da, ha.data(), n * sizeof(Fp), hipMemcpyHostToDevice));
+    CK(hipMemcpy(db, hb.data(), n * sizeof(Fp), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_check, dim3(n / 256), dim3(256), 0, 0, da, db, dp, ds, dd, dt, dr, n);
+    CK(hipDeviceSynchronize());
+    std::vector<Fp> hp(n), hs(n), hd(n), ht(n), hr(n);
+    CK(hipMemcpy(hp.data(), dp, n * sizeof(Fp), hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hs.data(), ds, n * sizeof(Fp), hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hd.data(), dd, n * sizeof(Fp), hipMemcpyDeviceToHost));
+    CK(hipMemcpy(ht.data(), dt, n * sizeof(Fp), hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hr.data(), dr, n * sizeof(Fp), hipMemcpyDeviceToHost));
+    int bad[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < n; ++i) {
+        if (hp[i] != mul(ha[i], hb[i])) ++bad[0];
+        if (hs[i] != add(ha[i], hb[i])) ++bad[1];
+        if (hd[i] != sub(ha[i], hb[i])) ++bad[2];
+        const Fp e = add(add(mul(add(ha[i], hb[i]), sub(ha[i], hb[i])), mul(ha[i], hb[i])), mul(hb[i], hb[i]));
+        if (ht[i] != e) ++bad[3];
+        if (hr[i] != ha[i]) ++bad[4];
+    }
+    printf("fq28 vs host field: mul %d, add %d, sub %d, lazy dot3 %d, round trip %d mismatches of %d -> %s\n", bad[0], bad[1], bad[2], bad[3], bad[4], n, (bad[0] | bad[1] | bad[2] | bad[3] | bad[4]) ? "FAIL" : "ok");
+
+    const int blocks = prop.multiProcessorCount * 8, iters = 4096;
+    CK(hipMalloc(&dout, (size_t)blocks * 256 * sizeof(Fp)));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto run = [&](const char* name, auto kern, double ops_per_iter) -> int {
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, da, dout, 16);
+        CK(hipDeviceSynchronize());
+        float best = 1e30f;
+        for (int r = 0; r < 3; ++r) {
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, da, dout, iters);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+        }
+        double ops = (double)blocks * 256 * iters * ops_per_iter;
+        printf("%-44s %8.3f ms   %7.2f G products/s\n", name, best, ops / (best * 1e-3) * 1e-9);
+        return 0;
+    };
+    run("fp  (12x32) mul chain", k_fp_mul_chain, 1);
+    run("fq28 (14x28) mul chain", k_fq_mul_chain, 1);
+    run("fp  dot<6> (6 products, 1 reduction)", k_fp_dot6_chain, 6);
+    run("fq28 dot<6> (6 products, 1 reduction)", k_fq_dot6_chain, 6);
+    run("fp  mix: (x+y)(z-x) per product", k_fp_mix_chain, 1);
+    run("fq28 mix: (x+y)(z-x) per product, lazy", k_fq_mix_chain, 1);
+    return 0;
+}

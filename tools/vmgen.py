@@ -1,17 +1,25 @@
 #!/usr/bin/env python3
-"""Static scheduler for the lane-parallel field VM (ripp_amd/csrc/vm.hpp).
+"""Static scheduler for the lane-parallel field VM (ripp_amd/csrc/vm.hpp), second form.
 
-Idea: G lanes of a wave cooperate on ONE element (a (P,Q) pair, a fold term, an Fp12 accumulator).  All Fp values
-of the element live in a per-element LDS workspace ("slots" of 48 B); a program is a sequence of LAYERS, and in one
-layer every lane executes one operation of the same kind:
+Idea: G lanes of a wave cooperate on ONE element (a (P,Q) pair, a fold term, an Fp12 accumulator).  All Fp values of the element live
+in a per-element LDS workspace ("slots", 14 limbs of 28 bits each: fq28.hpp); a program is a sequence of LAYERS, and in one layer
+every lane executes one operation of the same kind:
 
-    MUL   slot[dst] = (+-slot[a0] +-slot[a1]) * (+-slot[a2] +-slot[a3])        (Montgomery product in Fp)
-    LIN   slot[dst] = (+-slot[a0] +-slot[a1] +-slot[a2] +-slot[a3]) [/ 2]
+    MUL   slot[dst] = (+-slot[a0] +-slot[a1]) * (+-slot[a2] +-slot[a3])          (Montgomery product)
+    LIN   slot[dst] = sum_t coef[t] * slot[s[t]]   (<= TMAX terms, small signed integer coefficients)
 
-Formulas are written once in a tiny DSL over lazy linear forms (so Karatsuba sums, (1+u) twists, negations and small
-multiples cost nothing until they must be materialised); this file list-schedules the resulting DAG into layers for a
-given group size G, allocates workspace slots by liveness, EVALUATES the schedule with Python integers against the
-plain formulas (so a wrong schedule never reaches the GPU), and emits the tables as a C++ header.
+The carry-free radix makes a LIN with ARBITRARY small coefficients one pass of multiply-adds into 64-bit columns, so the chains of
++-1 additions, doublings and halvings the first form needed between two product layers (7 of the 9 layers of a Miller doubling step)
+collapse into ONE layer: doubling step 9 -> 4 layers, complete G2 addition 12 -> 7.  Halvings are gone: the projective formulas are
+rescaled by powers of two instead (same point; the lines change by factors in Fp, which the final exponentiation kills).
+
+Bounds (units of p) are tracked here and asserted: a MUL result is < 2p; a LIN result is < (sum of |coef| * bound + bias) p and is
+either left as it is ("light", <= LIGHT_MAX p) or reduced below 2p ("heavy": one quotient estimate + one more pass); MUL operands
+are sums of at most two slots, a negated term is K17 - x with K17 = 17p >= any slot value.
+
+Formulas are written once in a tiny DSL over lazy linear forms; this file list-schedules the resulting DAG into layers for a given
+group size G, allocates workspace slots by liveness, EVALUATES the schedule with Python integers against the plain formulas (so a
+wrong schedule never reaches the GPU), and emits the tables as a C++ header.
 
 Run:  python tools/vmgen.py   ->  ripp_amd/csrc/vm_programs.inc
 """
@@ -24,6 +32,13 @@ MUL, LIN = 0, 1
 ZERO_SLOT = 0          # workspace slot 0 always holds 0; slot 1 is a write-only dump for idle lanes
 DUMP_SLOT = 1
 FIRST_FREE = 2
+TMAX = 16              # terms of one LIN op
+COEF_MAX = 127
+BOUND_IN = 2           # program inputs are < 2p (callers store canonical values or results of earlier programs)
+LIGHT_MAX = 16         # a LIN result up to this many p stays unreduced
+HEAVY_MAX = 1000       # what the quotient estimate of a heavy LIN covers
+NEG_K = 17             # K17 = 17p: the bias of a negated MUL operand term
+VMAX = 2500            # fq28.hpp: operand value bounds must multiply to <= VMAX for the product to come out < 2p
 
 
 # ------------------------------------------------------------------------------------------------ DSL
@@ -31,10 +46,26 @@ class Val:
     """A materialised Fp value (an input or the result of one VM op)."""
     _n = 0
 
-    def __init__(self, prog, kind, args=None, name=None, half=False, sh=0):
-        self.prog, self.kind, self.args, self.name, self.half, self.sh = prog, kind, args, name, half, sh
+    def __init__(self, prog, kind, args=None, name=None):
+        self.prog, self.kind, self.args, self.name = prog, kind, args, name
         self.id = Val._n; Val._n += 1
         self.slot = None
+        self.heavy = False
+        self.nbias = 0
+        if kind == "in": self.bound = BOUND_IN
+        elif kind == MUL:
+            ba = sum((b.bound if sg > 0 else NEG_K) for sg, b in args[0]); bb = sum((b.bound if sg > 0 else NEG_K) for sg, b in args[1])
+            for sg, v in args[0] + args[1]: assert v.bound <= LIGHT_MAX
+            assert ba * bb <= VMAX, ("MUL operand bounds", ba, bb)
+            self.bound = 2
+        else:
+            assert 1 <= len(args) <= TMAX and all(abs(c) <= COEF_MAX and c != 0 for c, _ in args), args
+            pos = sum(c * v.bound for c, v in args if c > 0); neg = sum(-c * v.bound for c, v in args if c < 0)
+            self.nbias = neg + 1 if neg else 0
+            raw = pos + self.nbias
+            assert raw <= HEAVY_MAX, ("LIN bound", raw)
+            self.heavy = raw > LIGHT_MAX
+            self.bound = 2 if self.heavy else raw
 
     def __repr__(self):
         return f"v{self.id}" + (f"({self.name})" if self.name else "")
@@ -55,48 +86,35 @@ class Lin:
     def __sub__(self, o): return self + (Lin.of(o) * -1)
     def __neg__(self): return self * -1
     def __mul__(self, c): return Lin({k: v * c for k, v in self.t.items()})
-    def nterms(self): return sum(abs(c) for c in self.t.values())
-    def simple(self):  # encodable as a MUL operand: at most two +-1 terms
-        return self.nterms() <= 2
-    def expand(self):  # list of (sign, Val) with |coeff| repeats
-        out = []
-        for k, c in sorted(self.t.items(), key=lambda kv: kv[0].id):
-            out += [(1 if c > 0 else -1, k)] * abs(c)
-        return out
+    def nterms(self): return len(self.t)
+    def is_val(self): return len(self.t) == 1 and list(self.t.values())[0] == 1
+    def simple(self):  # encodable as a MUL operand: at most two terms with coefficient +-1
+        return len(self.t) <= 2 and all(abs(c) == 1 for c in self.t.values())
+    def terms(self): return [(c, k) for k, c in sorted(self.t.items(), key=lambda kv: kv[0].id)]
+    def key(self): return tuple((k.id, c) for k, c in sorted(self.t.items(), key=lambda kv: kv[0].id))
 
 
 class Prog:
     def __init__(self, name):
-        self.name = name; self.inputs = {}; self.outputs = []; self.nodes = []
+        self.name = name; self.inputs = {}; self.outputs = []; self.nodes = []; self.cache = {}
 
     def inp(self, name):
         v = Val(self, "in", name=name); self.inputs[name] = v; return Lin.of(v)
 
-    def materialise(self, L, half=False):
-        """Return a Lin of ONE Val equal to L (or L/2), emitting LIN ops (<= 4 signed terms each) as needed."""
+    def materialise(self, L):
+        """Return a Lin of ONE Val equal to L, emitting LIN ops (<= TMAX terms each) as needed; identical forms are shared."""
         L = Lin.of(L)
-        if not half and L.nterms() == 1 and list(L.t.values())[0] == 1:
-            return L
-        # factor the gcd of the coefficients: g = odd * 2^k.  L/g is summed first (few terms), the odd factor (3) is a
-        # second 3-term op and the power of two rides along as the op's shift -- keeps LIN chains short.
-        from math import gcd
-        g = 0
-        for c in L.t.values(): g = gcd(g, abs(c))
-        k = 0
-        while g % 2 == 0 and k < 3: g //= 2; k += 1
-        odd = g if g in (1, 3) else 1
-        scale = odd << k
-        L = Lin({kk: c // scale for kk, c in L.t.items()})
-        if half and k > 0: k -= 1; half = False
-        terms = L.expand()
-        while len(terms) > 4:  # fold the first four terms into one value
-            v = Val(self, LIN, args=terms[:4]); self.nodes.append(v); terms = [(1, v)] + terms[4:]
-        if odd == 3 and len(terms) > 1:
-            v = Val(self, LIN, args=terms); self.nodes.append(v); terms = [(1, v)] * 3
-        elif odd == 3:
-            terms = terms * 3
-        v = Val(self, LIN, args=terms, half=half, sh=k); self.nodes.append(v)
-        return Lin.of(v)
+        if L.is_val(): return L
+        k = L.key()
+        if k in self.cache: return self.cache[k]
+        terms = L.terms()
+        assert terms, "materialising zero"
+        while len(terms) > TMAX:  # fold the first TMAX terms into one value
+            v = Val(self, LIN, args=terms[:TMAX]); self.nodes.append(v); terms = [(1, v)] + terms[TMAX:]
+        # coefficients beyond COEF_MAX do not occur in these formulas
+        v = Val(self, LIN, args=terms); self.nodes.append(v)
+        self.cache[k] = Lin.of(v)
+        return self.cache[k]
 
     def operand(self, L):
         L = Lin.of(L)
@@ -104,14 +122,22 @@ class Prog:
 
     def mul(self, A, B):
         A, B = self.operand(A), self.operand(B)
-        v = Val(self, MUL, args=(A.expand(), B.expand())); self.nodes.append(v); return Lin.of(v)
-
-    def half(self, L): return self.materialise(L, half=True)
+        ta = [(c, k) for c, k in A.terms()] or [(1, None)]; tb = [(c, k) for c, k in B.terms()] or [(1, None)]
+        if ta == [(1, None)] or tb == [(1, None)]: return Lin()
+        v = Val(self, MUL, args=(ta, tb)); self.nodes.append(v); return Lin.of(v)
 
     def out(self, name, L, into=None):
         """Declare an output; `into` = name of the input whose slot it must end up in (loop-carried state)."""
-        L = self.materialise(L) if not (Lin.of(L).nterms() == 1 and list(Lin.of(L).t.values())[0] == 1 and list(Lin.of(L).t.keys())[0].kind != "in") else Lin.of(L)
-        self.outputs.append((name, list(L.t.keys())[0], into))
+        L = Lin.of(L)
+        if not (L.is_val() and list(L.t.keys())[0].kind != "in"): L = self.materialise_out(L)
+        v = list(L.t.keys())[0]
+        if v.kind == LIN and v.bound > BOUND_IN: v.heavy = True; v.bound = 2        # kernels read outputs back as canonical values: keep them < 2p
+        self.outputs.append((name, v, into))
+
+    def materialise_out(self, L):
+        if L.is_val():   # an input passed through: copy it with a 1-term LIN
+            v = Val(self, LIN, args=L.terms()); self.nodes.append(v); return Lin.of(v)
+        return self.materialise(L)
 
 
 class F2:
@@ -123,15 +149,21 @@ class F2:
     def __neg__(self): return F2(self.p, -self.c0, -self.c1)
     def scale(self, c): return F2(self.p, self.c0 * c, self.c1 * c)
     def mul_xi(self): return F2(self.p, self.c0 - self.c1, self.c0 + self.c1)           # * (1 + u)
+    def opnd(self):
+        """Components usable inside Karatsuba sums: each a single value or a +-1 pair that stays simple when the two are added."""
+        a = self
+        if not (a.c0.simple() and a.c1.simple() and (a.c0 + a.c1).simple() and (a.c0 - a.c1).simple()): a = a.mat()
+        return a
     def mul(self, o):                                                                    # Karatsuba, 3 products
-        t0, t1 = self.p.mul(self.c0, o.c0), self.p.mul(self.c1, o.c1)
-        m = self.p.mul(self.c0 + self.c1, o.c0 + o.c1)
+        a, b = self.opnd(), o.opnd()
+        t0, t1 = self.p.mul(a.c0, b.c0), self.p.mul(a.c1, b.c1)
+        m = self.p.mul(a.c0 + a.c1, b.c0 + b.c1)
         return F2(self.p, t0 - t1, m - t0 - t1)
     def sqr(self):                                                                       # (a0+a1)(a0-a1), 2 a0 a1
-        m = self.p.mul(self.c0, self.c1)
-        return F2(self.p, self.p.mul(self.c0 + self.c1, self.c0 - self.c1), m * 2)
+        a = self.opnd()
+        m = self.p.mul(a.c0, a.c1)
+        return F2(self.p, self.p.mul(a.c0 + a.c1, a.c0 - a.c1), m * 2)
     def mul_fp(self, s): return F2(self.p, self.p.mul(self.c0, s), self.p.mul(self.c1, s))
-    def half(self): return F2(self.p, self.p.half(self.c0), self.p.half(self.c1))
     def mat(self): return F2(self.p, self.p.materialise(self.c0), self.p.materialise(self.c1))
 
 
@@ -146,18 +178,18 @@ class F1:
     def mul_xi(self): return self                               # G1: b = 4, no twist factor
     def mul(self, o): return F1(self.p, self.p.mul(self.c0, o.c0))
     def sqr(self): return F1(self.p, self.p.mul(self.c0, self.c0))
-    def half(self): return F1(self.p, self.p.half(self.c0))
     def mat(self): return F1(self.p, self.p.materialise(self.c0))
 
 
 # ------------------------------------------------------------------------------------------------ scheduling
+def srcs_of(v):
+    return [t[1] for t in v.args] if v.kind == LIN else [t[1] for t in v.args[0] + v.args[1]]
+
+
 def schedule(prog, G):
     """List-schedule prog.nodes into homogeneous layers of <= G ops.  Returns list of (kind, [Val])."""
     nodes = prog.nodes
-    deps = {}
-    for v in nodes:
-        srcs = [t[1] for t in v.args] if v.kind == LIN else [t[1] for t in v.args[0] + v.args[1]]
-        deps[v] = {s for s in srcs if s.kind != "in"}
+    deps = {v: {s for s in srcs_of(v) if s.kind != "in"} for v in nodes}
     # critical-path priority (longest path to a sink, MUL weighted 4, LIN 1)
     users = {v: [] for v in nodes}
     for v in nodes:
@@ -167,11 +199,11 @@ def schedule(prog, G):
         prio[v] = (4 if v.kind == MUL else 1) + max([prio[u] for u in users[v]], default=0)
     done, layers, remaining = set(), [], list(nodes)
     while remaining:
-        # (1) every LIN chain that is ready, level by level, each level packed into ceil(n/G) layers
+        # (1) every LIN that is ready, level by level, each level packed into ceil(n/G) layers (heavy ones first: a layer is heavy if any op is)
         while True:
             rl = [v for v in remaining if v.kind == LIN and deps[v] <= done]
             if not rl: break
-            rl.sort(key=lambda v: -prio[v])
+            rl.sort(key=lambda v: (not v.heavy, -prio[v]))
             for i in range(0, len(rl), G): layers.append((LIN, rl[i:i + G]))
             done |= set(rl); remaining = [v for v in remaining if v not in done]
         # (2) every product that is ready now
@@ -192,14 +224,13 @@ def allocate(prog, layers, nslots_hint=None):
     last_use = {}
     for li, (_, ops) in enumerate(layers):
         for v in ops:
-            srcs = [t[1] for t in v.args] if v.kind == LIN else [t[1] for t in v.args[0] + v.args[1]]
-            for s in srcs: last_use[s] = li
+            for s in srcs_of(v): last_use[s] = li
     outvals = {v for _, v, _ in prog.outputs}
     pinned_into = {v: prog.inputs[into] for _, v, into in prog.outputs if into}
     free = []
     live_inputs = set(prog.inputs.values())
     for li, (_, ops) in enumerate(layers):
-        # values (incl. inputs not loop-carried... inputs are never freed: they are the caller's) whose last use was an earlier layer
+        # values whose last use was an earlier layer (inputs are never freed: they are the caller's)
         for v, s in list(slot.items()):
             if v in live_inputs or v in outvals: continue
             if last_use.get(v, -1) < li and s is not None and s not in free and s >= FIRST_FREE and v.slot_released is False:
@@ -226,27 +257,27 @@ def compile_prog(prog, G):
     for v in prog.inputs.values(): v.slot_released = False
     layers = schedule(prog, G)
     slot, nslots, fixups = allocate(prog, layers)
-    if fixups:   # append LIN copy layer(s)
-        copies = []
-        for src, dst in fixups:
-            c = Val(prog, LIN, args=[(1, None)]); c.copy = (src, dst); copies.append(c)
-        for i in range(0, len(copies), G): layers.append((LIN, copies[i:i + G]))
+    assert nslots <= 255
     table = []
     for kind, ops in layers:
         row = []
         for v in ops:
-            if hasattr(v, "copy"):
-                row.append(dict(dst=v.copy[1], a=[v.copy[0], ZERO_SLOT, ZERO_SLOT, ZERO_SLOT], neg=0, half=0, sh=0)); continue
             if kind == MUL:
                 A, B = v.args
                 terms = (A + [(1, None)] * (2 - len(A))) + (B + [(1, None)] * (2 - len(B)))
+                a = [ZERO_SLOT if t[1] is None else slot[t[1]] for t in terms]
+                neg = sum((1 << i) for i, t in enumerate(terms) if t[0] < 0)
+                row.append(dict(dst=slot[v], a=a, neg=neg))
             else:
-                terms = v.args + [(1, None)] * (4 - len(v.args))
-            a = [ZERO_SLOT if t[1] is None else slot[t[1]] for t in terms]
-            neg = sum((1 << i) for i, t in enumerate(terms) if t[0] < 0)
-            row.append(dict(dst=slot[v], a=a, neg=neg, half=1 if v.half else 0, sh=getattr(v, "sh", 0) if kind == LIN else 0))
-        while len(row) < G: row.append(dict(dst=DUMP_SLOT, a=[ZERO_SLOT] * 4, neg=0, half=0, sh=0))
+                row.append(dict(dst=slot[v], terms=[(c, slot[x]) for c, x in v.args], nbias=v.nbias, heavy=v.heavy))
+        while len(row) < G:
+            row.append(dict(dst=DUMP_SLOT, a=[ZERO_SLOT] * 4, neg=0) if kind == MUL else dict(dst=DUMP_SLOT, terms=[], nbias=0, heavy=False))
         table.append((kind, row))
+    if fixups:   # outputs that could not be written in place: copy layer(s) at the end
+        for i in range(0, len(fixups), G):
+            row = [dict(dst=dst, terms=[(1, src)], nbias=0, heavy=False) for src, dst in fixups[i:i + G]]
+            while len(row) < G: row.append(dict(dst=DUMP_SLOT, terms=[], nbias=0, heavy=False))
+            table.append((LIN, row))
     outs = {name: (slot[prog.inputs[into]] if into else slot[v]) for name, v, into in prog.outputs}
     ins = {name: slot[v] for name, v in prog.inputs.items()}
     return dict(name=prog.name, G=G, layers=table, nslots=nslots, ins=ins, outs=outs,
@@ -255,19 +286,22 @@ def compile_prog(prog, G):
 
 
 def run_compiled(c, inputs):
-    """Evaluate the slot program with integers mod p."""
+    """Evaluate the slot program with integers mod p, tracking the UNREDUCED magnitudes the device sees (in units of p)."""
     ws = [0] * max(c["nslots"], 2)
     for name, s in c["ins"].items(): ws[s] = inputs[name] % P
-    inv2 = pow(2, -1, P)
     for kind, row in c["layers"]:
-        rd = [[ws[s] for s in op["a"]] for op in row]        # all reads before all writes
-        for op, r in zip(row, rd):
-            sg = [(-1 if (op["neg"] >> i) & 1 else 1) for i in range(4)]
-            if kind == MUL: val = ((sg[0] * r[0] + sg[1] * r[1]) * (sg[2] * r[2] + sg[3] * r[3])) % P
-            else:
-                val = ((sg[0] * r[0] + sg[1] * r[1] + sg[2] * r[2] + sg[3] * r[3]) << op["sh"]) % P
-                if op["half"]: val = val * inv2 % P
-            if op["dst"] != DUMP_SLOT: ws[op["dst"]] = val
+        if kind == MUL:
+            rd = [[ws[s] for s in op["a"]] for op in row]        # all reads before all writes
+            for op, r in zip(row, rd):
+                sg = [(-1 if (op["neg"] >> i) & 1 else 1) for i in range(4)]
+                val = ((sg[0] * r[0] + sg[1] * r[1]) * (sg[2] * r[2] + sg[3] * r[3])) % P
+                if op["dst"] != DUMP_SLOT: ws[op["dst"]] = val
+        else:
+            rd = [[ws[s] for _, s in op["terms"]] for op in row]
+            for op, r in zip(row, rd):
+                val = sum(cf * x for (cf, _), x in zip(op["terms"], r)) + op["nbias"] * P
+                assert val >= 0, "bias does not cover the negative terms"
+                if op["dst"] != DUMP_SLOT: ws[op["dst"]] = val % P
         ws[ZERO_SLOT] = 0
     return {name: ws[s] for name, s in c["outs"].items()}
 
@@ -279,24 +313,22 @@ def f2out(p, name, v, into=None):
 
 
 def prog_line_double():
-    """T <- 2T in homogeneous projective coordinates + tangent line scaled for P (bls12_381/pairing.hpp line_double)."""
+    """T <- 2T in homogeneous projective coordinates + tangent line scaled for P: the step of bls12_381/pairing.hpp line_double with the
+    new point scaled by 4 (no halvings: X3 = 2 XY (b - f), Y3 = (b + f)^2 - 12 e^2, Z3 = 4 b h, h = 2 Y Z) -- 2 product layers."""
     p = Prog("line_double")
     X, Y, Z = f2in(p, "X"), f2in(p, "Y"), f2in(p, "Z")
     xP, yP = p.inp("xP"), p.inp("yP")
-    a = X.mul(Y).half()
-    b, c = Y.sqr().mat(), Z.sqr().mat()
-    e = c.mul_xi().scale(12).mat()                     # 4(1+u) * 3c
-    f = e.scale(3).mat()
-    g = (b + f).half()
-    h = ((Y + Z).sqr() - (b + c)).mat()
+    b, c = Y.sqr(), Z.sqr()
+    e = c.mul_xi().scale(12)                           # 4(1+u) * 3c
+    f = e.scale(3)
+    h = Y.mul(Z).scale(2)                              # (Y + Z)^2 - (b + c)
     i = e - b
     j = X.sqr()
-    e2 = e.sqr()
-    X3 = a.mul((b - f).mat())
-    Y3 = g.sqr() - e2.scale(3)
-    Z3 = b.mul(h)
+    X3 = X.mul(Y).scale(2).mul(b - f)
+    Y3 = (b + f).sqr() - e.sqr().scale(12)
+    Z3 = b.mul(h).scale(4)
     f2out(p, "X", X3, into="X"); f2out(p, "Y", Y3, into="Y"); f2out(p, "Z", Z3, into="Z")
-    f2out(p, "L0", i); f2out(p, "L1", j.scale(3).mat().mul_fp(xP)); f2out(p, "L2", (-h).mul_fp(yP))
+    f2out(p, "L0", i); f2out(p, "L1", j.mul_fp(xP).scale(3)); f2out(p, "L2", (-h.mat()).mul_fp(yP))
     return p
 
 
@@ -307,15 +339,15 @@ def prog_line_add():
     xP, yP = p.inp("xP"), p.inp("yP")
     qx, qy = f2in(p, "qx"), f2in(p, "qy")
     theta = (Y - qy.mul(Z)).mat(); lam = (X - qx.mul(Z)).mat()
-    c, d = theta.sqr(), lam.sqr().mat()
-    e, f, g = lam.mul(d).mat(), Z.mul(c.mat()), X.mul(d).mat()
-    h = (e + f - g.scale(2)).mat()
+    c, d = theta.sqr(), lam.sqr()
+    e, f, g = lam.mul(d), Z.mul(c), X.mul(d)
+    h = e + f - g.scale(2)
     X3 = lam.mul(h)
-    Y3 = theta.mul((g - h).mat()) - e.mul(Y)
+    Y3 = theta.mul(g - h) - e.mul(Y)
     Z3 = Z.mul(e)
     j = theta.mul(qx) - lam.mul(qy)
     f2out(p, "X", X3, into="X"); f2out(p, "Y", Y3, into="Y"); f2out(p, "Z", Z3, into="Z")
-    f2out(p, "L0", j); f2out(p, "L1", (-theta).mat().mul_fp(xP)); f2out(p, "L2", lam.mul_fp(yP))
+    f2out(p, "L0", j); f2out(p, "L1", (-theta).mul_fp(xP)); f2out(p, "L2", lam.mul_fp(yP))
     return p
 
 
@@ -326,49 +358,33 @@ def fout(p, name, v, into=None):
 
 
 def prog_hom_double(deg):
-    """T <- 2T on y^2 = x^3 + b (b = 4 on G1, 4(1+u) on G2), homogeneous projective (x = X/Z, y = Y/Z): the
-    doubling of bls12_381/pairing.hpp line_double without the line -- product depth 2."""
+    """T <- 2T on y^2 = x^3 + b (b = 4 on G1, 4(1+u) on G2), homogeneous projective (x = X/Z, y = Y/Z): the doubling of line_double
+    without the line -- product depth 2."""
     p = Prog("g%d_hdbl" % deg)
     X, Y, Z = fin(p, "X", deg), fin(p, "Y", deg), fin(p, "Z", deg)
     fin(p, "qx", deg); fin(p, "qy", deg)                       # resident affine addend: slots reserved, not used here
-    a = X.mul(Y).half()
-    b, c = Y.sqr().mat(), Z.sqr().mat()
-    e = c.mul_xi().scale(12).mat()
-    f = e.scale(3).mat()
-    g = (b + f).half()
-    h = ((Y + Z).sqr() - (b + c)).mat()
-    e2 = e.sqr()
-    fout(p, "X", a.mul((b - f).mat()), into="X"); fout(p, "Y", g.sqr() - e2.scale(3), into="Y"); fout(p, "Z", b.mul(h), into="Z")
-    return p
-
-
-def prog_hom_add(deg):
-    """T <- T + Q, Q affine; lambda (= 0 iff T = +-Q, the exceptional case) is exported so the kernel can flag it."""
-    p = Prog("g%d_hadd" % deg)
-    X, Y, Z = fin(p, "X", deg), fin(p, "Y", deg), fin(p, "Z", deg)
-    qx, qy = fin(p, "qx", deg), fin(p, "qy", deg)
-    theta = (Y - qy.mul(Z)).mat(); lam = (X - qx.mul(Z)).mat()
-    c, d = theta.sqr(), lam.sqr().mat()
-    e, f, g = lam.mul(d).mat(), Z.mul(c.mat()), X.mul(d).mat()
-    h = (e + f - g.scale(2)).mat()
-    fout(p, "X", lam.mul(h), into="X"); fout(p, "Y", theta.mul((g - h).mat()) - e.mul(Y), into="Y"); fout(p, "Z", Z.mul(e), into="Z")
-    fout(p, "lam", lam)
+    b, c = Y.sqr(), Z.sqr()
+    e = c.mul_xi().scale(12)
+    f = e.scale(3)
+    h = Y.mul(Z).scale(2)
+    fout(p, "X", X.mul(Y).scale(2).mul(b - f), into="X"); fout(p, "Y", (b + f).sqr() - e.sqr().scale(12), into="Y"); fout(p, "Z", b.mul(h).scale(4), into="Z")
     return p
 
 
 def prog_hom_cadd(deg):
     """T <- T + Q with BOTH operands homogeneous projective: the complete addition law of Renes-Costello-Batina (2016, Alg. 7,
     a = 0).  No exceptional case: T = +-Q and the point at infinity (0:1:0) on either side are all handled by the same
-    straight-line code -- 12 products, depth 2.  b3 = 3b = 12 on G1, 12(1+u) on G2."""
+    straight-line code.  The cross terms are taken as two products each (no operand sums, hence no linear layer before the first
+    products): 15 products, depth 2.  b3 = 3b = 12 on G1, 12(1+u) on G2."""
     p = Prog("g%d_cadd" % deg)
     X1, Y1, Z1 = fin(p, "X", deg), fin(p, "Y", deg), fin(p, "Z", deg)
     X2, Y2, Z2 = fin(p, "qx", deg), fin(p, "qy", deg), fin(p, "qz", deg)
-    t0, t1, t2 = X1.mul(X2).mat(), Y1.mul(Y2).mat(), Z1.mul(Z2).mat()
-    t3 = ((X1 + Y1).mul(X2 + Y2) - (t0 + t1)).mat()            # X1 Y2 + X2 Y1
-    t4 = ((Y1 + Z1).mul(Y2 + Z2) - (t1 + t2)).mat()            # Y1 Z2 + Y2 Z1
-    t5 = ((X1 + Z1).mul(X2 + Z2) - (t0 + t2)).mat()            # X1 Z2 + X2 Z1
-    b3t2, b3t5 = t2.mul_xi().scale(12).mat(), t5.mul_xi().scale(12).mat()
-    m, pl, t03 = (t1 - b3t2).mat(), (t1 + b3t2).mat(), t0.scale(3).mat()
+    t0, t1, t2 = X1.mul(X2), Y1.mul(Y2), Z1.mul(Z2)
+    t3 = X1.mul(Y2) + X2.mul(Y1)
+    t4 = Y1.mul(Z2) + Y2.mul(Z1)
+    t5 = X1.mul(Z2) + X2.mul(Z1)
+    b3t2, b3t5 = t2.mul_xi().scale(12), t5.mul_xi().scale(12)
+    m, pl, t03 = t1 - b3t2, t1 + b3t2, t0.scale(3)
     fout(p, "X", t3.mul(m) - t4.mul(b3t5), into="X"); fout(p, "Y", m.mul(pl) + b3t5.mul(t03), into="Y"); fout(p, "Z", pl.mul(t4) + t03.mul(t3), into="Z")
     return p
 
@@ -378,13 +394,6 @@ class F6:
     def __add__(s, o): return F6(s.c0 + o.c0, s.c1 + o.c1, s.c2 + o.c2)
     def __sub__(s, o): return F6(s.c0 - o.c0, s.c1 - o.c1, s.c2 - o.c2)
     def mul_v(s): return F6(s.c2.mul_xi(), s.c0, s.c1)
-    def mul_by_01(s, b0, b1):
-        v0, v1 = s.c0.mul(b0), s.c1.mul(b1)
-        t0 = ((s.c1 + s.c2).mul(b1) - v1).mul_xi() + v0
-        t1 = (s.c0 + s.c1).mul(b0 + b1) - v0 - v1
-        t2 = (s.c0 + s.c2).mul(b0) - v0 + v1
-        return F6(t0, t1, t2)
-    def mul_by_1(s, b1): return F6(s.c2.mul(b1).mul_xi(), s.c0.mul(b1), s.c1.mul(b1))
     def mul(s, o):
         v0, v1, v2 = s.c0.mul(o.c0), s.c1.mul(o.c1), s.c2.mul(o.c2)
         t0 = ((s.c1 + s.c2).mul(o.c1 + o.c2) - v1 - v2).mul_xi() + v0
@@ -397,19 +406,6 @@ F12_NAMES = ["c00", "c01", "c02", "c10", "c11", "c12"]
 
 
 def f12in(p, pre): return [f2in(p, pre + n) for n in F12_NAMES]
-
-
-def prog_acc_014():
-    """f <- f * (l0 + l1 v + l4 v w)   (tower.hpp mul_by_014), f loop-carried in place."""
-    p = Prog("acc_014")
-    f = f12in(p, "f"); l0, l1, l4 = f2in(p, "l0"), f2in(p, "l1"), f2in(p, "l4")
-    c0, c1 = F6(*f[:3]), F6(*f[3:])
-    aa = c0.mul_by_01(l0, l1)
-    bb = c1.mul_by_1(l4)
-    s = (c1 + c0).mul_by_01(l0, l1 + l4) - aa - bb
-    r0 = bb.mul_v() + aa
-    for n, v in zip(F12_NAMES, [r0.c0, r0.c1, r0.c2, s.c0, s.c1, s.c2]): f2out(p, "f" + n, v, into="f" + n)
-    return p
 
 
 def prog_fp12_mul():
@@ -433,10 +429,11 @@ def f2xi(a): return ((a[0] - a[1]) % P, (a[0] + a[1]) % P)
 
 
 def ref_line_double(X, Y, Z, xP, yP):
+    """pairing.hpp line_double, the new point scaled by 4 (same point; the VM avoids the two halvings that way)"""
     i2 = pow(2, -1, P)
     a = f2k(f2m(X, Y), i2); b = f2m(Y, Y); c = f2m(Z, Z); e = f2xi(f2k(c, 12)); f = f2k(e, 3); g = f2k(f2a(b, f), i2)
     h = f2s(f2m(f2a(Y, Z), f2a(Y, Z)), f2a(b, c)); i = f2s(e, b); j = f2m(X, X); e2 = f2m(e, e)
-    return dict(X=f2m(a, f2s(b, f)), Y=f2s(f2m(g, g), f2k(e2, 3)), Z=f2m(b, h), L0=i, L1=f2k(f2k(j, 3), xP), L2=f2k(f2k(h, -1), yP))
+    return dict(X=f2k(f2m(a, f2s(b, f)), 4), Y=f2k(f2s(f2m(g, g), f2k(e2, 3)), 4), Z=f2k(f2m(b, h), 4), L0=i, L1=f2k(f2k(j, 3), xP), L2=f2k(f2k(h, -1), yP))
 
 
 def ref_line_add(X, Y, Z, qx, qy, xP, yP):
@@ -460,7 +457,7 @@ def validate():
     rnd = random.Random(7)
     rf = lambda: rnd.randrange(P); rf2 = lambda: (rf(), rf())
     progs = {}
-    for G in (16, 8):
+    for G in (16,):
         # line double
         c = compile_prog(prog_line_double(), G); progs[("line_double", G)] = c
         X, Y, Z, xP, yP = rf2(), rf2(), rf2(), rf(), rf()
@@ -473,15 +470,10 @@ def validate():
         out = run_compiled(c, dict(X0=X[0], X1=X[1], Y0=Y[0], Y1=Y[1], Z0=Z[0], Z1=Z[1], qx0=qx[0], qx1=qx[1], qy0=qy[0], qy1=qy[1], xP=xP, yP=yP))
         ref = ref_line_add(X, Y, Z, qx, qy, xP, yP)
         for k, v in ref.items(): assert (out[k + "0"], out[k + "1"]) == v, ("line_add", G, k)
-        # sparse accumulate and dense product
-        f = [rf2() for _ in range(6)]; g = [rf2() for _ in range(6)]; l0, l1, l4 = rf2(), rf2(), rf2()
+        # dense product
+        f = [rf2() for _ in range(6)]; g = [rf2() for _ in range(6)]
         inp = {}
         for n, v in zip(F12_NAMES, f): inp["f" + n + "0"], inp["f" + n + "1"] = v
-        c = compile_prog(prog_acc_014(), G); progs[("acc_014", G)] = c
-        out = run_compiled(c, dict(inp, l00=l0[0], l01=l0[1], l10=l1[0], l11=l1[1], l40=l4[0], l41=l4[1]))
-        sparse = [l0, l1, (0, 0), (0, 0), l4, (0, 0)]
-        ref = f12m(f, sparse)
-        for n, v in zip(F12_NAMES, ref): assert (out["f" + n + "0"], out["f" + n + "1"]) == v, ("acc_014", G, n)
         c = compile_prog(prog_fp12_mul(), G); progs[("fp12_mul", G)] = c
         for n, v in zip(F12_NAMES, g): inp["g" + n + "0"], inp["g" + n + "1"] = v
         out = run_compiled(c, inp)
@@ -530,9 +522,6 @@ def validate():
             c = compile_prog(prog_hom_double(deg), G); progs[("g%d_hdbl" % deg, G)] = c
             out = run_compiled(c, pack(["X", "Y", "Z", "qx", "qy"], Th + Q))
             zi = fi(unpack(out, "Z")); assert (fm(unpack(out, "X"), zi), fm(unpack(out, "Y"), zi)) == aff_add(T, T), ("hdbl", deg, G)
-            c = compile_prog(prog_hom_add(deg), G); progs[("g%d_hadd" % deg, G)] = c
-            out = run_compiled(c, pack(["X", "Y", "Z", "qx", "qy"], Th + Q))
-            zi = fi(unpack(out, "Z")); assert (fm(unpack(out, "X"), zi), fm(unpack(out, "Y"), zi)) == aff_add(T, Q), ("hadd", deg, G)
             # complete addition: generic, doubling, inverse, and infinity on either side
             c = compile_prog(prog_hom_cadd(deg), G); progs[("g%d_cadd" % deg, G)] = c
             z2 = rf() if deg == 1 else rf2()
@@ -561,16 +550,27 @@ def validate():
 def emit(progs, path):
     w = []
     w.append("// GENERATED by tools/vmgen.py -- do not edit.  Layer tables of the lane-parallel field VM (vm.hpp).")
-    w.append("// op = {dst, a0, a1, a2, a3, flags}: flags bits 0-3 = negate term i, bit 4 = halve, bits 5-6 = left shift (LIN only).")
+    w.append("// kind[l]: 0 = MUL layer; otherwise LIN layer: bits 0-4 = terms walked by the layer (max over its ops), bit 6 = heavy (results reduced below 2p).")
+    w.append("// op = {dst, flags, nbias, s[16], c[16]}: MUL uses s[0..3] (second term of an operand absent <=> slot 0) and flags bits 0-3 = negate term i;")
+    w.append("// LIN: dst = sum_t c[t] * slot[s[t]] + nbias * p  (unused terms: slot 0, coefficient 0).")
     w.append("#pragma once\nnamespace ripp { namespace vmprog {")
     for (name, G), c in sorted(progs.items()):
         tag = f"{name}_g{G}"
-        w.append(f"// {tag}: {c['mul_ops']} Fp products in {c['nmul']} MUL layers + {c['nlin']} LIN layers, {c['nslots']} slots; lane utilisation {c['mul_ops'] / max(1, c['nmul'] * G):.0%}")
+        w.append(f"// {tag}: {c['mul_ops']} Fp products in {c['nmul']} MUL layers + {c['lin_ops']} linear ops in {c['nlin']} LIN layers, {c['nslots']} slots; lane utilisation {c['mul_ops'] / max(1, c['nmul'] * G):.0%}")
         w.append(f"constexpr int {tag}_nlayers = {len(c['layers'])}, {tag}_nslots = {c['nslots']};")
-        w.append(f"__device__ const unsigned char {tag}_kind[{len(c['layers'])}] = {{" + ", ".join(str(k) for k, _ in c["layers"]) + "};")
+        kinds = []
         rows = []
-        for _, row in c["layers"]:
-            for op in row: rows.append("{%d,%d,%d,%d,%d,%d}" % (op["dst"], op["a"][0], op["a"][1], op["a"][2], op["a"][3], op["neg"] | (op["half"] << 4) | (op["sh"] << 5)))
+        for kind, row in c["layers"]:
+            if kind == MUL:
+                kinds.append(0)
+                for op in row: rows.append("{%d,%d,0,{%d,%d,%d,%d},{0}}" % (op["dst"], op["neg"], op["a"][0], op["a"][1], op["a"][2], op["a"][3]))
+            else:
+                tmax = max([len(op["terms"]) for op in row] + [1]); heavy = any(op["heavy"] for op in row)
+                kinds.append(0x80 | (0x40 if heavy else 0) | tmax)
+                for op in row:
+                    sl = [t[1] for t in op["terms"]]; cf = [t[0] for t in op["terms"]]
+                    rows.append("{%d,0,%d,{%s},{%s}}" % (op["dst"], op["nbias"], ",".join(map(str, sl)) or "0", ",".join(map(str, cf)) or "0"))
+        w.append(f"__device__ const unsigned char {tag}_kind[{len(kinds)}] = {{" + ", ".join(str(k) for k in kinds) + "};")
         w.append(f"__device__ const VmOp {tag}_ops[{len(rows)}] = {{" + ",".join(rows) + "};")
         w.append(f"__device__ const unsigned char {tag}_in[{len(c['ins'])}] = {{" + ", ".join(str(x) for x in c["ins"].values()) + "};   // declaration order")
         w.append(f"__device__ const unsigned char {tag}_out[{len(c['outs'])}] = {{" + ", ".join(str(x) for x in c["outs"].values()) + "};")
