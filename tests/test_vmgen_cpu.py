@@ -1,7 +1,7 @@
 """CPU: the lane-parallel VM's layer tables (ripp_amd/csrc/vm_programs.inc) are re-derived and re-validated:
 every program is list-scheduled, slot-allocated and EVALUATED with Python integers against the plain formulas
-(line double/add, sparse and dense Fp12 products, homogeneous group law on G1 and G2), and the committed header must be
-exactly what the generator emits."""
+(line double/add, dense Fp12 product, homogeneous doubling and complete addition on G1 and G2), the bounds the device arithmetic
+relies on are re-checked, and the committed header must be exactly what the generator emits."""
 import os
 import sys
 
@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 def test_vm_schedules_validate_and_header_is_current(tmp_path):
     import vmgen
     progs = vmgen.validate()                       # asserts inside compare each schedule with the reference formulas
-    assert {name for name, _ in progs} >= {"line_double", "line_add", "acc_014", "fp12_mul", "g1_hdbl", "g1_hadd", "g2_hdbl", "g2_hadd"}
+    assert {name for name, _ in progs} >= {"line_double", "line_add", "fp12_mul", "g1_hdbl", "g1_cadd", "g2_hdbl", "g2_cadd"}
     out = tmp_path / "vm_programs.inc"
     vmgen.emit(progs, str(out))
     committed = open(os.path.join(ROOT, "ripp_amd", "csrc", "vm_programs.inc")).read()
@@ -20,15 +20,32 @@ def test_vm_schedules_validate_and_header_is_current(tmp_path):
 
 
 def test_vm_layers_are_homogeneous_and_in_bounds():
+    """What vm.hpp::vm_run assumes about the tables: slot indices are bytes, a LIN op has at most 16 terms with |coefficient| <= 127 and a
+    bias that fits 16 bits and covers its negative terms (values < 2p for program inputs and products, < 16p for unreduced LIN results),
+    and a light LIN result stays below 16 p."""
     import vmgen
     for (name, G), c in vmgen.validate().items():
-        assert c["nslots"] <= 255                                  # slot indices are bytes
+        assert c["nslots"] <= 255
+        bound = {s: vmgen.BOUND_IN for s in c["ins"].values()}; bound[vmgen.ZERO_SLOT] = 0; bound[vmgen.DUMP_SLOT] = 0
         for kind, row in c["layers"]:
             assert kind in (vmgen.MUL, vmgen.LIN) and len(row) == G
+            new = {}
+            heavy_layer = kind == vmgen.LIN and any(op["heavy"] for op in row)
             for op in row:
-                assert 0 <= op["dst"] < c["nslots"] and all(0 <= a < c["nslots"] for a in op["a"])
+                assert 0 <= op["dst"] < c["nslots"]
                 if kind == vmgen.MUL:
-                    assert op["half"] == 0 and op["sh"] == 0
+                    assert all(0 <= a < c["nslots"] for a in op["a"]) and 0 <= op["neg"] < 16
+                    ob = [sum((vmgen.NEG_K if (op["neg"] >> (2 * h + t)) & 1 else bound[op["a"][2 * h + t]]) for t in range(2) if op["a"][2 * h + t] != vmgen.ZERO_SLOT or t == 0) for h in range(2)]
+                    assert all(bound[a] <= vmgen.LIGHT_MAX for a in op["a"]) and ob[0] * ob[1] <= vmgen.VMAX
+                    new[op["dst"]] = 2
+                else:
+                    assert len(op["terms"]) <= vmgen.TMAX and all(abs(cf) <= vmgen.COEF_MAX and 0 <= sl < c["nslots"] for cf, sl in op["terms"]) and 0 <= op["nbias"] < 65536
+                    neg = sum(-cf * bound[sl] for cf, sl in op["terms"] if cf < 0); pos = sum(cf * bound[sl] for cf, sl in op["terms"] if cf > 0)
+                    assert op["nbias"] >= neg and pos + op["nbias"] <= vmgen.HEAVY_MAX
+                    assert heavy_layer or pos + op["nbias"] <= vmgen.LIGHT_MAX
+                    new[op["dst"]] = 2 if heavy_layer else pos + op["nbias"]
+            bound.update(new)
+        for s in c["outs"].values(): assert bound[s] <= vmgen.BOUND_IN          # kernels read outputs back as canonical values
 
 
 def test_kaliski_fix_table():
