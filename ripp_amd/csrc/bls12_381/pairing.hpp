@@ -99,6 +99,20 @@ RIPP_FN Fp12 miller_combine(const Fp12* L) {
     return BLS_X_NEG ? conj(f) : f;
 }
 
+// The same recurrence over the bit range [hi, lo] only, started from 1 and NOT conjugated: with the bits cut into ranges R_1 > R_2 > ... the
+// whole value is  conj?( prod_j g_j^(2^(bits below R_j)) ),  so the ranges -- and their final exponentiations, a homomorphism -- can run on
+// different host threads and be joined with cheap cyclotomic squarings (engine.hip: pairing_values).
+RIPP_FN Fp12 miller_combine_range(const Fp12* L, int hi, int lo) {
+    int s = 0;
+    for (int b = 62; b > hi; --b) s += 1 + (int)((BLS_X_ABS >> b) & 1);      // rows consumed by the bits above the range
+    Fp12 f = Fp12::one(); bool first = true;
+    for (int b = hi; b >= lo; --b) {
+        if (first) { f = L[s++]; first = false; } else f = mul(sqr(f), L[s++]);
+        if ((BLS_X_ABS >> b) & 1) f = mul(f, L[s++]);
+    }
+    return f;
+}
+
 // f^|x| then conjugate (x < 0), on cyclotomic-subgroup elements
 RIPP_FN Fp12 exp_by_x(const Fp12& a) {
     Fp12 acc = a;

@@ -1,0 +1,146 @@
+// G1 group law and fold kernels on the carry-free field form (fq28.hpp): the throughput twins of kernels.hpp's k_fold_affine_naf<Fp> /
+// k_fold_g1_tab.  Same formulas (dbl-2009-l, madd-2007-bl), written over lazily bounded values: additions and subtractions are limb-wise
+// (no carry chains, no conditional subtractions), every multiplication is 196 + 196 multiply-adds instead of 288 + 288 with carries, and
+// the compiler checks every bound (fq28.hpp).  Coordinates are carried between group operations as normalised values < 4p.
+// The low-liveness forms do not cover the exceptional cases (T = +-Q, an operand at infinity): they REPORT them and the kernel recomputes
+// such a lane with the complete formulas of curve.hpp, exactly like k_fold_g2_tab.
+#pragma once
+#include "fq28.hpp"
+#include "kernels.hpp"
+
+namespace ripp {
+
+#if defined(__HIP_DEVICE_COMPILE__)
+using FqC = Fq<FQ_LN, 4>;                 // a coordinate between two group operations
+
+// value < VB p (VB <= ~2000)  ->  the representative in [0, 2p) with normalised limbs: one quotient estimate from the top limb
+// (never too large, at most one too small) and one signed carry pass
+template <uint64_t LM, int VB>
+__device__ __forceinline__ Fqn fq_reduce(const Fq<LM, VB>& a) {
+    using namespace fq28;
+    static_assert((uint64_t)VB * (P_TOP + 1) < ((uint64_t)1 << 31), "top limb must stay a positive int");
+    const Fq<FQ_LN, VB> n = fq_norm(a);
+    constexpr float INV = (1.0f - 1.0f / 1048576.0f) / (float)(P_TOP + 1);
+    const int q = (int)((float)n.l[NL - 1] * INV);
+    Fqn r; int64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < NL - 1; ++i) { const int64_t t = (int64_t)n.l[i] - (int64_t)q * (int32_t)P28.l[i] + carry; r.l[i] = (uint32_t)t & MASK; carry = t >> W; }
+    r.l[NL - 1] = (uint32_t)((int64_t)n.l[NL - 1] - (int64_t)q * (int32_t)P28.l[NL - 1] + carry);
+    return r;
+}
+// a == 0 mod p, for a reduced value (< 2p, normalised): all limbs zero, or equal to p
+__device__ __forceinline__ bool fq_is_zero(const Fqn& a) {
+    uint32_t z = 0, e = 0;
+#pragma unroll
+    for (int i = 0; i < fq28::NL; ++i) { z |= a.l[i]; e |= a.l[i] ^ fq28::P28.l[i]; }
+    return z == 0 || e == 0;
+}
+template <uint64_t LM, int VB> __device__ __forceinline__ FqC fq_coord(const Fq<LM, VB>& a) {
+    if constexpr (LM <= FQ_LN && VB <= 4) return fq_widen<FQ_LN, 4>(a);
+    else if constexpr (VB <= 4) return fq_widen<FQ_LN, 4>(fq_norm(a));
+    else return fq_widen<FQ_LN, 4>(fq_reduce(a));
+}
+
+struct JacQ { FqC x, y, z; };
+struct AffQ { Fqn x, y; };
+__device__ __forceinline__ AffQ affq_from(const G1A& p) { return {fq_from_fp(p.x), fq_from_fp(p.y)}; }
+__device__ __forceinline__ G1J jacq_to_g1j(const JacQ& p) { return {fq_to_fp(fq_reduce(p.x)), fq_to_fp(fq_reduce(p.y)), fq_to_fp(fq_reduce(p.z))}; }
+
+// dbl-2009-l (a = 0): 2M + 5S.  Z = 0 maps to Z3 = 0.
+__device__ __forceinline__ void jdbl_q(JacQ& p) {
+    const Fqn A = fq_sqr(p.x), B = fq_sqr(p.y), C = fq_sqr(B);
+    const auto D = fq_norm(fq_dbl(fq_sub(fq_sub(fq_sqr(fq_add(p.x, B)), A), C)));
+    const auto E = fq_add(fq_dbl(A), A);
+    const Fqn X3 = fq_reduce(fq_sub(fq_sub(fq_sqr(E), D), D));
+    const auto Z3 = fq_dbl(fq_mul(p.y, p.z));
+    p.y = fq_coord(fq_sub(fq_mul(E, fq_sub(D, X3)), fq_dbl(fq_dbl(fq_dbl(C)))));
+    p.x = fq_coord(X3);
+    p.z = fq_coord(Z3);
+}
+// madd-2007-bl, q affine and NOT the identity, p NOT the identity.  Returns true when the result is not valid (H = 0: p = +-q).
+__device__ __forceinline__ bool jmadd_q(JacQ& p, const Fqn& x2, const Fqn& y2) {
+    const Fqn Z1Z1 = fq_sqr(p.z);
+    const Fqn H = fq_reduce(fq_sub(fq_mul(x2, Z1Z1), p.x));
+    const bool special = fq_is_zero(H);
+    const auto rr = fq_norm(fq_dbl(fq_sub(fq_mul(fq_mul(y2, p.z), Z1Z1), p.y)));
+    const Fqn HH = fq_sqr(H);
+    const auto I = fq_dbl(fq_dbl(HH));
+    const Fqn J = fq_mul(H, I), V = fq_mul(p.x, I);
+    const Fqn X3 = fq_reduce(fq_sub(fq_sub(fq_sub(fq_sqr(rr), J), V), V));
+    const auto Z3 = fq_sub(fq_sub(fq_sqr(fq_add(p.z, H)), Z1Z1), HH);
+    p.y = fq_coord(fq_sub(fq_mul(rr, fq_sub(V, X3)), fq_dbl(fq_mul(p.y, J))));
+    p.x = fq_coord(X3);
+    p.z = fq_coord(Z3);
+    return special;
+}
+#endif
+
+// out[i] = s * hi[i] + lo[i], NAF digit string shared by the launch (the G1 fold of a SIPP round, sipp/src/lib.rs:87-91): the carry-free twin of
+// k_fold_affine_naf<Fp>.  The first non-zero digit loads the point instead of adding it, so the accumulator is never the identity inside the loop.
+__global__ void __launch_bounds__(256, 2) k_fold_g1_naf_q(const G1A* __restrict__ hi, const G1A* __restrict__ lo, uint32_t half, NafDigits dg, G1J* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= half) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const G1A p = hi[i], l = lo[i];
+    int pos = dg.len - 1;
+    while (pos >= 0 && dg.d[pos] == 0) --pos;                    // uniform
+    if (pos < 0 || is_inf(p)) { out[i] = to_jac(l); return; }   // s * hi = identity
+    const AffQ q = affq_from(p);
+    const Fqn ny = fq_reduce(fq_neg(q.y));
+    JacQ acc; acc.x = fq_coord(q.x); acc.y = fq_coord(dg.d[pos] < 0 ? ny : q.y); acc.z = fq_coord(fq_one());
+    bool bad = false;
+#pragma unroll 1
+    for (--pos; pos >= 0; --pos) {
+        jdbl_q(acc);
+        const int d = dg.d[pos];
+        if (d != 0) bad |= jmadd_q(acc, q.x, d < 0 ? ny : q.y);
+    }
+    if (!is_inf(l)) { const AffQ lq = affq_from(l); bad |= jmadd_q(acc, lq.x, lq.y); }
+    if (bad) {                                                   // an addition met T = +-Q: the complete formulas, for this lane only
+        G1J a2 = jac_inf<Fp>();
+#pragma unroll 1
+        for (int k = dg.len - 1; k >= 0; --k) { a2 = dbl(a2); const int d = dg.d[k]; if (d != 0) { G1A t = p; if (d < 0) t.y = neg(t.y); a2 = add_mixed(a2, t); } }
+        out[i] = add_mixed(a2, l);
+    } else out[i] = jacq_to_g1j(acc);
+#endif
+}
+
+// the table fold of round 0 (kernels.hpp k_fold_g1_tab): tab[e][i], e = M b + m: (2m + 1) * (base b of element i); four wNAF strings
+__global__ void __launch_bounds__(256, 2) k_fold_g1_tab_q(const G1A* __restrict__ tab, int M, const G1A* __restrict__ lo, uint32_t half, Wnaf4 dg, G1J* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= half) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+    JacQ acc; acc.x = acc.y = fq_coord(fq_one()); acc.z = fq_coord(fq_zero());
+    bool inf = true, bad = false;                               // inf is wave-uniform (shared digit strings); a table point at infinity makes the lane `bad`
+#pragma unroll 1
+    for (int pos = dg.len - 1; pos >= 0; --pos) {
+        if (!inf) jdbl_q(acc);
+#pragma unroll 1
+        for (int t = 0; t < 4; ++t) {
+            const int d = dg.d[t][pos];
+            if (d == 0) continue;
+            const G1A qa = tab[(size_t)(M * t + ((d < 0 ? -d : d) >> 1)) * half + i];
+            bad |= is_inf(qa);
+            AffQ q = affq_from(qa);
+            if (d < 0) q.y = fq_reduce(fq_neg(q.y));
+            if (inf) { acc.x = fq_coord(q.x); acc.y = fq_coord(q.y); acc.z = fq_coord(fq_one()); inf = false; }
+            else bad |= jmadd_q(acc, q.x, q.y);
+        }
+    }
+    const G1A l = lo[i];
+    if (inf) { out[i] = to_jac(l); return; }
+    if (!is_inf(l)) { const AffQ lq = affq_from(l); bad |= jmadd_q(acc, lq.x, lq.y); }
+    if (bad) {
+        G1J a2 = jac_inf<Fp>();
+#pragma unroll 1
+        for (int pos = dg.len - 1; pos >= 0; --pos) {
+            a2 = dbl(a2);
+#pragma unroll 1
+            for (int t = 0; t < 4; ++t) { const int d = dg.d[t][pos]; if (d != 0) { G1A q = tab[(size_t)(M * t + ((d < 0 ? -d : d) >> 1)) * half + i]; if (d < 0) q.y = neg(q.y); a2 = add_mixed(a2, q); } }
+        }
+        out[i] = add_mixed(a2, l);
+    } else out[i] = jacq_to_g1j(acc);
+#endif
+}
+
+}  // namespace ripp

@@ -84,6 +84,76 @@ __global__ void __launch_bounds__(256, 2) k_fp_dot6_chain(const Fp* in, Fp* out,
     out[tid] = acc;
 }
 
+
+// ---- experiment: the 12 x 32-bit product with SEVERAL limb products per asm block (hipcc puts one s_nop after every asm statement)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define M1(a,b) "v_mad_u64_u32 %0, vcc, " a ", " b ", %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+__device__ __forceinline__ void madc96_2(uint64_t& acc, uint32_t& c2, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1) {
+    asm(M1("%2","%3") M1("%4","%5") : "+v"(acc), "+v"(c2) : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "vcc");
+}
+__device__ __forceinline__ void madc96_4(uint64_t& acc, uint32_t& c2, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2, uint32_t x3, uint32_t y3) {
+    asm(M1("%2","%3") M1("%4","%5") M1("%6","%7") M1("%8","%9") : "+v"(acc), "+v"(c2) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3) : "vcc");
+}
+// column = list of (x, y) pairs gathered first, then issued in blocks of 4 / 2 / 1
+template <int N> struct Col { uint32_t x[N > 0 ? N : 1], y[N > 0 ? N : 1]; };
+template <int N> __device__ __forceinline__ void col_issue(uint64_t& acc, uint32_t& c2, const uint32_t* x, const uint32_t* y) {
+    int i = 0;
+#pragma unroll
+    for (; i + 4 <= N; i += 4) madc96_4(acc, c2, x[i], y[i], x[i + 1], y[i + 1], x[i + 2], y[i + 2], x[i + 3], y[i + 3]);
+#pragma unroll
+    for (; i + 2 <= N; i += 2) madc96_2(acc, c2, x[i], y[i], x[i + 1], y[i + 1]);
+#pragma unroll
+    for (; i < N; ++i) madc96(acc, c2, x[i], y[i]);
+}
+template <int K> struct ColStep {
+    __device__ __forceinline__ static void lo(uint64_t& acc, uint32_t& c2, const Fp& a, const Fp& b, uint32_t* m) {   // column K < 12
+        uint32_t x[2 * K + 1], y[2 * K + 1];
+#pragma unroll
+        for (int i = 0; i <= K; ++i) { x[i] = a.l[i]; y[i] = b.l[K - i]; }
+#pragma unroll
+        for (int i = 0; i < K; ++i) { x[K + 1 + i] = m[i]; y[K + 1 + i] = FpParams::mod(K - i); }
+        col_issue<2 * K + 1>(acc, c2, x, y);
+        m[K] = (uint32_t)acc * FpParams::INV;
+        madc96_s(acc, c2, m[K], FpParams::mod(0));
+        acc = (acc >> 32) | ((uint64_t)c2 << 32); c2 = 0;
+    }
+    __device__ __forceinline__ static void hi(uint64_t& acc, uint32_t& c2, const Fp& a, const Fp& b, const uint32_t* m, Fp& r) {   // column K >= 12
+        constexpr int N = 12, CNT = 2 * N - 1 - K;
+        uint32_t x[2 * CNT], y[2 * CNT];
+#pragma unroll
+        for (int i = 0; i < CNT; ++i) { x[i] = a.l[K - N + 1 + i]; y[i] = b.l[N - 1 - i]; x[CNT + i] = m[K - N + 1 + i]; y[CNT + i] = FpParams::mod(N - 1 - i); }
+        col_issue<2 * CNT>(acc, c2, x, y);
+        r.l[K - N] = (uint32_t)acc;
+        acc = (acc >> 32) | ((uint64_t)c2 << 32); c2 = 0;
+    }
+};
+template <int K> __device__ __forceinline__ void cols_lo(uint64_t& acc, uint32_t& c2, const Fp& a, const Fp& b, uint32_t* m) { if constexpr (K < 12) { ColStep<K>::lo(acc, c2, a, b, m); cols_lo<K + 1>(acc, c2, a, b, m); } }
+template <int K> __device__ __forceinline__ void cols_hi(uint64_t& acc, uint32_t& c2, const Fp& a, const Fp& b, const uint32_t* m, Fp& r) { if constexpr (K < 23) { ColStep<K>::hi(acc, c2, a, b, m, r); cols_hi<K + 1>(acc, c2, a, b, m, r); } }
+__device__ __forceinline__ Fp mul_blk(const Fp& a, const Fp& b) {
+    uint32_t m[12]; Fp r; uint64_t acc = 0; uint32_t c2 = 0;
+    cols_lo<0>(acc, c2, a, b, m);
+    cols_hi<12>(acc, c2, a, b, m, r);
+    r.l[11] = (uint32_t)acc;
+    reduce_once(r);
+    return r;
+}
+#endif
+__global__ void __launch_bounds__(256) k_fp_mulblk_chain(const Fp* in, Fp* out, int iters) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    Fp x = in[tid & 1023], y = in[(tid + 1) & 1023];
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (int i = 0; i < iters; ++i) x = mul_blk(x, y);
+#endif
+    out[tid] = x;
+}
+__global__ void k_check_blk(const Fp* a, const Fp* b, Fp* prod, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+    prod[i] = mul_blk(a[i], b[i]);
+#endif
+}
+
 static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
 static uint64_t splitmix() { uint64_t z = (rng_state += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
 
@@ -139,7 +209,12 @@ int main() {
         printf("%-44s %8.3f ms   %7.2f G products/s\n", name, best, ops / (best * 1e-3) * 1e-9);
         return 0;
     };
+    hipLaunchKernelGGL(k_check_blk, dim3(n / 256), dim3(256), 0, 0, da, db, dp, n);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(hp.data(), dp, n * sizeof(Fp), hipMemcpyDeviceToHost));
+    { int badb = 0; for (int i = 0; i < n; ++i) if (hp[i] != mul(ha[i], hb[i])) ++badb; printf("blocked-asm 12x32 mul vs host: %d mismatches\n", badb); }
     run("fp  (12x32) mul chain", k_fp_mul_chain, 1);
+    run("fp  (12x32) mul chain, 4 limb products / asm block", k_fp_mulblk_chain, 1);
     run("fq28 (14x28) mul chain", k_fq_mul_chain, 1);
     run("fp  dot<6> (6 products, 1 reduction)", k_fp_dot6_chain, 6);
     run("fq28 dot<6> (6 products, 1 reduction)", k_fq_dot6_chain, 6);
