@@ -26,6 +26,9 @@
 #include "msm.hpp"
 #include "scale.hpp"
 #include "vm.hpp"
+#include "fq_curve.hpp"
+#include "fq_curve2.hpp"
+#include "fq_line_products.hpp"
 #include "vm_fold2.hpp"
 #include "host_fs.hpp"
 #include "wire.hpp"
@@ -58,6 +61,9 @@ public:
         push([task]() { (*task)(); });
         return fut;
     }
+    // While `hot`, idle workers poll instead of sleeping (a futex wake-up costs 0.1-0.2 ms, as much as the tasks of a round's host phase).
+    // Off by default and during the statement hash: a polling sibling hyper-thread slows the hashing core down.
+    void set_hot(bool h) { hot_.store(h, std::memory_order_release); }
     // fn(0) .. fn(n - 1), fn(0) on the caller's thread; returns when all are done.  The waits SPIN (the tasks are 0.1-0.6 ms pieces of a
     // round's serial host phase, shorter than a futex sleep + wake-up): workers poll for ~2 ms after their last task before they block.
     template <class F> void parallel(int n, F&& fn) {
@@ -77,9 +83,9 @@ private:
         for (;;) {
             std::function<void()> job;
             const auto t0 = std::chrono::steady_clock::now();
-            for (int spin = 0; pending_.load(std::memory_order_acquire) == 0; ++spin) {      // hot wait
+            for (int spin = 0; hot_.load(std::memory_order_acquire) && pending_.load(std::memory_order_acquire) == 0; ++spin) {      // hot wait
                 RIPP_CPU_RELAX();
-                if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+                if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
             }
             {
                 std::unique_lock<std::mutex> lk(mu_);
@@ -92,7 +98,7 @@ private:
         }
     }
     std::vector<std::thread> th_; std::deque<std::function<void()>> q_; std::mutex mu_; std::condition_variable cv_; bool stop_ = false;
-    std::atomic<int> pending_{0}, sleepers_{0};
+    std::atomic<int> pending_{0}, sleepers_{0}; std::atomic<bool> hot_{false};
 };
 HostPool& host_pool() { static HostPool pool(6); return pool; }
 // out[k] = final_exponentiation(miller_combine(rows + k * N_LINES)), k < count, with the 63 bits of every product cut into `parts` ranges that run
@@ -172,6 +178,8 @@ struct Engine {
     // job whose round-0 tables they hold; a job that finds another owner falls back to the table-free fold.
     DevBuf fold_tab1, fold_mult, fold_tab, fold_jac1, fold_jac2;
     const void* tab_owner = nullptr;
+    size_t lp_fq_min = (size_t)1 << 12;   // pairs per launch from which k_line_products_q replaces k_line_products
+    size_t fq_min = (size_t)1 << 17;      // the carry-free fold kernels (fq_curve.hpp) win on THROUGHPUT: launches with >= 2 waves per SIMD
     size_t fold_tab_min = 32768;          // G2 folds of at least this many elements build in-round odd-multiple tables
     size_t msm_vm_merge_max = 16384;      // buckets (all windows) up to which the bucket merge runs on the field VM
     hipStream_t stream5 = nullptr;        // second G2 fold of a small GIPA round (own scratch there, so it need not queue behind the first)
@@ -187,15 +195,16 @@ struct Engine {
     size_t max_pairs_per_batch = (size_t)1 << 19;                        // lines buffer cap: 2^19 pairs * 19.6 KB = 10.3 GB
     ripp_stats stats{};
     // run-time switches: read from the environment ONCE per C-ABI call (get_engine), never inside round loops
-    struct Switches { bool no_vm = false, no_precompute = false, no_fold_tables = false, no_msm_glv = false, lp_one_lane = false, no_endo = false; } sw;
+    struct Switches { bool no_vm = false, no_precompute = false, no_fold_tables = false, no_msm_glv = false, lp_one_lane = false, no_endo = false, no_fq = false; } sw;
     void refresh_switches() {
         sw.no_vm = std::getenv("RIPP_NO_VM") != nullptr; sw.no_precompute = std::getenv("RIPP_NO_PRECOMPUTE") != nullptr;
         sw.no_fold_tables = std::getenv("RIPP_NO_FOLD_TABLES") != nullptr; sw.no_msm_glv = std::getenv("RIPP_NO_MSM_GLV") != nullptr;
         sw.lp_one_lane = std::getenv("RIPP_LP_ONE_LANE") != nullptr;
         sw.no_endo = std::getenv("RIPP_NO_ENDO") != nullptr;            // plain scalar multiplications in the folds / scaling (no GLV, no psi)
+        sw.no_fq = std::getenv("RIPP_NO_FQ") != nullptr;                // the 12 x 32-bit forms of the kernels that have a carry-free twin (fq_curve.hpp)
 #if defined(RIPP_BLS12_377)
         // this build carries no endomorphism constants and no VM programs for its tower: plain paths only
-        sw.no_vm = sw.no_precompute = sw.no_fold_tables = sw.no_msm_glv = sw.no_endo = true; sw.lp_one_lane = false;
+        sw.no_vm = sw.no_precompute = sw.no_fold_tables = sw.no_msm_glv = sw.no_endo = sw.no_fq = true; sw.lp_one_lane = false;
 #endif
     }
 
@@ -213,7 +222,7 @@ struct Engine {
         HIPCHK(hipEventCreate(&ev_t0)); HIPCHK(hipEventCreate(&ev_t1));
         { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n_simd = pr.multiProcessorCount * 4; }
         auto env_sz = [](const char* k, size_t& v) { if (const char* s = std::getenv(k)) v = (size_t)std::strtoull(s, nullptr, 10); };
-        env_sz("RIPP_VM_LINES_MAX", vm_lines_max); env_sz("RIPP_VM_FOLD_MAX", vm_fold_max); env_sz("RIPP_VM_TREE_MAX", vm_tree_max); env_sz("RIPP_GLS_SPLIT_MAX", gls_split_max); env_sz("RIPP_MSM_VM_MERGE_MAX", msm_vm_merge_max); env_sz("RIPP_FOLD_TAB_MIN", fold_tab_min);
+        env_sz("RIPP_VM_LINES_MAX", vm_lines_max); env_sz("RIPP_VM_FOLD_MAX", vm_fold_max); env_sz("RIPP_VM_TREE_MAX", vm_tree_max); env_sz("RIPP_GLS_SPLIT_MAX", gls_split_max); env_sz("RIPP_MSM_VM_MERGE_MAX", msm_vm_merge_max); env_sz("RIPP_FOLD_TAB_MIN", fold_tab_min); env_sz("RIPP_FQ_MIN", fq_min); env_sz("RIPP_LP_FQ_MIN", lp_fq_min);
         device = dev;
         return RIPP_OK;
     }
@@ -390,6 +399,8 @@ struct Engine {
 #if !defined(RIPP_BLS12_377)
             if (sw.lp_one_lane)
                 hipLaunchKernelGGL(k_line_products1, dim3(nblk(T, 64), (unsigned)nrows), dim3(64), 0, stream, lines.as<uint4>(), stride, (uint32_t)m, partA.as<uint4>(), T);
+            else if (!sw.no_fq && m * nprod >= lp_fq_min)          // throughput-sized launches: the carry-free twin (fq_line_products.hpp)
+                hipLaunchKernelGGL(k_line_products_q, dim3(nblk(T, LP_GROUPS_PER_WAVE), (unsigned)nrows), dim3(64), 0, stream, lines.as<uint4>(), stride, (uint32_t)m, partA.as<uint4>(), T);
             else
 #endif
                 hipLaunchKernelGGL(k_line_products, dim3(nblk(T, LP_GROUPS_PER_WAVE), (unsigned)nrows), dim3(64), 0, stream, lines.as<uint4>(), stride, (uint32_t)m, partA.as<uint4>(), T);
@@ -795,7 +806,10 @@ int32_t fold_g2_table(Engine* e, hipStream_t st, const G2A* hi, const G2A* lo, s
     HIPCHK(hipGetLastError());
     if ((rc = e->normalize_dev<Fp2>(e->fold_jac2.as<G2J>(), (size_t)(M - 1) * half, mult + half, st)) != RIPP_OK) return rc;
     hipLaunchKernelGGL(k_g2_tab_images, dim3(nblk(half, 64), M), dim3(64), 0, st, mult, (uint32_t)half, M, e->fold_tab.as<uint4>(), qstride);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab<GlsDigits, 4>), dim3(nblk(half, 64)), dim3(64), 0, st, e->fold_tab.as<uint4>(), qstride, M, lo, (uint32_t)half, gls_wnaf(s, 4), jac.as<G2J>());
+    if (!e->sw.no_fq && half >= e->fq_min)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab_q<GlsDigits, 4>), dim3(nblk(half, 64)), dim3(64), 0, st, e->fold_tab.as<uint4>(), qstride, M, lo, (uint32_t)half, gls_wnaf(s, 4), jac.as<G2J>());
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab<GlsDigits, 4>), dim3(nblk(half, 64)), dim3(64), 0, st, e->fold_tab.as<uint4>(), qstride, M, lo, (uint32_t)half, gls_wnaf(s, 4), jac.as<G2J>());
     HIPCHK(hipGetLastError());
     return RIPP_OK;
 }
@@ -817,7 +831,9 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true)
     HIPCHK(hipEventRecord(e->ev_fork, e->stream));
     HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
     const bool tab = j->tab_ready && e->tab_owner == j && fits_128(x); j->tab_ready = false;        // ... with the odd-multiple tables of four bases
-    if (tab)
+    if (tab && !e->sw.no_fq && half >= e->fq_min)
+        hipLaunchKernelGGL(k_fold_g1_tab_q, dim3(nblk(half, 256)), dim3(256), 0, e->stream2, e->fold_tab1.as<G1A>(), (int)FOLD_TAB_M, a, (uint32_t)half, split32_wnaf(x), j->jac1.as<G1J>());
+    else if (tab)
         hipLaunchKernelGGL(k_fold_g1_tab, dim3(nblk(half, 256)), dim3(256), 0, e->stream2, e->fold_tab1.as<G1A>(), (int)FOLD_TAB_M, a, (uint32_t)half, split32_wnaf(x), j->jac1.as<G1J>());
     else if (pre)
         hipLaunchKernelGGL(k_fold_g1_two, dim3(nblk(half, 256)), dim3(256), 0, e->stream2, a + half, j->a_pow.as<G1A>(), a, (uint32_t)half, split64_digits(x), j->jac1.as<G1J>());
@@ -827,6 +843,8 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true)
     }
     else if (use_vm)
         hipLaunchKernelGGL(k_vm_fold_g1, dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VM_G1_SLOTS * sizeof(VmSlot), e->stream2, a + half, a, (uint32_t)half, naf_digits(x), j->jac1.as<G1J>(), e->vm_flag.as<uint32_t>());
+    else if (!e->sw.no_fq && half >= e->fq_min)
+        hipLaunchKernelGGL(k_fold_g1_naf_q, dim3(nblk(half, 256)), dim3(256), 0, e->stream2, a + half, a, (uint32_t)half, naf_digits(x), j->jac1.as<G1J>());
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_affine_naf<Fp>), dim3(nblk(half, 256)), dim3(256), 0, e->stream2, a + half, a, (uint32_t)half, naf_digits(x), j->jac1.as<G1J>());
     HIPCHK(hipGetLastError());
@@ -835,6 +853,9 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true)
     if (pre_vm) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_fold_split2<Fp2>), dim3(nblk(half, 4 * VM_EPW), 8), dim3(256), 4 * VM_EPW * VmCurve<Fp2>::SLOTS * sizeof(VmSlot), e->stream, b + half, j->b_pow_h.as<G2J>(), (uint32_t)half, split_digits_g2(x_inv), 4, j->parts2.as<G2J>());
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_combine<Fp2>), dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VmCurve<Fp2>::SLOTS * sizeof(VmSlot), e->stream, j->parts2.as<G2J>(), 8, b, (uint32_t)half, j->jac2.as<G2J>());
+    } else
+    if (tab && !e->sw.no_fq && half >= e->fq_min) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab_q<Wnaf16, 16>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, e->fold_tab.as<uint4>(), j->tab2_stride, (int)FOLD_TAB_M, b, (uint32_t)half, gls16_wnaf(x_inv), j->jac2.as<G2J>());
     } else
     if (tab) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab<Wnaf16, 16>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, e->fold_tab.as<uint4>(), j->tab2_stride, (int)FOLD_TAB_M, b, (uint32_t)half, gls16_wnaf(x_inv), j->jac2.as<G2J>());
@@ -1322,6 +1343,7 @@ API int32_t ripp_sipp_job_prove(ripp_sipp_job* j, const ripp_gt* value, ripp_gt*
     Fp12 val; std::memcpy(&val, value, sizeof(Fp12));
     const double t_start = now_ms();
     job_start_hash(j, val);                                  // overlaps with the scaling + round-1 kernels
+    struct HotOff { ~HotOff() { host_pool().set_hot(false); } } hot_off;       // whatever the exit path, the workers go back to sleeping waits
     int32_t rc = job_begin(e, j); if (rc) return rc;
     if (trace_on()) fprintf(stderr, "[ripp] scale+normalize done at t=%.1f ms\n", now_ms() - t_start);
     size_t round = 0;
@@ -1356,6 +1378,7 @@ API int32_t ripp_sipp_job_prove(ripp_sipp_job* j, const ripp_gt* value, ripp_gt*
             if (j->hash_thread.joinable()) j->hash_thread.join();
             e->stats.hash_ms += now_ms() - th;               // time the prover actually WAITED for the statement hash
             j->rng.from_digest(j->digest); j->seeded = true;
+            host_pool().set_hot(true);                       // the remaining rounds hand 0.1-0.6 ms tasks to the workers every ~2 ms
         }
         const Fr x = fs::sipp_challenge(j->rng, zl, zr);
         x_prev = x;
@@ -1368,6 +1391,7 @@ API int32_t ripp_sipp_job_prove(ripp_sipp_job* j, const ripp_gt* value, ripp_gt*
         ++round;
     }
     if (j->hash_thread.joinable()) j->hash_thread.join();     // n == 1: no rounds
+    host_pool().set_hot(false);
     e->collect_kernel_stats();
     e->stats.total_ms = now_ms() - t_start;
     if (st) *st = e->stats;

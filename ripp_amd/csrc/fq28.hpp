@@ -227,6 +227,21 @@ __device__ __forceinline__ Fqn fq_canon(const Fqn& a) {
     for (int i = 0; i < NL; ++i) r.l[i] = bo ? a.l[i] : d[i];
     return r;
 }
+// x * 2^8 as limbs: the re-slicing of fq_unpack with an 8-bit offset (value < 256 p)
+__device__ __forceinline__ Fq<FQ_LN, 256> fq_unpack_shl8(const uint32_t (&x)[12]) {
+    using namespace fq28;
+    Fq<FQ_LN, 256> r;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        const int bit = W * k - 8;                                   // limb k = bits [28k - 8, 28k + 20) of x
+        uint32_t v;
+        if (bit < 0) v = x[0] << 8;
+        else { const int w = bit >> 5, s = bit & 31;
+               if (s + W <= 32 || w + 1 >= 12) v = x[w] >> s; else v = __builtin_amdgcn_alignbit(x[w + 1], x[w], s); }
+        r.l[k] = v & MASK;
+    }
+    return r;
+}
 // engine value (Mont-384, canonical) <-> Fq (Mont-392)
 __device__ __forceinline__ Fqn fq_from_fp(const Fp& x) { const Fqn t = fq_unpack(x.l); return fq_mul(t, fq_const<FQ_LN, 1>(fq28::C_IN)); }
 __device__ __forceinline__ Fp fq_to_fp(const Fqn& a) { const Fqn t = fq_canon(fq_mul(a, fq_const<FQ_LN, 1>(fq28::C_OUT))); Fp r; fq_pack(t, r.l); return r; }

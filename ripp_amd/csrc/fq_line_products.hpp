@@ -1,0 +1,123 @@
+// Stage 2a of the pairing product on the carry-free field form (fq28.hpp): the throughput twin of line_products.hpp's k_line_products.
+// Same decomposition -- the Fp12 accumulator lives in LDS, owned by a group of 3 lanes, lane j produces the w-basis coefficients j and j + 3
+// of f * (l0 + l1 w^2 + l2 w^3), each real / imaginary part as ONE lazily reduced sum of six products -- but
+//   * a limb product is ONE v_mad_u64_u32 into a 64-bit column (no carry instruction): 4 x (6 x 196 + 196) = 5 488 multiply-adds per line and
+//     lane instead of 4 x 7 x 288 = 8 064 multiply-adds PLUS as many carry instructions;
+//   * the negation of the real part and the factor xi = 1 + u are limb-wise lazy operations on the operands (no carry chains);
+//   * the accumulator needs 6 LDS slots, not 9: xi is applied to the LINE coefficient (f xi . l = f . xi l), once per line.
+// The line buffer is read as it is: the 12 x u32 words of a Montgomery-384 value, re-sliced into 28-bit limbs, ARE the Montgomery-392 form
+// of that value times 2^-8 -- every line, hence every per-step product, is merely scaled by an element of Fp, which the final exponentiation
+// removes (the same argument that lets stage 1 scale its lines, bls12_381/pairing.hpp).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "fq28.hpp"
+#include "line_products.hpp"
+
+namespace ripp {
+
+constexpr int LQ_SLOT_DW = 16;                                     // an Fq in LDS: 14 limbs + 2 (four 16-byte accesses)
+constexpr int LQ_ACC_DW = 6 * 2 * LQ_SLOT_DW;                      // f_0 .. f_5 in Fp2: 768 B per accumulator
+
+// grid = (ceil(T / 21), rows), block = 64 (one wave); same arguments and output layout as k_line_products
+__global__ void __launch_bounds__(64, 2) k_line_products_q(const uint4* __restrict__ lines, size_t stride, uint32_t M, uint4* __restrict__ partials, uint32_t T) {
+    __shared__ uint4 lds[LP_GROUPS_PER_WAVE * LQ_ACC_DW / 4];
+#if defined(__HIP_DEVICE_COMPILE__)
+    using namespace fq28;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t g = lane / LP_GROUP, j = lane - g * LP_GROUP;               // group in wave, lane in group (lane 63: g = 21, idle)
+    auto group_index = [&]() { uint32_t z = 0; asm volatile("" : "+s"(z));
+        const uint32_t l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
+        return blockIdx.x * LP_GROUPS_PER_WAVE + l / LP_GROUP; };
+    const uint32_t t = blockIdx.x * LP_GROUPS_PER_WAVE + g;
+    const bool active = g < (uint32_t)LP_GROUPS_PER_WAVE && t < T;
+    const size_t row = blockIdx.y;
+    uint4* acc = lds + (active ? g : 0) * (LQ_ACC_DW / 4);
+    auto ld_fq = [&](int slot, int part) { Fqn v; uint4 q[4];                    // slot = w-index 0..5, part = 0 (real) / 1 (imaginary)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) q[c] = acc[(slot * 2 + part) * 4 + c];
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(q);
+#pragma unroll
+        for (int i = 0; i < NL; ++i) v.l[i] = w[i];
+        return v; };
+    auto st_fq = [&](int slot, int part, const Fqn& v) { uint4 q[4]; uint32_t* w = reinterpret_cast<uint32_t*>(q);
+#pragma unroll
+        for (int i = 0; i < NL; ++i) w[i] = v.l[i];
+        w[14] = 0; w[15] = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[(slot * 2 + part) * 4 + c] = q[c]; };
+    if (active) {                                                               // accumulator <- 1
+        st_fq(j, 0, j == 0 ? fq_one() : fq_zero()); st_fq(j, 1, fq_zero()); st_fq(j + 3, 0, fq_zero()); st_fq(j + 3, 1, fq_zero());
+    }
+    __syncthreads();
+    // operand slots of this lane's outputs.  k = j + 3: (f_(j+3), f_(j+1), f_j) against (l0, l1, l2);
+    // k = j: (f_j, f_(j+4 mod 6), f_(j+3)) against (l0, xi^[j<2] l1, xi l2)
+    const int a1 = (int)((j + 4) % 6);
+    const bool xi1 = j < 2;
+    const uint32_t st = (uint32_t)stride;
+    const uint4* __restrict__ lrow = lines + row * 18 * stride;
+    const uint32_t iters = (M + T - 1) / T;
+    using FX = Fq<((uint64_t)1 << 29), 4>;                                       // an accumulator coefficient or its negation K - x
+    using FY = Fq<FQ_LN, 3>;                                                     // a line coefficient (canonical in HBM), possibly times xi (normalised)
+#pragma unroll 1
+    for (uint32_t it = 0; it < iters; ++it) {
+        const uint32_t i = group_index() + it * T;
+        const bool valid = active && i < M;
+        const uint32_t ii = valid ? i : 0;
+        FY y[6];                                                                 // l0.c0, l0.c1, l1.c0, l1.c1, l2.c0, l2.c1
+#pragma unroll
+        for (int f = 0; f < 6; ++f) {
+            uint4 q[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) q[c] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(lrow) + (((uint32_t)(3 * f + c) * st + ii) << 4));
+            uint32_t w[12];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { w[4 * c] = q[c].x; w[4 * c + 1] = q[c].y; w[4 * c + 2] = q[c].z; w[4 * c + 3] = q[c].w; }
+            { const Fqn u = fq_unpack(w); Fq<FQ_LN, 1> c; for (int q = 0; q < NL; ++q) c.l[q] = u.l[q]; y[f] = fq_widen<FQ_LN, 3>(c); }      // stage 1 stores canonical values (< p)
+        }
+        Fqn o1r, o1i, o0r, o0i;
+        // two outputs, each: imaginary part first (x as loaded), then the real part with x.c1 negated in place
+        auto two_dots = [&](int s0, int s1, int s2, Fqn& re, Fqn& im) {
+            FX x[6];
+            x[0] = fq_widen<((uint64_t)1 << 29), 4>(ld_fq(s0, 0)); x[1] = fq_widen<((uint64_t)1 << 29), 4>(ld_fq(s0, 1));
+            x[2] = fq_widen<((uint64_t)1 << 29), 4>(ld_fq(s1, 0)); x[3] = fq_widen<((uint64_t)1 << 29), 4>(ld_fq(s1, 1));
+            x[4] = fq_widen<((uint64_t)1 << 29), 4>(ld_fq(s2, 0)); x[5] = fq_widen<((uint64_t)1 << 29), 4>(ld_fq(s2, 1));
+            { const FY ys[6] = {y[1], y[0], y[3], y[2], y[5], y[4]}; im = fq_dot<6>(x, ys); }
+#pragma unroll
+            for (int f = 1; f < 6; f += 2) { Fqn xx; for (int q = 0; q < NL; ++q) xx.l[q] = x[f].l[q]; x[f] = fq_neg(xx); }      // K - x.c1 (x is a reduced value)
+            re = fq_dot<6>(x, y);
+        };
+        two_dots((int)j + 3, (int)j + 1, (int)j, o1r, o1i);                      // k = j + 3: plain line
+        {   // xi l2 always, xi l1 on lanes 0 and 1: (c0 - c1, c0 + c1), normalised
+            auto raw = [&](int f) { Fq<FQ_LN, 1> c; for (int q = 0; q < NL; ++q) c.l[q] = y[f].l[q]; return c; };       // still the canonical values loaded above
+            const auto d2 = fq_norm(fq_sub(raw(4), raw(5))); const auto s2 = fq_norm(fq_add(raw(4), raw(5)));
+            const auto d1 = fq_norm(fq_sub(raw(2), raw(3))); const auto s1 = fq_norm(fq_add(raw(2), raw(3)));
+            static_assert(sizeof(d2) == sizeof(FY) && sizeof(s2) == sizeof(FY), "");
+#pragma unroll
+            for (int q = 0; q < NL; ++q) { y[4].l[q] = d2.l[q]; y[5].l[q] = s2.l[q]; y[2].l[q] = xi1 ? d1.l[q] : y[2].l[q]; y[3].l[q] = xi1 ? s1.l[q] : y[3].l[q]; }
+        }
+        two_dots((int)j, a1, (int)j + 3, o0r, o0i);                              // k = j
+        __syncthreads();                                                         // every lane of the group has read the old coefficients
+        if (valid) { st_fq(j, 0, o0r); st_fq(j, 1, o0i); st_fq(j + 3, 0, o1r); st_fq(j + 3, 1, o1i); }
+        __syncthreads();
+    }
+    // write the group's accumulator: chunk c of the Fp12 in TOWER order (c0.c0, c0.c1, c0.c2, c1.c0, c1.c1, c1.c2) = w-index (0, 2, 4, 1, 3, 5)
+    if (active) {
+        uint4* __restrict__ prow = partials + row * 36 * T;
+        const uint32_t tt = group_index();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int k = j + 3 * u;
+            const int tower = (k & 1) ? 3 + (k >> 1) : (k >> 1);
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                const Fqn c = fq_canon(ld_fq(k, part));
+                uint32_t w[12]; fq_pack(c, w);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) prow[(uint32_t)(tower * 6 + part * 3 + q) * T + tt] = uint4{w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
+            }
+        }
+    }
+#endif
+}
+
+}  // namespace ripp
