@@ -178,6 +178,7 @@ struct Engine {
     // job whose round-0 tables they hold; a job that finds another owner falls back to the table-free fold.
     DevBuf fold_tab1, fold_mult, fold_tab, fold_jac1, fold_jac2;
     const void* tab_owner = nullptr;
+    size_t vm_joint_max = (size_t)1 << 13;                                // folds with <= this many outputs (and more than vm_fold_max) use the joint one-group-per-element VM forms
     size_t lp_fq_min = (size_t)1 << 12;   // pairs per launch from which k_line_products_q replaces k_line_products
     size_t fq_min = (size_t)1 << 17;      // the carry-free fold kernels (fq_curve.hpp) win on THROUGHPUT: launches with >= 2 waves per SIMD
     size_t fold_tab_min = 32768;          // G2 folds of at least this many elements build in-round odd-multiple tables
@@ -222,7 +223,7 @@ struct Engine {
         HIPCHK(hipEventCreate(&ev_t0)); HIPCHK(hipEventCreate(&ev_t1));
         { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n_simd = pr.multiProcessorCount * 4; }
         auto env_sz = [](const char* k, size_t& v) { if (const char* s = std::getenv(k)) v = (size_t)std::strtoull(s, nullptr, 10); };
-        env_sz("RIPP_VM_LINES_MAX", vm_lines_max); env_sz("RIPP_VM_FOLD_MAX", vm_fold_max); env_sz("RIPP_VM_TREE_MAX", vm_tree_max); env_sz("RIPP_GLS_SPLIT_MAX", gls_split_max); env_sz("RIPP_MSM_VM_MERGE_MAX", msm_vm_merge_max); env_sz("RIPP_FOLD_TAB_MIN", fold_tab_min); env_sz("RIPP_FQ_MIN", fq_min); env_sz("RIPP_LP_FQ_MIN", lp_fq_min);
+        env_sz("RIPP_VM_LINES_MAX", vm_lines_max); env_sz("RIPP_VM_FOLD_MAX", vm_fold_max); env_sz("RIPP_VM_TREE_MAX", vm_tree_max); env_sz("RIPP_GLS_SPLIT_MAX", gls_split_max); env_sz("RIPP_MSM_VM_MERGE_MAX", msm_vm_merge_max); env_sz("RIPP_FOLD_TAB_MIN", fold_tab_min); env_sz("RIPP_FQ_MIN", fq_min); env_sz("RIPP_LP_FQ_MIN", lp_fq_min); env_sz("RIPP_VM_JOINT_MAX", vm_joint_max);
         device = dev;
         return RIPP_OK;
     }
@@ -825,7 +826,8 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true)
     if ((rc = e->qtab.reserve(4 * G2A_CHUNKS * qstride * sizeof(uint4))) != RIPP_OK) return rc;
     // G1 half on stream2, G2 half on the main stream (small rounds leave most of the chip idle otherwise)
     const bool use_vm = allow_vm && half <= e->vm_fold_max && !e->sw.no_vm;
-    if (use_vm) { if ((rc = e->vm_flag.reserve(sizeof(uint32_t))) != RIPP_OK) return rc; HIPCHK(hipMemsetAsync(e->vm_flag.p, 0, sizeof(uint32_t), e->stream)); }
+    const bool mid_vm = allow_vm && !use_vm && half <= e->vm_joint_max && !e->sw.no_vm && !e->sw.no_endo;      // mid-size rounds: one VM group per element
+    if ((rc = e->vm_flag.reserve(sizeof(uint32_t))) != RIPP_OK) return rc;      // (kernel argument of the VM folds; they use the complete addition law and report nothing)
     const bool pre = j->pre_ready && fits_128(x); j->pre_ready = false;      // second bases prepared in the hash window (job_precompute_round0)
     const bool pre_vm = j->pre_vm_ready && fits_128(x) && allow_vm; j->pre_vm_ready = false;   // ... or on the VM during this round's host phase
     HIPCHK(hipEventRecord(e->ev_fork, e->stream));
@@ -841,7 +843,7 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_fold_split2<Fp>), dim3(nblk(half, 4 * VM_EPW), 2), dim3(256), 4 * VM_EPW * VmCurve<Fp>::SLOTS * sizeof(VmSlot), e->stream2, a + half, j->a_pow_h.as<G1J>(), (uint32_t)half, split_digits_g1(x), 1, j->parts1.as<G1J>());
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_combine<Fp>), dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VmCurve<Fp>::SLOTS * sizeof(VmSlot), e->stream2, j->parts1.as<G1J>(), 2, a, (uint32_t)half, j->jac1.as<G1J>());
     }
-    else if (use_vm)
+    else if (use_vm || mid_vm)
         hipLaunchKernelGGL(k_vm_fold_g1, dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VM_G1_SLOTS * sizeof(VmSlot), e->stream2, a + half, a, (uint32_t)half, naf_digits(x), j->jac1.as<G1J>(), e->vm_flag.as<uint32_t>());
     else if (!e->sw.no_fq && half >= e->fq_min)
         hipLaunchKernelGGL(k_fold_g1_naf_q, dim3(nblk(half, 256)), dim3(256), 0, e->stream2, a + half, a, (uint32_t)half, naf_digits(x), j->jac1.as<G1J>());
@@ -863,6 +865,9 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true)
     if (pre) {
         if ((rc = e->qtab.reserve(8 * G2A_CHUNKS * qstride * sizeof(uint4))) != RIPP_OK) return rc;
         hipLaunchKernelGGL(k_fold_g2_gls8, dim3(nblk(half, 64)), dim3(64), 0, e->stream, b + half, j->b_pow.as<G2A>(), b, (uint32_t)half, gls8_digits(x_inv), e->qtab.as<uint4>(), qstride, j->jac2.as<G2J>());
+    } else
+    if (mid_vm) {
+        hipLaunchKernelGGL(k_vm_fold_g2_joint, dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VM_G2_SLOTS * sizeof(VmSlot), e->stream, b + half, b, (uint32_t)half, gls_digits(x_inv), j->jac2.as<G2J>());
     } else
     if (use_vm) {
         if ((rc = e->qtab.reserve(std::max<size_t>(4 * G2A_CHUNKS * qstride * sizeof(uint4), 4 * half * sizeof(G2J)))) != RIPP_OK) return rc;
@@ -887,10 +892,6 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true)
     HIPCHK(hipEventRecord(t1, e->stream));
     if ((rc = e->sync()) != RIPP_OK) return rc;
     float ms = 0; (void)hipEventElapsedTime(&ms, t0, t1); e->stats.fold_ms += ms;
-    if (use_vm) {   // an addition met T = +-Q (lambda == 0): the VM formulas do not cover it -> redo with the scalar kernels
-        uint32_t flag = 0; HIPCHK(hipMemcpy(&flag, e->vm_flag.p, sizeof flag, hipMemcpyDeviceToHost));
-        if (flag) return job_fold(e, j, x, false);
-    }
     std::swap(j->a, j->a_next); std::swap(j->b, j->b_next);
     j->len = half;
     return RIPP_OK;

@@ -74,6 +74,9 @@ struct Fq {
 using Fqn = Fq<FQ_LN, 2>;         // what every multiplication returns
 
 __device__ __forceinline__ void mad64(uint64_t& acc, uint32_t x, uint32_t y) { acc += (uint64_t)x * y; }
+#ifndef FQ_NACC
+#define FQ_NACC 1
+#endif
 
 template <uint64_t LM, int VB> __device__ __forceinline__ Fq<LM, VB> fq_const(const fq28::Limbs& c) { Fq<LM, VB> r; for (int i = 0; i < fq28::NL; ++i) r.l[i] = c.l[i]; return r; }
 __device__ __forceinline__ Fqn fq_zero() { Fqn r; for (int i = 0; i < fq28::NL; ++i) r.l[i] = 0; return r; }
@@ -104,33 +107,51 @@ __device__ __forceinline__ Fqn fq_dot(const Fq<L1, V1> (&a)[NT], const Fq<L2, V2
     static_assert((long)NT * V1 * V2 <= VMAX, "value bound: the sum of products must stay below p R'");
     uint32_t m[NL];
     Fqn r;
-    uint64_t acc = 0;
+    // A dependent v_mad_u64_u32 has a latency of ~6 issue slots: at the 2 waves / SIMD the register-heavy kernels run with, ONE accumulator
+    // chain per column leaves the multiplier idle 40 % of the time.  The terms of a column therefore go round-robin into NACC independent
+    // accumulators (summed once per column); with the compiler interleaving two columns that is 2 NACC chains per wave.
+    constexpr int NACC = FQ_NACC;
+    uint64_t carry = 0;
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
+        uint64_t acc[NACC]; int u = 0;
+#pragma unroll
+        for (int c = 0; c < NACC; ++c) acc[c] = 0;
+        acc[0] = carry;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
 #pragma unroll
-            for (int i = 0; i <= k; ++i) mad64(acc, a[t].l[i], b[t].l[k - i]);
+            for (int i = 0; i <= k; ++i) { mad64(acc[u], a[t].l[i], b[t].l[k - i]); u = (u + 1) % NACC; }
         }
 #pragma unroll
-        for (int i = 0; i < k; ++i) mad64(acc, m[i], P28.l[k - i]);
-        m[k] = ((uint32_t)acc * INV28) & MASK;
-        mad64(acc, m[k], P28.l[0]);
-        acc >>= W;
+        for (int i = 0; i < k; ++i) { mad64(acc[u], m[i], P28.l[k - i]); u = (u + 1) % NACC; }
+        uint64_t s = acc[0];
+#pragma unroll
+        for (int c = 1; c < NACC; ++c) s += acc[c];
+        m[k] = ((uint32_t)s * INV28) & MASK;
+        mad64(s, m[k], P28.l[0]);
+        carry = s >> W;
     }
 #pragma unroll
     for (int k = NL; k < 2 * NL - 1; ++k) {
+        uint64_t acc[NACC]; int u = 0;
+#pragma unroll
+        for (int c = 0; c < NACC; ++c) acc[c] = 0;
+        acc[0] = carry;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
 #pragma unroll
-            for (int i = k - NL + 1; i < NL; ++i) mad64(acc, a[t].l[i], b[t].l[k - i]);
+            for (int i = k - NL + 1; i < NL; ++i) { mad64(acc[u], a[t].l[i], b[t].l[k - i]); u = (u + 1) % NACC; }
         }
 #pragma unroll
-        for (int i = k - NL + 1; i < NL; ++i) mad64(acc, m[i], P28.l[k - i]);
-        r.l[k - NL] = (uint32_t)acc & MASK;
-        acc >>= W;
+        for (int i = k - NL + 1; i < NL; ++i) { mad64(acc[u], m[i], P28.l[k - i]); u = (u + 1) % NACC; }
+        uint64_t s = acc[0];
+#pragma unroll
+        for (int c = 1; c < NACC; ++c) s += acc[c];
+        r.l[k - NL] = (uint32_t)s & MASK;
+        carry = s >> W;
     }
-    r.l[NL - 1] = (uint32_t)acc;        // value < 2p < 2^382: the top limb is < 2^18
+    r.l[NL - 1] = (uint32_t)carry;        // value < 2p < 2^382: the top limb is < 2^18
     return r;
 }
 template <uint64_t L1, int V1, uint64_t L2, int V2>

@@ -363,6 +363,55 @@ __global__ void __launch_bounds__(256) k_vm_combine_g2(const G2J* __restrict__ p
     }
 }
 
+// G2 fold for MID-SIZE rounds (a few thousand outputs): ONE group per element walks the four GLS digit strings jointly -- 65 VM doublings and
+// ~87 complete additions on one dependent chain (~1.4 ms), where the 4-lane scalar form (k_fold_g2_gls_split) needs ~4.7 ms for its 65
+// lone-lane doublings whatever the size, and the split-by-string VM form above spends 8 groups per element.  Lane j < 4 of the group keeps
+// psi^j(hi[i]) in registers and writes the addend when string j has a digit; the last addition brings lo[i] in.  out[i] Jacobian.
+__global__ void __launch_bounds__(256) k_vm_fold_g2_joint(const G2A* __restrict__ hi, const G2A* __restrict__ lo, uint32_t half, GlsDigits dg, G2J* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char vm_smem[];
+    VmSlot* const lds = reinterpret_cast<VmSlot*>(vm_smem);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lg = lane & (VM_G - 1), grp = lane / VM_G;
+    const uint32_t i = (blockIdx.x * 4 + wave) * VM_EPW + grp;
+    VmSlot* const ws = lds + (size_t)(wave * VM_EPW + grp) * VM_G2_SLOTS;
+    const bool active = i < half;
+    namespace vp = vmprog;
+    enum { SX = vp::g2_cadd_g16_in_X0, SY = vp::g2_cadd_g16_in_Y0, SZ = vp::g2_cadd_g16_in_Z0, SQX = vp::g2_cadd_g16_in_qx0, SQY = vp::g2_cadd_g16_in_qy0, SQZ = vp::g2_cadd_g16_in_qz0 };
+    auto put2 = [&](int s, const Fp2& v) { vm_put(ws, s, v.c0); vm_put(ws, s + 1, v.c1); };
+    G2A q = aff_inf<Fp2>(); bool qinf = true;
+    if (active && lg < 4) { q = gls_image(hi[i], lg); qinf = is_inf(q); }
+    if (lg == 0) { vm_zero(ws); put2(SX, Fp2::zero()); put2(SY, Fp2::one()); put2(SZ, Fp2::zero()); }      // T = identity (0 : 1 : 0)
+    int pos = dg.len - 1;
+    while (pos >= 0 && dg.d[0][pos] == 0 && dg.d[1][pos] == 0 && dg.d[2][pos] == 0 && dg.d[3][pos] == 0) --pos;      // uniform
+    bool first = true;
+#pragma unroll 1
+    for (; pos >= 0; --pos) {
+        if (!first) vm_run(ws, vp::g2_hdbl_g16_kind, vp::g2_hdbl_g16_ops, vp::g2_hdbl_g16_nlayers, lg);
+        first = false;
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j) {
+            const int d = dg.d[j][pos];
+            if (d == 0) continue;
+            if (lg == j) {                                                   // the addend (x : +-y : 1), or the identity for an element at infinity
+                if (qinf) { put2(SQX, Fp2::zero()); put2(SQY, Fp2::one()); put2(SQZ, Fp2::zero()); }
+                else { put2(SQX, q.x); put2(SQY, d < 0 ? neg(q.y) : q.y); put2(SQZ, Fp2::one()); }
+            }
+            vm_run(ws, vp::g2_cadd_g16_kind, vp::g2_cadd_g16_ops, vp::g2_cadd_g16_nlayers, lg);
+        }
+    }
+    if (lg == 0) {
+        G2A l = aff_inf<Fp2>(); if (active) l = lo[i];
+        if (is_inf(l)) { put2(SQX, Fp2::zero()); put2(SQY, Fp2::one()); put2(SQZ, Fp2::zero()); }
+        else { put2(SQX, l.x); put2(SQY, l.y); put2(SQZ, Fp2::one()); }
+    }
+    vm_run(ws, vp::g2_cadd_g16_kind, vp::g2_cadd_g16_ops, vp::g2_cadd_g16_nlayers, lg);
+    if (active && lg == 0) {
+        const Fp2 X = {vm_get(ws, SX), vm_get(ws, SX + 1)}, Y = {vm_get(ws, SY), vm_get(ws, SY + 1)}, Z = {vm_get(ws, SZ), vm_get(ws, SZ + 1)};
+        G2J r = jac_inf<Fp2>();
+        if (!Z.is_zero()) { r.x = mul(X, Z); r.y = mul(Y, sqr(Z)); r.z = Z; }          // (X/Z, Y/Z) -> Jacobian (XZ, YZ^2, Z)
+        out[i] = r;
+    }
+}
+
 // G1: single NAF digit string (the 128-bit SIPP challenge); out[i] = s*hi[i] + lo[i] (Jacobian)
 constexpr int VM_G1_SLOTS = (vmprog::g1_hdbl_g16_nslots > vmprog::g1_cadd_g16_nslots) ? vmprog::g1_hdbl_g16_nslots : vmprog::g1_cadd_g16_nslots;
 __global__ void __launch_bounds__(256) k_vm_fold_g1(const G1A* __restrict__ hi, const G1A* __restrict__ lo, uint32_t half, NafDigits dg, G1J* __restrict__ out, uint32_t* __restrict__ flag) {

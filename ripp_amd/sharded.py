@@ -164,27 +164,47 @@ class NativeComm:
         self.transport = transport
         if transport == "rccl":
             import torch
-            ident = np.zeros(128, dtype=np.uint8)
-            if self.rank == 0:
-                api._check(lib().ripp_comm_unique_id(api._p(ident)))
-            t = torch.from_numpy(ident)
-            if dist.get_backend() == "nccl":
-                t = t.cuda()
-            dist.broadcast(t, src=0)
-            ident = t.cpu().numpy().copy()
-            api._check(lib().ripp_comm_init(api._p(ident), ctypes.c_int32(self.rank), ctypes.c_int32(self.world)))
-        else:
+            on_gpu = dist.get_backend() == "nccl"
+            ok = 1
+            try:
+                ident = np.zeros(128, dtype=np.uint8)
+                if self.rank == 0:
+                    api._check(lib().ripp_comm_unique_id(api._p(ident)))
+            except Exception as exc:          # librccl not loadable beside this process's HIP runtime: every rank must learn it
+                ok = 0; self.rccl_error = str(exc)
+            flag = torch.tensor([ok], dtype=torch.int32); flag = flag.cuda() if on_gpu else flag
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()):
+                t = torch.from_numpy(ident); t = t.cuda() if on_gpu else t
+                dist.broadcast(t, src=0)
+                ident = t.cpu().numpy().copy()
+                try:
+                    api._check(lib().ripp_comm_init(api._p(ident), ctypes.c_int32(self.rank), ctypes.c_int32(self.world)))
+                except Exception as exc:
+                    ok = 0; self.rccl_error = str(exc)
+                flag = torch.tensor([ok], dtype=torch.int32); flag = flag.cuda() if on_gpu else flag
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if not int(flag.item()):
+                # The library's own communicator could not be brought up on every rank: run its collectives through the host's process
+                # group instead (same all-gather + local multiply, the 576-byte partials just take the torch.distributed route).
+                lib().ripp_comm_destroy()
+                self.transport = transport = "callback"
+                if self.rank == 0:
+                    import sys
+                    print("[ripp] native RCCL communicator unavailable (%s): collectives go through torch.distributed" % getattr(self, "rccl_error", "another rank failed"), file=sys.stderr)
+        if transport == "callback":
             import torch
+            on_gpu = dist.get_backend() == "nccl"
             FN = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
 
             def allgather(_user, send, recv, nbytes):
                 try:
                     src = np.ctypeslib.as_array(ctypes.cast(send, ctypes.POINTER(ctypes.c_uint8)), shape=(nbytes,))
-                    t = torch.from_numpy(src.copy())
+                    t = torch.from_numpy(src.copy()); t = t.cuda() if on_gpu else t
                     outs = [torch.empty_like(t) for _ in range(self.world)]
                     dist.all_gather(outs, t)
                     dst = np.ctypeslib.as_array(ctypes.cast(recv, ctypes.POINTER(ctypes.c_uint8)), shape=(nbytes * self.world,))
-                    dst[:] = torch.cat(outs).numpy()
+                    dst[:] = torch.cat(outs).cpu().numpy()
                     return 0
                 except Exception:          # never unwind through the C frames
                     return 1

@@ -154,6 +154,38 @@ __global__ void k_check_blk(const Fp* a, const Fp* b, Fp* prod, int n) {
 #endif
 }
 
+
+// occupancy-limited chains (dynamic LDS caps the waves per SIMD): what the register-heavy kernels see
+__global__ void __launch_bounds__(256) k_fq_mul_chain_occ(const Fp* in, Fp* out, int iters) {
+    extern __shared__ uint32_t occ_smem[];
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+#if defined(__HIP_DEVICE_COMPILE__)
+    Fqn x = fq_unpack(in[tid & 1023].l), y = fq_unpack(in[(tid + 1) & 1023].l);
+    for (int i = 0; i < iters; ++i) x = fq_mul(x, y);
+    if (iters < 0) occ_smem[threadIdx.x] = x.l[0];
+    Fp r; fq_pack(x, r.l); out[tid] = r;
+#endif
+}
+__global__ void __launch_bounds__(64) k_fq_dot2_chain_occ(const Fp* in, Fp* out, int iters) {
+    extern __shared__ uint32_t occ_smem[];
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+#if defined(__HIP_DEVICE_COMPILE__)
+    Fqn x[2], y[2];
+    x[0] = fq_unpack(in[tid & 1023].l); x[1] = fq_unpack(in[(tid + 3) & 1023].l); y[0] = fq_unpack(in[(tid + 1) & 1023].l); y[1] = fq_unpack(in[(tid + 2) & 1023].l);
+    for (int i = 0; i < iters; ++i) { const Fqn r = fq_dot<2>(x, y); x[i & 1] = r; }
+    if (iters < 0) occ_smem[threadIdx.x] = x[0].l[0];
+    Fp r; fq_pack(x[0], r.l); out[tid] = r;
+#endif
+}
+__global__ void __launch_bounds__(64) k_fp_mul_chain_occ(const Fp* in, Fp* out, int iters) {
+    extern __shared__ uint32_t occ_smem[];
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    Fp x = in[tid & 1023], y = in[(tid + 1) & 1023];
+    for (int i = 0; i < iters; ++i) x = mul(x, y);
+    if (iters < 0) occ_smem[threadIdx.x] = x.l[0];
+    out[tid] = x;
+}
+
 static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
 static uint64_t splitmix() { uint64_t z = (rng_state += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
 
@@ -220,5 +252,38 @@ int main() {
     run("fq28 dot<6> (6 products, 1 reduction)", k_fq_dot6_chain, 6);
     run("fp  mix: (x+y)(z-x) per product", k_fp_mix_chain, 1);
     run("fq28 mix: (x+y)(z-x) per product, lazy", k_fq_mix_chain, 1);
+    auto run_occ = [&](const char* name, auto kern, int waves_per_simd, double ops_per_iter, int bs = 64) -> int {
+        const size_t lds = (size_t)(160 * 1024 / (4 * waves_per_simd) * (bs / 64)) - 512;          // per block
+        if (lds > 64 * 1024) { printf("%s: block of %d needs %zu B of LDS at %d waves/SIMD: skipped\n", name, bs, lds, waves_per_simd); return 0; }
+        const int nb = prop.multiProcessorCount * 4 * waves_per_simd * (waves_per_simd >= 8 ? 1 : 2) / (bs / 64);
+        hipLaunchKernelGGL(kern, dim3(nb), dim3(bs), lds, 0, da, dout, 16);
+        CK(hipDeviceSynchronize());
+        float best = 1e30f;
+        for (int r = 0; r < 3; ++r) {
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(kern, dim3(nb), dim3(bs), lds, 0, da, dout, 2048);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+        }
+        double ops = (double)nb * bs * 2048 * ops_per_iter;
+        printf("%-40s %d waves/SIMD %8.3f ms   %7.2f G products/s\n", name, waves_per_simd, best, ops / (best * 1e-3) * 1e-9);
+        return 0;
+    };
+    auto run_grid = [&](const char* name, auto kern, int waves_per_simd, int bs) -> int {      // occupancy set by the GRID size (no LDS), one resident batch
+        const int nb = prop.multiProcessorCount * 4 * waves_per_simd * 64 / bs;
+        hipLaunchKernelGGL(kern, dim3(nb), dim3(bs), 0, 0, da, dout, 16);
+        CK(hipDeviceSynchronize());
+        float best = 1e30f;
+        for (int r = 0; r < 3; ++r) {
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(kern, dim3(nb), dim3(bs), 0, 0, da, dout, 4096);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+        }
+        printf("%-34s grid-limited %d waves/SIMD, blocks of %3d: %8.3f ms   %7.2f G products/s\n", name, waves_per_simd, bs, best, (double)nb * bs * 4096 / (best * 1e-3) * 1e-9);
+        return 0;
+    };
+    for (int w = 1; w <= 8; w *= 2) for (int bs = 64; bs <= 256; bs *= 2) run_grid("fq28 mul chain", k_fq_mul_chain_occ, w, bs);
+    for (int w = 1; w <= 8; w *= 2) { run_occ("fp  mul chain", k_fp_mul_chain_occ, w, 1); run_occ("fq28 mul chain, blocks of 64", k_fq_mul_chain_occ, w, 1); run_occ("fq28 mul chain, blocks of 128", k_fq_mul_chain_occ, w, 1, 128); run_occ("fq28 mul chain, blocks of 256", k_fq_mul_chain_occ, w, 1, 256); run_occ("fq28 dot<2> chain", k_fq_dot2_chain_occ, w, 2); }
     return 0;
 }
