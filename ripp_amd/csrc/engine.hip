@@ -196,16 +196,17 @@ struct Engine {
     size_t max_pairs_per_batch = (size_t)1 << 19;                        // lines buffer cap: 2^19 pairs * 19.6 KB = 10.3 GB
     ripp_stats stats{};
     // run-time switches: read from the environment ONCE per C-ABI call (get_engine), never inside round loops
-    struct Switches { bool no_vm = false, no_precompute = false, no_fold_tables = false, no_msm_glv = false, lp_one_lane = false, no_endo = false, no_fq = false; } sw;
+    struct Switches { bool no_vm = false, no_precompute = false, no_fold_tables = false, no_msm_glv = false, lp_one_lane = false, no_endo = false, no_fq = false, no_xscale = false; } sw;
     void refresh_switches() {
         sw.no_vm = std::getenv("RIPP_NO_VM") != nullptr; sw.no_precompute = std::getenv("RIPP_NO_PRECOMPUTE") != nullptr;
         sw.no_fold_tables = std::getenv("RIPP_NO_FOLD_TABLES") != nullptr; sw.no_msm_glv = std::getenv("RIPP_NO_MSM_GLV") != nullptr;
         sw.lp_one_lane = std::getenv("RIPP_LP_ONE_LANE") != nullptr;
         sw.no_endo = std::getenv("RIPP_NO_ENDO") != nullptr;            // plain scalar multiplications in the folds / scaling (no GLV, no psi)
+        sw.no_xscale = std::getenv("RIPP_NO_XSCALE") != nullptr;        // G2 folds always on the plain vector with the full-width x^-1
         sw.no_fq = std::getenv("RIPP_NO_FQ") != nullptr;                // the 12 x 32-bit forms of the kernels that have a carry-free twin (fq_curve.hpp)
 #if defined(RIPP_BLS12_377)
         // this build carries no endomorphism constants and no VM programs for its tower: plain paths only
-        sw.no_vm = sw.no_precompute = sw.no_fold_tables = sw.no_msm_glv = sw.no_endo = sw.no_fq = true; sw.lp_one_lane = false;
+        sw.no_vm = sw.no_precompute = sw.no_fold_tables = sw.no_msm_glv = sw.no_endo = sw.no_fq = sw.no_xscale = true; sw.lp_one_lane = false;
 #endif
     }
 
@@ -671,6 +672,10 @@ struct ripp_sipp_job {
     DevBuf a0, b0, r0;                    // resident statement shard
     DevBuf a, b, a_next, b_next, jac1, jac2;   // working vectors
     size_t tab2_stride = 0; bool tab_ready = false;   // round-0 tables (odd multiples of four bases) of this job are in the engine's fold_* buffers
+    // x-SCALED G2 vector (single-GPU prover, large rounds): the device holds bt = bs * b instead of b, folded as bt' = x bt_l + bt_r with the
+    // 128-bit challenge x (two GLS digit strings instead of four: ~36 % less G2 fold work); the round's two GT values are then z^bs and
+    // the host takes them to the power 1/bs.  The first round below the table-fold size returns to the plain vector in its own fold.
+    Fr bs = Fr::one(); bool bs_on = false; bool tab_on_lo = false; bool xs_enabled = false;      // xs_enabled: set by ripp_sipp_job_prove only
     DevBuf a_pow, b_pow; bool pre_ready = false;   // 2^64 * a_r and 2^32 * b_r of round 0, prepared while the statement hash finishes
     // round 1's z_l pre-evaluated in the hash window through bilinearity (see job_preevaluate_round1): the four quarter products
     Fp12 pre_zl[4]; bool pre_zl_ready = false;
@@ -706,6 +711,7 @@ int32_t job_begin(Engine* e, ripp_sipp_job* j) {
     if ((rc = e->sync()) != RIPP_OK) return rc;
     float ms = 0; (void)hipEventElapsedTime(&ms, t0, t1); e->stats.scale_ms += ms;
     j->len = n; j->seeded = false; j->world = j->world0;
+    j->bs = Fr::one(); j->bs_on = false;
     return RIPP_OK;
 }
 
@@ -721,6 +727,13 @@ int32_t job_round_partials(Engine* e, ripp_sipp_job* j, Fp12* rows /* [2][68] */
     return rc;
 }
 
+bool fold_g2_table_pays(const Engine* e, size_t half) { return half >= e->fold_tab_min && half > e->gls_split_max && !e->sw.no_fold_tables; }
+// rounds whose G2 fold runs on the x-scaled vector (see ripp_sipp_job::bs): the table folds of a single-GPU proof
+bool xscale_round(const Engine* e, const ripp_sipp_job* j, size_t half) {
+    if (!j->xs_enabled || j->world0 != 1 || e->sw.no_endo || e->sw.no_xscale) return false;
+    if (fold_g2_table_pays(e, half)) return true;
+    return j->bs_on && half <= e->gls_split_max && 2 * half > e->vm_joint_max && half > e->vm_fold_max;      // stays scaled down to the largest joint-VM round: the return is cheapest on the smallest VM round that walks one group per element
+}
 // Round 0 only, single-GPU proofs: enqueue hi2 = 2^64 a_r and 2^32 b_r (normalised) behind the round's pairing products.  The GPU would
 // otherwise idle until the statement hash delivers the first challenge; the fold then needs half the doublings (k_fold_g1_two /
 // k_fold_g2_gls8).  Not worth it for small rounds (latency-bound) -- and skipped when the hash is already done.
@@ -766,7 +779,8 @@ int32_t job_precompute_round0(Engine* e, ripp_sipp_job* j) {
     G1A* t1 = e->fold_tab1.as<G1A>(); G2A* t2 = e->fold_mult.as<G2A>();
     G1J* sj1 = e->fold_jac1.as<G1J>(); G2J* sj2 = e->fold_jac2.as<G2J>();
     HIPCHK(hipMemcpyAsync(t1, j->a.as<G1A>() + half, half * sizeof(G1A), hipMemcpyDeviceToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(t2, j->b.as<G2A>() + half, half * sizeof(G2A), hipMemcpyDeviceToDevice, e->stream));
+    j->tab_on_lo = xscale_round(e, j, half);                    // scaled fold: x multiplies the LOW half
+    HIPCHK(hipMemcpyAsync(t2, j->b.as<G2A>() + (j->tab_on_lo ? 0 : half), half * sizeof(G2A), hipMemcpyDeviceToDevice, e->stream));
     for (int b = 0; b < 4; ++b) {
         G1A* base1 = t1 + M * b * half; G2A* base2 = t2 + M * b * half;
         if (b > 0) {
@@ -793,7 +807,6 @@ int32_t job_precompute_round0(Engine* e, ripp_sipp_job* j) {
 // G2 fold of a throughput-bound round over in-round tables: odd multiples {1,3,5,7} of every hi element (batch-normalised: the inversion
 // is shared by 16 points) and their psi images, then width-4 wNAF strings -- 65 doublings + ~52 additions instead of 65 + ~87 for
 // ~350 Fp products of table work per element.  Leaves the Jacobian result in jac (first `half` entries).
-bool fold_g2_table_pays(const Engine* e, size_t half) { return half >= e->fold_tab_min && half > e->gls_split_max && !e->sw.no_fold_tables; }
 int32_t fold_g2_table(Engine* e, hipStream_t st, const G2A* hi, const G2A* lo, size_t half, const Fr& s, DevBuf& jac) {
     constexpr int M = 4;
     const size_t qstride = (half + 63) & ~(size_t)63;
@@ -852,22 +865,45 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true)
     HIPCHK(hipGetLastError());
     if ((rc = e->normalize_dev<Fp>(j->jac1.as<G1J>(), half, j->a_next.as<G1A>(), e->stream2)) != RIPP_OK) return rc;
     HIPCHK(hipEventRecord(e->ev_join, e->stream2));
+    // ---- G2 side.  xs: this round folds the x-scaled vector, bt' = x bt_l + bt_r (x multiplies the LOW half, the high half is the addend);
+    //      unscale: the vector is scaled by bs but this round is too small for the table fold: b' = (1/bs) bt_l + (1/(bs x)) bt_r in one pass
+    const bool xs = xscale_round(e, j, half) && fits_128(x) && (!tab || j->tab_on_lo);
+    const bool unscale = j->bs_on && !xs;
+    if (tab && j->tab_on_lo != xs) return (set_err("fold tables were built for the other half"), RIPP_ERR_ARG);
+    const G2A* g2_hi = xs ? b : b + half; const G2A* g2_lo = xs ? b + half : b;
+    const Fr g2_s = xs ? x : x_inv;
+    if (unscale) {
+        // two full-width scalars on two bases: the 4-lane GLS form on each (8 lanes per element, one dependent chain of 65 doublings), then one sum
+        const Fr s_inv = inv(j->bs), sx_inv = mul(s_inv, x_inv);
+        if (mid_vm) {                                   // one VM group per element walks all 8 strings: +~1 ms over an ordinary fold of this size
+            GlsDigits2 d2; d2.a = gls_digits(s_inv); d2.b = gls_digits(sx_inv);
+            hipLaunchKernelGGL(k_vm_fold_g2_joint2, dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VM_G2_SLOTS * sizeof(VmSlot), e->stream, b, b + half, (uint32_t)half, d2, j->jac2.as<G2J>());
+        } else {
+        if ((rc = e->qtab.reserve(8 * half * sizeof(G2J))) != RIPP_OK) return rc;
+        hipLaunchKernelGGL(k_fold_g2_gls_split, dim3(nblk(half, 64), 4), dim3(64), 0, e->stream, b, (uint32_t)half, gls_digits(s_inv), e->qtab.as<G2J>());
+        HIPCHK(hipStreamWaitEvent(e->stream3, e->ev_fork, 0));                        // the two multiplications side by side: they are latency-bound
+        hipLaunchKernelGGL(k_fold_g2_gls_split, dim3(nblk(half, 64), 4), dim3(64), 0, e->stream3, b + half, (uint32_t)half, gls_digits(sx_inv), e->qtab.as<G2J>() + 4 * half);
+        HIPCHK(hipEventRecord(e->ev_join3, e->stream3)); HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join3, 0));
+        hipLaunchKernelGGL(k_fold_g2_combine8, dim3(nblk(half, 64)), dim3(64), 0, e->stream, e->qtab.as<G2J>(), (uint32_t)half, j->jac2.as<G2J>());
+        }
+        j->bs = Fr::one(); j->bs_on = false;
+    } else
     if (pre_vm) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_fold_split2<Fp2>), dim3(nblk(half, 4 * VM_EPW), 8), dim3(256), 4 * VM_EPW * VmCurve<Fp2>::SLOTS * sizeof(VmSlot), e->stream, b + half, j->b_pow_h.as<G2J>(), (uint32_t)half, split_digits_g2(x_inv), 4, j->parts2.as<G2J>());
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_combine<Fp2>), dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VmCurve<Fp2>::SLOTS * sizeof(VmSlot), e->stream, j->parts2.as<G2J>(), 8, b, (uint32_t)half, j->jac2.as<G2J>());
     } else
     if (tab && !e->sw.no_fq && half >= e->fq_min) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab_q<Wnaf16, 16>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, e->fold_tab.as<uint4>(), j->tab2_stride, (int)FOLD_TAB_M, b, (uint32_t)half, gls16_wnaf(x_inv), j->jac2.as<G2J>());
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab_q<Wnaf16, 16>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, e->fold_tab.as<uint4>(), j->tab2_stride, (int)FOLD_TAB_M, g2_lo, (uint32_t)half, gls16_wnaf(g2_s), j->jac2.as<G2J>());
     } else
     if (tab) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab<Wnaf16, 16>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, e->fold_tab.as<uint4>(), j->tab2_stride, (int)FOLD_TAB_M, b, (uint32_t)half, gls16_wnaf(x_inv), j->jac2.as<G2J>());
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab<Wnaf16, 16>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, e->fold_tab.as<uint4>(), j->tab2_stride, (int)FOLD_TAB_M, g2_lo, (uint32_t)half, gls16_wnaf(g2_s), j->jac2.as<G2J>());
     } else
     if (pre) {
         if ((rc = e->qtab.reserve(8 * G2A_CHUNKS * qstride * sizeof(uint4))) != RIPP_OK) return rc;
         hipLaunchKernelGGL(k_fold_g2_gls8, dim3(nblk(half, 64)), dim3(64), 0, e->stream, b + half, j->b_pow.as<G2A>(), b, (uint32_t)half, gls8_digits(x_inv), e->qtab.as<uint4>(), qstride, j->jac2.as<G2J>());
     } else
     if (mid_vm) {
-        hipLaunchKernelGGL(k_vm_fold_g2_joint, dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VM_G2_SLOTS * sizeof(VmSlot), e->stream, b + half, b, (uint32_t)half, gls_digits(x_inv), j->jac2.as<G2J>());
+        hipLaunchKernelGGL(k_vm_fold_g2_joint, dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VM_G2_SLOTS * sizeof(VmSlot), e->stream, g2_hi, g2_lo, (uint32_t)half, gls_digits(g2_s), j->jac2.as<G2J>());
     } else
     if (use_vm) {
         if ((rc = e->qtab.reserve(std::max<size_t>(4 * G2A_CHUNKS * qstride * sizeof(uint4), 4 * half * sizeof(G2J)))) != RIPP_OK) return rc;
@@ -879,14 +915,15 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true)
     } else
     if (half <= e->gls_split_max) {     // latency-bound round: 4 lanes per element
         if ((rc = e->qtab.reserve(std::max<size_t>(4 * G2A_CHUNKS * qstride * sizeof(uint4), 4 * half * sizeof(G2J)))) != RIPP_OK) return rc;
-        hipLaunchKernelGGL(k_fold_g2_gls_split, dim3(nblk(half, 64), 4), dim3(64), 0, e->stream, b + half, (uint32_t)half, gls_digits(x_inv), e->qtab.as<G2J>());
-        hipLaunchKernelGGL(k_fold_g2_combine, dim3(nblk(half, 64)), dim3(64), 0, e->stream, e->qtab.as<G2J>(), b, (uint32_t)half, j->jac2.as<G2J>());
+        hipLaunchKernelGGL(k_fold_g2_gls_split, dim3(nblk(half, 64), 4), dim3(64), 0, e->stream, g2_hi, (uint32_t)half, gls_digits(g2_s), e->qtab.as<G2J>());
+        hipLaunchKernelGGL(k_fold_g2_combine, dim3(nblk(half, 64)), dim3(64), 0, e->stream, e->qtab.as<G2J>(), g2_lo, (uint32_t)half, j->jac2.as<G2J>());
     } else if (fold_g2_table_pays(e, half)) {
-        if ((rc = fold_g2_table(e, e->stream, b + half, b, half, x_inv, j->jac2)) != RIPP_OK) return rc;
+        if ((rc = fold_g2_table(e, e->stream, g2_hi, g2_lo, half, g2_s, j->jac2)) != RIPP_OK) return rc;
     } else {
         hipLaunchKernelGGL(k_fold_g2_gls, dim3(nblk(half, 64)), dim3(64), 0, e->stream, b + half, b, (uint32_t)half, gls_digits(x_inv), e->qtab.as<uint4>(), qstride, j->jac2.as<G2J>());
     }
     HIPCHK(hipGetLastError());
+    if (xs) { j->bs = j->bs_on ? mul(j->bs, x) : x; j->bs_on = true; }          // the new vector is (bs x) b'
     if ((rc = e->normalize_dev<Fp2>(j->jac2.as<G2J>(), half, j->b_next.as<G2A>())) != RIPP_OK) return rc;
     HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
     HIPCHK(hipEventRecord(t1, e->stream));
@@ -1345,6 +1382,8 @@ API int32_t ripp_sipp_job_prove(ripp_sipp_job* j, const ripp_gt* value, ripp_gt*
     const double t_start = now_ms();
     job_start_hash(j, val);                                  // overlaps with the scaling + round-1 kernels
     struct HotOff { ~HotOff() { host_pool().set_hot(false); } } hot_off;       // whatever the exit path, the workers go back to sleeping waits
+    struct XsOff { ripp_sipp_job* j; ~XsOff() { j->xs_enabled = false; } } xs_off{j};
+    j->xs_enabled = true;
     int32_t rc = job_begin(e, j); if (rc) return rc;
     if (trace_on()) fprintf(stderr, "[ripp] scale+normalize done at t=%.1f ms\n", now_ms() - t_start);
     size_t round = 0;
@@ -1373,6 +1412,11 @@ API int32_t ripp_sipp_job_prove(ripp_sipp_job* j, const ripp_gt* value, ripp_gt*
             pairing_values(rows + N_LINES, 1, &zr);
             zl = mul(mul(j->pre_zl[0], p1.get()), mul(p2.get(), j->pre_zl[3]));
         } else { Fp12 z2[2]; pairing_values(rows, 2, z2); zl = z2[0]; zr = z2[1]; }
+        if (j->bs_on) {      // the device holds bs * b: what it evaluated is z^bs (the pre-evaluated z_l of round 1 came from the plain quarters)
+            const Fr si = inv(j->bs);
+            Fp12* zz[2] = {&zl, &zr};
+            host_pool().parallel(2, [&](int k) { if (k == 0 && have_zl) return; *zz[k] = gt_pow_gls(*zz[k], si); });
+        }
         if (round == 0 && !j->seeded && (rc = job_preevaluate_round1(e, j))) return rc;      // blocks on the GPU while the hash thread is still busy
         if (!j->seeded) {
             const double th = now_ms();

@@ -316,6 +316,17 @@ __global__ void __launch_bounds__(64) k_fold_g2_combine(const G2J* __restrict__ 
     out[i] = add_mixed(acc, lo[i]);
 }
 
+// out[i] = sum of the 8 partial points parts[t][i] (two 4-string GLS multiplications of one element: the fold that returns an x-scaled
+// vector to the plain one, engine.hip job_fold)
+__global__ void __launch_bounds__(64) k_fold_g2_combine8(const G2J* __restrict__ parts, uint32_t half, G2J* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= half) return;
+    G2J acc = add(parts[i], parts[(size_t)half + i]);
+#pragma unroll 1
+    for (int t = 2; t < 8; ++t) acc = add(acc, parts[(size_t)t * half + i]);
+    out[i] = acc;
+}
+
 // Single-scalar NAF fold (G1 with the 128-bit SIPP challenge): out[i] = s*hi[i] + lo[i]
 struct NafDigits { int8_t d[260]; int len; };
 template <class F>

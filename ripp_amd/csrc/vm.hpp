@@ -412,6 +412,48 @@ __global__ void __launch_bounds__(256) k_vm_fold_g2_joint(const G2A* __restrict_
     }
 }
 
+// The same joint walk over TWO bases with a full-width scalar each: out[i] = s1 * p1[i] + s2 * p2[i] (8 GLS digit strings; lanes 0..3 keep the
+// images of p1[i], lanes 4..7 those of p2[i]).  This is the fold that returns an x-scaled G2 vector to the plain one (engine.hip job_fold).
+struct GlsDigits2 { GlsDigits a, b; };
+__global__ void __launch_bounds__(256) k_vm_fold_g2_joint2(const G2A* __restrict__ p1, const G2A* __restrict__ p2, uint32_t half, GlsDigits2 dg, G2J* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char vm_smem[];
+    VmSlot* const lds = reinterpret_cast<VmSlot*>(vm_smem);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lg = lane & (VM_G - 1), grp = lane / VM_G;
+    const uint32_t i = (blockIdx.x * 4 + wave) * VM_EPW + grp;
+    VmSlot* const ws = lds + (size_t)(wave * VM_EPW + grp) * VM_G2_SLOTS;
+    const bool active = i < half;
+    namespace vp = vmprog;
+    enum { SX = vp::g2_cadd_g16_in_X0, SY = vp::g2_cadd_g16_in_Y0, SZ = vp::g2_cadd_g16_in_Z0, SQX = vp::g2_cadd_g16_in_qx0, SQY = vp::g2_cadd_g16_in_qy0, SQZ = vp::g2_cadd_g16_in_qz0 };
+    auto put2 = [&](int s, const Fp2& v) { vm_put(ws, s, v.c0); vm_put(ws, s + 1, v.c1); };
+    G2A q = aff_inf<Fp2>(); bool qinf = true;
+    if (active && lg < 8) { q = gls_image(lg < 4 ? p1[i] : p2[i], lg & 3); qinf = is_inf(q); }
+    if (lg == 0) { vm_zero(ws); put2(SX, Fp2::zero()); put2(SY, Fp2::one()); put2(SZ, Fp2::zero()); }      // T = identity (0 : 1 : 0)
+    const int len = dg.a.len > dg.b.len ? dg.a.len : dg.b.len;
+    auto digit = [&](int t, int pos) -> int { const GlsDigits& g = t < 4 ? dg.a : dg.b; return pos < g.len ? g.d[t & 3][pos] : 0; };
+    bool first = true;
+#pragma unroll 1
+    for (int pos = len - 1; pos >= 0; --pos) {
+        if (!first) vm_run(ws, vp::g2_hdbl_g16_kind, vp::g2_hdbl_g16_ops, vp::g2_hdbl_g16_nlayers, lg);
+#pragma unroll 1
+        for (int t = 0; t < 8; ++t) {
+            const int d = digit(t, pos);
+            if (d == 0) continue;
+            first = false;
+            if (lg == t) {
+                if (qinf) { put2(SQX, Fp2::zero()); put2(SQY, Fp2::one()); put2(SQZ, Fp2::zero()); }
+                else { put2(SQX, q.x); put2(SQY, d < 0 ? neg(q.y) : q.y); put2(SQZ, Fp2::one()); }
+            }
+            vm_run(ws, vp::g2_cadd_g16_kind, vp::g2_cadd_g16_ops, vp::g2_cadd_g16_nlayers, lg);
+        }
+    }
+    if (active && lg == 0) {
+        const Fp2 X = {vm_get(ws, SX), vm_get(ws, SX + 1)}, Y = {vm_get(ws, SY), vm_get(ws, SY + 1)}, Z = {vm_get(ws, SZ), vm_get(ws, SZ + 1)};
+        G2J r = jac_inf<Fp2>();
+        if (!Z.is_zero()) { r.x = mul(X, Z); r.y = mul(Y, sqr(Z)); r.z = Z; }
+        out[i] = r;
+    }
+}
+
 // G1: single NAF digit string (the 128-bit SIPP challenge); out[i] = s*hi[i] + lo[i] (Jacobian)
 constexpr int VM_G1_SLOTS = (vmprog::g1_hdbl_g16_nslots > vmprog::g1_cadd_g16_nslots) ? vmprog::g1_hdbl_g16_nslots : vmprog::g1_cadd_g16_nslots;
 __global__ void __launch_bounds__(256) k_vm_fold_g1(const G1A* __restrict__ hi, const G1A* __restrict__ lo, uint32_t half, NafDigits dg, G1J* __restrict__ out, uint32_t* __restrict__ flag) {
