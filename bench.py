@@ -24,12 +24,13 @@ sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_PAIR = 288          # one affine G1 (96 B) + one affine G2 (192 B) read once
 HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-# Integer-ALU roofs for the 381-bit Montgomery product (12 x 32-bit limbs: 288 v_mad_u64_u32 per product):
+# Integer-ALU roofs for the 381-bit Montgomery product of the dominant kernel (12 x 32-bit limbs: 288 v_mad_u64_u32 per product):
 #   "mad_issue": the hardware's measured v_mad_u64_u32 issue rate, 34.7 T lane-MAD/s (profiles/r01_ubench_valu_rates.txt) / 288
-#   "multiplier": the production multiplier's own measured chip rate (every MAD is followed by the v_addc_co_u32 that captures its
-#                 carry: 578 issue slots per product), profiles/r02_fpbench_production.txt
+#   "multiplier": the multiplier's own measured chip rate (every MAD is followed by the v_addc_co_u32 that captures its carry),
+#                 profiles/r02_fpbench_production.txt.  (The carry-free 14 x 28-bit form of the fold kernels and the field VM, fq28.hpp,
+#                 reaches 78.5 G products/s: profiles/r02_fqbench.txt.)
 MAD_ISSUE_PEAK_G = 34.72e3 / 288
-FP_MUL_PEAK_G = 59.6
+FP_MUL_PEAK_G = 59.96
 
 
 def csrc_sha256():
@@ -176,7 +177,8 @@ def main():
     if rank == 0:
         # dominant kernel of the path on this rank, from HIP events recorded on the engine's own stream
         k_lines = (stats["kernel_miller_lines_ms_sum"], stats["kernel_miller_lines_launches"], stats["pairs_lines"], "k_miller_lines")
-        k_prod = (stats["kernel_line_products_ms_sum"], stats["kernel_line_products_launches"], stats["pairs_products"], "k_line_products")
+        lp_name = "k_line_products_q" if os.environ.get("RIPP_LP_FQ_MIN") and not os.environ.get("RIPP_NO_FQ") else "k_line_products"       # the kernel the engine launches for throughput-sized products
+        k_prod = (stats["kernel_line_products_ms_sum"], stats["kernel_line_products_launches"], stats["pairs_products"], lp_name)
         dom = max(k_lines, k_prod, key=lambda k: k[0])
         achieved = (dom[2] * ALG_BYTES_PER_PAIR) / (dom[0] * 1e-3) / 1e9 if dom[0] > 0 else 0.0
         # HBM bytes per launch of that kernel from rocprofv3 PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE, separate passes, this
@@ -204,13 +206,13 @@ def main():
                          "avg_launch_ms": dom[0] / max(dom[1], 1), "launches_per_step": dom[1], "pairs_per_step": dom[2],
                          # the roof that actually binds: 381-bit Montgomery products on the VALU.  Algorithmic Fp products per pair of the
                          # kernel (k_line_products: 68 sparse mul_by_014 of 13 Fp2 = 39 Fp products; k_miller_lines: 63 doubling steps of 25
-                         # + 5 addition steps of 41) against the multiplier's measured chip rate (profiles/r01_fpbench_cios_baseline.txt).
+                         # + 5 addition steps of 41) against the multiplier's measured chip rate (profiles/r02_fpbench_production.txt).
                          "int_alu": (lambda fpm: {"unit": "G Fp-mul/s", "achieved": dom[2] * fpm / (dom[0] * 1e-3) / 1e9 if dom[0] > 0 else 0.0,
                                                   "peak": MAD_ISSUE_PEAK_G, "peak_kind": "hardware v_mad_u64_u32 issue rate / 288 MADs per product",
                                                   "frac": (dom[2] * fpm / (dom[0] * 1e-3) / 1e9 / MAD_ISSUE_PEAK_G) if dom[0] > 0 else 0.0,
                                                   "multiplier_peak": FP_MUL_PEAK_G,
                                                   "frac_of_multiplier": (dom[2] * fpm / (dom[0] * 1e-3) / 1e9 / FP_MUL_PEAK_G) if dom[0] > 0 else 0.0,
-                                                  "fp_products_per_pair": fpm})(68 * 39 if dom[3] == "k_line_products" else 63 * 25 + 5 * 41),
+                                                  "fp_products_per_pair": fpm})(68 * 39 if dom[3].startswith("k_line_products") else 63 * 25 + 5 * 41),
                          "note": "integer-ALU bound (381-bit Montgomery arithmetic, ~5e3 Fp products per 288 input bytes); see DESIGN.md"},
             "phase_ms": {k: round(v, 3) for k, v in stats.items() if k.endswith("_ms")},
         }

@@ -179,7 +179,8 @@ struct Engine {
     DevBuf fold_tab1, fold_mult, fold_tab, fold_jac1, fold_jac2;
     const void* tab_owner = nullptr;
     size_t vm_joint_max = (size_t)1 << 13;                                // folds with <= this many outputs (and more than vm_fold_max) use the joint one-group-per-element VM forms
-    size_t lp_fq_min = (size_t)1 << 12;   // pairs per launch from which k_line_products_q replaces k_line_products
+    size_t lp_fq_min = ~(size_t)0;        // pairs per launch from which k_line_products_q replaces k_line_products.  OFF by default: the carry-free twin is 7 % faster
+                                          // (27.7 vs 29.9 ms per 2^19 pairs) but keeps ~50 dwords in scratch, i.e. 3-5x the HBM traffic of the spill-free kernel (RIPP_LP_FQ_MIN=4096 enables it)
     size_t fq_min = (size_t)1 << 17;      // the carry-free fold kernels (fq_curve.hpp) win on THROUGHPUT: launches with >= 2 waves per SIMD
     size_t fold_tab_min = 32768;          // G2 folds of at least this many elements build in-round odd-multiple tables
     size_t msm_vm_merge_max = 16384;      // buckets (all windows) up to which the bucket merge runs on the field VM

@@ -56,7 +56,6 @@ __global__ void __launch_bounds__(64, 2) k_line_products_q(const uint4* __restri
     const uint32_t st = (uint32_t)stride;
     const uint4* __restrict__ lrow = lines + row * 18 * stride;
     const uint32_t iters = (M + T - 1) / T;
-    using FX = Fq<((uint64_t)1 << 29), 4>;                                       // an accumulator coefficient or its negation K - x
     using FY = Fq<FQ_LN, 3>;                                                     // a line coefficient (canonical in HBM), possibly times xi (normalised)
 #pragma unroll 1
     for (uint32_t it = 0; it < iters; ++it) {
@@ -75,16 +74,61 @@ __global__ void __launch_bounds__(64, 2) k_line_products_q(const uint4* __restri
             { const Fqn u = fq_unpack(w); Fq<FQ_LN, 1> c; for (int q = 0; q < NL; ++q) c.l[q] = u.l[q]; y[f] = fq_widen<FQ_LN, 3>(c); }      // stage 1 stores canonical values (< p)
         }
         Fqn o1r, o1i, o0r, o0i;
-        // two outputs, each: imaginary part first (x as loaded), then the real part with x.c1 negated in place
-        auto two_dots = [&](int s0, int s1, int s2, Fqn& re, Fqn& im) {
-            FX x[6];
-            x[0] = fq_widen<((uint64_t)1 << 29), 4>(ld_fq(s0, 0)); x[1] = fq_widen<((uint64_t)1 << 29), 4>(ld_fq(s0, 1));
-            x[2] = fq_widen<((uint64_t)1 << 29), 4>(ld_fq(s1, 0)); x[3] = fq_widen<((uint64_t)1 << 29), 4>(ld_fq(s1, 1));
-            x[4] = fq_widen<((uint64_t)1 << 29), 4>(ld_fq(s2, 0)); x[5] = fq_widen<((uint64_t)1 << 29), 4>(ld_fq(s2, 1));
-            { const FY ys[6] = {y[1], y[0], y[3], y[2], y[5], y[4]}; im = fq_dot<6>(x, ys); }
+        // One output coefficient part = sum of six products with ONE reduction, evaluated ROW-WISE: the limbs of the accumulator operands are
+        // streamed from LDS four at a time and every limb feeds 14 multiply-adds into 14 DIFFERENT 64-bit columns -- no operand array of the
+        // accumulator side in registers (84 fewer live registers than the column-wise fq_dot: the kernel no longer spills) and 14
+        // independent dependency chains for the multiplier.  xsel[t]: slot / part of the t-th accumulator operand, neg: take K - x
+        // (K = 3p with limbs that dominate a reduced value's: fq28::sub_bias), ysel[t]: index of the line-side operand.
+        static_assert(dot_fits(6, (uint64_t)1 << 29, FQ_LN) && 6 * 4 * 3 <= VMAX, "six products of (x or K - x) by a line coefficient fit the 64-bit columns");
+        constexpr Limbs KN = sub_bias<FQ_LN, 2>();
+        // col += (x or K - x) * yt, x = accumulator coefficient (slot, part) streamed from LDS
+        auto rows = [&](uint64_t (&col)[2 * NL - 1], int slot, int part, bool neg, const FY& yt) {
 #pragma unroll
-            for (int f = 1; f < 6; f += 2) { Fqn xx; for (int q = 0; q < NL; ++q) xx.l[q] = x[f].l[q]; x[f] = fq_neg(xx); }      // K - x.c1 (x is a reduced value)
-            re = fq_dot<6>(x, y);
+            for (int q = 0; q < 4; ++q) {
+                const uint4 xv = acc[(slot * 2 + part) * 4 + q];
+                const uint32_t xl[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = 4 * q + u;
+                    if (i >= NL) continue;
+                    const uint32_t xi = neg ? KN.l[i] - xl[u] : xl[u];
+#pragma unroll
+                    for (int jj = 0; jj < NL; ++jj) col[i + jj] += (uint64_t)xi * yt.l[jj];
+                }
+            }
+        };
+        auto reduce_cols = [&](uint64_t (&col)[2 * NL - 1]) {
+            Fqn r; uint64_t carry = 0;
+#pragma unroll
+            for (int k = 0; k < NL; ++k) {
+                uint64_t sacc = col[k] + carry;
+                const uint32_t m = ((uint32_t)sacc * INV28) & MASK;
+#pragma unroll
+                for (int jj = 1; jj < NL; ++jj) col[k + jj] += (uint64_t)m * P28.l[jj];
+                sacc += (uint64_t)m * P28.l[0];
+                carry = sacc >> W;
+            }
+#pragma unroll
+            for (int k = NL; k < 2 * NL - 1; ++k) { const uint64_t sacc = col[k] + carry; r.l[k - NL] = (uint32_t)sacc & MASK; carry = sacc >> W; }
+            r.l[NL - 1] = (uint32_t)carry;
+            return r;
+        };
+        // (s0, s1, s2) against (l0, l1, l2):  im = sum x.c0 y.c1 + x.c1 y.c0,  re = sum x.c0 y.c0 + (K - x.c1) y.c1
+        auto two_dots = [&](int s0, int s1, int s2, Fqn& re, Fqn& im) {
+            {
+                uint64_t col[2 * NL - 1];
+#pragma unroll
+                for (int c = 0; c < 2 * NL - 1; ++c) col[c] = 0;
+                rows(col, s0, 0, false, y[1]); rows(col, s0, 1, false, y[0]); rows(col, s1, 0, false, y[3]); rows(col, s1, 1, false, y[2]); rows(col, s2, 0, false, y[5]); rows(col, s2, 1, false, y[4]);
+                im = reduce_cols(col);
+            }
+            {
+                uint64_t col[2 * NL - 1];
+#pragma unroll
+                for (int c = 0; c < 2 * NL - 1; ++c) col[c] = 0;
+                rows(col, s0, 0, false, y[0]); rows(col, s0, 1, true, y[1]); rows(col, s1, 0, false, y[2]); rows(col, s1, 1, true, y[3]); rows(col, s2, 0, false, y[4]); rows(col, s2, 1, true, y[5]);
+                re = reduce_cols(col);
+            }
         };
         two_dots((int)j + 3, (int)j + 1, (int)j, o1r, o1i);                      // k = j + 3: plain line
         {   // xi l2 always, xi l1 on lanes 0 and 1: (c0 - c1, c0 + c1), normalised

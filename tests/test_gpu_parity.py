@@ -266,11 +266,17 @@ def test_sipp_prove_2p17_vs_oracle_with_precomputed_round0(engine, orc):
     rc, eproof, _ = orc.sipp_prove(a, b, r, value)
     assert rc == 0
     assert np.array_equal(engine.SIPP.prove(a, b, r, value), eproof)
-    os.environ["RIPP_NO_FOLD_TABLES"] = "1"
-    try:
-        assert np.array_equal(engine.SIPP.prove(a, b, r, value), eproof)
-    finally:
-        del os.environ["RIPP_NO_FOLD_TABLES"]
+    # every implementation of the same folds stays pinned to the oracle (the library reads the switches at every call):
+    #   RIPP_NO_FOLD_TABLES  two-base NAF kernels            RIPP_NO_XSCALE   G2 folds on the plain vector with the full-width x^-1
+    #   RIPP_FQ_MIN=4096     the carry-free (14 x 28-bit) fold kernels and k_line_products_q already at this size -- with the degenerate
+    #                        rows above, so their exceptional-case fallback runs         RIPP_NO_FQ   the 12 x 32-bit kernels everywhere
+    for env in ({"RIPP_NO_FOLD_TABLES": "1"}, {"RIPP_NO_XSCALE": "1"}, {"RIPP_FQ_MIN": "4096", "RIPP_LP_FQ_MIN": "1"},
+                {"RIPP_FQ_MIN": "4096", "RIPP_NO_XSCALE": "1"}, {"RIPP_NO_FQ": "1"}):
+        os.environ.update(env)
+        try:
+            assert np.array_equal(engine.SIPP.prove(a, b, r, value), eproof), env
+        finally:
+            for k in env: del os.environ[k]
 
 
 def test_sipp_rejects_non_power_of_two(engine, orc):
