@@ -7,6 +7,7 @@
 // Same group elements as the one-base forms, hence bit-identical proofs.
 #pragma once
 #include "msm.hpp"      // VmCurve<F>
+#include "scale.hpp"    // scale_bias / scale_digit
 
 namespace ripp {
 
@@ -176,6 +177,81 @@ __global__ void __launch_bounds__(256) k_vm_combine_aff_b(FoldBatch<F> fb, int n
         if (!Z.is_zero()) { const F zi = finv(Z); r.x = fmul(C::get(ws, C::SX), zi); r.y = fmul(C::get(ws, C::SY), zi); }
         fb.s[v].out[i] = r;
     }
+}
+
+// ---- per-element scalar multiplication in latency form: out[i] = k[i] * base[i * base_stride] (Jacobian) ---------------------------------------
+// The throughput kernel (scale.hpp k_scale_g1_glv) is one lane per element: 132 doublings + 66 additions of a LONE lane, ~3.9 ms whatever n.
+// Here one VM group per element: the GLV halves of its own scalar as 33 signed base-16 digits each (the same recoding), a table of the
+// multiples 1..8 of the base in the group's workspace (with -Y and beta X beside them, so a lookup is three slot copies), then 128 VM
+// doublings and 66 complete additions (a zero digit adds the identity: uniform control flow).  ~1.3 ms for n <= 1 K elements.
+constexpr int VM_SCALE_TAB = 8;
+constexpr int VM_SCALE_SLOTS = VmCurve<Fp>::SLOTS + 5 * VM_SCALE_TAB;       // T_m = (X, Y, Z), -Y, beta X  for m = 1..8
+__global__ void __launch_bounds__(256) k_vm_scale_g1(const G1A* __restrict__ base, uint32_t base_stride, const Fr* __restrict__ k_mont, uint32_t n, G1J* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char vm_smem[];
+#if defined(__HIP_DEVICE_COMPILE__)
+    using C = VmCurve<Fp>;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lg = lane & (VM_G - 1), grp = lane / VM_G;
+    const uint32_t i = (blockIdx.x * 4 + wave) * VM_EPW + grp;
+    VmSlot* const ws = reinterpret_cast<VmSlot*>(vm_smem) + (size_t)(wave * VM_EPW + grp) * VM_SCALE_SLOTS;
+    const bool active = i < n;
+    constexpr int TX = C::SLOTS, TY = TX + VM_SCALE_TAB, TZ = TY + VM_SCALE_TAB, TNY = TZ + VM_SCALE_TAB, TBX = TNY + VM_SCALE_TAB;
+    uint32_t d1[5] = {0x88888888u, 0x88888888u, 0x88888888u, 0x88888888u, 8u}, d2[5] = {0x88888888u, 0x88888888u, 0x88888888u, 0x88888888u, 8u};     // all digits zero
+    G1A p = aff_inf<Fp>();
+    if (active && lg == 0) {
+        Fr k = from_mont(k_mont[i]);
+        const uint32_t lam[8] = RIPP_GLV_LAMBDA;
+        const uint32_t lam_mu[5] = {0xf6cfee30u, 0x63f6e522u, 0xe01faaddu, 0x7c6becf1u, 0x00000001u};     // floor(2^256 / lambda)
+        uint32_t rem[5];
+        msm_divmod<4, 5>(k.l, lam, lam_mu, rem);                      // k = q * lambda + rem
+        scale_bias(rem, d1); scale_bias(k.l, d2);
+        p = base[(size_t)i * base_stride];
+    }
+    auto copy_slot = [&](int dst, int src) { vm_st(ws, dst, vm_ld(ws, src)); };
+    if (lg == 0) {
+        vm_zero(ws);
+        const bool pinf = is_inf(p);                                  // the identity stays the identity: (0 : 1 : 0)
+        C::put(ws, C::SX, pinf ? Fp::zero() : p.x); C::put(ws, C::SY, pinf ? Fp::one() : p.y); C::put(ws, C::SZ, pinf ? Fp::zero() : Fp::one());
+        C::put(ws, C::QX, pinf ? Fp::zero() : p.x); C::put(ws, C::QY, pinf ? Fp::one() : p.y); C::put(ws, C::QZ, pinf ? Fp::zero() : Fp::one());
+        copy_slot(TX, C::SX); copy_slot(TY, C::SY); copy_slot(TZ, C::SZ);
+    }
+    // table: T_2 = 2 T_1, T_(m+1) = T_m + T_1 (the addend slots are rewritten before every addition: the programs use them as scratch)
+    // (block barriers around the first program: measured necessary HERE -- without them the doubling's results end up overwritten by the
+    //  initial point on lane 0, with wavefront- and workgroup-scope fences alike; every other program call of the VM kernels sits in a loop)
+    __syncthreads();
+    C::dbl_(ws, lg);
+    __syncthreads();
+    if (lg == 0) { copy_slot(TX + 1, C::SX); copy_slot(TY + 1, C::SY); copy_slot(TZ + 1, C::SZ); }
+#pragma unroll 1
+    for (int m = 2; m < VM_SCALE_TAB; ++m) {
+        if (lg == 0) { copy_slot(C::QX, TX); copy_slot(C::QY, TY); copy_slot(C::QZ, TZ); }
+        C::add_(ws, lg);
+        if (lg == 0) { copy_slot(TX + m, C::SX); copy_slot(TY + m, C::SY); copy_slot(TZ + m, C::SZ); }
+    }
+    if (lg < VM_SCALE_TAB) {                                         // -Y_m and beta X_m, one table row per lane
+        vm_put(ws, TNY + lg, neg(vm_get(ws, TY + lg)));
+        vm_put(ws, TBX + lg, fmul(vm_get(ws, TX + lg), fp_const(RIPP_GLV_BETA)));
+    }
+    if (lg == 0) { C::put(ws, C::SX, Fp::zero()); C::put(ws, C::SY, Fp::one()); C::put(ws, C::SZ, Fp::zero()); }      // acc = identity
+#pragma unroll 1
+    for (int j = 32; j >= 0; --j) {
+        if (j != 32) { C::dbl_(ws, lg); C::dbl_(ws, lg); C::dbl_(ws, lg); C::dbl_(ws, lg); }
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+            if (lg == 0) {
+                const int d = scale_digit(h ? d2 : d1, j);
+                if (d == 0) { C::put(ws, C::QX, Fp::zero()); C::put(ws, C::QY, Fp::one()); C::put(ws, C::QZ, Fp::zero()); }
+                else { const int m = (d < 0 ? -d : d) - 1; copy_slot(C::QX, (h ? TBX : TX) + m); copy_slot(C::QY, (d < 0 ? TNY : TY) + m); copy_slot(C::QZ, TZ + m); }
+            }
+            C::add_(ws, lg);
+        }
+    }
+    if (active && lg == 0) {
+        const Fp X = C::get(ws, C::SX), Y = C::get(ws, C::SY), Z = C::get(ws, C::SZ);
+        G1J r = jac_inf<Fp>();
+        if (!Z.is_zero()) { r.x = fmul(X, Z); r.y = fmul(Y, fsqr(Z)); r.z = Z; }
+        out[i] = r;
+    }
+#endif
 }
 
 }  // namespace ripp

@@ -387,3 +387,26 @@ def test_c_abi_demo_program(engine, tmp_path):
     p = subprocess.run([_build_c_demo(tmp_path), "10"], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "verify accepts" in p.stdout and "tampered proof rejected" in p.stdout
+
+
+def test_per_element_scaling_small_vectors(engine, orc):
+    """a_i <- r_i a_i (sipp/src/lib.rs:61-65) for few elements runs on the field VM (one group per element, GLV halves as signed base-16
+    digits over a table of the multiples 1..8): every digit value and sign, zero scalars, the identity and full-width scalars, checked
+    through product_of_pairings_with_coeffs against the oracle; and the same sizes with the throughput kernel (RIPP_VM_SCALE_MAX=0)."""
+    import os
+    n = 40
+    a, b = orc.gen_g1(321, n), orc.gen_g2(654, n)
+    small = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 15, 16, 17, 0x21, 0x78, 0x87, 0x88, 0x89, 0xff, 0x100, (1 << 64) + 1, (1 << 127) + 3, (1 << 128) - 1]
+    r = orc.gen_scalars(99, n)
+    r[:len(small)] = orc.fr_array(small)
+    a[30] = 0                                                     # the identity, with a full-width scalar
+    for m in (1, 2, 7, n):
+        exp = orc.product_of_pairings_with_coeffs(a[:m], b[:m], r[:m])
+        assert np.array_equal(engine.product_of_pairings_with_coeffs(a[:m], b[:m], r[:m]), exp), m
+        os.environ["RIPP_VM_SCALE_MAX"] = "0"
+        try:
+            assert np.array_equal(engine.product_of_pairings_with_coeffs(a[:m], b[:m], r[:m]), exp), m
+        finally:
+            del os.environ["RIPP_VM_SCALE_MAX"]
+    for k in range(len(small)):                                    # one element at a time: each digit pattern on its own
+        assert np.array_equal(engine.product_of_pairings_with_coeffs(a[k:k + 1], b[k:k + 1], r[k:k + 1]), orc.product_of_pairings_with_coeffs(a[k:k + 1], b[k:k + 1], r[k:k + 1])), hex(small[k])
