@@ -149,6 +149,8 @@ int32_t ripp_sipp_job_prove(ripp_sipp_job* job, const ripp_gt* value, ripp_gt* p
  *   round_partials: this shard's two MILLER VALUES (before the final exponentiation) of the current round's
  *                   z_l and z_r.  prod_ranks miller_combine(rows_rank) == miller_combine(prod_ranks rows_rank) because the
  *                   f <- f^2 * L recurrence is multiplicative, so every rank folds its own 68 step products first.
+ *                   A Miller value is defined UP TO A FACTOR IN Fp* (the kernels scale line elements freely; the final
+ *                   exponentiation removes such factors): only its image under ripp_final_exp is a reference value.
  *   round_finish: given the product over ranks of those values, final-exponentiate to z_l, z_r, derive x, fold the
  *                 local halves.  seed_digest: Blake2s digest of the statement (needed in round 0 only). */
 int32_t ripp_sipp_job_begin(ripp_sipp_job* job);
@@ -317,6 +319,10 @@ size_t  ripp_ser_g2_compressed(const ripp_g2a* p, uint8_t out[96]);
 /* ---- host-side helpers (no device needed): what the host code around the kernels computes ---------------- */
 int32_t ripp_final_exp(const ripp_gt* miller_value, ripp_gt* out);                 /* Pairing::final_exponentiation */
 int32_t ripp_miller_combine(const ripp_gt* step_products /* [68] */, ripp_gt* out); /* stage (3) of pairing.hpp */
+/* out[k] = ripp_final_exp(ripp_miller_combine(step_products + 68 k)), k < count, the way the provers compute it between two kernels: the 63 bits
+ * of every product cut into `parts` ranges (0 = the library's default) that run on the library's host workers and are joined with cyclotomic
+ * squarings -- the final exponentiation is a homomorphism, so the value is the same field element. */
+int32_t ripp_pairing_values(const ripp_gt* step_products /* [count][68] */, int32_t count, int32_t parts, ripp_gt* out /* [count] */);
 int32_t ripp_gt_mul(const ripp_gt* a, const ripp_gt* b, ripp_gt* out);
 int32_t ripp_gt_pow(const ripp_gt* a, const ripp_fr* k, ripp_gt* out);
 int32_t ripp_fr_inverse(const ripp_fr* a, ripp_fr* out);

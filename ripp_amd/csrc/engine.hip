@@ -178,7 +178,7 @@ struct Engine {
     // job whose round-0 tables they hold; a job that finds another owner falls back to the table-free fold.
     DevBuf fold_tab1, fold_mult, fold_tab, fold_jac1, fold_jac2;
     const void* tab_owner = nullptr;
-    size_t vm_scale_max = (size_t)1 << 10;                                // per-element G1 scalings of <= this many elements run on the VM
+    size_t vm_scale_max = (size_t)1 << 12;                                // per-element G1 scalings of <= this many elements run on the VM
     size_t vm_joint_max = (size_t)1 << 13;                                // folds with <= this many outputs (and more than vm_fold_max) use the joint one-group-per-element VM forms
     size_t lp_fq_min = ~(size_t)0;        // pairs per launch from which k_line_products_q replaces k_line_products.  OFF by default: the carry-free twin is 7 % faster
                                           // (27.7 vs 29.9 ms per 2^19 pairs) but keeps ~50 dwords in scratch, i.e. 3-5x the HBM traffic of the spill-free kernel (RIPP_LP_FQ_MIN=4096 enables it)
@@ -190,7 +190,7 @@ struct Engine {
     Fp12* pinned_rows = nullptr;          // pinned host landing zone for per-step products
     size_t pinned_rows_cap = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_lines, ev_prod;   // per-launch event pairs of the two dominant kernels
-    size_t vm_tree_max = (size_t)1 << 14;                                 // tree levels with <= this many products use the VM Fp12 multiplier
+    size_t vm_tree_max = (size_t)1 << 16;                                 // tree levels with <= this many products use the VM Fp12 multiplier
     size_t vm_fold_max = (size_t)1 << 11;                                 // folds with <= this many outputs use the VM scalar multiplications
     DevBuf vm_flag;
     size_t vm_lines_max = (size_t)1 << 15;                                // launches with <= this many pairs use the 16-lanes-per-pair VM line kernel (measured crossover)
@@ -1477,6 +1477,14 @@ API int32_t ripp_sipp_seed_digest(const ripp_g1a* a, const ripp_g2a* b, const ri
 
 // ---- host helpers ----------------------------------------------------------------------------------------------------
 API int32_t ripp_final_exp(const ripp_gt* f, ripp_gt* out) { if (!f || !out) return RIPP_ERR_ARG; Fp12 x; std::memcpy(&x, f, sizeof x); const Fp12 r = final_exponentiation(x); std::memcpy(out, &r, sizeof r); return RIPP_OK; }
+API int32_t ripp_pairing_values(const ripp_gt* rows, int32_t count, int32_t parts, ripp_gt* out) {
+    if (!rows || !out || count < 0 || parts < 0 || parts > 63) return RIPP_ERR_ARG;
+    std::vector<Fp12> L((size_t)count * N_LINES), z((size_t)count);
+    std::memcpy(L.data(), rows, L.size() * sizeof(Fp12));
+    pairing_values(L.data(), count, z.data(), parts);
+    std::memcpy(out, z.data(), z.size() * sizeof(Fp12));
+    return RIPP_OK;
+}
 API int32_t ripp_miller_combine(const ripp_gt* rows, ripp_gt* out) { if (!rows || !out) return RIPP_ERR_ARG; std::vector<Fp12> L(N_LINES); std::memcpy(L.data(), rows, N_LINES * sizeof(Fp12)); const Fp12 r = miller_combine(L.data()); std::memcpy(out, &r, sizeof r); return RIPP_OK; }
 // sum of a few projective points on the host (the cross-rank reduction of sharded MSM partials: G-1 additions)
 API int32_t ripp_sum_g1_j(const ripp_g1j* pts, size_t n, ripp_g1j* out) { if (!out || (n && !pts)) return RIPP_ERR_ARG; G1J acc = jac_inf<Fp>(); for (size_t i = 0; i < n; ++i) { G1J p; std::memcpy(&p, &pts[i], sizeof p); acc = add(acc, p); } std::memcpy(out, &acc, sizeof acc); return RIPP_OK; }

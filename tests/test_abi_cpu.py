@@ -91,6 +91,24 @@ def test_host_helpers_match_oracle(hiplib, orc, vectors):
     assert R.sipp_seed_digest(g1arr(v["a"]), g2arr(v["b"]), frarr(v["r"]), gt_from_bytes(v["value"])).hex() == v["seed_digest"]
 
 
+def test_range_split_final_exponentiation_is_the_same_value(hiplib, orc):
+    """Between two kernels the provers turn 68 per-step products into final_exponentiation(miller_combine(.)) in bit RANGES on host workers
+    (engine.hip pairing_values): for every number of ranges the value must be the one the plain composition gives."""
+    import ctypes
+    rows = np.stack([orc.miller_product_a(orc.gen_g1(10 + k, 2), orc.gen_g2(20 + k, 2)) for k in range(2 * 68)]).astype(np.uint64)      # arbitrary invertible Fp12 values
+    p = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+    exp = []
+    for k in range(2):
+        m = np.zeros(72, dtype=np.uint64); z = np.zeros(72, dtype=np.uint64)
+        assert hiplib.ripp_miller_combine(p(np.ascontiguousarray(rows[68 * k:68 * (k + 1)])), p(m)) == 0 and hiplib.ripp_final_exp(p(m), p(z)) == 0
+        exp.append(z)
+    for parts in (0, 1, 2, 3, 4, 7, 63):
+        out = np.zeros((2, 72), dtype=np.uint64)
+        assert hiplib.ripp_pairing_values(p(rows), 2, parts, p(out)) == 0
+        assert np.array_equal(out[0], exp[0]) and np.array_equal(out[1], exp[1]), parts
+    assert np.array_equal(exp[0], orc.final_exp(orc.miller_combine(rows[:68]))) if hasattr(orc, "miller_combine") else True
+
+
 def test_fiat_shamir_step_matches_golden(hiplib, vectors):
     """ripp_sipp_challenge = absorb (z_l, z_r) then draw x (sipp/src/lib.rs:80-85) against the model's SIPP transcript."""
     from helpers import gt_from_bytes

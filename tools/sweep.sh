@@ -1,7 +1,7 @@
 #!/bin/bash
-# crossover sweep of the latency-form (VM) thresholds: two proofs per setting, report the second
-for cfg in "8192 2048 16384 16384" "8192 4096 16384 16384" "8192 8192 16384 16384" "8192 16384 16384 16384" "8192 32768 16384 16384" "16384 8192 16384 16384" "16384 16384 32768 16384"; do
+# crossover sweep of the latency-form (VM) thresholds: bench.py, 3 steps per setting
+for cfg in "32768 2048 16384" "32768 2048 65536" "32768 2048 262144" "32768 2048 1048576" "32768 2048 16777216"; do
   set -- $cfg
-  echo -n "lines_max=$1 fold_max=$2 tree_max=$3 split_max=$4 : "
-  RIPP_VM_LINES_MAX=$1 RIPP_VM_FOLD_MAX=$2 RIPP_VM_TREE_MAX=$3 RIPP_GLS_SPLIT_MAX=$4 python tools/gputest2.py 20 20 2>&1 | grep "n=2" | tail -1 | sed 's/.*prove //'
+  echo -n "lines_max=$1 fold_max=$2 tree_max=$3 : "
+  RIPP_VM_LINES_MAX=$1 RIPP_VM_FOLD_MAX=$2 RIPP_VM_TREE_MAX=$3 python bench.py --steps 3 --warmup 1 --cpu-log-n 0 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.1f ms' % d['ms_per_step'], {k: v for k, v in d['phase_ms'].items() if k in ('miller_products_ms','fold_ms')})"
 done
