@@ -264,6 +264,18 @@ RIPP_HD G2A gls_image(const G2A& q, int j) {
     return {mul(odd ? conj(q.x) : q.x, cx), mul(odd ? conj(q.y) : q.y, cy)};
 }
 
+// the two coordinates of gls_image separately (the low-liveness addition fetches them where it uses them)
+RIPP_HD Fp2 gls_image_x(const Fp2& x, int j) {
+    if (j == 0) return x;
+    const Fp2 c = j == 1 ? Fp2{fp_const(RIPP_PSI1_CX0), fp_const(RIPP_PSI1_CX1)} : j == 2 ? Fp2{fp_const(RIPP_PSI2_CX0), fp_const(RIPP_PSI2_CX1)} : Fp2{fp_const(RIPP_PSI3_CX0), fp_const(RIPP_PSI3_CX1)};
+    return mul((j & 1) ? conj(x) : x, c);
+}
+RIPP_HD Fp2 gls_image_y(const Fp2& y, int j) {
+    if (j == 0) return y;
+    const Fp2 c = j == 1 ? Fp2{fp_const(RIPP_PSI1_CY0), fp_const(RIPP_PSI1_CY1)} : j == 2 ? Fp2{fp_const(RIPP_PSI2_CY0), fp_const(RIPP_PSI2_CY1)} : Fp2{fp_const(RIPP_PSI3_CY0), fp_const(RIPP_PSI3_CY1)};
+    return mul((j & 1) ? conj(y) : y, c);
+}
+
 __global__ void __launch_bounds__(64, RIPP_OCC) k_fold_g2_gls(const G2A* __restrict__ hi, const G2A* __restrict__ lo, uint32_t half, GlsDigits dg,
                                                      uint4* __restrict__ qtab, size_t stride, G2J* __restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -24,6 +24,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <type_traits>
 #include "bls12_381/curve.hpp"
 #include "vm.hpp"
 
@@ -201,6 +202,15 @@ __device__ __forceinline__ G2A msm_term_base(const G2A* __restrict__ bases, uint
     return gls_image(bases[t - j * nreal], (int)j);
 }
 
+// the textbook loop of one slot, out of line: the complete-formula fallback of the low-liveness G2 form must not shape its register allocation
+template <class F>
+__device__ __noinline__ void msm_slot_sum_complete(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ sorted_w, uint32_t begin, uint32_t end, uint32_t nreal, Jac<F>* out) {
+    Jac<F> acc = jac_inf<F>();
+#pragma unroll 1
+    for (uint32_t k = begin; k < end; ++k) acc = add_mixed(acc, msm_term_base(bases, sorted_w[k], nreal));
+    *out = acc;
+}
+
 // grid.y = window; lane = slot index within the window (max_slots lanes per window, surplus lanes exit)
 template <class F>
 __global__ void __launch_bounds__(64, 2) k_msm_slot_sum(const Affine<F>* __restrict__ bases, MsmPlan p, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offs,
@@ -221,8 +231,31 @@ __global__ void __launch_bounds__(64, 2) k_msm_slot_sum(const Affine<F>* __restr
     const uint32_t begin = offs[(size_t)w * p.nb + d] + part * p.ch;
     const uint32_t end = min(offs[(size_t)w * p.nb + d] + cnt, begin + p.ch);
     Jac<F> acc = jac_inf<F>();
+    if constexpr (std::is_same<F, Fp2>::value) {
+        // G2: the textbook mixed addition keeps ~9 Fp2 temporaries beside the accumulator and spilled 78 dwords per lane (7.8 GB of scratch writes per
+        // launch at n = 2^20).  The low-liveness form of the fold kernels (kernels.hpp jmadd_lo: coordinates of the addend fetched where they are
+        // used -- here: the psi image formed from a re-loaded base --, Y1 parked in LDS) needs no scratch; it REPORTS the exceptional cases and such a
+        // lane redoes its slot with the complete formulas.
+        __shared__ uint4 park_[6 * 64];
+        uint4* park = park_ + threadIdx.x;
+        Fp2 X = Fp2::one(), Y = Fp2::one(), Z = Fp2::zero();
+        bool inf = true, bad = false;
 #pragma unroll 1
-    for (uint32_t k = begin; k < end; ++k) acc = add_mixed(acc, msm_term_base(bases, sorted[(size_t)w * p.n + k], p.nreal));
+        for (uint32_t k = begin; k < end; ++k) {
+            const uint32_t t = sorted[(size_t)w * p.n + k];
+            const int jj = t < p.nreal ? 0 : (int)(t / p.nreal);
+            const G2A* bp = bases + (t - (uint32_t)jj * p.nreal);
+            auto lx = [&]() { return gls_image_x(opaque(bp)->x, jj); };
+            auto ly = [&]() { return gls_image_y(opaque(bp)->y, jj); };
+            if (inf) { X = lx(); Y = ly(); Z = Fp2::one(); inf = false; bad |= X.is_zero() && Y.is_zero(); }
+            else bad |= jmadd_lo(X, Y, Z, lx, ly, false, park);
+        }
+        if (bad) msm_slot_sum_complete<F>(bases, sorted + (size_t)w * p.n, begin, end, p.nreal, &acc);
+        else if (!inf) acc = Jac<F>{X, Y, Z};
+    } else {
+#pragma unroll 1
+        for (uint32_t k = begin; k < end; ++k) acc = add_mixed(acc, msm_term_base(bases, sorted[(size_t)w * p.n + k], p.nreal));
+    }
     slot_sums[(size_t)w * max_slots + s] = hom ? msm_jac_to_h(acc) : acc;
 }
 
