@@ -11,6 +11,7 @@ down to ONE element (L == G) the G remaining elements are all-gathered and the l
 The engine (device job) and the communicator are injected, so the N > 1 control flow is testable on CPU with gloo
 and an oracle-backed stand-in (tests/test_sharded_gloo.py); production uses ripp_amd.api.SippJob + TorchComm.
 """
+import os
 import numpy as np
 
 
@@ -168,6 +169,8 @@ class NativeComm:
             ok = 1
             try:
                 ident = np.zeros(128, dtype=np.uint8)
+                if os.environ.get("RIPP_COMM_NO_RCCL"):        # (tests: take the fallback below without needing a machine where RCCL really fails)
+                    raise RuntimeError("RIPP_COMM_NO_RCCL is set")
                 if self.rank == 0:
                     api._check(lib().ripp_comm_unique_id(api._p(ident)))
             except Exception as exc:          # librccl not loadable beside this process's HIP runtime: every rank must learn it

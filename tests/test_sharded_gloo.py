@@ -190,7 +190,10 @@ def _native_worker(rank, world, port, n, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         R.init(0)
-        comm = NativeComm("callback")                    # both ranks share cuda:0: RCCL needs one device per rank, gloo carries the all-gather
+        # both ranks share cuda:0: RCCL needs one device per rank, gloo carries the all-gather.  With RIPP_COMM_NO_RCCL the RCCL transport is
+        # REQUESTED and its bring-up made to fail, so the ranks must agree on the fallback to the host's process group (what bench.py relies on)
+        comm = NativeComm("rccl" if os.environ.get("RIPP_COMM_NO_RCCL") else "callback")
+        assert comm.transport == "callback"
         a, b, r = o.gen_g1(123, n), o.gen_g2(456, n), o.gen_scalars(7, n)
         value = o.product_of_pairings_with_coeffs(a, b, r)
         job = R.SippJob(shard(a, rank, world), shard(b, rank, world), shard(r, rank, world), rank=rank, world=world)
@@ -219,6 +222,20 @@ def test_native_sharded_driver_world2_callback_transport(engine, n):
     import torch.multiprocessing as mp
     mgr = mp.Manager(); ret = mgr.dict()
     mp.spawn(_native_worker, args=(2, _free_port(), n, ret), nprocs=2, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+@pytest.mark.gpu
+def test_native_comm_falls_back_to_the_process_group(engine):
+    """bench.py asks for the library's own RCCL communicator; when that cannot be brought up on every rank the ranks agree (one all-reduce)
+    to run the library's collectives through torch.distributed instead.  Forced here with RIPP_COMM_NO_RCCL on two ranks sharing cuda:0."""
+    import torch.multiprocessing as mp
+    os.environ["RIPP_COMM_NO_RCCL"] = "1"
+    try:
+        mgr = mp.Manager(); ret = mgr.dict()
+        mp.spawn(_native_worker, args=(2, _free_port(), 64, ret), nprocs=2, join=True)
+    finally:
+        del os.environ["RIPP_COMM_NO_RCCL"]
     assert dict(ret) == {0: True, 1: True}
 
 
