@@ -5,6 +5,7 @@ cp $S/kstats/k_kernel_stats.csv profiles/${R}_bench_kernel_stats_rocprofv3.csv
 cp $S/bench_n1.json profiles/${R}_bench_n1.json
 cp $S/fpbench.txt profiles/${R}_fpbench_production.txt
 cp $S/fqbench.txt profiles/${R}_fqbench.txt
+cp $S/invbench.txt profiles/${R}_invbench.txt
 cp $S/hbm_traffic.csv profiles/${R}_hbm_traffic_pmc.csv
 cp $S/traffic.json profiles/traffic_current.json
 cp $S/msm_sweep.txt profiles/${R}_msm_2p20.txt

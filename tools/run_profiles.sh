@@ -7,6 +7,7 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 ./tools/ubench/build/fpbench > $OUT/fpbench.txt 2>&1
 ./tools/ubench/build/fqbench > $OUT/fqbench.txt 2>&1
+./tools/ubench/build/invbench > $OUT/invbench.txt 2>&1
 timeout 300 python3 bench.py --steps 5 --warmup 1 > $OUT/bench_n1.json 2> $OUT/bench_n1.err
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/kstats -o k --output-format csv -- python3 bench.py --steps 3 --warmup 1 --cpu-log-n 0 > $OUT/kstats.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o f --output-format csv -- python3 bench.py --steps 1 --warmup 0 --cpu-log-n 0 > $OUT/pmc_fetch.log 2>&1
