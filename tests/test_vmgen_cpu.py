@@ -72,3 +72,10 @@ def test_kaliski_fix_table():
             assert k <= 768
         r = r - p if r >= p else r
         assert (p - r) * (pow(R, 3, p) * pow(2, -k, p) % p) * pow(R, -1, p) % p == pow(a, -1, p) * R % p
+
+
+def test_binary_gcd_inversion_model():
+    """tools/inv_model.py restates the device inversion (fp_inv_bingcd) limb for limb on Python integers and asserts its invariants; the GPU
+    tests compare the kernel itself with the host's Fermat inverse through every normalisation."""
+    import inv_model
+    assert inv_model.self_test(samples=300) == 26

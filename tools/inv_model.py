@@ -1,4 +1,7 @@
-# Limb-level model (14 limbs of 28 bits) of the device inversion: K = 30 inner iterations, approximations = low 30 bits + top 34 bits.
+"""Limb-level model (14 limbs of 28 bits, Python integers) of the device inversion ripp_amd/csrc/bls12_381/fp_inv.hpp::fp_inv_bingcd:
+binary GCD with K = 30 inner steps on 64-bit approximations (low 30 bits + the 34 bits below the top bit of a | b), 26 outer iterations,
+exact division by 2^30 of (a, b) and modular division of (u, v) per outer iteration (Pornin, eprint 2020/972, Alg. 2).  Every step asserts
+the invariants the device code relies on (factor bounds, exact divisibility, |u|, |v| < 64 p, a = 0 and b = 1 at the end)."""
 import random
 P = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
 W, NL, MASK = 28, 14, (1 << 28) - 1
@@ -77,7 +80,12 @@ def inv(y):
     assert val(a) == 0 and val(b) == 1
     return val(v) % P
 
-rnd = random.Random(2)
-for y in [1, 2, 3, P - 1, P - 2, (P + 1) // 2, 1 << 380, (1 << 381) - 1 - (1 << 300), 1 << 56, (1 << 57) + 1, 1 << 84, 5 << 100] + [rnd.randrange(1, P) for _ in range(3000)] + [rnd.randrange(1, 1 << rnd.randrange(1, 381)) for _ in range(2000)]:
-    assert inv(y) * y % P == 1, hex(y)
-print("ok", ITER, hex(MINV))
+def self_test(samples=3000):
+    rnd = random.Random(2)
+    for y in [1, 2, 3, P - 1, P - 2, (P + 1) // 2, 1 << 380, (1 << 381) - 1 - (1 << 300), 1 << 56, (1 << 57) + 1, 1 << 84, 5 << 100] + [rnd.randrange(1, P) for _ in range(samples)] + [rnd.randrange(1, 1 << rnd.randrange(1, 381)) for _ in range(samples)]:
+        assert inv(y) * y % P == 1, hex(y)
+    return ITER
+
+
+if __name__ == "__main__":
+    print("ok", self_test(), hex(MINV))
