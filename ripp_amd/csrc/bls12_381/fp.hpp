@@ -215,8 +215,53 @@ RIPP_HD void madc96(uint64_t& acc, uint32_t& c2, uint32_t x, uint32_t y) {
 RIPP_HD void madc96_s(uint64_t& acc, uint32_t& c2, uint32_t x, uint32_t y_const) {   // y in an SGPR (modulus limb)
     asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc), "+v"(c2) : "v"(x), "s"(y_const) : "vcc");
 }
+// two limb products per asm statement: hipcc puts one s_nop behind EVERY inline-asm statement, so pairing them halves those issue slots
+RIPP_HD void madc96_2(uint64_t& acc, uint32_t& c2, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1) {
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\tv_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+        : "+v"(acc), "+v"(c2) : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "vcc");
+}
+// sum_{i = LO}^{HI} a_i b_(K-i), pairwise
+template <int LO, int HI, int K, class P>
+RIPP_HD void madc96_row(uint64_t& acc, uint32_t& c2, const Mont<P>& a, const Mont<P>& b) {
+#pragma unroll
+    for (int i = LO; i + 1 <= HI; i += 2) madc96_2(acc, c2, a.l[i], b.l[K - i], a.l[i + 1], b.l[K - i - 1]);
+    if constexpr (((HI - LO + 1) & 1) != 0) madc96(acc, c2, a.l[HI], b.l[K - HI]);
+}
+template <int K, int N, class P> RIPP_HD void mul_cols_lo(uint64_t& acc, uint32_t& c2, const Mont<P>& a, const Mont<P>& b, uint32_t (&m)[N]) {
+    if constexpr (K < N) {
+        madc96_row<0, K, K>(acc, c2, a, b);
+#pragma unroll
+        for (int i = 0; i < K; ++i) madc96_s(acc, c2, m[i], P::mod(K - i));
+        m[K] = (uint32_t)acc * P::INV;
+        madc96_s(acc, c2, m[K], P::mod(0));                 // low word becomes 0
+        acc = (acc >> 32) | ((uint64_t)c2 << 32); c2 = 0;
+        mul_cols_lo<K + 1, N>(acc, c2, a, b, m);
+    }
+}
+template <int K, int N, class P> RIPP_HD void mul_cols_hi(uint64_t& acc, uint32_t& c2, const Mont<P>& a, const Mont<P>& b, const uint32_t (&m)[N], Mont<P>& r) {
+    if constexpr (K < 2 * N - 1) {
+        madc96_row<K - N + 1, N - 1, K>(acc, c2, a, b);
+#pragma unroll
+        for (int i = K - N + 1; i < N; ++i) madc96_s(acc, c2, m[i], P::mod(K - i));
+        r.l[K - N] = (uint32_t)acc;
+        acc = (acc >> 32) | ((uint64_t)c2 << 32); c2 = 0;
+        mul_cols_hi<K + 1, N>(acc, c2, a, b, m, r);
+    }
+}
 template <class P>
 RIPP_HD Mont<P> mul(const Mont<P>& a, const Mont<P>& b) {
+    constexpr int N = P::N;
+    uint32_t m[N];
+    Mont<P> r;
+    uint64_t acc = 0; uint32_t c2 = 0;
+    mul_cols_lo<0, N>(acc, c2, a, b, m);
+    mul_cols_hi<N, N>(acc, c2, a, b, m, r);
+    r.l[N - 1] = (uint32_t)acc;                             // result < 2p < 2^(32N): acc >> 32 == 0
+    reduce_once(r);
+    return r;
+}
+template <class P>
+RIPP_HD Mont<P> mul_single(const Mont<P>& a, const Mont<P>& b) {      // one asm statement per limb product (the form before the pairing; A/B reference)
     constexpr int N = P::N;
     uint32_t m[N];
     Mont<P> r;
@@ -256,7 +301,7 @@ RIPP_HD Mont<P> mul2_add(const Mont<P>& a, const Mont<P>& b, const Mont<P>& c, c
 #pragma unroll
     for (int k = 0; k < N; ++k) {
 #pragma unroll
-        for (int i = 0; i <= k; ++i) { madc96(acc, c2, a.l[i], b.l[k - i]); madc96(acc, c2, c.l[i], d.l[k - i]); }
+        for (int i = 0; i <= k; ++i) madc96_2(acc, c2, a.l[i], b.l[k - i], c.l[i], d.l[k - i]);
 #pragma unroll
         for (int i = 0; i < k; ++i) madc96_s(acc, c2, m[i], P::mod(k - i));
         m[k] = (uint32_t)acc * P::INV;
@@ -266,7 +311,7 @@ RIPP_HD Mont<P> mul2_add(const Mont<P>& a, const Mont<P>& b, const Mont<P>& c, c
 #pragma unroll
     for (int k = N; k < 2 * N - 1; ++k) {
 #pragma unroll
-        for (int i = k - N + 1; i < N; ++i) { madc96(acc, c2, a.l[i], b.l[k - i]); madc96(acc, c2, c.l[i], d.l[k - i]); }
+        for (int i = k - N + 1; i < N; ++i) madc96_2(acc, c2, a.l[i], b.l[k - i], c.l[i], d.l[k - i]);
 #pragma unroll
         for (int i = k - N + 1; i < N; ++i) madc96_s(acc, c2, m[i], P::mod(k - i));
         r.l[k - N] = (uint32_t)acc;

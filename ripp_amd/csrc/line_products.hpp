@@ -20,6 +20,32 @@
 namespace ripp {
 
 #if defined(__HIP_DEVICE_COMPILE__)
+// Several limb products per asm statement: hipcc's hazard recogniser puts one s_nop behind EVERY inline-asm statement (it cannot see that the
+// statement ends in a v_addc), i.e. one per limb product in the single-product form -- 3 850 issue slots per line and lane in this kernel.
+#define RIPP_M1(a, b) "v_mad_u64_u32 %0, vcc, " a ", " b ", %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+__device__ __forceinline__ void madc96_x2(uint64_t& acc, uint32_t& c2, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1) {
+    asm(RIPP_M1("%2", "%3") RIPP_M1("%4", "%5") : "+v"(acc), "+v"(c2) : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "vcc");
+}
+__device__ __forceinline__ void madc96_x3(uint64_t& acc, uint32_t& c2, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2) {
+    asm(RIPP_M1("%2", "%3") RIPP_M1("%4", "%5") RIPP_M1("%6", "%7") : "+v"(acc), "+v"(c2) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2) : "vcc");
+}
+__device__ __forceinline__ void madc96_x6(uint64_t& acc, uint32_t& c2, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2,
+                                          uint32_t x3, uint32_t y3, uint32_t x4, uint32_t y4, uint32_t x5, uint32_t y5) {
+    asm(RIPP_M1("%2", "%3") RIPP_M1("%4", "%5") RIPP_M1("%6", "%7") RIPP_M1("%8", "%9") RIPP_M1("%10", "%11") RIPP_M1("%12", "%13")
+        : "+v"(acc), "+v"(c2) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3), "v"(x4), "v"(y4), "v"(x5), "v"(y5) : "vcc");
+}
+#undef RIPP_M1
+// the NT limb products a[t][i] * b[t][j] of one (i, j), in as few asm statements as possible
+template <int NT>
+__device__ __forceinline__ void madc96_terms(uint64_t& acc, uint32_t& c2, const Fp (&a)[NT], const Fp (&b)[NT], int i, int j) {
+    if constexpr (NT == 6) { madc96_x3(acc, c2, a[0].l[i], b[0].l[j], a[1].l[i], b[1].l[j], a[2].l[i], b[2].l[j]); madc96_x3(acc, c2, a[3].l[i], b[3].l[j], a[4].l[i], b[4].l[j], a[5].l[i], b[5].l[j]); }
+    else if constexpr (NT == 3) madc96_x3(acc, c2, a[0].l[i], b[0].l[j], a[1].l[i], b[1].l[j], a[2].l[i], b[2].l[j]);
+    else if constexpr (NT == 2) madc96_x2(acc, c2, a[0].l[i], b[0].l[j], a[1].l[i], b[1].l[j]);
+    else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) madc96(acc, c2, a[t].l[i], b[t].l[j]);
+    }
+}
 // sum_{t < NT} a[t] * b[t] * R^-1 mod p with one Montgomery reduction.  Inputs < p (b[t] <= p allowed); NT p^2 < p R must hold (NT <= 9).
 template <int NT>
 __device__ __forceinline__ Fp fp_dot(const Fp (&a)[NT], const Fp (&b)[NT]) {
@@ -30,10 +56,7 @@ __device__ __forceinline__ Fp fp_dot(const Fp (&a)[NT], const Fp (&b)[NT]) {
 #pragma unroll
     for (int k = 0; k < N; ++k) {
 #pragma unroll
-        for (int i = 0; i <= k; ++i) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) madc96(acc, c2, a[t].l[i], b[t].l[k - i]);
-        }
+        for (int i = 0; i <= k; ++i) madc96_terms<NT>(acc, c2, a, b, i, k - i);
 #pragma unroll
         for (int i = 0; i < k; ++i) madc96_s(acc, c2, m[i], FpParams::mod(k - i));
         m[k] = (uint32_t)acc * FpParams::INV;
@@ -43,10 +66,7 @@ __device__ __forceinline__ Fp fp_dot(const Fp (&a)[NT], const Fp (&b)[NT]) {
 #pragma unroll
     for (int k = N; k < 2 * N - 1; ++k) {
 #pragma unroll
-        for (int i = k - N + 1; i < N; ++i) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) madc96(acc, c2, a[t].l[i], b[t].l[k - i]);
-        }
+        for (int i = k - N + 1; i < N; ++i) madc96_terms<NT>(acc, c2, a, b, i, k - i);
 #pragma unroll
         for (int i = k - N + 1; i < N; ++i) madc96_s(acc, c2, m[i], FpParams::mod(k - i));
         r.l[k - N] = (uint32_t)acc;
