@@ -124,8 +124,14 @@ __device__ __forceinline__ void vm_carry(const int64_t (&col)[fq28::NL], uint32_
 // a LIN whose bound is small) is skipped by WAVE-UNIFORM tests -- no divergence.
 __device__ __forceinline__ void vm_run(VmSlot* ws, const unsigned char* __restrict__ kind, const VmOp* __restrict__ ops, int nlayers, int lg) {
     using namespace fq28;
+    // The layers rely on the wave running them in LOCKSTEP (every lane's reads of a layer are issued before any lane's writes, LDS is in
+    // order).  The callers bracket vm_run with lane-0-only slot writes; without a CONVERGENT operation here the compiler may thread the
+    // `lg == 0` condition through a program that is not inside a loop and run it once for lane 0 and once for the other lanes, which
+    // breaks that assumption (seen in k_vm_scale_g1's first doubling).  wave_barrier is convergent and emits no instruction.
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll 1
     for (int l = 0; l < nlayers; ++l) {
+        __builtin_amdgcn_wave_barrier();
         const VmOp* __restrict__ opp = ops + (l * VM_G + lg);
         const unsigned k = kind[l];
         const unsigned dst = opp->dst;
@@ -164,6 +170,7 @@ __device__ __forceinline__ void vm_run(VmSlot* ws, const unsigned char* __restri
             vm_st(ws, dst, o);
         }
     }
+    __builtin_amdgcn_wave_barrier();
 }
 #else
 struct VmValHost {};

@@ -215,11 +215,8 @@ __global__ void __launch_bounds__(256) k_vm_scale_g1(const G1A* __restrict__ bas
         copy_slot(TX, C::SX); copy_slot(TY, C::SY); copy_slot(TZ, C::SZ);
     }
     // table: T_2 = 2 T_1, T_(m+1) = T_m + T_1 (the addend slots are rewritten before every addition: the programs use them as scratch)
-    // (block barriers around the first program: measured necessary HERE -- without them the doubling's results end up overwritten by the
-    //  initial point on lane 0, with wavefront- and workgroup-scope fences alike; every other program call of the VM kernels sits in a loop)
-    __syncthreads();
+    // (this doubling is the one program call of the VM kernels that is not inside a loop: see the convergence note in vm_run)
     C::dbl_(ws, lg);
-    __syncthreads();
     if (lg == 0) { copy_slot(TX + 1, C::SX); copy_slot(TY + 1, C::SY); copy_slot(TZ + 1, C::SZ); }
 #pragma unroll 1
     for (int m = 2; m < VM_SCALE_TAB; ++m) {
