@@ -145,6 +145,28 @@ struct DevBuf {
     template <class T> T* as() { return reinterpret_cast<T*>(p); }
 };
 
+// Engine-owned pinned host staging.  Host data this library PRODUCES (scalar vectors of the verifiers and KZG openings, gathered tails)
+// reaches the device through these, never by a hipMemcpy from a short-lived malloc'ed vector: the runtime registers such memory with the
+// driver for the copy, and in some processes its release (free -> munmap / heap trim) stalled the NEXT device operation by 15-40 ms, in
+// steps of 10 ms (measured on the n = 2^13..2^14 SIPP verifier: 13.7 ms became 30-50 ms; tools/kdev/verify_lat2.py).
+struct PinBuf {
+    void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool pending = false;
+    int32_t wait() { if (pending) { HIPCHK(hipEventSynchronize(ev)); pending = false; } return RIPP_OK; }      // the previous copy out of this buffer has landed
+    int32_t reserve(size_t bytes) {
+        int32_t rc = wait(); if (rc) return rc;
+        if (!ev) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        if (bytes <= cap) return RIPP_OK;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        HIPCHK(hipHostMalloc(&p, bytes, hipHostMallocDefault)); cap = bytes; return RIPP_OK;
+    }
+    // dst <- this buffer's first `bytes` on stream st (the caller filled it after reserve())
+    int32_t send(void* dst, size_t bytes, hipStream_t st) {
+        HIPCHK(hipMemcpyAsync(dst, p, bytes, hipMemcpyHostToDevice, st)); HIPCHK(hipEventRecord(ev, st)); pending = true; return RIPP_OK;
+    }
+    void release() { if (pending && ev) (void)hipEventSynchronize(ev); pending = false; if (p) (void)hipHostFree(p); p = nullptr; cap = 0; if (ev) (void)hipEventDestroy(ev); ev = nullptr; }
+    template <class T> T* as() { return reinterpret_cast<T*>(p); }
+};
+
 // scratch of ONE in-flight MSM (two MSMs of a GIPA-with-SSM round run side by side on two streams)
 struct MsmScratch {
     DevBuf digits, hist, offs, cursor, slotoffs, spw, sorted, slots, buckets, seg, seg2, win, out;
@@ -169,6 +191,7 @@ struct Engine {
     DevBuf qtab;                          // [u^j]Q table of the GLS G2 fold
     MsmScratch msm_scratch[2];
     DevBuf kzg_q[2];                      // quotient-polynomial coefficients of the (up to two concurrent) KZG openings
+    PinBuf stage[4];                      // pinned staging of host-produced vectors: [0], [1] scalar vectors of the two concurrent MSMs, [2] r-powers, [3] gathered tails
     DevBuf kzg_bases[2];                  // sharded openings: this rank's residue class of the SRS powers, gathered contiguously
     hipStream_t stream3 = nullptr;        // second MSM of a pair
     hipStream_t stream4 = nullptr;        // unscaled twin of m_a in the implicit-shift TIPP core
@@ -178,7 +201,7 @@ struct Engine {
     // job whose round-0 tables they hold; a job that finds another owner falls back to the table-free fold.
     DevBuf fold_tab1, fold_mult, fold_tab, fold_jac1, fold_jac2;
     const void* tab_owner = nullptr;
-    size_t vm_scale_max = (size_t)1 << 12;                                // per-element G1 scalings of <= this many elements run on the VM
+    size_t vm_scale_max = (size_t)1 << 14;                                // per-element G1 scalings of <= this many elements run on the VM (measured: direct product 6.1 -> 3.8 ms at 2^13, 7.1 -> 6.2 ms at 2^14, level at 2^15)
     size_t vm_joint_max = (size_t)1 << 13;                                // folds with <= this many outputs (and more than vm_fold_max) use the joint one-group-per-element VM forms
     size_t lp_fq_min = ~(size_t)0;        // pairs per launch from which k_line_products_q replaces k_line_products.  OFF by default: the carry-free twin is 7 % faster
                                           // (27.7 vs 29.9 ms per 2^19 pairs) but keeps ~50 dwords in scratch, i.e. 3-5x the HBM traffic of the spill-free kernel (RIPP_LP_FQ_MIN=4096 enables it)
@@ -237,6 +260,7 @@ struct Engine {
         if (stream4) (void)hipStreamDestroy(stream4); if (ev_join4) (void)hipEventDestroy(ev_join4);
         if (stream5) (void)hipStreamDestroy(stream5); if (ev_join5) (void)hipEventDestroy(ev_join5);
         if (pinned_rows) (void)hipHostFree(pinned_rows);
+        for (PinBuf& b : stage) b.release();
         for (auto& e : ev_lines) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         for (auto& e : ev_prod) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         if (stream) (void)hipStreamDestroy(stream);
@@ -640,7 +664,17 @@ void statement_digest(const G1A* a, const G2A* b, const Fr* r, size_t n, const F
     struct Seg { int kind; size_t s, e; };
     std::vector<Seg> segs;
     for (int kind = 0; kind < 3; ++kind) for (size_t s0 = 0; s0 < n; s0 += BLK) segs.push_back({kind, s0, std::min(n, s0 + BLK)});
-    std::vector<uint8_t> buf[RING]; for (auto& v : buf) v.resize(BLK * 192);
+    // The ring is taken from a process-wide pool and NEVER freed: allocating and releasing 9 MB of host memory per call makes glibc map /
+    // trim it per call, and an unmap next to (same 2 MB huge page as) a caller array the HIP runtime has pinned for an upload invalidates
+    // that registration -- the driver then evicts and restores the process's GPU queues, which stalled the next device operation of the
+    // n = 2^13..2^14 verifier by 15-40 ms in steps of 10 ms in most processes (tools/kdev/verify_lat2.py).
+    struct Ring { std::vector<uint8_t> b[RING]; };
+    static std::mutex pool_mu; static std::vector<std::unique_ptr<Ring>> pool;
+    std::unique_ptr<Ring> ring;
+    { std::lock_guard<std::mutex> lk(pool_mu); if (!pool.empty()) { ring = std::move(pool.back()); pool.pop_back(); } }
+    if (!ring) { ring.reset(new Ring()); for (auto& v : ring->b) v.resize(BLK * 192); }
+    struct Return { std::unique_ptr<Ring>& r; std::mutex& m; std::vector<std::unique_ptr<Ring>>& p; ~Return() { std::lock_guard<std::mutex> lk(m); p.emplace_back(std::move(r)); } } give_back{ring, pool_mu, pool};
+    std::vector<uint8_t>* const buf = ring->b;
     std::vector<std::future<void>> fut(segs.size());
     auto launch = [&](size_t j) {
         const Seg sg = segs[j]; uint8_t* out = buf[j % RING].data();
@@ -1217,11 +1251,14 @@ API int32_t ripp_sipp_verify(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr
     size_t lg = 0; while (((size_t)1 << lg) < n) ++lg;
     if (proof_rounds != lg) return RIPP_ERR_ARG;                          // :122-123
     LOCK; ENGINE;
+    const double tv0 = now_ms(); double tv1 = tv0;
+    auto mark = [&](const char* what) { if (trace_on()) { const double t = now_ms(); fprintf(stderr, "[ripp] verify %-10s %.2f ms (t=%.2f)\n", what, t - tv1, t - tv0); tv1 = t; } };
     // the bases do not depend on the challenges: their upload runs while the host hashes the statement (the verifier's serial floor too)
     G1A* da; G2A* db; int32_t rc;
     if ((rc = upload<G1A>(e, e->affG1, a, n, &da)) || (rc = upload<G2A>(e, e->affG2, b, n, &db))) return rc;
     uint8_t digest[32];
     if ((rc = ripp_sipp_seed_digest(a, b, r, n, claimed, digest))) return rc;      // :126-132
+    mark("digest");
     fs::FiatShamirRng rng; rng.from_digest(digest);
     const Fp12* pr = reinterpret_cast<const Fp12*>(proof);
     std::vector<Fp12> P(2 * lg); std::memcpy(P.data(), pr, 2 * lg * sizeof(Fp12));
@@ -1229,20 +1266,27 @@ API int32_t ripp_sipp_verify(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr
     for (size_t j = 0; j < lg; ++j) { xs[j] = fs::sipp_challenge(rng, P[2 * j], P[2 * j + 1]); xinv[j] = inv(xs[j]); }   // :134-149
     // z' = z * prod z_l^x z_r^(x^-1)  (:151-158): 2 log n independent GT exponentiations on the host workers.  The proof's elements are
     // untrusted Fp12 values, so this uses the plain square-and-multiply (gt_pow_host's cyclotomic squarings assume GT membership).
+    // They are queued BEFORE the scalar vectors are built when that build is single-threaded (it then overlaps them), and AFTER it when
+    // its chunks go through the same FIFO pool (n >= 2^14: the chunks would wait 2-3 ms behind the powers, which overlap the MSMs instead).
     auto gt_pow = [](const Fp12& x, const Fr& k) { const Fr c = from_mont(k); Fp12 acc = Fp12::one(); bool st = false;
         for (int i = 255; i >= 0; --i) { if (st) acc = sqr(acc); if ((c.l[i >> 5] >> (i & 31)) & 1u) { acc = st ? mul(acc, x) : x; st = true; } } return acc; };
     std::vector<std::future<Fp12>> pw;
-    // the tasks below read P / xs / xinv by reference: every exit path (the HIP error returns included) waits for them first
+    // the tasks read P / xs / xinv by reference: every exit path (the HIP error returns included) waits for them first
     struct Drain { std::vector<std::future<Fp12>>& v; ~Drain() { for (auto& f : v) if (f.valid()) f.wait(); } } drain{pw};
-    for (size_t j = 0; j < lg; ++j) {
-        pw.push_back(host_pool().submit([&, j]() { return gt_pow(P[2 * j], xs[j]); }));
-        pw.push_back(host_pool().submit([&, j]() { return gt_pow(P[2 * j + 1], xinv[j]); }));
-    }
+    auto submit_powers = [&]() {
+        for (size_t j = 0; j < lg; ++j) {
+            pw.push_back(host_pool().submit([&, j]() { return gt_pow(P[2 * j], xs[j]); }));
+            pw.push_back(host_pool().submit([&, j]() { return gt_pow(P[2 * j + 1], xinv[j]); }));
+        }
+    };
+    constexpr size_t POOLED_MIN = (size_t)1 << 14;
+    if (n < POOLED_MIN) submit_powers();
     // s_i = r_i * prod_{j : bit (lg-1-j) of i set} x_j ;  s_inv likewise (:160-172), built by doubling; long levels are split over the workers
-    std::vector<Fr> s(n), si(n); s[0] = Fr::one(); si[0] = Fr::one();
+    if ((rc = e->stage[0].reserve(n * sizeof(Fr))) || (rc = e->stage[1].reserve(n * sizeof(Fr)))) return rc;
+    Fr* const s = e->stage[0].as<Fr>(); Fr* const si = e->stage[1].as<Fr>(); s[0] = Fr::one(); si[0] = Fr::one();
     const Fr* rr = reinterpret_cast<const Fr*>(r);
     auto parallel_for = [](size_t count, const std::function<void(size_t, size_t)>& body) {
-        const size_t chunks = count >= ((size_t)1 << 14) ? 6 : 1, per = (count + chunks - 1) / chunks;
+        const size_t chunks = count >= POOLED_MIN ? 6 : 1, per = (count + chunks - 1) / chunks;
         std::vector<std::future<void>> f;
         for (size_t c = 1; c < chunks; ++c) { const size_t lo = c * per, hi = std::min(count, lo + per); if (lo < hi) f.push_back(host_pool().submit([&body, lo, hi]() { body(lo, hi); })); }
         body(0, std::min(count, per));
@@ -1255,20 +1299,26 @@ API int32_t ripp_sipp_verify(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr
     const bool aligned = ((uintptr_t)r & 15u) == 0;
     std::vector<Fr> rcopy; if (!aligned) { rcopy.resize(n); std::memcpy(rcopy.data(), r, n * sizeof(Fr)); rr = rcopy.data(); }
     parallel_for(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) s[i] = mul(s[i], rr[i]); });
+    if (n >= POOLED_MIN) submit_powers();
+    mark("scalars");
     // the two MSMs (:174-175) side by side on two streams against the bases already resident
     if ((rc = e->kzg_q[0].reserve(n * sizeof(Fr))) || (rc = e->kzg_q[1].reserve(n * sizeof(Fr)))) return rc;
-    HIPCHK(hipMemcpyAsync(e->kzg_q[0].p, s.data(), n * sizeof(Fr), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(e->kzg_q[1].p, si.data(), n * sizeof(Fr), hipMemcpyHostToDevice, e->stream));
+    if ((rc = e->stage[0].send(e->kzg_q[0].p, n * sizeof(Fr), e->stream)) || (rc = e->stage[1].send(e->kzg_q[1].p, n * sizeof(Fr), e->stream))) return rc;
     if ((rc = e->sync())) return rc;
+    mark("h2d");
     if ((rc = e->msm_launch<Fp>(e->msm_scratch[1], e->stream3, da, e->kzg_q[0].as<Fr>(), n))) return rc;
     if ((rc = e->msm_launch<Fp2>(e->msm_scratch[0], e->stream, db, e->kzg_q[1].as<Fr>(), n))) return rc;
+    mark("msm launch");
     if ((rc = e->sync())) return rc; HIPCHK(hipStreamSynchronize(e->stream3));
+    mark("msm sync");
     const G1A apa = to_affine(*reinterpret_cast<const G1J*>(e->msm_scratch[1].host_out)); const G2A bpa = to_affine(*reinterpret_cast<const G2J*>(e->msm_scratch[0].host_out));
     Fp12 zp; std::memcpy(&zp, claimed, sizeof zp);
     for (auto& f : pw) zp = mul(zp, f.get());
+    mark("gt powers");
     G1A* d1; G2A* d2; ripp_gt e12;
     if ((rc = upload<G1A>(e, e->tmpA, &apa, 1, &d1)) || (rc = upload<G2A>(e, e->tmpB, &bpa, 1, &d2))) return rc;
     if ((rc = pairing_product_dev(e, d1, d2, 1, &e12))) return rc;                                                       // :177
+    mark("pairing");
     Fp12 ev; std::memcpy(&ev, &e12, sizeof ev);
     *accept = (ev == zp) ? 1 : 0;
     return RIPP_OK;

@@ -410,3 +410,19 @@ def test_per_element_scaling_small_vectors(engine, orc):
             del os.environ["RIPP_VM_SCALE_MAX"]
     for k in range(len(small)):                                    # one element at a time: each digit pattern on its own
         assert np.array_equal(engine.product_of_pairings_with_coeffs(a[k:k + 1], b[k:k + 1], r[k:k + 1]), orc.product_of_pairings_with_coeffs(a[k:k + 1], b[k:k + 1], r[k:k + 1])), hex(small[k])
+
+
+def test_per_element_scaling_mid_size_on_the_vm(engine, orc):
+    """4 K < n <= 16 K elements are still scaled by k_vm_scale_g1 (two waves per SIMD of 16-lane groups; a ragged last block): the direct
+    product with coefficients (sipp/src/lib.rs:184-219) at n = 2^13 + 37 against the oracle, and against the throughput kernel."""
+    import os
+    n = (1 << 13) + 37
+    a, b, r = orc.gen_g1(77, n), orc.gen_g2(88, n), orc.gen_scalars(5, n)
+    a[n - 1] = 0                                                   # the identity in the ragged tail
+    exp = orc.product_of_pairings_with_coeffs(a, b, r)
+    assert np.array_equal(engine.product_of_pairings_with_coeffs(a, b, r), exp)
+    os.environ["RIPP_VM_SCALE_MAX"] = "0"
+    try:
+        assert np.array_equal(engine.product_of_pairings_with_coeffs(a, b, r), exp)
+    finally:
+        del os.environ["RIPP_VM_SCALE_MAX"]

@@ -13,3 +13,14 @@ cp $S/msm_hbm_traffic.csv profiles/${R}_msm_2p20_hbm_traffic_pmc.csv
 cp $S/msm_kstats/k_kernel_stats.csv profiles/${R}_msm_2p20_kernel_stats_rocprofv3.csv
 cp $S/sq_counters.csv profiles/${R}_sq_counters_pmc.csv
 ls -la profiles | tail -30
+# the sweeps of tools/run_final.sh <tag> (gpurun_out/final_<tag>/), when present
+F=gpurun_out/final_$TAG
+if [ -d $F ]; then
+  cp $F/ipp-mi355x-hip.csv profiles/${R}_scaling_ipp_mi355x.csv
+  cp $F/ipp-cpu-oracle.csv profiles/${R}_scaling_ipp_cpu_oracle_16thr.csv
+  cp $F/c377/ipp-mi355x-hip-bls12_377.csv profiles/${R}_scaling_ipp_bls12_377_mi355x.csv
+  cp $F/c377/ipp-cpu-oracle-bls12_377.csv profiles/${R}_scaling_ipp_bls12_377_cpu_oracle_16thr.csv
+  cp $F/aggregate_2p14.json profiles/${R}_aggregate_2p14.json
+  cp $F/bench_n2_single_device_gloo.json profiles/${R}_bench_n2_single_device_gloo.json
+  [ -s $F/poly_commit_bench.csv ] && cp $F/poly_commit_bench.csv profiles/${R}_poly_commit_bench.csv
+fi
