@@ -142,7 +142,8 @@ typedef struct ripp_sipp_job ripp_sipp_job;
 int32_t ripp_sipp_job_create(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr* r, size_t n_local,
                              int32_t rank, int32_t world, ripp_sipp_job** job);
 void    ripp_sipp_job_destroy(ripp_sipp_job* job);
-/* whole proof on one GPU (world == 1) from the resident statement */
+/* whole proof on one GPU (world == 1) from the resident statement; the job's working vectors are consumed (ripp_sipp_job_local_len() == 0
+ * afterwards: the prover discards the last fold, sipp/src/lib.rs:87-104, so it is not computed); ripp_sipp_job_begin() restarts from the statement */
 int32_t ripp_sipp_job_prove(ripp_sipp_job* job, const ripp_gt* value, ripp_gt* proof, ripp_fr* challenges, ripp_stats* stats);
 /* staged interface for world > 1 (the caller all-gathers 2 x 576 B per round over RCCL):
  *   begin: re-arm the job from the resident statement (scaling a_i <- r_i a_i of this shard)

@@ -213,6 +213,7 @@ struct Engine {
     Fp12* pinned_rows = nullptr;          // pinned host landing zone for per-step products
     size_t pinned_rows_cap = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_lines, ev_prod;   // per-launch event pairs of the two dominant kernels
+    size_t tail_pipe_max = (size_t)1 << 11;                               // SIPP rounds of at most this length run pipelined (job_tail_enqueue); 0 = off
     size_t vm_tree_max = (size_t)1 << 16;                                 // tree levels with <= this many products use the VM Fp12 multiplier
     size_t vm_fold_max = (size_t)1 << 11;                                 // folds with <= this many outputs use the VM scalar multiplications
     DevBuf vm_flag;
@@ -249,7 +250,7 @@ struct Engine {
         HIPCHK(hipEventCreate(&ev_t0)); HIPCHK(hipEventCreate(&ev_t1));
         { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n_simd = pr.multiProcessorCount * 4; }
         auto env_sz = [](const char* k, size_t& v) { if (const char* s = std::getenv(k)) v = (size_t)std::strtoull(s, nullptr, 10); };
-        env_sz("RIPP_VM_LINES_MAX", vm_lines_max); env_sz("RIPP_VM_FOLD_MAX", vm_fold_max); env_sz("RIPP_VM_TREE_MAX", vm_tree_max); env_sz("RIPP_GLS_SPLIT_MAX", gls_split_max); env_sz("RIPP_MSM_VM_MERGE_MAX", msm_vm_merge_max); env_sz("RIPP_FOLD_TAB_MIN", fold_tab_min); env_sz("RIPP_FQ_MIN", fq_min); env_sz("RIPP_LP_FQ_MIN", lp_fq_min); env_sz("RIPP_VM_JOINT_MAX", vm_joint_max); env_sz("RIPP_VM_SCALE_MAX", vm_scale_max);
+        env_sz("RIPP_VM_LINES_MAX", vm_lines_max); env_sz("RIPP_VM_FOLD_MAX", vm_fold_max); env_sz("RIPP_VM_TREE_MAX", vm_tree_max); env_sz("RIPP_GLS_SPLIT_MAX", gls_split_max); env_sz("RIPP_MSM_VM_MERGE_MAX", msm_vm_merge_max); env_sz("RIPP_FOLD_TAB_MIN", fold_tab_min); env_sz("RIPP_FQ_MIN", fq_min); env_sz("RIPP_LP_FQ_MIN", lp_fq_min); env_sz("RIPP_VM_JOINT_MAX", vm_joint_max); env_sz("RIPP_VM_SCALE_MAX", vm_scale_max); env_sz("RIPP_TAIL_PIPE_MAX", tail_pipe_max);
         device = dev;
         return RIPP_OK;
     }
@@ -395,6 +396,63 @@ struct Engine {
 
     // ---- pairing product: per-step products of `nprod` products of M pairs each ---------------------------
     // a[p], b[p]: device pointers to M affine pairs for product p.  rows_out: host, [nprod][68] Fp12 (Montgomery).
+    // One batch of `nprod` pairing products over the pairs [off, off + m): stage 1 (lines), stage 2 (per-step products + tree) and the copy of
+    // the nprod * 68 per-step values into `dst_pinned`, all ENQUEUED on `stream` -- no synchronisation.
+    int32_t enqueue_products(const G1A* const* a, const G2A* const* b, int nprod, size_t off, size_t m, Fp12* dst_pinned) {
+        const size_t nrows = (size_t)nprod * N_LINES;
+        int32_t rc;
+        const size_t stride = (m + 63) & ~(size_t)63;
+        if ((rc = lines.reserve(nrows * LINE_CHUNKS * stride * sizeof(uint4))) != RIPP_OK) return rc;
+        // stage 1: one launch, grid.y = product
+        {
+            PairSets ps{}; for (int p = 0; p < nprod; ++p) { ps.a[p] = a[p] + off; ps.b[p] = b[p] + off; }
+            if ((rc = mark(ev_lines, true)) != RIPP_OK) return rc;
+            if (m * nprod <= vm_lines_max && !sw.no_vm)
+                hipLaunchKernelGGL(k_vm_miller_lines, dim3(nblk(m, 4 * VM_EPW), nprod), dim3(256), 4 * VM_EPW * VM_LINES_SLOTS * sizeof(VmSlot), stream, ps, (uint32_t)m, lines.as<uint4>(), stride);
+            else
+                hipLaunchKernelGGL(k_miller_lines, dim3(nblk(m, 256), nprod), dim3(256), 0, stream, ps, (uint32_t)m, lines.as<uint4>(), stride);
+            HIPCHK(hipGetLastError());
+            if ((rc = mark(ev_lines, false)) != RIPP_OK) return rc;
+            stats.pairs_lines += m * nprod;
+        }
+        // stage 2a: T lanes per row
+        // one resident batch: rows * T / 64 waves <= SIMDs * RIPP_OCC, so no partially filled second batch
+        // T accumulators per row.  Spill-free form (line_products.hpp): 3 lanes per accumulator, 21 accumulators per wave;
+        // RIPP_LP_ONE_LANE=1 selects the one-lane-per-accumulator kernel (A/B reference).
+        const uint32_t per_wave = sw.lp_one_lane ? 64 : LP_GROUPS_PER_WAVE;
+        uint32_t T = (uint32_t)std::max<size_t>(per_wave, ((size_t)n_simd * RIPP_OCC_PROD / nrows) * per_wave);
+        if (T > m) T = (uint32_t)m;
+        if ((rc = partA.reserve(nrows * FP12_CHUNKS * (size_t)T * sizeof(uint4))) != RIPP_OK) return rc;
+        if ((rc = partB.reserve(nrows * FP12_CHUNKS * (size_t)((T + 1) / 2) * sizeof(uint4))) != RIPP_OK) return rc;
+        if ((rc = mark(ev_prod, true)) != RIPP_OK) return rc;
+#if !defined(RIPP_BLS12_377)
+        if (sw.lp_one_lane)
+            hipLaunchKernelGGL(k_line_products1, dim3(nblk(T, 64), (unsigned)nrows), dim3(64), 0, stream, lines.as<uint4>(), stride, (uint32_t)m, partA.as<uint4>(), T);
+        else if (!sw.no_fq && m * nprod >= lp_fq_min)          // throughput-sized launches: the carry-free twin (fq_line_products.hpp)
+            hipLaunchKernelGGL(k_line_products_q, dim3(nblk(T, LP_GROUPS_PER_WAVE), (unsigned)nrows), dim3(64), 0, stream, lines.as<uint4>(), stride, (uint32_t)m, partA.as<uint4>(), T);
+        else
+#endif
+            hipLaunchKernelGGL(k_line_products, dim3(nblk(T, LP_GROUPS_PER_WAVE), (unsigned)nrows), dim3(64), 0, stream, lines.as<uint4>(), stride, (uint32_t)m, partA.as<uint4>(), T);
+        HIPCHK(hipGetLastError());
+        if ((rc = mark(ev_prod, false)) != RIPP_OK) return rc;
+        stats.pairs_products += m * nprod;
+        // stage 2b: dense tree, radix 4
+        uint4* cur = partA.as<uint4>(); uint4* nxt = partB.as<uint4>();
+        while (T > 1) {
+            // radix 4 while the level still fills the chip, radix 2 (one dependent Fp12 product per level) once it is latency-bound
+            const int R = ((size_t)T * nrows > (size_t)n_simd * 64) ? 4 : 2;
+            const uint32_t Tout = (T + R - 1) / R;
+            if (R == 2 && (size_t)Tout * nrows <= vm_tree_max && !sw.no_vm)
+                hipLaunchKernelGGL(k_vm_fp12_tree, dim3(nblk(Tout, 2 * VM_EPW), (unsigned)nrows), dim3(128), 2 * VM_EPW * VM_F12_SLOTS * sizeof(VmSlot), stream, cur, T, nxt, Tout);
+            else
+            hipLaunchKernelGGL(k_fp12_tree, dim3(nblk(Tout, 64), (unsigned)nrows), dim3(64), 0, stream, cur, T, nxt, Tout, R);
+            HIPCHK(hipGetLastError());
+            std::swap(cur, nxt); T = Tout;
+        }
+        // rows are now [nrows][36][1] == nrows contiguous Fp12
+        HIPCHK(hipMemcpyAsync(dst_pinned, cur, nrows * sizeof(Fp12), hipMemcpyDeviceToHost, stream));
+        return RIPP_OK;
+    }
     int32_t step_products(const G1A* const* a, const G2A* const* b, int nprod, size_t M, Fp12* rows_out) {
         const size_t nrows = (size_t)nprod * N_LINES;
         for (size_t r = 0; r < nrows; ++r) rows_out[r] = Fp12::one();
@@ -405,56 +463,7 @@ struct Engine {
         const size_t batch = std::min(M, std::max<size_t>(1, max_pairs_per_batch / nprod));
         for (size_t off = 0; off < M; off += batch) {
             const size_t m = std::min(batch, M - off);
-            const size_t stride = (m + 63) & ~(size_t)63;
-            if ((rc = lines.reserve(nrows * LINE_CHUNKS * stride * sizeof(uint4))) != RIPP_OK) return rc;
-            // stage 1: one launch, grid.y = product
-            {
-                PairSets ps{}; for (int p = 0; p < nprod; ++p) { ps.a[p] = a[p] + off; ps.b[p] = b[p] + off; }
-                if ((rc = mark(ev_lines, true)) != RIPP_OK) return rc;
-                if (m * nprod <= vm_lines_max && !sw.no_vm)
-                    hipLaunchKernelGGL(k_vm_miller_lines, dim3(nblk(m, 4 * VM_EPW), nprod), dim3(256), 4 * VM_EPW * VM_LINES_SLOTS * sizeof(VmSlot), stream, ps, (uint32_t)m, lines.as<uint4>(), stride);
-                else
-                    hipLaunchKernelGGL(k_miller_lines, dim3(nblk(m, 256), nprod), dim3(256), 0, stream, ps, (uint32_t)m, lines.as<uint4>(), stride);
-                HIPCHK(hipGetLastError());
-                if ((rc = mark(ev_lines, false)) != RIPP_OK) return rc;
-                stats.pairs_lines += m * nprod;
-            }
-            // stage 2a: T lanes per row
-            // one resident batch: rows * T / 64 waves <= SIMDs * RIPP_OCC, so no partially filled second batch
-            // T accumulators per row.  Spill-free form (line_products.hpp): 3 lanes per accumulator, 21 accumulators per wave;
-            // RIPP_LP_ONE_LANE=1 selects the one-lane-per-accumulator kernel (A/B reference).
-            const uint32_t per_wave = sw.lp_one_lane ? 64 : LP_GROUPS_PER_WAVE;
-            uint32_t T = (uint32_t)std::max<size_t>(per_wave, ((size_t)n_simd * RIPP_OCC_PROD / nrows) * per_wave);
-            if (T > m) T = (uint32_t)m;
-            if ((rc = partA.reserve(nrows * FP12_CHUNKS * (size_t)T * sizeof(uint4))) != RIPP_OK) return rc;
-            if ((rc = partB.reserve(nrows * FP12_CHUNKS * (size_t)((T + 1) / 2) * sizeof(uint4))) != RIPP_OK) return rc;
-            if ((rc = mark(ev_prod, true)) != RIPP_OK) return rc;
-#if !defined(RIPP_BLS12_377)
-            if (sw.lp_one_lane)
-                hipLaunchKernelGGL(k_line_products1, dim3(nblk(T, 64), (unsigned)nrows), dim3(64), 0, stream, lines.as<uint4>(), stride, (uint32_t)m, partA.as<uint4>(), T);
-            else if (!sw.no_fq && m * nprod >= lp_fq_min)          // throughput-sized launches: the carry-free twin (fq_line_products.hpp)
-                hipLaunchKernelGGL(k_line_products_q, dim3(nblk(T, LP_GROUPS_PER_WAVE), (unsigned)nrows), dim3(64), 0, stream, lines.as<uint4>(), stride, (uint32_t)m, partA.as<uint4>(), T);
-            else
-#endif
-                hipLaunchKernelGGL(k_line_products, dim3(nblk(T, LP_GROUPS_PER_WAVE), (unsigned)nrows), dim3(64), 0, stream, lines.as<uint4>(), stride, (uint32_t)m, partA.as<uint4>(), T);
-            HIPCHK(hipGetLastError());
-            if ((rc = mark(ev_prod, false)) != RIPP_OK) return rc;
-            stats.pairs_products += m * nprod;
-            // stage 2b: dense tree, radix 4
-            uint4* cur = partA.as<uint4>(); uint4* nxt = partB.as<uint4>();
-            while (T > 1) {
-                // radix 4 while the level still fills the chip, radix 2 (one dependent Fp12 product per level) once it is latency-bound
-                const int R = ((size_t)T * nrows > (size_t)n_simd * 64) ? 4 : 2;
-                const uint32_t Tout = (T + R - 1) / R;
-                if (R == 2 && (size_t)Tout * nrows <= vm_tree_max && !sw.no_vm)
-                    hipLaunchKernelGGL(k_vm_fp12_tree, dim3(nblk(Tout, 2 * VM_EPW), (unsigned)nrows), dim3(128), 2 * VM_EPW * VM_F12_SLOTS * sizeof(VmSlot), stream, cur, T, nxt, Tout);
-                else
-                hipLaunchKernelGGL(k_fp12_tree, dim3(nblk(Tout, 64), (unsigned)nrows), dim3(64), 0, stream, cur, T, nxt, Tout, R);
-                HIPCHK(hipGetLastError());
-                std::swap(cur, nxt); T = Tout;
-            }
-            // rows are now [nrows][36][1] == nrows contiguous Fp12
-            HIPCHK(hipMemcpyAsync(pinned_rows, cur, nrows * sizeof(Fp12), hipMemcpyDeviceToHost, stream));
+            if ((rc = enqueue_products(a, b, nprod, off, m, pinned_rows)) != RIPP_OK) return rc;
             if ((rc = sync()) != RIPP_OK) return rc;
             for (size_t r = 0; r < nrows; ++r) rows_out[r] = (off == 0) ? pinned_rows[r] : mul(rows_out[r], pinned_rows[r]);
         }
@@ -721,6 +730,9 @@ struct ripp_sipp_job {
     // round 1's z_l pre-evaluated in the hash window through bilinearity (see job_preevaluate_round1): the four quarter products
     Fp12 pre_zl[4]; bool pre_zl_ready = false;
     DevBuf a_pow_h, b_pow_h, parts1, parts2; bool pre_vm_ready = false;   // the same for the small rounds, on the field VM (vm_fold2.hpp)
+    // pipelined tail (job_tail_enqueue): per-step values of the eight quarter products that give round R's (z_l, z_r) once x_(R-1) is known,
+    // evaluated from round R-1's UNFOLDED vectors; slot R & 1, tp_round[slot] = R while they are enqueued / waiting to be used
+    PinBuf tp_rows[2]; size_t tp_round[2] = {~(size_t)0, ~(size_t)0};
     std::vector<G1A> ha; std::vector<G2A> hb; std::vector<Fr> hr;   // host copy of the statement (rank 0 hashes it)
     const G1A* ha_ext = nullptr; const G2A* hb_ext = nullptr; const Fr* hr_ext = nullptr;   // one-shot proofs hash the CALLER's buffers in place
     bool hash_prestarted = false;
@@ -753,6 +765,7 @@ int32_t job_begin(Engine* e, ripp_sipp_job* j) {
     float ms = 0; (void)hipEventElapsedTime(&ms, t0, t1); e->stats.scale_ms += ms;
     j->len = n; j->seeded = false; j->world = j->world0;
     j->bs = Fr::one(); j->bs_on = false;
+    j->pre_vm_ready = false; j->pre_ready = false; j->pre_zl_ready = false; j->tp_round[0] = j->tp_round[1] = ~(size_t)0;      // nothing prepared for these vectors yet
     return RIPP_OK;
 }
 
@@ -869,7 +882,7 @@ int32_t fold_g2_table(Engine* e, hipStream_t st, const G2A* hi, const G2A* lo, s
     return RIPP_OK;
 }
 
-int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true) {
+int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true, bool async = false) {
     const size_t half = j->len / 2;
     int32_t rc;
     const Fr x_inv = inv(x);                                                        // sipp/src/lib.rs:94
@@ -968,8 +981,10 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true)
     if ((rc = e->normalize_dev<Fp2>(j->jac2.as<G2J>(), half, j->b_next.as<G2A>())) != RIPP_OK) return rc;
     HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
     HIPCHK(hipEventRecord(t1, e->stream));
-    if ((rc = e->sync()) != RIPP_OK) return rc;
-    float ms = 0; (void)hipEventElapsedTime(&ms, t0, t1); e->stats.fold_ms += ms;
+    if (!async) {                 // pipelined tail rounds (async): everything that follows is ordered behind the fold on the engine's streams
+        if ((rc = e->sync()) != RIPP_OK) return rc;
+        float ms = 0; (void)hipEventElapsedTime(&ms, t0, t1); e->stats.fold_ms += ms;
+    }
     std::swap(j->a, j->a_next); std::swap(j->b, j->b_next);
     j->len = half;
     return RIPP_OK;
@@ -1371,6 +1386,7 @@ API void ripp_sipp_job_destroy(ripp_sipp_job* j) {
     if (!j) return; LOCK;
     if (j->hash_thread.joinable()) j->hash_thread.join();
     for (DevBuf* b : {&j->a0, &j->b0, &j->r0, &j->a, &j->b, &j->a_next, &j->b_next, &j->jac1, &j->jac2, &j->a_pow, &j->b_pow, &j->a_pow_h, &j->b_pow_h, &j->parts1, &j->parts2}) b->release();
+    j->tp_rows[0].release(); j->tp_rows[1].release();
     if (g_engine && g_engine->tab_owner == j) g_engine->tab_owner = nullptr;
     delete j; --g_live_handles;
 }
@@ -1433,6 +1449,54 @@ API int32_t ripp_combine_partials(const ripp_gt* gathered, int32_t world, size_t
 }
 API int32_t ripp_sipp_job_stats(const ripp_sipp_job* j, ripp_stats* st) { LOCK; ENGINE; if (!j || !st) return RIPP_ERR_ARG; e->collect_kernel_stats(); *st = e->stats; return RIPP_OK; }
 
+// ---- pipelined tail rounds -------------------------------------------------------------------------------------------------------------
+// A latency-bound round is  products (0.5 ms, device) -> final exponentiations + hash (0.65 ms, host) -> fold (0.7 ms, device): 1.8 ms in which
+// device and host wait for each other.  With the quarters a = [a0|a1|a2|a3], b = [b0|b1|b2|b3] of the CURRENT vectors and this round's
+// challenge x, the NEXT round's values are (bilinearity, as in job_preevaluate_round1)
+//     z_l' = E(a1,b0) E(a1,b2)^(1/x) E(a3,b0)^x E(a3,b2),      z_r' = E(a0,b1) E(a0,b3)^(1/x) E(a2,b1)^x E(a2,b3),
+// eight quarter-size products that need no challenge: four times the pairs, which costs nothing while a round does not fill the chip.  They
+// are enqueued BEHIND the previous fold; the fold itself is no longer waited for: once x is known the host goes straight to the next
+// round's six final exponentiations and four GT powers while the device folds and evaluates the round after that.  Same group elements,
+// same proof bytes.
+static bool tail_pipe_ok(const Engine* e, const ripp_sipp_job* j) {
+    return j->len >= 4 && j->len <= e->tail_pipe_max && j->len / 2 <= e->vm_fold_max && 2 * j->len <= e->max_pairs_per_batch && !j->bs_on && j->world0 == 1 && !e->sw.no_vm && !e->sw.no_precompute && !e->sw.no_endo;
+}
+// enqueue the eight quarter products of the current vectors: they become round `for_round`'s values
+static int32_t job_tail_enqueue(Engine* e, ripp_sipp_job* j, size_t for_round) {
+    const size_t q = j->len / 4; const int slot = (int)(for_round & 1);
+    const G1A* a = j->a.as<G1A>(); const G2A* b = j->b.as<G2A>();
+    const G1A* as[8] = {a + q, a + q, a + 3 * q, a + 3 * q, a, a, a + 2 * q, a + 2 * q};
+    const G2A* bs[8] = {b, b + 2 * q, b, b + 2 * q, b + q, b + 3 * q, b + q, b + 3 * q};
+    PinBuf& buf = j->tp_rows[slot];
+    int32_t rc = buf.reserve(8 * N_LINES * sizeof(Fp12)); if (rc) return rc;
+    if ((rc = e->enqueue_products(as, bs, 8, 0, q, buf.as<Fp12>()))) return rc;
+    HIPCHK(hipEventRecord(buf.ev, e->stream)); buf.pending = true;
+    j->tp_round[slot] = for_round;
+    return RIPP_OK;
+}
+// (z_l, z_r) of round `round` from its enqueued quarter products and the previous challenge
+static int32_t job_tail_values(ripp_sipp_job* j, size_t round, const Fr& x_prev, Fp12* zl, Fp12* zr) {
+    const int slot = (int)(round & 1);
+    PinBuf& buf = j->tp_rows[slot];
+    int32_t rc = buf.wait(); if (rc) return rc;
+    j->tp_round[slot] = ~(size_t)0;
+    const Fp12* rows = buf.as<Fp12>();
+    Fp12 T[6];          // per side: E0 * E3 (one final exponentiation for the pair), E1, E2
+    host_pool().parallel(6, [&](int t) {
+        const Fp12* base = rows + (size_t)(t / 3) * 4 * N_LINES; const int kind = t % 3;
+        if (kind == 0) {
+            Fp12 prod[N_LINES];
+            for (int s2 = 0; s2 < N_LINES; ++s2) prod[s2] = mul(base[s2], base[3 * N_LINES + s2]);
+            T[t] = final_exponentiation(miller_combine(prod));
+        } else T[t] = final_exponentiation(miller_combine(base + (size_t)kind * N_LINES));
+    });
+    const Fr xi = inv(x_prev);
+    Fp12 P[4];
+    host_pool().parallel(4, [&](int t) { P[t] = gt_pow_gls(T[3 * (t >> 1) + 1 + (t & 1)], (t & 1) ? x_prev : xi); });
+    *zl = mul(mul(T[0], P[0]), P[1]); *zr = mul(mul(T[3], P[2]), P[3]);
+    return RIPP_OK;
+}
+
 API int32_t ripp_sipp_job_prove(ripp_sipp_job* j, const ripp_gt* value, ripp_gt* proof, ripp_fr* challenges, ripp_stats* st) {
     LOCK; ENGINE; if (!j || !value || !proof || j->world0 != 1) return RIPP_ERR_ARG;
     Fp12 val; std::memcpy(&val, value, sizeof(Fp12));
@@ -1446,12 +1510,15 @@ API int32_t ripp_sipp_job_prove(ripp_sipp_job* j, const ripp_gt* value, ripp_gt*
     size_t round = 0;
     Fr x_prev = Fr::zero();
     j->pre_zl_ready = false;
+    j->tp_round[0] = j->tp_round[1] = ~(size_t)0;
     while (j->len > 1) {
         Fp12 rows[2 * N_LINES];
         const double tr0 = now_ms();
         const bool have_zl = round == 1 && j->pre_zl_ready;                                  // z_l of round 1 was evaluated in the hash window
         j->pre_zl_ready = false;
-        if (have_zl) {                                                                       // only z_r = prod e(a_l, b_r) on the device
+        const bool tp_round = j->tp_round[round & 1] == round;                               // pipelined tail: this round's products were enqueued a round ago
+        if (tp_round) {
+        } else if (have_zl) {                                                                // only z_r = prod e(a_l, b_r) on the device
             const size_t half = j->len / 2;
             const G1A* as[1] = {j->a.as<G1A>()}; const G2A* bs[1] = {j->b.as<G2A>() + half};
             const double tp = now_ms();
@@ -1459,10 +1526,12 @@ API int32_t ripp_sipp_job_prove(ripp_sipp_job* j, const ripp_gt* value, ripp_gt*
             e->stats.miller_products_ms += now_ms() - tp;
         } else if ((rc = job_round_partials(e, j, rows))) return rc;
         if (round == 0 && !j->seeded && (rc = job_precompute_round0(e, j))) return rc;      // asynchronous: overlaps the host work below and the hash
-        if ((rc = job_precompute_vm(e, j))) return rc;                                       // small rounds: the same on the VM, during the host phase
+        if (!j->pre_vm_ready && (rc = job_precompute_vm(e, j))) return rc;                   // small rounds: the same on the VM, during the host phase
+        if (!tp_round && tail_pipe_ok(e, j) && (rc = job_tail_enqueue(e, j, round + 1))) return rc;      // entry into the pipelined tail
         const double t0 = now_ms();
         Fp12 zl, zr;
-        if (have_zl) {          // E(a1,b0) * E(a1,b2)^(1/x) * E(a3,b0)^x * E(a3,b2): two GT powers on host threads (values of GT proper)
+        if (tp_round) { if ((rc = job_tail_values(j, round, x_prev, &zl, &zr))) return rc; }
+        else if (have_zl) {          // E(a1,b0) * E(a1,b2)^(1/x) * E(a3,b0)^x * E(a3,b2): two GT powers on host threads (values of GT proper)
             const Fr xi = inv(x_prev);
             auto p1 = host_pool().submit([j, xi]() { return gt_pow_gls(j->pre_zl[1], xi); });
             auto p2 = host_pool().submit([j, x_prev]() { return gt_pow_gls(j->pre_zl[2], x_prev); });
@@ -1488,12 +1557,19 @@ API int32_t ripp_sipp_job_prove(ripp_sipp_job* j, const ripp_gt* value, ripp_gt*
         std::memcpy(&proof[2 * round], &zl, sizeof(Fp12)); std::memcpy(&proof[2 * round + 1], &zr, sizeof(Fp12));
         if (challenges) std::memcpy(&challenges[round], &x, sizeof(Fr));
         const double tf0 = now_ms();
-        if ((rc = job_fold(e, j, x))) return rc;
+        const bool pipelined = j->tp_round[(round + 1) & 1] == round + 1;      // the next round's values are on their way: nobody waits for this fold
+        if (j->len == 2) { j->len = 0; j->pre_vm_ready = false; }      // the one-element vectors of the LAST fold are discarded by the prover (sipp/src/lib.rs:87-104 ends the loop): not computed
+        else if ((rc = job_fold(e, j, x, true, pipelined))) return rc;
+        if (pipelined) {              // behind the fold, on the new vectors: the second fold bases of the next round, the values of the round after it
+            if (!j->pre_vm_ready && (rc = job_precompute_vm(e, j))) return rc;
+            if (tail_pipe_ok(e, j) && (rc = job_tail_enqueue(e, j, round + 2))) return rc;
+        }
         if (trace_on()) fprintf(stderr, "[ripp] round %2zu len %8zu: products %.2f ms, host %.2f ms, fold %.2f ms (t=%.1f)\n", round, j->len * 2, t0 - tr0, tf0 - t0, now_ms() - tf0, now_ms() - t_start);
         ++round;
     }
     if (j->hash_thread.joinable()) j->hash_thread.join();     // n == 1: no rounds
     host_pool().set_hot(false);
+    if ((rc = e->sync())) return rc; HIPCHK(hipStreamSynchronize(e->stream2));      // the pipelined tail does not wait for its folds
     e->collect_kernel_stats();
     e->stats.total_ms = now_ms() - t_start;
     if (st) *st = e->stats;

@@ -49,7 +49,7 @@ __device__ __forceinline__ T load_chunks(const uint4* buf, size_t row, size_t st
 // ---- stage 1: line elements --------------------------------------------------------------------------------
 // grid.y = product index p: pairs (a[p][i], b[p][i]), i < M, rows p*68 .. p*68+67 of lines[rows][18][stride].
 // Pairs with a point at infinity emit the unit line.  Both pairing products of a SIPP round go in ONE launch.
-constexpr int MAX_PRODUCTS = 6;     // pairing products sharing one launch (2 per SIPP round, 6 per GIPA/TIPP round)
+constexpr int MAX_PRODUCTS = 8;     // pairing products sharing one launch (2 per SIPP round, 6 per GIPA/TIPP round, 8 quarter products of a pipelined SIPP tail round)
 struct PairSets { const G1A* a[MAX_PRODUCTS]; const G2A* b[MAX_PRODUCTS]; };
 // Register discipline of this kernel (it used to spill 273 dwords, ~35 GB of scratch traffic per launch): the steps below are written in
 // a LOW-LIVENESS order pinned with scheduling barriers -- every line coefficient is stored the moment it is complete, P and Q are

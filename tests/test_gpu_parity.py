@@ -426,3 +426,28 @@ def test_per_element_scaling_mid_size_on_the_vm(engine, orc):
         assert np.array_equal(engine.product_of_pairings_with_coeffs(a, b, r), exp)
     finally:
         del os.environ["RIPP_VM_SCALE_MAX"]
+
+
+@pytest.mark.parametrize("n", [2, 4, 8, 64, 1 << 12])
+def test_pipelined_tail_rounds_and_job_reuse(engine, orc, n):
+    """Rounds of <= 2^11 elements take their (z_l, z_r) from eight quarter products of the PREVIOUS round's unfolded vectors and the previous
+    challenge (engine.hip job_tail_enqueue / job_tail_values), their folds are not waited for and the last fold is not computed
+    (sipp/src/lib.rs:69-104): same proof bytes as the oracle, as the round-by-round form (RIPP_TAIL_PIPE_MAX=0), and again when the same
+    resident job is proved a second and a third time (nothing prepared for one proof may leak into the next)."""
+    import os
+    a, b, r = orc.gen_g1(31, n), orc.gen_g2(32, n), orc.gen_scalars(33, n)
+    v = orc.product_of_pairings_with_coeffs(a, b, r)
+    rc, eproof, ech = orc.sipp_prove(a, b, r, v)
+    assert rc == 0
+    job = engine.SippJob(a, b, r)
+    try:
+        for rep in range(3):
+            if rep == 1: os.environ["RIPP_TAIL_PIPE_MAX"] = "0"
+            try:
+                proof, ch, _ = job.prove(v)
+            finally:
+                os.environ.pop("RIPP_TAIL_PIPE_MAX", None)
+            assert np.array_equal(proof, eproof), (n, rep)
+            assert np.array_equal(ch, ech), (n, rep)
+    finally:
+        job.close()
