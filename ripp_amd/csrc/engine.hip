@@ -1478,7 +1478,9 @@ static int32_t job_tail_enqueue(Engine* e, ripp_sipp_job* j, size_t for_round) {
 static int32_t job_tail_values(ripp_sipp_job* j, size_t round, const Fr& x_prev, Fp12* zl, Fp12* zr) {
     const int slot = (int)(round & 1);
     PinBuf& buf = j->tp_rows[slot];
+    const double tw0 = now_ms();
     int32_t rc = buf.wait(); if (rc) return rc;
+    const double tw1 = now_ms();
     j->tp_round[slot] = ~(size_t)0;
     const Fp12* rows = buf.as<Fp12>();
     Fp12 T[6];          // per side: E0 * E3 (one final exponentiation for the pair), E1, E2
@@ -1490,10 +1492,16 @@ static int32_t job_tail_values(ripp_sipp_job* j, size_t round, const Fr& x_prev,
             T[t] = final_exponentiation(miller_combine(prod));
         } else T[t] = final_exponentiation(miller_combine(base + (size_t)kind * N_LINES));
     });
-    const Fr xi = inv(x_prev);
-    Fp12 P[4];
-    host_pool().parallel(4, [&](int t) { P[t] = gt_pow_gls(T[3 * (t >> 1) + 1 + (t & 1)], (t & 1) ? x_prev : xi); });
-    *zl = mul(mul(T[0], P[0]), P[1]); *zr = mul(mul(T[3], P[2]), P[3]);
+    const double tw2 = now_ms();
+    // per side: E1^(1/x) as two tasks of two digit strings each (1/x is full width: four strings), E2^x as one (x is 128 bits: two strings)
+    const GlsDigits gx = gls_digits(x_prev), gxi = gls_digits(inv(x_prev));
+    Fp12 P[6];
+    host_pool().parallel(6, [&](int t) {
+        const int side = t / 3, part = t % 3;
+        P[t] = part == 2 ? gt_pow_gls_strings(T[3 * side + 2], gx, 15u) : gt_pow_gls_strings(T[3 * side + 1], gxi, part == 0 ? 3u : 12u);
+    });
+    *zl = mul(mul(T[0], P[0]), mul(P[1], P[2])); *zr = mul(mul(T[3], P[3]), mul(P[4], P[5]));
+    if (trace_on()) fprintf(stderr, "[ripp] tail values: waited %.2f ms for the device, final exponentiations %.2f ms, powers %.2f ms\n", tw1 - tw0, tw2 - tw1, now_ms() - tw2);
     return RIPP_OK;
 }
 
@@ -1539,9 +1547,10 @@ API int32_t ripp_sipp_job_prove(ripp_sipp_job* j, const ripp_gt* value, ripp_gt*
             zl = mul(mul(j->pre_zl[0], p1.get()), mul(p2.get(), j->pre_zl[3]));
         } else { Fp12 z2[2]; pairing_values(rows, 2, z2); zl = z2[0]; zr = z2[1]; }
         if (j->bs_on) {      // the device holds bs * b: what it evaluated is z^bs (the pre-evaluated z_l of round 1 came from the plain quarters)
-            const Fr si = inv(j->bs);
-            Fp12* zz[2] = {&zl, &zr};
-            host_pool().parallel(2, [&](int k) { if (k == 0 && have_zl) return; *zz[k] = gt_pow_gls(*zz[k], si); });
+            const GlsDigits gsi = gls_digits(inv(j->bs));                     // two tasks of two digit strings per value
+            Fp12* zz[2] = {&zl, &zr}; Fp12 part[4];
+            host_pool().parallel(4, [&](int t) { if ((t >> 1) == 0 && have_zl) return; part[t] = gt_pow_gls_strings(*zz[t >> 1], gsi, (t & 1) ? 12u : 3u); });
+            for (int k = 0; k < 2; ++k) if (!(k == 0 && have_zl)) *zz[k] = mul(part[2 * k], part[2 * k + 1]);
         }
         if (round == 0 && !j->seeded && (rc = job_preevaluate_round1(e, j))) return rc;      // blocks on the GPU while the hash thread is still busy
         if (!j->seeded) {
