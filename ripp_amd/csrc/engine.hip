@@ -729,7 +729,7 @@ struct ripp_sipp_job {
     DevBuf a_pow, b_pow; bool pre_ready = false;   // 2^64 * a_r and 2^32 * b_r of round 0, prepared while the statement hash finishes
     // round 1's z_l pre-evaluated in the hash window through bilinearity (see job_preevaluate_round1): the four quarter products
     Fp12 pre_zl[4]; bool pre_zl_ready = false;
-    DevBuf a_pow_h, b_pow_h, parts1, parts2; bool pre_vm_ready = false;   // the same for the small rounds, on the field VM (vm_fold2.hpp)
+    DevBuf a_pow_h, b_pow_h, parts1, parts2; bool pre_vm_ready = false, pre_vm_side = false;   // the same for the small rounds, on the field VM (vm_fold2.hpp); side: b_pow_h comes from stream3 (ev_join3)
     // pipelined tail (job_tail_enqueue): per-step values of the eight quarter products that give round R's (z_l, z_r) once x_(R-1) is known,
     // evaluated from round R-1's UNFOLDED vectors; slot R & 1, tp_round[slot] = R while they are enqueued / waiting to be used
     PinBuf tp_rows[2]; size_t tp_round[2] = {~(size_t)0, ~(size_t)0};
@@ -765,7 +765,7 @@ int32_t job_begin(Engine* e, ripp_sipp_job* j) {
     float ms = 0; (void)hipEventElapsedTime(&ms, t0, t1); e->stats.scale_ms += ms;
     j->len = n; j->seeded = false; j->world = j->world0;
     j->bs = Fr::one(); j->bs_on = false;
-    j->pre_vm_ready = false; j->pre_ready = false; j->pre_zl_ready = false; j->tp_round[0] = j->tp_round[1] = ~(size_t)0;      // nothing prepared for these vectors yet
+    j->pre_vm_ready = false; j->pre_vm_side = false; j->pre_ready = false; j->pre_zl_ready = false; j->tp_round[0] = j->tp_round[1] = ~(size_t)0;      // nothing prepared for these vectors yet
     return RIPP_OK;
 }
 
@@ -793,14 +793,20 @@ bool xscale_round(const Engine* e, const ripp_sipp_job* j, size_t half) {
 // k_fold_g2_gls8).  Not worth it for small rounds (latency-bound) -- and skipped when the hash is already done.
 // Small rounds (VM regime), every round: the same second bases on the field VM, projective (no normalisation), enqueued behind the
 // round's pairing products so that they run during the host's final exponentiations.
-int32_t job_precompute_vm(Engine* e, ripp_sipp_job* j) {
+// side: (pipelined tail, called right after an un-waited fold) the G2 doublings go to stream3 behind that fold, so that the quarter products
+// enqueued next on the main stream run beside them instead of after them; the next fold waits for ev_join3.
+int32_t job_precompute_vm(Engine* e, ripp_sipp_job* j, bool side = false) {
     const size_t half = j->len / 2;
     if (half == 0 || half > e->vm_fold_max || e->sw.no_vm || e->sw.no_precompute) return RIPP_OK;
     int32_t rc;
     if ((rc = j->a_pow_h.reserve(half * sizeof(G1J))) || (rc = j->b_pow_h.reserve(half * sizeof(G2J))) || (rc = j->parts1.reserve(2 * half * sizeof(G1J))) || (rc = j->parts2.reserve(8 * half * sizeof(G2J)))) return rc;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_pow2<Fp>), dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VmCurve<Fp>::SLOTS * sizeof(VmSlot), e->stream2, j->a.as<G1A>() + half, (uint32_t)half, 64, j->a_pow_h.as<G1J>());
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_pow2<Fp2>), dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VmCurve<Fp2>::SLOTS * sizeof(VmSlot), e->stream, j->b.as<G2A>() + half, (uint32_t)half, 32, j->b_pow_h.as<G2J>());
+    hipStream_t s2 = e->stream;
+    if (side) { HIPCHK(hipStreamWaitEvent(e->stream3, e->ev_t1, 0)); s2 = e->stream3; }      // ev_t1: recorded by job_fold at the end of the fold
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_pow2<Fp2>), dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VmCurve<Fp2>::SLOTS * sizeof(VmSlot), s2, j->b.as<G2A>() + half, (uint32_t)half, 32, j->b_pow_h.as<G2J>());
     HIPCHK(hipGetLastError());
+    if (side) HIPCHK(hipEventRecord(e->ev_join3, e->stream3));
+    j->pre_vm_side = side;
     j->pre_vm_ready = true;
     return RIPP_OK;
 }
@@ -943,6 +949,7 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true,
         j->bs = Fr::one(); j->bs_on = false;
     } else
     if (pre_vm) {
+        if (j->pre_vm_side) { HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join3, 0)); j->pre_vm_side = false; }
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_fold_split2<Fp2>), dim3(nblk(half, 4 * VM_EPW), 8), dim3(256), 4 * VM_EPW * VmCurve<Fp2>::SLOTS * sizeof(VmSlot), e->stream, b + half, j->b_pow_h.as<G2J>(), (uint32_t)half, split_digits_g2(x_inv), 4, j->parts2.as<G2J>());
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_combine<Fp2>), dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VmCurve<Fp2>::SLOTS * sizeof(VmSlot), e->stream, j->parts2.as<G2J>(), 8, b, (uint32_t)half, j->jac2.as<G2J>());
     } else
@@ -1570,7 +1577,7 @@ API int32_t ripp_sipp_job_prove(ripp_sipp_job* j, const ripp_gt* value, ripp_gt*
         if (j->len == 2) { j->len = 0; j->pre_vm_ready = false; }      // the one-element vectors of the LAST fold are discarded by the prover (sipp/src/lib.rs:87-104 ends the loop): not computed
         else if ((rc = job_fold(e, j, x, true, pipelined))) return rc;
         if (pipelined) {              // behind the fold, on the new vectors: the second fold bases of the next round, the values of the round after it
-            if (!j->pre_vm_ready && (rc = job_precompute_vm(e, j))) return rc;
+            if (!j->pre_vm_ready && (rc = job_precompute_vm(e, j, true))) return rc;
             if (tail_pipe_ok(e, j) && (rc = job_tail_enqueue(e, j, round + 2))) return rc;
         }
         if (trace_on()) fprintf(stderr, "[ripp] round %2zu len %8zu: products %.2f ms, host %.2f ms, fold %.2f ms (t=%.1f)\n", round, j->len * 2, t0 - tr0, tf0 - t0, now_ms() - tf0, now_ms() - t_start);
@@ -1578,7 +1585,7 @@ API int32_t ripp_sipp_job_prove(ripp_sipp_job* j, const ripp_gt* value, ripp_gt*
     }
     if (j->hash_thread.joinable()) j->hash_thread.join();     // n == 1: no rounds
     host_pool().set_hot(false);
-    if ((rc = e->sync())) return rc; HIPCHK(hipStreamSynchronize(e->stream2));      // the pipelined tail does not wait for its folds
+    if ((rc = e->sync())) return rc; HIPCHK(hipStreamSynchronize(e->stream2)); HIPCHK(hipStreamSynchronize(e->stream3));      // the pipelined tail does not wait for its folds
     e->collect_kernel_stats();
     e->stats.total_ms = now_ms() - t_start;
     if (st) *st = e->stats;
