@@ -1066,6 +1066,7 @@ API int32_t ripp_release_scratch(void) {
     if (hipSetDevice(e->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { set_err("ripp_release_scratch: device synchronisation failed"); return RIPP_ERR_DEVICE; }
     for (DevBuf* b : {&e->lines, &e->partA, &e->partB, &e->jacG1, &e->jacG2, &e->tmpA, &e->tmpB, &e->tmpR, &e->affG1, &e->affG2, &e->qtab, &e->scale_tab, &e->fold_tab1, &e->fold_mult, &e->fold_tab, &e->fold_jac1, &e->fold_jac2}) b->release();
     e->msm_scratch[0].release(); e->msm_scratch[1].release(); e->kzg_q[0].release(); e->kzg_q[1].release(); e->kzg_bases[0].release(); e->kzg_bases[1].release();
+    for (PinBuf& pb : e->stage) pb.release();             // pinned host staging (up to 2 x 32 MB after a verifier call at n = 2^20)
     e->tab_owner = nullptr;
     return RIPP_OK;
 }
