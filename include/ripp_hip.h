@@ -47,6 +47,10 @@ typedef struct {
     double kernel_miller_lines_ms_sum, kernel_line_products_ms_sum;   /* summed launch durations of the two dominant kernels */
     uint64_t kernel_miller_lines_launches, kernel_line_products_launches;
     uint64_t pairs_lines, pairs_products;                             /* units processed by those launches */
+    /* sharded proofs and the hash-window look-ahead (appended in build round 3; older callers read a prefix) */
+    double exchange_ms;                                               /* time spent in the per-round all-gathers (incl. waiting for the slowest rank) */
+    double look_ms;                                                   /* device + host time of the look-ahead evaluation of rounds 1..k in the hash window */
+    uint64_t look_items, look_pairs;                                  /* (round, side) values pre-evaluated; pairs that took */
 } ripp_stats;
 
 /* ---- lifecycle.  The traits are static (inner_products/src/lib.rs:40-49: no &self), so the engine is a

@@ -16,7 +16,8 @@ class RippStats(ctypes.Structure):
     _fields_ = [(n, ctypes.c_double) for n in (
         "total_ms", "upload_ms", "scale_ms", "miller_lines_ms", "miller_products_ms", "fold_ms", "normalize_ms",
         "host_ms", "hash_ms", "kernel_miller_lines_ms_sum", "kernel_line_products_ms_sum")] + [
-        (n, ctypes.c_uint64) for n in ("kernel_miller_lines_launches", "kernel_line_products_launches", "pairs_lines", "pairs_products")]
+        (n, ctypes.c_uint64) for n in ("kernel_miller_lines_launches", "kernel_line_products_launches", "pairs_lines", "pairs_products")] + [
+        ("exchange_ms", ctypes.c_double), ("look_ms", ctypes.c_double), ("look_items", ctypes.c_uint64), ("look_pairs", ctypes.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

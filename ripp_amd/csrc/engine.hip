@@ -213,6 +213,7 @@ struct Engine {
     Fp12* pinned_rows = nullptr;          // pinned host landing zone for per-step products
     size_t pinned_rows_cap = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_lines, ev_prod;   // per-launch event pairs of the two dominant kernels
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_fold_async;       // folds nobody waited for (pipelined / pre-evaluated rounds): their device time is added to stats.fold_ms when the proof ends
     size_t tail_pipe_max = (size_t)1 << 11;                               // SIPP rounds of at most this length run pipelined (job_tail_enqueue); 0 = off
     size_t vm_tree_max = (size_t)1 << 16;                                 // tree levels with <= this many products use the VM Fp12 multiplier
     size_t vm_fold_max = (size_t)1 << 11;                                 // folds with <= this many outputs use the VM scalar multiplications
@@ -223,7 +224,15 @@ struct Engine {
     ripp_stats stats{};
     // run-time switches: read from the environment ONCE per C-ABI call (get_engine), never inside round loops
     struct Switches { bool no_vm = false, no_precompute = false, no_fold_tables = false, no_msm_glv = false, lp_one_lane = false, no_endo = false, no_fq = false, no_xscale = false; } sw;
+    // crossover sizes: the member initialisers above are the defaults, the environment overrides them PER CALL (a test or
+    // an A/B run flips them on a live engine)
+    struct Sizes { size_t vm_lines_max, vm_fold_max, vm_tree_max, gls_split_max, msm_vm_merge_max, fold_tab_min, fq_min, lp_fq_min, vm_joint_max, vm_scale_max, tail_pipe_max; } defaults{};
     void refresh_switches() {
+        auto env_sz = [](const char* k, size_t dflt, size_t& v) { const char* s = std::getenv(k); v = s ? (size_t)std::strtoull(s, nullptr, 10) : dflt; };
+        env_sz("RIPP_VM_LINES_MAX", defaults.vm_lines_max, vm_lines_max); env_sz("RIPP_VM_FOLD_MAX", defaults.vm_fold_max, vm_fold_max); env_sz("RIPP_VM_TREE_MAX", defaults.vm_tree_max, vm_tree_max);
+        env_sz("RIPP_GLS_SPLIT_MAX", defaults.gls_split_max, gls_split_max); env_sz("RIPP_MSM_VM_MERGE_MAX", defaults.msm_vm_merge_max, msm_vm_merge_max); env_sz("RIPP_FOLD_TAB_MIN", defaults.fold_tab_min, fold_tab_min);
+        env_sz("RIPP_FQ_MIN", defaults.fq_min, fq_min); env_sz("RIPP_LP_FQ_MIN", defaults.lp_fq_min, lp_fq_min); env_sz("RIPP_VM_JOINT_MAX", defaults.vm_joint_max, vm_joint_max);
+        env_sz("RIPP_VM_SCALE_MAX", defaults.vm_scale_max, vm_scale_max); env_sz("RIPP_TAIL_PIPE_MAX", defaults.tail_pipe_max, tail_pipe_max);
         sw.no_vm = std::getenv("RIPP_NO_VM") != nullptr; sw.no_precompute = std::getenv("RIPP_NO_PRECOMPUTE") != nullptr;
         sw.no_fold_tables = std::getenv("RIPP_NO_FOLD_TABLES") != nullptr; sw.no_msm_glv = std::getenv("RIPP_NO_MSM_GLV") != nullptr;
         sw.lp_one_lane = std::getenv("RIPP_LP_ONE_LANE") != nullptr;
@@ -249,8 +258,8 @@ struct Engine {
         HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_join3, hipEventDisableTiming));
         HIPCHK(hipEventCreate(&ev_t0)); HIPCHK(hipEventCreate(&ev_t1));
         { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n_simd = pr.multiProcessorCount * 4; }
-        auto env_sz = [](const char* k, size_t& v) { if (const char* s = std::getenv(k)) v = (size_t)std::strtoull(s, nullptr, 10); };
-        env_sz("RIPP_VM_LINES_MAX", vm_lines_max); env_sz("RIPP_VM_FOLD_MAX", vm_fold_max); env_sz("RIPP_VM_TREE_MAX", vm_tree_max); env_sz("RIPP_GLS_SPLIT_MAX", gls_split_max); env_sz("RIPP_MSM_VM_MERGE_MAX", msm_vm_merge_max); env_sz("RIPP_FOLD_TAB_MIN", fold_tab_min); env_sz("RIPP_FQ_MIN", fq_min); env_sz("RIPP_LP_FQ_MIN", lp_fq_min); env_sz("RIPP_VM_JOINT_MAX", vm_joint_max); env_sz("RIPP_VM_SCALE_MAX", vm_scale_max); env_sz("RIPP_TAIL_PIPE_MAX", tail_pipe_max);
+        defaults = Sizes{vm_lines_max, vm_fold_max, vm_tree_max, gls_split_max, msm_vm_merge_max, fold_tab_min, fq_min, lp_fq_min, vm_joint_max, vm_scale_max, tail_pipe_max};
+        refresh_switches();
         device = dev;
         return RIPP_OK;
     }
@@ -264,6 +273,7 @@ struct Engine {
         for (PinBuf& b : stage) b.release();
         for (auto& e : ev_lines) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         for (auto& e : ev_prod) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+        for (auto& e : ev_fold_async) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         if (stream) (void)hipStreamDestroy(stream);
         if (stream2) (void)hipStreamDestroy(stream2);
         if (ev_fork) (void)hipEventDestroy(ev_fork); if (ev_join) (void)hipEventDestroy(ev_join); if (ev_join3) (void)hipEventDestroy(ev_join3);
@@ -289,6 +299,7 @@ struct Engine {
             v.clear(); };
         drain(ev_lines, stats.kernel_miller_lines_ms_sum, stats.kernel_miller_lines_launches);
         drain(ev_prod, stats.kernel_line_products_ms_sum, stats.kernel_line_products_launches);
+        uint64_t nf = 0; drain(ev_fold_async, stats.fold_ms, nf);
     }
 
     // ---- per-element G1 scalar multiplication (GLV + signed windows, scale.hpp); out may not alias base -----------------
@@ -727,8 +738,15 @@ struct ripp_sipp_job {
     // the host takes them to the power 1/bs.  The first round below the table-fold size returns to the plain vector in its own fold.
     Fr bs = Fr::one(); bool bs_on = false; bool tab_on_lo = false; bool xs_enabled = false;      // xs_enabled: set by ripp_sipp_job_prove only
     DevBuf a_pow, b_pow; bool pre_ready = false;   // 2^64 * a_r and 2^32 * b_r of round 0, prepared while the statement hash finishes
-    // round 1's z_l pre-evaluated in the hash window through bilinearity (see job_preevaluate_round1): the four quarter products
-    Fp12 pre_zl[4]; bool pre_zl_ready = false;
+    // values of rounds 1..k pre-evaluated in the hash window through bilinearity (see job_lookahead): one item per (round, side)
+    struct LookItem {
+        int R = 0, side = 0, level = 0;            // round whose value this gives; 0 = z_l, 1 = z_r; challenges x_0 .. x_(level-1) already applied
+        std::vector<Fp12> Z;                        // 3^(R - level) GT values, index = sum_t (d_t + 1) 3^(R-1-t) over the challenges still to come
+        std::vector<std::future<Fp12>> fe, pend;    // final exponentiations still running; GT powers of the level being applied (3 per output)
+    };
+    std::vector<LookItem> look; PinBuf look_rows[2];
+    bool no_window = false;                         // sharded proofs: rank 0 was handed the digest, nobody hashes, nothing to hide work behind
+    size_t hash_n = 0;                              // length of the statement ha_ext / hb_ext / hr_ext point to (the FULL statement on rank 0 of a sharded proof)
     DevBuf a_pow_h, b_pow_h, parts1, parts2; bool pre_vm_ready = false, pre_vm_side = false;   // the same for the small rounds, on the field VM (vm_fold2.hpp); side: b_pow_h comes from stream3 (ev_join3)
     // pipelined tail (job_tail_enqueue): per-step values of the eight quarter products that give round R's (z_l, z_r) once x_(R-1) is known,
     // evaluated from round R-1's UNFOLDED vectors; slot R & 1, tp_round[slot] = R while they are enqueued / waiting to be used
@@ -765,7 +783,7 @@ int32_t job_begin(Engine* e, ripp_sipp_job* j) {
     float ms = 0; (void)hipEventElapsedTime(&ms, t0, t1); e->stats.scale_ms += ms;
     j->len = n; j->seeded = false; j->world = j->world0;
     j->bs = Fr::one(); j->bs_on = false;
-    j->pre_vm_ready = false; j->pre_vm_side = false; j->pre_ready = false; j->pre_zl_ready = false; j->tp_round[0] = j->tp_round[1] = ~(size_t)0;      // nothing prepared for these vectors yet
+    j->pre_vm_ready = false; j->pre_vm_side = false; j->pre_ready = false; j->look.clear(); j->tp_round[0] = j->tp_round[1] = ~(size_t)0;      // nothing prepared for these vectors yet
     return RIPP_OK;
 }
 
@@ -782,9 +800,10 @@ int32_t job_round_partials(Engine* e, ripp_sipp_job* j, Fp12* rows /* [2][68] */
 }
 
 bool fold_g2_table_pays(const Engine* e, size_t half) { return half >= e->fold_tab_min && half > e->gls_split_max && !e->sw.no_fold_tables; }
-// rounds whose G2 fold runs on the x-scaled vector (see ripp_sipp_job::bs): the table folds of a single-GPU proof
+// rounds whose G2 fold runs on the x-scaled vector (see ripp_sipp_job::bs): the table folds of a proof driven by sipp_prove_core (every rank of a
+// sharded proof scales ITS shard: z^bs -> z is a homomorphism, so the ranks' corrected partial values multiply to the same group element)
 bool xscale_round(const Engine* e, const ripp_sipp_job* j, size_t half) {
-    if (!j->xs_enabled || j->world0 != 1 || e->sw.no_endo || e->sw.no_xscale) return false;
+    if (!j->xs_enabled || e->sw.no_endo || e->sw.no_xscale) return false;
     if (fold_g2_table_pays(e, half)) return true;
     return j->bs_on && half <= e->gls_split_max && 2 * half > e->vm_joint_max && half > e->vm_fold_max;      // stays scaled down to the largest joint-VM round: the return is cheapest on the smallest VM round that walks one group per element
 }
@@ -813,7 +832,7 @@ int32_t job_precompute_vm(Engine* e, ripp_sipp_job* j, bool side = false) {
 
 int32_t job_precompute_round0(Engine* e, ripp_sipp_job* j) {
     const size_t half = j->len / 2;
-    if (half < ((size_t)1 << 16) || j->digest_ready.load() || e->sw.no_precompute) return RIPP_OK;
+    if (half < ((size_t)1 << 16) || j->digest_ready.load() || j->no_window || e->sw.no_precompute) return RIPP_OK;
     int32_t rc;
     const bool tables = !e->sw.no_fold_tables;
     const size_t qstride = (half + 63) & ~(size_t)63;
@@ -894,6 +913,7 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true,
     const Fr x_inv = inv(x);                                                        // sipp/src/lib.rs:94
     hipEvent_t t0 = e->ev_t0, t1 = e->ev_t1;
     HIPCHK(hipEventRecord(t0, e->stream));
+    if (async) { hipEvent_t fa, fb; HIPCHK(hipEventCreate(&fa)); HIPCHK(hipEventCreate(&fb)); e->ev_fold_async.emplace_back(fa, fb); HIPCHK(hipEventRecord(fa, e->stream)); }
     G1A* a = j->a.as<G1A>(); G2A* b = j->b.as<G2A>();
     const size_t qstride = (half + 63) & ~(size_t)63;
     if ((rc = e->qtab.reserve(4 * G2A_CHUNKS * qstride * sizeof(uint4))) != RIPP_OK) return rc;
@@ -988,38 +1008,12 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true,
     if ((rc = e->normalize_dev<Fp2>(j->jac2.as<G2J>(), half, j->b_next.as<G2A>())) != RIPP_OK) return rc;
     HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
     HIPCHK(hipEventRecord(t1, e->stream));
-    if (!async) {                 // pipelined tail rounds (async): everything that follows is ordered behind the fold on the engine's streams
+    if (!async) {                 // pipelined tail / pre-evaluated rounds (async): everything that follows is ordered behind the fold on the engine's streams
         if ((rc = e->sync()) != RIPP_OK) return rc;
         float ms = 0; (void)hipEventElapsedTime(&ms, t0, t1); e->stats.fold_ms += ms;
-    }
+    } else HIPCHK(hipEventRecord(e->ev_fold_async.back().second, e->stream));
     std::swap(j->a, j->a_next); std::swap(j->b, j->b_next);
     j->len = half;
-    return RIPP_OK;
-}
-
-// Round 1's z_l BEFORE the first challenge is known.  With the quarters a = [a0|a1|a2|a3], b = [b0|b1|b2|b3] of round 0, the folded
-// vectors are a' = [a0 + x a2 | a1 + x a3], b' = [b0 + x^-1 b2 | b1 + x^-1 b3], so round 1's
-//     z_l = prod e(a'_r, b'_l) = prod e(a1 + x a3, b0 + x^-1 b2) = E(a1,b0) * E(a1,b2)^(x^-1) * E(a3,b0)^x * E(a3,b2)
-// with E(u, v) = prod_i e(u_i, v_i) over n/4 pairs -- four products that need NO challenge.  On one GPU the statement hash (sequential
-// Blake2s, ~0.31 s at n = 2^20) ends ~110 ms after the GPU has finished round 0 and the fold tables: the four products (n pairs, ~97 ms)
-// run in that window; once x is known z_l costs two GT powers on host threads, and round 1 evaluates only z_r on the device.
-// Same group element, hence the same proof bytes.  (z_r as well would need another n pairs: the window is not that long.)
-int32_t job_preevaluate_round1(Engine* e, ripp_sipp_job* j) {
-    j->pre_zl_ready = false;
-    const size_t q = j->len / 4;
-    if (q < ((size_t)1 << 15) || j->digest_ready.load() || e->sw.no_precompute) return RIPP_OK;      // small statements: the hash is done long before
-    const G1A* a = j->a.as<G1A>(); const G2A* b = j->b.as<G2A>();
-    const G1A* as[4] = {a + q, a + q, a + 3 * q, a + 3 * q};
-    const G2A* bs[4] = {b, b + 2 * q, b, b + 2 * q};
-    std::vector<Fp12> rows(4 * N_LINES);
-    const double t0 = now_ms();
-    int32_t rc = e->step_products(as, bs, 4, q, rows.data()); if (rc) return rc;
-    std::vector<std::future<Fp12>> f;
-    for (int k = 1; k < 4; ++k) f.push_back(host_pool().submit([&rows, k]() { return final_exponentiation(miller_combine(rows.data() + (size_t)k * N_LINES)); }));
-    j->pre_zl[0] = final_exponentiation(miller_combine(rows.data()));
-    for (int k = 1; k < 4; ++k) j->pre_zl[k] = f[k - 1].get();
-    j->pre_zl_ready = true;
-    if (trace_on()) fprintf(stderr, "[ripp] round-1 z_l pre-evaluated in the hash window: %.1f ms (hash %s)\n", now_ms() - t0, j->digest_ready.load() ? "already done" : "still running");
     return RIPP_OK;
 }
 
@@ -1027,10 +1021,9 @@ void job_start_hash(ripp_sipp_job* j, const Fp12& value) {
     if (j->hash_prestarted) { j->hash_prestarted = false; return; }      // ripp_sipp_prove started it before the upload
     if (j->hash_thread.joinable()) j->hash_thread.join();
     j->digest_ready = false;
-    j->hash_thread = std::thread([j, value]() {
-        if (j->ha_ext) statement_digest(j->ha_ext, j->hb_ext, j->hr_ext, j->n_local, value, j->digest);
-        else statement_digest(j->ha.data(), j->hb.data(), j->hr.data(), j->ha.size(), value, j->digest);
-        j->digest_ready = true; });
+    const G1A* pa = j->ha_ext ? j->ha_ext : j->ha.data(); const G2A* pb = j->ha_ext ? j->hb_ext : j->hb.data(); const Fr* pr = j->ha_ext ? j->hr_ext : j->hr.data();
+    const size_t pn = j->ha_ext ? j->hash_n : j->ha.size();
+    j->hash_thread = std::thread([j, value, pa, pb, pr, pn]() { statement_digest(pa, pb, pr, pn, value, j->digest); j->digest_ready = true; });
 }
 
 }  // namespace
@@ -1362,7 +1355,7 @@ static int32_t sipp_job_create_impl(const ripp_g1a* a, const ripp_g2a* b, const 
     j->n_local = n_local; j->rank = rank; j->world = world; j->world0 = world;
     const bool borrow = borrow_value && world == 1 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)r) & 15u) == 0;
     if (borrow) {
-        j->ha_ext = reinterpret_cast<const G1A*>(a); j->hb_ext = reinterpret_cast<const G2A*>(b); j->hr_ext = reinterpret_cast<const Fr*>(r);
+        j->ha_ext = reinterpret_cast<const G1A*>(a); j->hb_ext = reinterpret_cast<const G2A*>(b); j->hr_ext = reinterpret_cast<const Fr*>(r); j->hash_n = n_local;
         Fp12 v; std::memcpy(&v, borrow_value, sizeof v);
         job_start_hash(j, v); j->hash_prestarted = true;
     }
@@ -1467,7 +1460,7 @@ API int32_t ripp_sipp_job_stats(const ripp_sipp_job* j, ripp_stats* st) { LOCK; 
 // round's six final exponentiations and four GT powers while the device folds and evaluates the round after that.  Same group elements,
 // same proof bytes.
 static bool tail_pipe_ok(const Engine* e, const ripp_sipp_job* j) {
-    return j->len >= 4 && j->len <= e->tail_pipe_max && j->len / 2 <= e->vm_fold_max && 2 * j->len <= e->max_pairs_per_batch && !j->bs_on && j->world0 == 1 && !e->sw.no_vm && !e->sw.no_precompute && !e->sw.no_endo;
+    return j->len >= 4 && j->len <= e->tail_pipe_max && j->len / 2 <= e->vm_fold_max && 2 * j->len <= e->max_pairs_per_batch && !j->bs_on && j->xs_enabled && !e->sw.no_vm && !e->sw.no_precompute && !e->sw.no_endo;
 }
 // enqueue the eight quarter products of the current vectors: they become round `for_round`'s values
 static int32_t job_tail_enqueue(Engine* e, ripp_sipp_job* j, size_t for_round) {
@@ -1513,84 +1506,315 @@ static int32_t job_tail_values(ripp_sipp_job* j, size_t round, const Fr& x_prev,
     return RIPP_OK;
 }
 
-API int32_t ripp_sipp_job_prove(ripp_sipp_job* j, const ripp_gt* value, ripp_gt* proof, ripp_fr* challenges, ripp_stats* st) {
-    LOCK; ENGINE; if (!j || !value || !proof || j->world0 != 1) return RIPP_ERR_ARG;
-    Fp12 val; std::memcpy(&val, value, sizeof(Fp12));
+// ---- look-ahead: the values of rounds 1..k from the ROUND-0 vectors, evaluated in the hash window ----------------------------------------
+// With the current vectors cut into 2^(R+1) blocks A_0.., B_0.. (block index = the top R+1 bits of the element index), R folds with the
+// challenges x_0 .. x_(R-1) give   a^(R)_c = sum_e (prod_t x_t^(e_t)) A_(e,c),   b^(R)_c = sum_f (prod_t x_t^(-f_t)) B_(f,c)   (e, f in {0,1}^R,
+// (e,c) = the block index with bits e_0 .. e_(R-1), c), hence by bilinearity
+//     z_l^(R) = E(a^(R)_1, b^(R)_0) = prod_(e,f) E(A_(e,1), B_(f,0))^(prod_t x_t^(e_t - f_t)),      z_r^(R) likewise with (c_a, c_b) = (0, 1):
+// 4^R products of len / 2^(R+1) pairs each that need NO challenge.  Products with the same exponent vector d = e - f (3^R of them) are multiplied
+// per step on the host before their ONE final exponentiation.  The statement hash (sequential Blake2s, ~0.32 s at n = 2^20) is the window:
+// one GPU fits z_l of round 1 behind round 0 and the fold tables (the former job_preevaluate_round1); G ranks have a G times longer window
+// relative to their shard and take both values of rounds 1..k (look_plan).  When x_t arrives, level t of every item is applied,
+//     Z'[rest] = Z[d_t = -1, rest]^(1/x_t) * Z[0, rest] * Z[+1, rest]^(x_t),
+// on the host workers (GT powers in base |x|: the values are outputs of our own final exponentiation): the item of round t + 1 first -- two
+// powers per value on the critical path -- the deeper ones in the background.  Same group elements, hence the same proof bytes.
+// In a sharded proof every rank does this on its shard: all maps involved are homomorphisms, the ranks' values multiply to the whole one.
+constexpr int LOOK_MAX_R = 3;
+static int pow3(int r) { int v = 1; while (r-- > 0) v *= 3; return v; }
+static HostPool& look_pool() { static HostPool pool(3); return pool; }      // own workers: the statement hash's serialisation tasks must never queue behind these
+// how many (round, side) items -- in the order (1,l) (1,r) (2,l) (2,r) .. -- fit the hash window.  Decided by rank 0 (it knows whether anybody hashes) and sent to the others.
+static int look_plan(const Engine* e, size_t n_local, int world, bool window) {
+    if (!window || e->sw.no_precompute || e->sw.no_endo || e->sw.no_vm) return 0;
+    if (const char* s = std::getenv("RIPP_LOOK_ITEMS")) return std::max(0, std::min(2 * LOOK_MAX_R, std::atoi(s)));
+    const double nl = (double)n_local, n = nl * world;
+    if (n < (double)((size_t)1 << 17)) return 0;                    // small statements: the hash is done long before the GPU is
+    const double ms_per_pair = 9.25e-5;                             // 2^20 pairs through lines + products: ~97 ms (profiles/r02_*)
+    const double hash_ms = n * 336.0 / 1.06e6;                      // 1.06 GB/s in situ
+    double budget = hash_ms - (nl * (4.1e-5 + ms_per_pair + 6.2e-5) + 1.0);      // scaling, round 0, fold tables
+    int items = 0;
+    for (int it = 0; it < 2 * LOOK_MAX_R; ++it) {
+        const int R = it / 2 + 1;
+        if (n_local >> (R + 1) < 1024) break;
+        const double cost = nl * (double)(1 << (R - 1)) * ms_per_pair + 0.3 * pow3(R);
+        if (cost > budget + 0.2 * cost) break;                      // an overrun costs its length, a skipped item its whole device time after the hash
+        budget -= cost; ++items;
+    }
+    return items;
+}
+static int32_t job_lookahead(Engine* e, ripp_sipp_job* j, int items, bool forced) {
+    j->look.clear();
+    if (items <= 0 || (j->digest_ready.load() && !forced)) return RIPP_OK;      // the hash is already done: nothing to hide the work behind (forced: RIPP_LOOK_ITEMS, tests)
+    const double t0 = now_ms();
+    const size_t len = j->len;
+    const G1A* a = j->a.as<G1A>(); const G2A* b = j->b.as<G2A>();
+    int32_t rc;
+    for (int it = 0; it < items; ++it) {
+        const int R = it / 2 + 1, side = it & 1;
+        const size_t q = len >> (R + 1);
+        if (q == 0 || q > e->max_pairs_per_batch) break;
+        const int ngroups = pow3(R);
+        struct Prod { const G1A* a; const G2A* b; int g; };
+        std::vector<Prod> prods;
+        for (int eb = 0; eb < (1 << R); ++eb) for (int fb = 0; fb < (1 << R); ++fb) {
+            int g = 0;
+            for (int t = 0; t < R; ++t) g = g * 3 + (((eb >> (R - 1 - t)) & 1) - ((fb >> (R - 1 - t)) & 1) + 1);
+            const size_t ia = ((size_t)eb << 1) | (side == 0 ? 1u : 0u), ib = ((size_t)fb << 1) | (side == 0 ? 0u : 1u);
+            prods.push_back({a + ia * q, b + ib * q, g});
+        }
+        std::vector<Fp12> grows((size_t)ngroups * N_LINES); std::vector<char> gset((size_t)ngroups, 0);
+        const size_t cmax = std::min<size_t>(MAX_PRODUCTS, std::max<size_t>(1, e->max_pairs_per_batch / q));
+        const size_t nch = (prods.size() + cmax - 1) / cmax;
+        auto absorb = [&](size_t c) -> int32_t {                 // chunk c's per-step values into their groups (the device is busy with chunk c + 1)
+            PinBuf& buf = j->look_rows[c & 1];
+            int32_t r2 = buf.wait(); if (r2) return r2;
+            const Fp12* rows = buf.as<Fp12>();
+            const size_t lo = c * cmax, hi = std::min(prods.size(), lo + cmax);
+            for (size_t k = lo; k < hi; ++k) {
+                Fp12* dst = grows.data() + (size_t)prods[k].g * N_LINES; const Fp12* src = rows + (k - lo) * N_LINES;
+                if (!gset[prods[k].g]) { std::memcpy(dst, src, N_LINES * sizeof(Fp12)); gset[prods[k].g] = 1; }
+                else for (int s2 = 0; s2 < N_LINES; ++s2) dst[s2] = mul(dst[s2], src[s2]);
+            }
+            return RIPP_OK;
+        };
+        for (size_t c = 0; c < nch; ++c) {
+            PinBuf& buf = j->look_rows[c & 1];
+            if ((rc = buf.reserve(MAX_PRODUCTS * N_LINES * sizeof(Fp12)))) return rc;
+            const size_t lo = c * cmax, hi = std::min(prods.size(), lo + cmax);
+            const G1A* as[MAX_PRODUCTS]; const G2A* bs[MAX_PRODUCTS];
+            for (size_t k = lo; k < hi; ++k) { as[k - lo] = prods[k].a; bs[k - lo] = prods[k].b; }
+            if ((rc = e->enqueue_products(as, bs, (int)(hi - lo), 0, q, buf.as<Fp12>()))) return rc;
+            HIPCHK(hipEventRecord(buf.ev, e->stream)); buf.pending = true;
+            e->stats.look_pairs += (hi - lo) * q;
+            if (c > 0 && (rc = absorb(c - 1))) return rc;
+        }
+        if ((rc = absorb(nch - 1))) return rc;
+        j->look.emplace_back();
+        ripp_sipp_job::LookItem& li = j->look.back();
+        li.R = R; li.side = side; li.level = 0;
+        for (int g = 0; g < ngroups; ++g) {
+            auto rows = std::make_shared<std::vector<Fp12>>(grows.begin() + (size_t)g * N_LINES, grows.begin() + (size_t)(g + 1) * N_LINES);
+            li.fe.push_back(look_pool().submit([rows]() { return final_exponentiation(miller_combine(rows->data())); }));
+        }
+        ++e->stats.look_items;
+    }
+    e->stats.look_ms += now_ms() - t0;
+    if (trace_on()) fprintf(stderr, "[ripp] look-ahead: %zu of %d (round, side) values pre-evaluated in the hash window, %.1f ms (hash %s)\n", j->look.size(), items, now_ms() - t0, j->digest_ready.load() ? "already done" : "still running");
+    return RIPP_OK;
+}
+static void look_finish_level(ripp_sipp_job::LookItem& it) {
+    if (it.pend.empty()) return;
+    const size_t S = it.Z.size() / 3;
+    std::vector<Fp12> Zn(S);
+    for (size_t r = 0; r < S; ++r) { const Fp12 lo = mul(it.pend[3 * r].get(), it.pend[3 * r + 1].get()); Zn[r] = mul(mul(lo, it.Z[S + r]), it.pend[3 * r + 2].get()); }
+    it.pend.clear(); it.Z.swap(Zn); ++it.level;
+}
+static void look_start_level(ripp_sipp_job::LookItem& it, const GlsDigits& gx, const GlsDigits& gxi) {
+    if (!it.fe.empty()) { it.Z.resize(it.fe.size()); for (size_t i = 0; i < it.fe.size(); ++i) it.Z[i] = it.fe[i].get(); it.fe.clear(); }
+    const size_t S = it.Z.size() / 3;
+    for (size_t r = 0; r < S; ++r) {          // 1/x is full width (four digit strings: two tasks), x is 128 bits (two strings: one task)
+        const Fp12 zm = it.Z[r], zp = it.Z[2 * S + r];
+        it.pend.push_back(host_pool().submit([zm, gxi]() { return gt_pow_gls_strings(zm, gxi, 3u); }));
+        it.pend.push_back(host_pool().submit([zm, gxi]() { return gt_pow_gls_strings(zm, gxi, 12u); }));
+        it.pend.push_back(host_pool().submit([zp, gx]() { return gt_pow_gls_strings(zp, gx, 15u); }));
+    }
+}
+// challenge x_t is known: apply it to every item of a later round -- the next round's first (critical), the deeper ones behind it
+static void look_apply(ripp_sipp_job* j, size_t t, const Fr& x) {
+    bool any = false; for (auto& it : j->look) any = any || (size_t)it.R > t;
+    if (!any) return;
+    const GlsDigits gx = gls_digits(x), gxi = gls_digits(inv(x));
+    for (int pass = 0; pass < 2; ++pass) for (auto& it : j->look) {
+        if ((size_t)it.R <= t || ((size_t)it.R == t + 1) != (pass == 0)) continue;
+        look_finish_level(it);
+        look_start_level(it, gx, gxi);
+    }
+}
+static ripp_sipp_job::LookItem* look_find(ripp_sipp_job* j, size_t round, int side) { for (auto& it : j->look) if ((size_t)it.R == round && it.side == side) return &it; return nullptr; }
+
+// ---- SIPP::prove (sipp/src/lib.rs:42-106) on this rank's shard; world0 == 1: the whole proof on one GPU --------------------------------------
+// One protocol for every world size: the ranks walk the same sequence of exchanges (plan, one per round while the vectors are sharded, the
+// tail gather), every message carries the sender's status, and a rank that failed locally keeps walking until the next exchange has told the
+// others -- no rank is left blocked in a collective (all ranks return an error together).
+struct SippPlanMsg { uint64_t n_local; int32_t world, rank, look_items, window, rc, pad; };
+struct SippRoundMsg { Fp12 z[2]; uint8_t digest[32]; int32_t rc, pad[3]; };
+struct SippTailMsg { G1A a; G2A b; int32_t rc, pad[3]; };
+static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, const uint8_t* seed_digest, ripp_gt* proof, ripp_fr* challenges, ripp_stats* st) {
+    const int world0 = j->world0, rank = j->rank;
     const double t_start = now_ms();
-    job_start_hash(j, val);                                  // overlaps with the scaling + round-1 kernels
+    double exchange_ms = 0;
+    // rank 0 (the only rank of a single-GPU proof) hashes the statement on a host thread: THE serial floor, started before anything else
+    const bool window = rank == 0 && !seed_digest;
+    if (rank == 0) {
+        if (seed_digest) { if (j->hash_thread.joinable()) j->hash_thread.join(); std::memcpy(j->digest, seed_digest, 32); j->digest_ready = true; j->hash_prestarted = false; }
+        else job_start_hash(j, val);
+    }
+    const bool look_forced = std::getenv("RIPP_LOOK_ITEMS") != nullptr;
+    int look_items = (rank == 0 || look_forced) ? look_plan(e, j->n_local, world0, window || look_forced) : 0;
+    j->no_window = !window;
+    if (world0 > 1) {
+        SippPlanMsg mine{(uint64_t)j->n_local, world0, rank, look_items, window ? 1 : 0, RIPP_OK, 0};
+        std::vector<SippPlanMsg> all((size_t)world0);
+        const double tx = now_ms();
+        int32_t rc = comm_allgather(e, &mine, all.data(), sizeof mine); if (rc) return rc;
+        exchange_ms += now_ms() - tx;
+        for (int w = 0; w < world0; ++w)
+            if (all[w].n_local != (uint64_t)j->n_local || all[w].world != world0 || all[w].rank != w) { set_err("sharded SIPP proof: the ranks disagree on the shard size / world size / rank order"); return RIPP_ERR_ARG; }
+        look_items = all[0].look_items; j->no_window = !all[0].window;
+    }
     struct HotOff { ~HotOff() { host_pool().set_hot(false); } } hot_off;       // whatever the exit path, the workers go back to sleeping waits
     struct XsOff { ripp_sipp_job* j; ~XsOff() { j->xs_enabled = false; } } xs_off{j};
-    j->xs_enabled = true;
-    int32_t rc = job_begin(e, j); if (rc) return rc;
+    // whatever the exit path: nothing enqueued by this proof may still be running when the caller gets control back (engine scratch, tp_rows and
+    // the job's vectors are reused by the next call), and no prepared state may leak into the next proof
+    struct Quiesce { Engine* e; ripp_sipp_job* j; ~Quiesce() {
+        (void)hipStreamSynchronize(e->stream); (void)hipStreamSynchronize(e->stream2); (void)hipStreamSynchronize(e->stream3);
+        j->tp_round[0] = j->tp_round[1] = ~(size_t)0; j->pre_vm_ready = false; j->pre_vm_side = false; j->pre_ready = false; j->tab_ready = false; j->look.clear();
+        if (j->hash_thread.joinable()) j->hash_thread.join();      // it reads the caller's buffers (borrowed statement): never left running behind a return
+        j->ha_ext = nullptr; j->hb_ext = nullptr; j->hr_ext = nullptr; } } quiesce{e, j};
+    j->xs_enabled = true; j->seeded = false;
+    int32_t lrc = job_begin(e, j);                                        // local status: carried to the next exchange while the proof is sharded
+    if (lrc && world0 == 1) return lrc;
+    e->stats.look_items = 0; e->stats.look_pairs = 0; e->stats.look_ms = 0;
     if (trace_on()) fprintf(stderr, "[ripp] scale+normalize done at t=%.1f ms\n", now_ms() - t_start);
+    size_t len = j->n_local;                                              // protocol view of the local length (j->len follows it unless a local step failed)
+    bool sharded = world0 > 1, digest_sent = world0 == 1;
     size_t round = 0;
     Fr x_prev = Fr::zero();
-    j->pre_zl_ready = false;
     j->tp_round[0] = j->tp_round[1] = ~(size_t)0;
-    while (j->len > 1) {
+    while ((sharded ? len * (size_t)world0 : len) > 1) {
+        if (sharded && len == 1) {
+            // tail: every rank holds ONE element; gather them (rank order == global order) and finish replicated (sipp/src/lib.rs:69-104 on world0 elements)
+            SippTailMsg mine; std::memset((void*)&mine, 0, sizeof mine);
+            if (!lrc) {
+                auto grab = [&]() -> int32_t {
+                    HIPCHK(hipStreamSynchronize(e->stream2)); HIPCHK(hipStreamSynchronize(e->stream3));
+                    HIPCHK(hipMemcpyAsync(&mine.a, j->a.p, sizeof(G1A), hipMemcpyDeviceToHost, e->stream));
+                    HIPCHK(hipMemcpyAsync(&mine.b, j->b.p, sizeof(G2A), hipMemcpyDeviceToHost, e->stream));
+                    return e->sync(); };
+                lrc = grab();
+            }
+            mine.rc = lrc;
+            std::vector<SippTailMsg> all((size_t)world0);
+            const double tx = now_ms();
+            int32_t rc = comm_allgather(e, &mine, all.data(), sizeof mine); if (rc) return rc;
+            exchange_ms += now_ms() - tx;
+            for (int w = 0; w < world0; ++w) if (all[w].rc) { if (!lrc) set_err("sharded SIPP proof: rank " + std::to_string(w) + " failed (status " + std::to_string(all[w].rc) + ")"); return lrc ? lrc : RIPP_ERR_DEVICE; }
+            const size_t L = (size_t)world0;
+            if ((rc = j->a.reserve(L * sizeof(G1A))) || (rc = j->b.reserve(L * sizeof(G2A))) || (rc = j->a_next.reserve(L * sizeof(G1A))) ||
+                (rc = j->b_next.reserve(L * sizeof(G2A))) || (rc = j->jac1.reserve(L * sizeof(G1J))) || (rc = j->jac2.reserve(L * sizeof(G2J))) || (rc = e->stage[3].reserve(L * (sizeof(G1A) + sizeof(G2A))))) return rc;
+            G1A* ha = e->stage[3].as<G1A>(); G2A* hb = reinterpret_cast<G2A*>(ha + L);
+            for (size_t w = 0; w < L; ++w) { ha[w] = all[w].a; hb[w] = all[w].b; }
+            if (j->bs_on) { set_err("sharded SIPP proof: the G2 vector is still x-scaled at the tail gather"); return RIPP_ERR_ARG; }      // (cannot happen: small rounds fold the plain vector)
+            HIPCHK(hipMemcpyAsync(j->a.p, ha, L * sizeof(G1A), hipMemcpyHostToDevice, e->stream));
+            HIPCHK(hipMemcpyAsync(j->b.p, hb, L * sizeof(G2A), hipMemcpyHostToDevice, e->stream));
+            if ((rc = e->sync())) return rc;
+            j->len = len = L; j->world = 1; sharded = false;
+            j->pre_vm_ready = false;
+            continue;
+        }
         Fp12 rows[2 * N_LINES];
         const double tr0 = now_ms();
-        const bool have_zl = round == 1 && j->pre_zl_ready;                                  // z_l of round 1 was evaluated in the hash window
-        j->pre_zl_ready = false;
-        const bool tp_round = j->tp_round[round & 1] == round;                               // pipelined tail: this round's products were enqueued a round ago
-        if (tp_round) {
-        } else if (have_zl) {                                                                // only z_r = prod e(a_l, b_r) on the device
-            const size_t half = j->len / 2;
-            const G1A* as[1] = {j->a.as<G1A>()}; const G2A* bs[1] = {j->b.as<G2A>() + half};
-            const double tp = now_ms();
-            if ((rc = e->step_products(as, bs, 1, half, rows + N_LINES))) return rc;
-            e->stats.miller_products_ms += now_ms() - tp;
-        } else if ((rc = job_round_partials(e, j, rows))) return rc;
-        if (round == 0 && !j->seeded && (rc = job_precompute_round0(e, j))) return rc;      // asynchronous: overlaps the host work below and the hash
-        if (!j->pre_vm_ready && (rc = job_precompute_vm(e, j))) return rc;                   // small rounds: the same on the VM, during the host phase
-        if (!tp_round && tail_pipe_ok(e, j) && (rc = job_tail_enqueue(e, j, round + 1))) return rc;      // entry into the pipelined tail
-        const double t0 = now_ms();
-        Fp12 zl, zr;
-        if (tp_round) { if ((rc = job_tail_values(j, round, x_prev, &zl, &zr))) return rc; }
-        else if (have_zl) {          // E(a1,b0) * E(a1,b2)^(1/x) * E(a3,b0)^x * E(a3,b2): two GT powers on host threads (values of GT proper)
-            const Fr xi = inv(x_prev);
-            auto p1 = host_pool().submit([j, xi]() { return gt_pow_gls(j->pre_zl[1], xi); });
-            auto p2 = host_pool().submit([j, x_prev]() { return gt_pow_gls(j->pre_zl[2], x_prev); });
-            pairing_values(rows + N_LINES, 1, &zr);
-            zl = mul(mul(j->pre_zl[0], p1.get()), mul(p2.get(), j->pre_zl[3]));
-        } else { Fp12 z2[2]; pairing_values(rows, 2, z2); zl = z2[0]; zr = z2[1]; }
-        if (j->bs_on) {      // the device holds bs * b: what it evaluated is z^bs (the pre-evaluated z_l of round 1 came from the plain quarters)
-            const GlsDigits gsi = gls_digits(inv(j->bs));                     // two tasks of two digit strings per value
-            Fp12* zz[2] = {&zl, &zr}; Fp12 part[4];
-            host_pool().parallel(4, [&](int t) { if ((t >> 1) == 0 && have_zl) return; part[t] = gt_pow_gls_strings(*zz[t >> 1], gsi, (t & 1) ? 12u : 3u); });
-            for (int k = 0; k < 2; ++k) if (!(k == 0 && have_zl)) *zz[k] = mul(part[2 * k], part[2 * k + 1]);
-        }
-        if (round == 0 && !j->seeded && (rc = job_preevaluate_round1(e, j))) return rc;      // blocks on the GPU while the hash thread is still busy
-        if (!j->seeded) {
+        ripp_sipp_job::LookItem* lk_l = lrc ? nullptr : look_find(j, round, 0);
+        ripp_sipp_job::LookItem* lk_r = lrc ? nullptr : look_find(j, round, 1);
+        const bool tp_round = !lrc && j->tp_round[round & 1] == round;                       // pipelined tail: this round's products were enqueued a round ago
+        double t0 = tr0;
+        Fp12 zl = Fp12::one(), zr = Fp12::one();
+        auto local_values = [&]() -> int32_t {
+            int32_t rc;
+            if (tp_round || (lk_l && lk_r)) {
+            } else if (lk_l) {                                                               // only z_r = prod e(a_l, b_r) on the device
+                const size_t half = j->len / 2;
+                const G1A* as[1] = {j->a.as<G1A>()}; const G2A* bs[1] = {j->b.as<G2A>() + half};
+                const double tp = now_ms();
+                if ((rc = e->step_products(as, bs, 1, half, rows + N_LINES))) return rc;
+                e->stats.miller_products_ms += now_ms() - tp;
+            } else if ((rc = job_round_partials(e, j, rows))) return rc;
+            if (round == 0 && !j->seeded && (rc = job_precompute_round0(e, j))) return rc;      // asynchronous: overlaps the host work below and the hash
+            if (!j->pre_vm_ready && (rc = job_precompute_vm(e, j))) return rc;                   // small rounds: the same on the VM, during the host phase
+            // entry into the pipelined tail -- unless the look-ahead has (round 0: is about to get) both values of the next round
+            const bool next_known = round == 0 ? (look_items >= 2 && j->len >= 4 && (look_forced || !j->digest_ready.load())) : (look_find(j, round + 1, 0) && look_find(j, round + 1, 1));
+            if (!tp_round && !next_known && tail_pipe_ok(e, j) && (rc = job_tail_enqueue(e, j, round + 1))) return rc;
+            t0 = now_ms();
+            if (tp_round) { if ((rc = job_tail_values(j, round, x_prev, &zl, &zr))) return rc; }
+            else {
+                if (lk_l) { look_finish_level(*lk_l); zl = lk_l->Z[0]; }
+                if (lk_r) { look_finish_level(*lk_r); zr = lk_r->Z[0]; }
+                if (lk_l && !lk_r) pairing_values(rows + N_LINES, 1, &zr);
+                else if (!lk_l) { Fp12 z2[2]; pairing_values(rows, 2, z2); zl = z2[0]; zr = z2[1]; }
+                if (j->bs_on && !(lk_l && lk_r)) {      // the device holds bs * b: what it evaluated is z^bs (look-ahead values came from the plain round-0 blocks)
+                    const GlsDigits gsi = gls_digits(inv(j->bs));                     // two tasks of two digit strings per value
+                    Fp12* zz[2] = {&zl, &zr}; Fp12 part[4];
+                    const bool skip_l = lk_l != nullptr;
+                    host_pool().parallel(4, [&](int t) { if ((t >> 1) == 0 && skip_l) return; part[t] = gt_pow_gls_strings(*zz[t >> 1], gsi, (t & 1) ? 12u : 3u); });
+                    for (int k = 0; k < 2; ++k) if (!(k == 0 && skip_l)) *zz[k] = mul(part[2 * k], part[2 * k + 1]);
+                }
+            }
+            if (round == 0 && !j->seeded && (rc = job_lookahead(e, j, look_items, look_forced))) return rc;      // blocks on the GPU while the hash thread is still busy
+            return RIPP_OK;
+        };
+        if (!lrc) lrc = local_values();
+        if (lrc && !sharded) return lrc;
+        if (!j->seeded && rank == 0) {
             const double th = now_ms();
             if (j->hash_thread.joinable()) j->hash_thread.join();
             e->stats.hash_ms += now_ms() - th;               // time the prover actually WAITED for the statement hash
+        }
+        if (sharded || !digest_sent) {
+            // the ranks' values multiply to the whole one (Miller recurrence, final exponentiation, GT powers: all homomorphisms); rank 0's first
+            // message also carries the digest of the statement
+            SippRoundMsg mine; std::memset((void*)&mine, 0, sizeof mine);
+            mine.z[0] = zl; mine.z[1] = zr; mine.rc = lrc;
+            if (rank == 0) std::memcpy(mine.digest, j->digest, 32);
+            std::vector<SippRoundMsg> all((size_t)world0);
+            const double tx = now_ms();
+            int32_t rc = comm_allgather(e, &mine, all.data(), sizeof mine); if (rc) return rc;
+            exchange_ms += now_ms() - tx;
+            for (int w = 0; w < world0; ++w) if (all[w].rc) { if (!lrc) set_err("sharded SIPP proof: rank " + std::to_string(w) + " failed (status " + std::to_string(all[w].rc) + ")"); return lrc ? lrc : RIPP_ERR_DEVICE; }
+            if (sharded) { zl = all[0].z[0]; zr = all[0].z[1]; for (int w = 1; w < world0; ++w) { zl = mul(zl, all[w].z[0]); zr = mul(zr, all[w].z[1]); } }
+            if (!digest_sent) { std::memcpy(j->digest, all[0].digest, 32); digest_sent = true; }
+        }
+        if (!j->seeded) {
             j->rng.from_digest(j->digest); j->seeded = true;
             host_pool().set_hot(true);                       // the remaining rounds hand 0.1-0.6 ms tasks to the workers every ~2 ms
         }
         const Fr x = fs::sipp_challenge(j->rng, zl, zr);
         x_prev = x;
+        look_apply(j, round, x);                             // GT powers of the pre-evaluated rounds start on the workers right away
         e->stats.host_ms += now_ms() - t0;
         std::memcpy(&proof[2 * round], &zl, sizeof(Fp12)); std::memcpy(&proof[2 * round + 1], &zr, sizeof(Fp12));
         if (challenges) std::memcpy(&challenges[round], &x, sizeof(Fr));
         const double tf0 = now_ms();
-        const bool pipelined = j->tp_round[(round + 1) & 1] == round + 1;      // the next round's values are on their way: nobody waits for this fold
-        if (j->len == 2) { j->len = 0; j->pre_vm_ready = false; }      // the one-element vectors of the LAST fold are discarded by the prover (sipp/src/lib.rs:87-104 ends the loop): not computed
-        else if ((rc = job_fold(e, j, x, true, pipelined))) return rc;
-        if (pipelined) {              // behind the fold, on the new vectors: the second fold bases of the next round, the values of the round after it
-            if (!j->pre_vm_ready && (rc = job_precompute_vm(e, j, true))) return rc;
-            if (tail_pipe_ok(e, j) && (rc = job_tail_enqueue(e, j, round + 2))) return rc;
+        // nobody waits for this fold when the next round's values are already on their way (pipelined tail) or known (look-ahead)
+        const bool pipelined = j->tp_round[(round + 1) & 1] == round + 1;
+        const bool known = look_find(j, round + 1, 0) && look_find(j, round + 1, 1);
+        if (!sharded && len == 2) { j->len = 0; j->pre_vm_ready = false; }      // the one-element vectors of the LAST fold are discarded by the prover (sipp/src/lib.rs:87-104 ends the loop): not computed
+        else {
+            if (!lrc) lrc = job_fold(e, j, x, true, pipelined || known);
+            if (!lrc && pipelined) {              // behind the fold, on the new vectors: the second fold bases of the next round, the values of the round after it
+                if (!j->pre_vm_ready) lrc = job_precompute_vm(e, j, true);
+                if (!lrc && tail_pipe_ok(e, j)) lrc = job_tail_enqueue(e, j, round + 2);
+            }
+            if (lrc && !sharded) return lrc;
         }
-        if (trace_on()) fprintf(stderr, "[ripp] round %2zu len %8zu: products %.2f ms, host %.2f ms, fold %.2f ms (t=%.1f)\n", round, j->len * 2, t0 - tr0, tf0 - t0, now_ms() - tf0, now_ms() - t_start);
+        len /= 2;
+        if (trace_on()) fprintf(stderr, "[ripp] round %2zu len %8zu: products %.2f ms, host %.2f ms, fold %.2f ms%s (t=%.1f)\n", round, len * 2, t0 - tr0, tf0 - t0, now_ms() - tf0, (pipelined || known) ? " (enqueued)" : "", now_ms() - t_start);
         ++round;
     }
     if (j->hash_thread.joinable()) j->hash_thread.join();     // n == 1: no rounds
     host_pool().set_hot(false);
+    if (lrc) return lrc;
+    int32_t rc;
     if ((rc = e->sync())) return rc; HIPCHK(hipStreamSynchronize(e->stream2)); HIPCHK(hipStreamSynchronize(e->stream3));      // the pipelined tail does not wait for its folds
     e->collect_kernel_stats();
+    e->stats.exchange_ms = exchange_ms;
     e->stats.total_ms = now_ms() - t_start;
     if (st) *st = e->stats;
     return RIPP_OK;
+}
+
+API int32_t ripp_sipp_job_prove(ripp_sipp_job* j, const ripp_gt* value, ripp_gt* proof, ripp_fr* challenges, ripp_stats* st) {
+    LOCK; ENGINE; if (!j || !value || !proof || j->world0 != 1) return RIPP_ERR_ARG;
+    Fp12 val; std::memcpy(&val, value, sizeof(Fp12));
+    return sipp_prove_core(e, j, val, nullptr, proof, challenges, st);
 }
 
 API int32_t ripp_sipp_prove(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr* r, size_t n, const ripp_gt* value, ripp_gt* proof, ripp_fr* challenges, ripp_stats* st) {

@@ -26,6 +26,7 @@ pub struct RippStats {
     pub kernel_miller_lines_ms_sum: f64, pub kernel_line_products_ms_sum: f64,
     pub kernel_miller_lines_launches: u64, pub kernel_line_products_launches: u64,
     pub pairs_lines: u64, pub pairs_products: u64,
+    pub exchange_ms: f64, pub look_ms: f64, pub look_items: u64, pub look_pairs: u64,
 }
 
 #[cfg(feature = "ffi")]

@@ -44,3 +44,19 @@ def engine():
         pytest.skip("no HIP device in this environment")
     R.init(0)
     return R
+
+
+@pytest.fixture(scope="session")
+def sipp_2p20(engine, orc, tmp_path_factory):
+    """The headline statement (bench.py's: a_i = (1000 + i) G1, b_i = (2000 + i) G2, r_i = SplitMix64(0), n = 2^20) with the ORACLE's
+    proof of it -- one ~80 s oracle run per session, shared by the one-GPU and the two-rank tests (the latter load it from `path`)."""
+    import numpy as np
+    n = 1 << 20
+    a, b, r = engine.synth_g1(1000, n), engine.synth_g2(2000, n), engine.synth_fr(0, n)
+    value = engine.product_of_pairings_with_coeffs(a, b, r)
+    assert np.array_equal(value, orc.product_of_pairings_with_coeffs(a, b, r))
+    rc, eproof, ech = orc.sipp_prove(a, b, r, value)
+    assert rc == 0
+    path = str(tmp_path_factory.mktemp("sipp2p20") / "oracle_proof.npz")
+    np.savez(path, value=value, proof=eproof, ch=ech)
+    return {"n": n, "a": a, "b": b, "r": r, "value": value, "proof": eproof, "ch": ech, "path": path}

@@ -48,19 +48,73 @@ def test_msm_2p20_adversarial_scalars_vs_oracle(engine, orc, statement):
     assert np.array_equal(got, orc.g1_to_affine(orc.msm_g1_a(a, minus1)).reshape(1, 12))
 
 
-def test_sipp_prove_2p20_vs_oracle(engine, orc, statement):
+def test_pairing_product_config2_jacobian_2p16_vs_oracle(engine, orc):
+    """Config 2 exactly as SURVEY.md section 8(d) states it: PairingInnerProduct::inner_product at n = 2^16 on JACOBIAN inputs with random
+    non-unit Z (ripp_pairing_product_j: normalize_batch on the device, then the product) against the oracle on the whole vectors."""
+    n = 1 << 16
+    aj, bj = orc.blind_g1(engine.synth_g1(1000, n), 1), orc.blind_g2(engine.synth_g2(2000, n), 1)
+    got = engine.PairingInnerProduct.inner_product(aj, bj)
+    rc, exp = orc.pairing_product_j(aj, bj)
+    assert rc == 0 and np.array_equal(got, exp)
+
+
+def test_sipp_prove_2p20_vs_oracle(engine, orc, sipp_2p20):
     """The headline workload itself: all 40 GT elements and all 20 challenges of the GPU proof equal the oracle's, the oracle's
     verifier accepts the GPU proof, and the engine's verifier accepts it too."""
-    a, b, r = statement
-    value = engine.product_of_pairings_with_coeffs(a, b, r)
+    a, b, r, value, eproof, ech = (sipp_2p20[k] for k in ("a", "b", "r", "value", "proof", "ch"))
     proof, ch, _ = engine.SIPP.prove_with_stats(a, b, r, value)
     assert proof.shape == (40, 72)
-    assert np.array_equal(value, orc.product_of_pairings_with_coeffs(a, b, r))
-    rc, eproof, ech = orc.sipp_prove(a, b, r, value)
-    assert rc == 0
     assert np.array_equal(proof[:6], eproof[:6]), "rounds 0-2 differ from the oracle"
     assert np.array_equal(proof, eproof) and np.array_equal(ch, ech)
     assert orc.sipp_verify(a, b, r, value, proof) == 1
     assert engine.SIPP.verify(a, b, r, value, proof)
     # the one-shot entry point on host slices (hash started on the caller's buffers before the upload) gives the same bytes
     assert np.array_equal(engine.SIPP.prove(a, b, r, value), eproof)
+
+
+def _sharded_2p20_worker(rank, world, port, path, look_items, ret):
+    import os
+    import sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    if look_items is not None:
+        os.environ["RIPP_LOOK_ITEMS"] = str(look_items)
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import ripp_amd as R
+    from ripp_amd.sharded import NativeComm, native_sipp_job_prove
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        R.init(0)                                      # both ranks share cuda:0; gloo carries the library's all-gather (callback transport)
+        comm = NativeComm("callback")
+        n = N; nl = n // world
+        exp = np.load(path)
+        a, b, r = R.synth_g1(1000, nl, first=rank, stride=world), R.synth_g2(2000, nl, first=rank, stride=world), R.synth_fr(0, nl, first=rank, stride=world)
+        full = (R.synth_g1(1000, n), R.synth_g2(2000, n), R.synth_fr(0, n)) if rank == 0 else None
+        job = R.SippJob(a, b, r, rank=rank, world=world)
+        proof, ch, st = native_sipp_job_prove(job, exp["value"], full=full)
+        ok = np.array_equal(proof, exp["proof"]) and np.array_equal(ch, exp["ch"])
+        job.close(); comm.close()
+        ret[rank] = (bool(ok), int(st["look_items"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("look_items", [None, 3])
+def test_sipp_prove_2p20_sharded_world2_vs_oracle(engine, sipp_2p20, look_items):
+    """Config 4's sharded code path at its own size: ripp_sipp_job_prove_sharded with two ranks (index residues mod 2, both on cuda:0, the
+    library's all-gather carried by gloo) -- the single-GPU schedule on every shard (x-scaled folds, fold tables, look-ahead in the hash
+    window, pipelined tail).  All 40 GT elements and 20 challenges equal the ORACLE's proof of the unsharded statement.  look_items = 3:
+    the two-GPU plan (both values of round 1 and z_l of round 2 pre-evaluated), which a shared GPU would not choose by itself."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_sharded_2p20_worker, args=(2, port, sipp_2p20["path"], look_items, ret), nprocs=2, join=True)
+    got = dict(ret)
+    assert got[0][0] and got[1][0], got
+    if look_items is not None:
+        assert got[0][1] == look_items and got[1][1] == look_items, got

@@ -451,3 +451,30 @@ def test_pipelined_tail_rounds_and_job_reuse(engine, orc, n):
             assert np.array_equal(ch, ech), (n, rep)
     finally:
         job.close()
+
+
+@pytest.mark.parametrize("n,items", [(8, 6), (64, 6), (1 << 12, 2), (1 << 13, 6), (1 << 15, 3)])
+def test_lookahead_rounds_vs_oracle(engine, orc, n, items):
+    """Rounds 1..3 taken from the look-ahead (engine.hip job_lookahead: 4^R block products of the ROUND-0 vectors grouped into 3^R values,
+    reduced level by level as the challenges arrive; folds of those rounds are not waited for) instead of from the folded vectors:
+    RIPP_LOOK_ITEMS forces the plan a multi-GPU proof chooses at n = 2^20 onto small statements.  Same proof bytes as the oracle, for every
+    prefix of the item order (1,l) (1,r) (2,l) (2,r) (3,l) (3,r), and again on the reused job without the look-ahead."""
+    import os
+    a, b, r = orc.gen_g1(41, n), orc.gen_g2(42, n), orc.gen_scalars(43, n)
+    a[n // 2 + 1] = 0; b[n // 4] = 0                                 # identities inside the blocks
+    v = orc.product_of_pairings_with_coeffs(a, b, r)
+    rc, eproof, ech = orc.sipp_prove(a, b, r, v)
+    assert rc == 0
+    job = engine.SippJob(a, b, r)
+    try:
+        for k in sorted({items, max(items - 1, 0), 1, 0}, reverse=True):
+            os.environ["RIPP_LOOK_ITEMS"] = str(k)
+            try:
+                proof, ch, st = job.prove(v)
+            finally:
+                os.environ.pop("RIPP_LOOK_ITEMS", None)
+            assert np.array_equal(proof, eproof) and np.array_equal(ch, ech), (n, k)
+            lg = n.bit_length() - 1
+            assert st["look_items"] == min(k, 2 * max(min(lg - 1, 3), 0)), (n, k, st["look_items"])
+    finally:
+        job.close()

@@ -215,13 +215,29 @@ def _native_worker(rank, world, port, n, ret):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [2, 64, 1 << 12])
+@pytest.mark.parametrize("n", [2, 4, 64, 1 << 12])
 def test_native_sharded_driver_world2_callback_transport(engine, n):
     """ripp_sipp_job_prove_sharded / ripp_*_sharded_j: the library's own round loop and collectives, two ranks on cuda:0 with the
     all-gather supplied by the host (gloo): proofs, pairing product and MSMs equal the oracle's on the unsharded vectors."""
     import torch.multiprocessing as mp
     mgr = mp.Manager(); ret = mgr.dict()
     mp.spawn(_native_worker, args=(2, _free_port(), n, ret), nprocs=2, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,items", [(16, 6), (64, 4), (1 << 12, 6), (1 << 14, 3)])
+def test_native_sharded_driver_world2_with_lookahead(engine, n, items):
+    """The sharded prover with the multi-GPU look-ahead plan forced onto small statements (RIPP_LOOK_ITEMS): every rank pre-evaluates the
+    values of rounds 1..3 from ITS shard's round-0 blocks, reduces them with the challenges and contributes the partial GT values; folds of
+    those rounds are not waited for.  Proofs equal the oracle's on the unsharded vectors."""
+    import torch.multiprocessing as mp
+    os.environ["RIPP_LOOK_ITEMS"] = str(items)
+    try:
+        mgr = mp.Manager(); ret = mgr.dict()
+        mp.spawn(_native_worker, args=(2, _free_port(), n, ret), nprocs=2, join=True)
+    finally:
+        del os.environ["RIPP_LOOK_ITEMS"]
     assert dict(ret) == {0: True, 1: True}
 
 
@@ -331,7 +347,7 @@ def _agg_worker(rank, world, port, n, ret):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [2, 8, 256])
+@pytest.mark.parametrize("n", [2, 8, 256, 1 << 14])
 def test_sharded_gipa_and_aggregate_world2(engine, n):
     """ripp_gipa_tipp_prove_sharded / ripp_aggregate_proofs_sharded with two ranks (callback transport on cuda:0): commitments of every
     round, transcripts, base cases, KZG openings and the aggregate's members equal the oracle's on the unsharded vectors."""
