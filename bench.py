@@ -80,8 +80,19 @@ def cpu_baseline(log_n_sample):
     rc, _, _ = o.sipp_prove(a, b, r, value)
     dt = time.perf_counter() - t0
     assert rc == 0
-    return {"value": n / dt, "unit": "pairs/s", "cores": int(o.lib().orc_num_threads()), "kind": "port",
-            "sample": f"oracle sipp_prove, n=2^{log_n_sample}, same synthetic generator (seeds 1000/2000/0), one run of {dt:.2f} s"}
+    out = {"value": n / dt, "unit": "pairs/s", "cores": int(o.lib().orc_num_threads()), "kind": "port",
+           "sample": f"oracle sipp_prove, n=2^{log_n_sample}, same synthetic generator (seeds 1000/2000/0), one run of {dt:.2f} s"}
+    # the per-core figure BASELINE.md section 2 asks for: the same prover on ONE thread, on a smaller sample of the same statement
+    n1 = 1 << min(log_n_sample, 13)
+    o.lib().orc_set_num_threads(1)
+    v1 = o.product_of_pairings_with_coeffs(a[:n1], b[:n1], r[:n1])
+    t0 = time.perf_counter()
+    rc, _, _ = o.sipp_prove(a[:n1], b[:n1], r[:n1], v1)
+    d1 = time.perf_counter() - t0
+    o.lib().orc_set_num_threads(o.effective_cpus())
+    assert rc == 0
+    out["one_thread"] = {"value": n1 / d1, "unit": "pairs/s", "cores": 1, "sample": f"oracle sipp_prove, n=2^{n1.bit_length() - 1}, one run of {d1:.2f} s"}
+    return out
 
 
 def main():
@@ -110,6 +121,7 @@ def main():
     single_dev = bool(os.environ.get("RIPP_BENCH_SINGLE_DEVICE"))
     if single_dev:
         local_rank = 0
+        os.environ.setdefault("RIPP_RANKS_PER_DEVICE", str(world))       # the look-ahead plan prices the hash window per DEVICE: all ranks' work lands on this one
     backend = os.environ.get("RIPP_BENCH_BACKEND", "gloo" if single_dev else "nccl")    # RCCL needs one device per rank
     if world > 1 and not single_dev and torch.cuda.device_count() < world:
         sys.exit(f"bench.py --gpus {world}: only {torch.cuda.device_count()} device(s) visible (RIPP_BENCH_SINGLE_DEVICE=1 runs all ranks on device 0 over gloo, for control-flow tests only)")
@@ -174,6 +186,17 @@ def main():
         tt = torch.tensor([total], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu"); dist.all_reduce(tt, op=dist.ReduceOp.MAX); total = float(tt.item())
     ms_per_step = total / args.steps * 1e3
 
+    # the call SURVEY.md section 8(d) defines the metric on: ripp_sipp_prove from HOST slices (upload of the 336 MB statement inside the call,
+    # the statement hash started on the caller's buffers before it).  Reported beside `value` (resident statement), never as `value`.
+    host_slices_ms = None
+    if world == 1:
+        job.close(); job = None
+        ts = []
+        for _ in range(2):
+            t0 = time.perf_counter(); p2 = R.SIPP.prove(a, b, r, value); ts.append(time.perf_counter() - t0)
+            assert np.array_equal(p2, ref_proof), "one-shot proof differs from the resident-statement proof"
+        host_slices_ms = min(ts) * 1e3
+
     if rank == 0:
         # dominant kernel of the path on this rank, from HIP events recorded on the engine's own stream
         k_lines = (stats["kernel_miller_lines_ms_sum"], stats["kernel_miller_lines_launches"], stats["pairs_lines"], "k_miller_lines")
@@ -216,10 +239,24 @@ def main():
                          "note": "integer-ALU bound (381-bit Montgomery arithmetic, ~5e3 Fp products per 288 input bytes); see DESIGN.md"},
             "phase_ms": {k: round(v, 3) for k, v in stats.items() if k.endswith("_ms")},
         }
+        # What the statement hash hides: the prover cannot draw its first challenge before rank 0 has hashed the whole
+        # statement with a sequential Blake2s.  hash_wait_ms = time rank 0 was BLOCKED on that hash (everything the GPUs could do without a
+        # challenge -- scaling, round 0, fold tables, the look-ahead of rounds 1..k -- was done by then); gpu_phase_ms = the rest of the step;
+        # value_excl_hash = n / gpu_phase_ms -- the figure that scales with the number of GPUs.  `value` stays end to end.
+        hd = R.statement_hash_times()
+        out["phase_ms"]["hash_wait_ms"] = round(stats["hash_ms"], 3)
+        out["phase_ms"]["statement_hash_ms"] = round(hd[0] + hd[1], 3)
+        out["gpu_phase_ms"] = ms_per_step - stats["hash_ms"]
+        out["value_excl_hash"] = n / ((ms_per_step - stats["hash_ms"]) * 1e-3)
+        out["look_ahead"] = {"items": int(stats["look_items"]), "pairs": int(stats["look_pairs"]), "order": "(1,l) (1,r) (2,l) (2,r) (3,l) (3,r)"}
+        if host_slices_ms is not None:
+            out["host_slices_ms"] = host_slices_ms
+            out["value_host_slices"] = n / (host_slices_ms * 1e-3)
         if world == 1 and args.cpu_log_n > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_log_n)
         print(json.dumps(out), flush=True)
-    job.close()
+    if job is not None:
+        job.close()
     if dist is not None:
         dist.barrier(); comm.close(); dist.destroy_process_group()
 

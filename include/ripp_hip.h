@@ -175,6 +175,9 @@ int32_t ripp_sipp_job_import(ripp_sipp_job* job, const ripp_g1a* a, const ripp_g
 int32_t ripp_combine_partials(const ripp_gt* gathered /* [world][count] */, int32_t world, size_t count, ripp_gt* out /* [count] */);
 /* Blake2s digest of (a, b, r, value).serialize_uncompressed for a FULL statement held on the host (sipp/src/lib.rs:56-59) */
 int32_t ripp_sipp_seed_digest(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr* r, size_t n, const ripp_gt* value, uint8_t digest[32]);
+/* timing of the LAST statement hash of this process: milliseconds spent in Blake2s itself / waiting for the serialisation workers
+ * (the sequential hash is the serial floor of a proof; bench.py reports it beside the time the prover was blocked on it) */
+void    ripp_statement_hash_times(double* hash_ms, double* wait_ms);
 
 /* ---- multi-GPU: one process per GPU, collectives INSIDE the library ----------------------------------
  * Transport "rccl": librccl.so is loaded on first use; rank 0 creates the 128-byte id, the HOST hands it to the other ranks (it owns

@@ -96,6 +96,7 @@ def load_library(path):
     for name in ("ripp_ser_gt", "ripp_ser_g1", "ripp_ser_g2", "ripp_ser_fr", "ripp_sipp_job_rounds_left", "ripp_sipp_job_local_len", "ripp_vec_len"):
         getattr(L, name).restype = ctypes.c_size_t
     L.ripp_vec_free.restype = None; L.ripp_vec_free.argtypes = [ctypes.c_void_p]
+    L.ripp_statement_hash_times.restype = None
     return L
 
 

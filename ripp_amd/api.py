@@ -18,7 +18,7 @@ __all__ = ["InnerProductError", "DeviceError", "Vec", "PairingInnerProduct", "Mu
            "PedersenCommitmentG2", "SIPP", "SippJob", "GIPA_TIPP", "SRS", "TIPA_TIPP", "TIPAWithSSM", "aggregate_proofs", "aggregate_proofs_sharded", "gipa_tipp_prove_sharded", "verify_aggregate_proof", "AggregateProof", "ser_tipa_tipp_proof", "de_tipa_tipp_proof", "ser_tipa_ssm_proof", "de_tipa_ssm_proof", "ser_g1_compressed", "ser_g2_compressed", "product_of_pairings", "product_of_pairings_with_coeffs",
            "normalize_batch_g1", "normalize_batch_g2", "fold_g1_affine", "fold_g2_affine", "fold_g1", "fold_g2",
            "scale_g1_affine", "synth_g1", "synth_g2", "synth_fr", "init", "device_count", "final_exponentiation",
-           "ser_gt", "ser_g1", "ser_g2", "ser_fr", "sipp_seed_digest", "gt_mul"]
+           "ser_gt", "ser_g1", "ser_g2", "ser_fr", "sipp_seed_digest", "gt_mul", "statement_hash_times"]
 
 
 class InnerProductError(Exception):
@@ -720,6 +720,12 @@ def sipp_seed_digest(a, b, r, value):
     a, b, r = _c(a, 12), _c(b, 24), _c(r, 4); value = np.ascontiguousarray(value, dtype=np.uint64).reshape(72)
     out = np.zeros(32, dtype=np.uint8)
     _check(lib().ripp_sipp_seed_digest(_p(a), _p(b), _p(r), ctypes.c_size_t(len(a)), _p(value), _p(out))); return bytes(out)
+
+
+def statement_hash_times():
+    """(Blake2s ms, ms waiting for the serialisation workers) of the last statement hash in this process."""
+    h, w = ctypes.c_double(), ctypes.c_double()
+    lib().ripp_statement_hash_times(ctypes.byref(h), ctypes.byref(w)); return h.value, w.value
 
 
 def synth_g1(start, n, first=0, stride=1):

@@ -227,7 +227,9 @@ struct Engine {
     // crossover sizes: the member initialisers above are the defaults, the environment overrides them PER CALL (a test or
     // an A/B run flips them on a live engine)
     struct Sizes { size_t vm_lines_max, vm_fold_max, vm_tree_max, gls_split_max, msm_vm_merge_max, fold_tab_min, fq_min, lp_fq_min, vm_joint_max, vm_scale_max, tail_pipe_max; } defaults{};
+    MsmTune msm_tune;
     void refresh_switches() {
+        { const char* s; msm_tune = MsmTune(); if ((s = std::getenv("RIPP_MSM_C"))) msm_tune.c = std::atoi(s); if ((s = std::getenv("RIPP_MSM_CH"))) msm_tune.ch = (uint32_t)std::strtoul(s, nullptr, 10); if ((s = std::getenv("RIPP_MSM_GMIN"))) msm_tune.gmin = (uint32_t)std::strtoul(s, nullptr, 10); }
         auto env_sz = [](const char* k, size_t dflt, size_t& v) { const char* s = std::getenv(k); v = s ? (size_t)std::strtoull(s, nullptr, 10) : dflt; };
         env_sz("RIPP_VM_LINES_MAX", defaults.vm_lines_max, vm_lines_max); env_sz("RIPP_VM_FOLD_MAX", defaults.vm_fold_max, vm_fold_max); env_sz("RIPP_VM_TREE_MAX", defaults.vm_tree_max, vm_tree_max);
         env_sz("RIPP_GLS_SPLIT_MAX", defaults.gls_split_max, gls_split_max); env_sz("RIPP_MSM_VM_MERGE_MAX", defaults.msm_vm_merge_max, msm_vm_merge_max); env_sz("RIPP_FOLD_TAB_MIN", defaults.fold_tab_min, fold_tab_min);
@@ -344,7 +346,7 @@ struct Engine {
         if (n == 0) { *reinterpret_cast<Jac<F>*>(ms.host_out) = jac_inf<F>(); return RIPP_OK; }
         const bool no_glv = sw.no_msm_glv;
         const size_t nreal = n;
-        const MsmPlan p = msm_plan(nreal, no_glv ? 1 : std::is_same<F, Fp>::value ? 2 : 4);
+        const MsmPlan p = msm_plan(nreal, no_glv ? 1 : std::is_same<F, Fp>::value ? 2 : 4, msm_tune);
         n = p.n;                                                                  // terms (2 * nreal in the GLV form, 4 * nreal in the GLS form)
         const size_t nwb = (size_t)p.nwin * p.nb;
         const uint32_t max_slots = (uint32_t)(n / p.ch + std::min<size_t>(p.nb, n) + 1);
@@ -1036,7 +1038,7 @@ extern "C" {
 #define ENGINE Engine* e; { int32_t rc_ = get_engine(&e); if (rc_ != RIPP_OK) return rc_; }
 
 API const char* ripp_last_error(void) { return g_err.c_str(); }
-API void ripp_debug_digest_times(double* hash_ms, double* wait_ms) { *hash_ms = g_digest_hash_ms; *wait_ms = g_digest_wait_ms; }
+API void ripp_statement_hash_times(double* hash_ms, double* wait_ms) { if (hash_ms) *hash_ms = g_digest_hash_ms; if (wait_ms) *wait_ms = g_digest_wait_ms; }
 API int32_t ripp_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 API int32_t ripp_init(int32_t dev) {
     LOCK;
@@ -1050,7 +1052,13 @@ API int32_t ripp_init(int32_t dev) {
     if (rc != RIPP_OK) { delete e; return rc; }
     g_engine = e; return RIPP_OK;
 }
-API void ripp_shutdown(void) { LOCK; if (g_engine) { g_engine->destroy(); delete g_engine; g_engine = nullptr; } }
+API void ripp_shutdown(void) {
+    LOCK; if (!g_engine) return;
+    // job / SRS / vector handles hold device memory and refer to this engine's streams and tables: tearing it down under them would let the
+    // next call create a fresh engine (possibly on another device) that those handles then run on.  Refuse, like ripp_init does.
+    if (g_live_handles.load() > 0) { set_err("ripp_shutdown: " + std::to_string(g_live_handles.load()) + " job / SRS / vector handle(s) are still alive; destroy them first"); fprintf(stderr, "[ripp] %s\n", g_err.c_str()); return; }
+    g_engine->destroy(); delete g_engine; g_engine = nullptr;
+}
 // frees the engine's grow-only scratch (line buffer, fold tables -- ~19 GB after an n = 2^20 proof --, MSM scratch): the next call re-allocates
 // what it needs.  Job and SRS handles keep their own buffers.
 API int32_t ripp_release_scratch(void) {
@@ -1423,6 +1431,7 @@ API int32_t ripp_sipp_job_round_finish(ripp_sipp_job* j, const ripp_gt* combined
 API size_t ripp_sipp_job_local_len(const ripp_sipp_job* j) { return j ? j->len : 0; }
 API int32_t ripp_sipp_job_export(ripp_sipp_job* j, ripp_g1a* a_out, ripp_g2a* b_out) {
     LOCK; ENGINE; if (!j || !a_out || !b_out) return RIPP_ERR_ARG;
+    if (j->len == 0) { set_err("ripp_sipp_job_export: the job's working vectors were consumed by a whole proof (ripp_sipp_job_begin re-arms it)"); return RIPP_ERR_ARG; }
     HIPCHK(hipMemcpyAsync(a_out, j->a.p, j->len * sizeof(G1A), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemcpyAsync(b_out, j->b.p, j->len * sizeof(G2A), hipMemcpyDeviceToHost, e->stream));
     return e->sync();
@@ -1526,7 +1535,9 @@ static HostPool& look_pool() { static HostPool pool(3); return pool; }      // o
 static int look_plan(const Engine* e, size_t n_local, int world, bool window) {
     if (!window || e->sw.no_precompute || e->sw.no_endo || e->sw.no_vm) return 0;
     if (const char* s = std::getenv("RIPP_LOOK_ITEMS")) return std::max(0, std::min(2 * LOOK_MAX_R, std::atoi(s)));
-    const double nl = (double)n_local, n = nl * world;
+    double share = 1.0;                                             // ranks sharing this rank's GPU (test rigs: several ranks on one device): their work adds up in the same window
+    if (const char* s = std::getenv("RIPP_RANKS_PER_DEVICE")) share = std::max(1.0, std::atof(s));
+    const double nl = (double)n_local * share, n = (double)n_local * world;
     if (n < (double)((size_t)1 << 17)) return 0;                    // small statements: the hash is done long before the GPU is
     const double ms_per_pair = 9.25e-5;                             // 2^20 pairs through lines + products: ~97 ms (profiles/r02_*)
     const double hash_ms = n * 336.0 / 1.06e6;                      // 1.06 GB/s in situ
@@ -1535,7 +1546,7 @@ static int look_plan(const Engine* e, size_t n_local, int world, bool window) {
     for (int it = 0; it < 2 * LOOK_MAX_R; ++it) {
         const int R = it / 2 + 1;
         if (n_local >> (R + 1) < 1024) break;
-        const double cost = nl * (double)(1 << (R - 1)) * ms_per_pair + 0.3 * pow3(R);
+        const double cost = nl * (double)(1 << (R - 1)) * ms_per_pair + 0.3 * pow3(R) * share;
         if (cost > budget + 0.2 * cost) break;                      // an overrun costs its length, a skipped item its whole device time after the hash
         budget -= cost; ++items;
     }
@@ -1876,7 +1887,12 @@ API int32_t ripp_sipp_challenge(uint8_t seed[32], const ripp_gt* z_l, const ripp
 
 #include "vec_api.inc"       // device-resident vectors (ripp_vec_*)
 
+#if !defined(RIPP_BLS12_377)
+// BLS12-381 only: wire.hpp's COMPRESSED point encodings and square roots are the zcash layout of ark-bls12-381 (p = 3 mod 4); ark-bls12-377
+// keeps the generic SWFlags layout and needs Tonelli-Shanks (p = 1 mod 2^46).  The 377 library does not export these entry points
+// (tests/test_abi_cpu.py asserts their absence) rather than exporting ones that would give wrong bytes.
 #include "wire_api.inc"      // CanonicalSerialize / CanonicalDeserialize images of the proof structs
+#endif
 
 #include "comm_api.inc"      // RCCL / callback communicator, sharded inner products and the sharded SIPP prover
 

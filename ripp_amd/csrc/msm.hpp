@@ -39,7 +39,8 @@ constexpr int MSM_SEG_FAN = 4;       // segment sums added per lane in k_msm_seg
 // (kernels.hpp::gls_image, two Fp2 products).  Same number of gathered additions, 1/2 resp. 1/4 of the windows and Horner doublings.
 struct MsmPlan { int c, nwin; uint32_t nb; uint32_t n; uint32_t ch, seg; uint32_t nreal, gmin; };   // ch: max terms per slot, seg: buckets per segment lane
 
-inline MsmPlan msm_plan(size_t nreal, int split = 1) {
+struct MsmTune { int c = 0; uint32_t ch = 0, gmin = 0; };      // 0 = the plan's own choice (RIPP_MSM_C / RIPP_MSM_CH / RIPP_MSM_GMIN, read once per C-ABI call by the engine)
+inline MsmPlan msm_plan(size_t nreal, int split = 1, const MsmTune& tune = MsmTune()) {
     const size_t n = (size_t)split * nreal;
     int lg = 0; while (((size_t)1 << (lg + 1)) <= n) ++lg;
     int c0 = lg - 6; if (c0 < 4) c0 = 4; if (c0 > 13) c0 = 13;
@@ -53,15 +54,15 @@ inline MsmPlan msm_plan(size_t nreal, int split = 1) {
         const int score = 2 * deficit + (cc == c0 ? 0 : 1);
         if (score < best) { best = score; c = cc; }
     }
-    if (const char* e = std::getenv("RIPP_MSM_C")) c = std::atoi(e);
+    if (tune.c) c = tune.c;
     MsmPlan p; p.c = c; p.nwin = (nbits + c - 1) / c; p.nb = 1u << c; p.n = (uint32_t)n; p.nreal = (uint32_t)nreal;
     // slot length: the shortest chain that still gives every SIMD two waves (131072 lanes; a lone wave issues at half rate), between
     // 4 and 32 terms; 64 once the launch is throughput bound (measured crossover, tools/msm_sweep.py)
     const size_t adds = n * (size_t)p.nwin;
     p.ch = 4; while (p.ch < 32 && (size_t)p.ch * 131072 < adds) p.ch *= 2;
     if (n > ((size_t)1 << 20)) p.ch = 64;
-    if (const char* e = std::getenv("RIPP_MSM_CH")) p.ch = (uint32_t)std::strtoul(e, nullptr, 10);
-    p.gmin = 16; if (const char* e = std::getenv("RIPP_MSM_GMIN")) p.gmin = (uint32_t)std::strtoul(e, nullptr, 10);   // buckets of <= gmin slots go straight to the merge
+    if (tune.ch) p.ch = tune.ch;
+    p.gmin = tune.gmin ? tune.gmin : 16;   // buckets of <= gmin slots go straight to the merge
     p.seg = 4;                                   // nb >= 16; chain of 2 * seg additions + the (lo - 1) multiple per lane
     return p;
 }

@@ -63,8 +63,9 @@ inline bool get_fr(const uint8_t* in, Fr& out) {
 // an Fq12 that is not in the order-r subgroup (zero included: 0^r = 0) is InvalidData.  Plain square-and-multiply: the value is untrusted,
 // so the cyclotomic squaring formulas do not apply.  ~0.5 ms per element on the host; arkworks pays the same exponentiation.
 inline bool gt_in_subgroup(const Fp12& f) {
-    Fp12 acc = f;                                                   // r has bit 254 set
-    for (int i = 253; i >= 0; --i) { acc = sqr(acc); if ((FrParams::mod(i >> 5) >> (i & 31)) & 1u) acc = mul(acc, f); }
+    int top = 255; while (top > 0 && !((FrParams::mod(top >> 5) >> (top & 31)) & 1u)) --top;      // bit length of r from the parameters (255 bits on BLS12-381, 253 on BLS12-377)
+    Fp12 acc = f;
+    for (int i = top - 1; i >= 0; --i) { acc = sqr(acc); if ((FrParams::mod(i >> 5) >> (i & 31)) & 1u) acc = mul(acc, f); }
     return acc == Fp12::one();
 }
 inline bool get_gt(const uint8_t* in, Fp12& f) {

@@ -30,6 +30,20 @@ def test_every_declared_symbol_is_exported(hiplib):
     assert not missing, f"declared in include/ripp_hip.h but not exported: {missing}"
 
 
+WIRE_381_ONLY = ("ripp_ser_tipa_tipp_proof", "ripp_de_tipa_tipp_proof", "ripp_ser_tipa_ssm_proof", "ripp_de_tipa_ssm_proof", "ripp_ser_g1_compressed", "ripp_ser_g2_compressed")
+
+
+def test_bls12_377_library_exports_the_same_abi_minus_the_381_wire_format():
+    """libripp_hip_377.so is the same engine: every declared symbol except the proof-struct wire format, whose compressed encodings are the
+    zcash layout of ark-bls12-381 (ark-bls12-377 uses the generic SWFlags layout) -- those must be ABSENT, not silently wrong."""
+    import ripp_amd.bls12_377 as R7
+    L = R7.lib()
+    missing = [n for n in declared_symbols() if n not in WIRE_381_ONLY and not hasattr(L, n)]
+    assert not missing, missing
+    present = [n for n in WIRE_381_ONLY if hasattr(L, n)]
+    assert not present, f"BLS12-381-only wire entry points exported by the BLS12-377 build: {present}"
+
+
 def test_no_cpu_fallback_without_device(hiplib):
     if hiplib.ripp_device_count() > 0:
         pytest.skip("a HIP device is present; the refusal path is exercised on the CPU-only builder")

@@ -355,3 +355,25 @@ def test_sharded_gipa_and_aggregate_world2(engine, n):
     mgr = mp.Manager(); ret = mgr.dict()
     mp.spawn(_agg_worker, args=(2, _free_port(), n, ret), nprocs=2, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_device_reports_the_hash_excluded_figures(engine):
+    """`bench.py --gpus 2` end to end (self-launch through torch.distributed.run, two rank processes on cuda:0, the library's collectives over
+    gloo): the JSON line keeps `value` end to end and adds what makes an N > 1 curve readable -- the time rank 0 was blocked on the statement
+    hash, the rest of the step, the hash-excluded rate, the look-ahead the ranks ran in the window, the time in the per-round exchanges."""
+    import json
+    import subprocess
+    env = dict(os.environ, RIPP_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--log-n", "17"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["n"] == 1 << 17
+    for k in ("hash_wait_ms", "statement_hash_ms", "exchange_ms", "look_ms"):
+        assert k in out["phase_ms"], k
+    assert out["gpu_phase_ms"] > 0 and abs(out["gpu_phase_ms"] - (out["ms_per_step"] - out["phase_ms"]["hash_wait_ms"])) < 1e-3
+    assert abs(out["value_excl_hash"] - out["config"]["n"] / (out["gpu_phase_ms"] * 1e-3)) < 1e-6 * out["value_excl_hash"]
+    assert out["value"] <= out["value_excl_hash"] * (1 + 1e-9)
+    assert set(out["look_ahead"]) >= {"items", "pairs"}
+    assert "cpu_baseline" not in out                                  # rank 0 at N = 1 only

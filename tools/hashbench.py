@@ -9,4 +9,4 @@ print("digest: %.3fs -> %.0f MB/s ; ok=%s"%(dt, n*320/dt/1e6, d==o.sipp_seed_dig
 import ctypes
 hm=ctypes.c_double(); wm=ctypes.c_double()
 from ripp_amd._lib import lib
-lib().ripp_debug_digest_times(ctypes.byref(hm), ctypes.byref(wm)); print("hash %.1f ms, wait-for-serialisation %.1f ms"%(hm.value, wm.value))
+lib().ripp_statement_hash_times(ctypes.byref(hm), ctypes.byref(wm)); print("hash %.1f ms, wait-for-serialisation %.1f ms"%(hm.value, wm.value))
