@@ -1,5 +1,5 @@
 # Copy the summaries collected by tools/run_profiles.sh <tag> (gpurun_out/prof_<tag>/) into profiles/ under the round's names.
-TAG=${1:-r02c}; R=${2:-r02}
+TAG=${1:-r03}; R=${2:-r03}
 S=gpurun_out/prof_$TAG
 cp $S/kstats/k_kernel_stats.csv profiles/${R}_bench_kernel_stats_rocprofv3.csv
 cp $S/bench_n1.json profiles/${R}_bench_n1.json

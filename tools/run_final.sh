@@ -1,6 +1,6 @@
 # End-of-round measurement set on the CURRENT build (GPU box): bash tools/run_final.sh <tag>
 set -x
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 bash tools/run_profiles.sh $TAG > gpurun_out/prof_$TAG.log 2>&1
 O=gpurun_out/final_$TAG; mkdir -p $O
