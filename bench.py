@@ -199,8 +199,11 @@ def main():
 
     if rank == 0:
         # dominant kernel of the path on this rank, from HIP events recorded on the engine's own stream
-        k_lines = (stats["kernel_miller_lines_ms_sum"], stats["kernel_miller_lines_launches"], stats["pairs_lines"], "k_miller_lines")
-        lp_name = "k_line_products_q" if os.environ.get("RIPP_LP_FQ_MIN") and not os.environ.get("RIPP_NO_FQ") else "k_line_products"       # the kernel the engine launches for throughput-sized products
+        # the kernels the engine launches for throughput-sized products: the carry-free twins unless switched off
+        no_fq = bool(os.environ.get("RIPP_NO_FQ"))
+        lp_name = "k_line_products" if no_fq or int(os.environ.get("RIPP_LP_FQ_MIN", "0")) > (1 << 19) else "k_line_products_q"
+        ml_name = "k_miller_lines" if no_fq or int(os.environ.get("RIPP_ML_FQ_MIN", "0")) > (1 << 19) else "k_miller_lines_q"
+        k_lines = (stats["kernel_miller_lines_ms_sum"], stats["kernel_miller_lines_launches"], stats["pairs_lines"], ml_name)
         k_prod = (stats["kernel_line_products_ms_sum"], stats["kernel_line_products_launches"], stats["pairs_products"], lp_name)
         dom = max(k_lines, k_prod, key=lambda k: k[0])
         achieved = (dom[2] * ALG_BYTES_PER_PAIR) / (dom[0] * 1e-3) / 1e9 if dom[0] > 0 else 0.0

@@ -29,6 +29,7 @@
 #include "fq_curve.hpp"
 #include "fq_curve2.hpp"
 #include "fq_line_products.hpp"
+#include "fq_miller.hpp"
 #include "vm_fold2.hpp"
 #include "host_fs.hpp"
 #include "wire.hpp"
@@ -203,8 +204,9 @@ struct Engine {
     const void* tab_owner = nullptr;
     size_t vm_scale_max = (size_t)1 << 14;                                // per-element G1 scalings of <= this many elements run on the VM (measured: direct product 6.1 -> 3.8 ms at 2^13, 7.1 -> 6.2 ms at 2^14, level at 2^15)
     size_t vm_joint_max = (size_t)1 << 13;                                // folds with <= this many outputs (and more than vm_fold_max) use the joint one-group-per-element VM forms
-    size_t lp_fq_min = ~(size_t)0;        // pairs per launch from which k_line_products_q replaces k_line_products.  OFF by default: the carry-free twin is 7 % faster
-                                          // (27.7 vs 29.9 ms per 2^19 pairs) but keeps ~50 dwords in scratch, i.e. 3-5x the HBM traffic of the spill-free kernel (RIPP_LP_FQ_MIN=4096 enables it)
+    size_t lp_fq_min = 0;                 // pairs per launch from which k_line_products_q replaces k_line_products: always (11 % faster per launch: 5.8 vs 6.5 ms at the proof's launch
+                                          // mix; it keeps ~47 dwords per lane in scratch, which costs HBM traffic, not time -- the kernel is issue-bound).  RIPP_LP_FQ_MIN=4294967295 / RIPP_NO_FQ select k_line_products
+    size_t ml_fq_min = 0;                 // pairs per launch from which k_miller_lines_q (fq_miller.hpp) replaces k_miller_lines: every throughput launch (the VM kernel covers the small ones)
     size_t fq_min = (size_t)1 << 17;      // the carry-free fold kernels (fq_curve.hpp) win on THROUGHPUT: launches with >= 2 waves per SIMD
     size_t fold_tab_min = 32768;          // G2 folds of at least this many elements build in-round odd-multiple tables
     size_t msm_vm_merge_max = 16384;      // buckets (all windows) up to which the bucket merge runs on the field VM
@@ -226,7 +228,7 @@ struct Engine {
     struct Switches { bool no_vm = false, no_precompute = false, no_fold_tables = false, no_msm_glv = false, lp_one_lane = false, no_endo = false, no_fq = false, no_xscale = false; } sw;
     // crossover sizes: the member initialisers above are the defaults, the environment overrides them PER CALL (a test or
     // an A/B run flips them on a live engine)
-    struct Sizes { size_t vm_lines_max, vm_fold_max, vm_tree_max, gls_split_max, msm_vm_merge_max, fold_tab_min, fq_min, lp_fq_min, vm_joint_max, vm_scale_max, tail_pipe_max; } defaults{};
+    struct Sizes { size_t vm_lines_max, vm_fold_max, vm_tree_max, gls_split_max, msm_vm_merge_max, fold_tab_min, fq_min, lp_fq_min, vm_joint_max, vm_scale_max, tail_pipe_max, ml_fq_min; } defaults{};
     MsmTune msm_tune;
     void refresh_switches() {
         { const char* s; msm_tune = MsmTune(); if ((s = std::getenv("RIPP_MSM_C"))) msm_tune.c = std::atoi(s); if ((s = std::getenv("RIPP_MSM_CH"))) msm_tune.ch = (uint32_t)std::strtoul(s, nullptr, 10); if ((s = std::getenv("RIPP_MSM_GMIN"))) msm_tune.gmin = (uint32_t)std::strtoul(s, nullptr, 10); }
@@ -234,7 +236,7 @@ struct Engine {
         env_sz("RIPP_VM_LINES_MAX", defaults.vm_lines_max, vm_lines_max); env_sz("RIPP_VM_FOLD_MAX", defaults.vm_fold_max, vm_fold_max); env_sz("RIPP_VM_TREE_MAX", defaults.vm_tree_max, vm_tree_max);
         env_sz("RIPP_GLS_SPLIT_MAX", defaults.gls_split_max, gls_split_max); env_sz("RIPP_MSM_VM_MERGE_MAX", defaults.msm_vm_merge_max, msm_vm_merge_max); env_sz("RIPP_FOLD_TAB_MIN", defaults.fold_tab_min, fold_tab_min);
         env_sz("RIPP_FQ_MIN", defaults.fq_min, fq_min); env_sz("RIPP_LP_FQ_MIN", defaults.lp_fq_min, lp_fq_min); env_sz("RIPP_VM_JOINT_MAX", defaults.vm_joint_max, vm_joint_max);
-        env_sz("RIPP_VM_SCALE_MAX", defaults.vm_scale_max, vm_scale_max); env_sz("RIPP_TAIL_PIPE_MAX", defaults.tail_pipe_max, tail_pipe_max);
+        env_sz("RIPP_VM_SCALE_MAX", defaults.vm_scale_max, vm_scale_max); env_sz("RIPP_TAIL_PIPE_MAX", defaults.tail_pipe_max, tail_pipe_max); env_sz("RIPP_ML_FQ_MIN", defaults.ml_fq_min, ml_fq_min);
         sw.no_vm = std::getenv("RIPP_NO_VM") != nullptr; sw.no_precompute = std::getenv("RIPP_NO_PRECOMPUTE") != nullptr;
         sw.no_fold_tables = std::getenv("RIPP_NO_FOLD_TABLES") != nullptr; sw.no_msm_glv = std::getenv("RIPP_NO_MSM_GLV") != nullptr;
         sw.lp_one_lane = std::getenv("RIPP_LP_ONE_LANE") != nullptr;
@@ -260,7 +262,7 @@ struct Engine {
         HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_join3, hipEventDisableTiming));
         HIPCHK(hipEventCreate(&ev_t0)); HIPCHK(hipEventCreate(&ev_t1));
         { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n_simd = pr.multiProcessorCount * 4; }
-        defaults = Sizes{vm_lines_max, vm_fold_max, vm_tree_max, gls_split_max, msm_vm_merge_max, fold_tab_min, fq_min, lp_fq_min, vm_joint_max, vm_scale_max, tail_pipe_max};
+        defaults = Sizes{vm_lines_max, vm_fold_max, vm_tree_max, gls_split_max, msm_vm_merge_max, fold_tab_min, fq_min, lp_fq_min, vm_joint_max, vm_scale_max, tail_pipe_max, ml_fq_min};
         refresh_switches();
         device = dev;
         return RIPP_OK;
@@ -422,6 +424,8 @@ struct Engine {
             if ((rc = mark(ev_lines, true)) != RIPP_OK) return rc;
             if (m * nprod <= vm_lines_max && !sw.no_vm)
                 hipLaunchKernelGGL(k_vm_miller_lines, dim3(nblk(m, 4 * VM_EPW), nprod), dim3(256), 4 * VM_EPW * VM_LINES_SLOTS * sizeof(VmSlot), stream, ps, (uint32_t)m, lines.as<uint4>(), stride);
+            else if (!sw.no_fq && m * nprod >= ml_fq_min)         // the carry-free twin (fq_miller.hpp): ~25 % fewer instructions on an issue-bound kernel
+                hipLaunchKernelGGL(k_miller_lines_q, dim3(nblk(m, 256), nprod), dim3(256), 0, stream, ps, (uint32_t)m, lines.as<uint4>(), stride);
             else
                 hipLaunchKernelGGL(k_miller_lines, dim3(nblk(m, 256), nprod), dim3(256), 0, stream, ps, (uint32_t)m, lines.as<uint4>(), stride);
             HIPCHK(hipGetLastError());
@@ -743,6 +747,7 @@ struct ripp_sipp_job {
     // values of rounds 1..k pre-evaluated in the hash window through bilinearity (see job_lookahead): one item per (round, side)
     struct LookItem {
         int R = 0, side = 0, level = 0;            // round whose value this gives; 0 = z_l, 1 = z_r; challenges x_0 .. x_(level-1) already applied
+        size_t npairs = 0, q = 0;                   // pairs [0, npairs) of every block (of q pairs) are covered; a PARTIAL item (npairs < q) leaves pairs [npairs, q) of that round's product to the device
         std::vector<Fp12> Z;                        // 3^(R - level) GT values, index = sum_t (d_t + 1) 3^(R-1-t) over the challenges still to come
         std::vector<std::future<Fp12>> fe, pend;    // final exponentiations still running; GT powers of the level being applied (3 per output)
     };
@@ -1532,28 +1537,35 @@ constexpr int LOOK_MAX_R = 3;
 static int pow3(int r) { int v = 1; while (r-- > 0) v *= 3; return v; }
 static HostPool& look_pool() { static HostPool pool(3); return pool; }      // own workers: the statement hash's serialisation tasks must never queue behind these
 // how many (round, side) items -- in the order (1,l) (1,r) (2,l) (2,r) .. -- fit the hash window.  Decided by rank 0 (it knows whether anybody hashes) and sent to the others.
+// Returned in EIGHTHS of an item: 8 k + f = the first k items in full and f/8 of the pairs of the next one (the window is a fixed budget; a
+// whole item of round R costs 2^(R-1) n pairs, so the last one is cut to what is left).
 static int look_plan(const Engine* e, size_t n_local, int world, bool window) {
     if (!window || e->sw.no_precompute || e->sw.no_endo || e->sw.no_vm) return 0;
-    if (const char* s = std::getenv("RIPP_LOOK_ITEMS")) return std::max(0, std::min(2 * LOOK_MAX_R, std::atoi(s)));
+    if (const char* s = std::getenv("RIPP_LOOK_EIGHTHS")) return std::max(0, std::min(16 * LOOK_MAX_R, std::atoi(s)));
+    if (const char* s = std::getenv("RIPP_LOOK_ITEMS")) return 8 * std::max(0, std::min(2 * LOOK_MAX_R, std::atoi(s)));
     double share = 1.0;                                             // ranks sharing this rank's GPU (test rigs: several ranks on one device): their work adds up in the same window
     if (const char* s = std::getenv("RIPP_RANKS_PER_DEVICE")) share = std::max(1.0, std::atof(s));
     const double nl = (double)n_local * share, n = (double)n_local * world;
     if (n < (double)((size_t)1 << 17)) return 0;                    // small statements: the hash is done long before the GPU is
-    const double ms_per_pair = 9.25e-5;                             // 2^20 pairs through lines + products: ~97 ms (profiles/r02_*)
-    const double hash_ms = n * 336.0 / 1.06e6;                      // 1.06 GB/s in situ
+    const double ms_per_pair = 7.7e-5;                              // 2^20 pairs through lines + products: ~80 ms with the carry-free kernels (profiles/r03_*)
+    const double hash_ms = n * 336.0 / 1.12e6;                      // the statement hash: 313-317 ms at n = 2^20 (1.06 GB/s of Blake2s in situ + serialisation hidden)
     double budget = hash_ms - (nl * (4.1e-5 + ms_per_pair + 6.2e-5) + 1.0);      // scaling, round 0, fold tables
     int items = 0;
     for (int it = 0; it < 2 * LOOK_MAX_R; ++it) {
         const int R = it / 2 + 1;
         if (n_local >> (R + 1) < 1024) break;
         const double cost = nl * (double)(1 << (R - 1)) * ms_per_pair + 0.3 * pow3(R) * share;
-        if (cost > budget + 0.2 * cost) break;                      // an overrun costs its length, a skipped item its whole device time after the hash
+        if (cost > budget) {                                        // an overrun costs its length 1 : 1, a pre-evaluated pair saves a quarter of its cost: cut, do not stretch
+            const int f = (int)(8.0 * budget / cost + 0.5);
+            return 8 * items + (f >= 2 ? std::min(f, 7) : 0);
+        }
         budget -= cost; ++items;
     }
-    return items;
+    return 8 * items;
 }
-static int32_t job_lookahead(Engine* e, ripp_sipp_job* j, int items, bool forced) {
+static int32_t job_lookahead(Engine* e, ripp_sipp_job* j, int eighths, bool forced) {
     j->look.clear();
+    const int items = (eighths + 7) / 8;
     if (items <= 0 || (j->digest_ready.load() && !forced)) return RIPP_OK;      // the hash is already done: nothing to hide the work behind (forced: RIPP_LOOK_ITEMS, tests)
     const double t0 = now_ms();
     const size_t len = j->len;
@@ -1561,8 +1573,11 @@ static int32_t job_lookahead(Engine* e, ripp_sipp_job* j, int items, bool forced
     int32_t rc;
     for (int it = 0; it < items; ++it) {
         const int R = it / 2 + 1, side = it & 1;
-        const size_t q = len >> (R + 1);
-        if (q == 0 || q > e->max_pairs_per_batch) break;
+        const size_t qblk = len >> (R + 1);
+        if (qblk == 0 || qblk > e->max_pairs_per_batch) break;
+        const int frac = std::min(8, eighths - 8 * it);                  // the last item may be partial: the first frac/8 of every block's pairs
+        const size_t q = frac >= 8 ? qblk : (qblk * (size_t)frac / 8) & ~(size_t)63;
+        if (q == 0) break;
         const int ngroups = pow3(R);
         struct Prod { const G1A* a; const G2A* b; int g; };
         std::vector<Prod> prods;
@@ -1570,7 +1585,7 @@ static int32_t job_lookahead(Engine* e, ripp_sipp_job* j, int items, bool forced
             int g = 0;
             for (int t = 0; t < R; ++t) g = g * 3 + (((eb >> (R - 1 - t)) & 1) - ((fb >> (R - 1 - t)) & 1) + 1);
             const size_t ia = ((size_t)eb << 1) | (side == 0 ? 1u : 0u), ib = ((size_t)fb << 1) | (side == 0 ? 0u : 1u);
-            prods.push_back({a + ia * q, b + ib * q, g});
+            prods.push_back({a + ia * qblk, b + ib * qblk, g});
         }
         std::vector<Fp12> grows((size_t)ngroups * N_LINES); std::vector<char> gset((size_t)ngroups, 0);
         const size_t cmax = std::min<size_t>(MAX_PRODUCTS, std::max<size_t>(1, e->max_pairs_per_batch / q));
@@ -1601,7 +1616,7 @@ static int32_t job_lookahead(Engine* e, ripp_sipp_job* j, int items, bool forced
         if ((rc = absorb(nch - 1))) return rc;
         j->look.emplace_back();
         ripp_sipp_job::LookItem& li = j->look.back();
-        li.R = R; li.side = side; li.level = 0;
+        li.R = R; li.side = side; li.level = 0; li.npairs = q; li.q = qblk;
         for (int g = 0; g < ngroups; ++g) {
             auto rows = std::make_shared<std::vector<Fp12>>(grows.begin() + (size_t)g * N_LINES, grows.begin() + (size_t)(g + 1) * N_LINES);
             li.fe.push_back(look_pool().submit([rows]() { return final_exponentiation(miller_combine(rows->data())); }));
@@ -1641,6 +1656,8 @@ static void look_apply(ripp_sipp_job* j, size_t t, const Fr& x) {
     }
 }
 static ripp_sipp_job::LookItem* look_find(ripp_sipp_job* j, size_t round, int side) { for (auto& it : j->look) if ((size_t)it.R == round && it.side == side) return &it; return nullptr; }
+// both values of `round` are known in full: nothing of that round is left for the device
+static bool look_full(ripp_sipp_job* j, size_t round) { const auto* l = look_find(j, round, 0); const auto* r = look_find(j, round, 1); return l && r && l->npairs == l->q && r->npairs == r->q; }
 
 // ---- SIPP::prove (sipp/src/lib.rs:42-106) on this rank's shard; world0 == 1: the whole proof on one GPU --------------------------------------
 // One protocol for every world size: the ranks walk the same sequence of exchanges (plan, one per round while the vectors are sharded, the
@@ -1659,7 +1676,7 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
         if (seed_digest) { if (j->hash_thread.joinable()) j->hash_thread.join(); std::memcpy(j->digest, seed_digest, 32); j->digest_ready = true; j->hash_prestarted = false; }
         else job_start_hash(j, val);
     }
-    const bool look_forced = std::getenv("RIPP_LOOK_ITEMS") != nullptr;
+    const bool look_forced = std::getenv("RIPP_LOOK_ITEMS") != nullptr || std::getenv("RIPP_LOOK_EIGHTHS") != nullptr;
     int look_items = (rank == 0 || look_forced) ? look_plan(e, j->n_local, world0, window || look_forced) : 0;
     j->no_window = !window;
     if (world0 > 1) {
@@ -1731,33 +1748,39 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
         Fp12 zl = Fp12::one(), zr = Fp12::one();
         auto local_values = [&]() -> int32_t {
             int32_t rc;
-            if (tp_round || (lk_l && lk_r)) {
-            } else if (lk_l) {                                                               // only z_r = prod e(a_l, b_r) on the device
-                const size_t half = j->len / 2;
-                const G1A* as[1] = {j->a.as<G1A>()}; const G2A* bs[1] = {j->b.as<G2A>() + half};
+            // what the look-ahead has not covered goes to the device: pairs [start_s, half) of z_l = prod e(a_r, b_l) (s = 0) and z_r = prod e(a_l, b_r) (s = 1)
+            const size_t half = j->len / 2;
+            const size_t start[2] = {lk_l ? std::min(lk_l->npairs, half) : 0, lk_r ? std::min(lk_r->npairs, half) : 0};
+            const bool dev[2] = {!tp_round && start[0] < half, !tp_round && start[1] < half};
+            if (dev[0] && dev[1] && start[0] == 0 && start[1] == 0) { if ((rc = job_round_partials(e, j, rows))) return rc; }
+            else for (int sd = 0; sd < 2; ++sd) {
+                if (!dev[sd]) continue;
+                const G1A* as[1] = {j->a.as<G1A>() + (sd == 0 ? half : 0) + start[sd]}; const G2A* bs[1] = {j->b.as<G2A>() + (sd == 0 ? 0 : half) + start[sd]};
                 const double tp = now_ms();
-                if ((rc = e->step_products(as, bs, 1, half, rows + N_LINES))) return rc;
+                if ((rc = e->step_products(as, bs, 1, half - start[sd], rows + sd * N_LINES))) return rc;
                 e->stats.miller_products_ms += now_ms() - tp;
-            } else if ((rc = job_round_partials(e, j, rows))) return rc;
+            }
             if (round == 0 && !j->seeded && (rc = job_precompute_round0(e, j))) return rc;      // asynchronous: overlaps the host work below and the hash
             if (!j->pre_vm_ready && (rc = job_precompute_vm(e, j))) return rc;                   // small rounds: the same on the VM, during the host phase
             // entry into the pipelined tail -- unless the look-ahead has (round 0: is about to get) both values of the next round
-            const bool next_known = round == 0 ? (look_items >= 2 && j->len >= 4 && (look_forced || !j->digest_ready.load())) : (look_find(j, round + 1, 0) && look_find(j, round + 1, 1));
+            const bool next_known = round == 0 ? (look_items >= 16 && j->len >= 4 && (look_forced || !j->digest_ready.load())) : look_full(j, round + 1);
             if (!tp_round && !next_known && tail_pipe_ok(e, j) && (rc = job_tail_enqueue(e, j, round + 1))) return rc;
             t0 = now_ms();
             if (tp_round) { if ((rc = job_tail_values(j, round, x_prev, &zl, &zr))) return rc; }
             else {
-                if (lk_l) { look_finish_level(*lk_l); zl = lk_l->Z[0]; }
-                if (lk_r) { look_finish_level(*lk_r); zr = lk_r->Z[0]; }
-                if (lk_l && !lk_r) pairing_values(rows + N_LINES, 1, &zr);
-                else if (!lk_l) { Fp12 z2[2]; pairing_values(rows, 2, z2); zl = z2[0]; zr = z2[1]; }
-                if (j->bs_on && !(lk_l && lk_r)) {      // the device holds bs * b: what it evaluated is z^bs (look-ahead values came from the plain round-0 blocks)
+                Fp12 zd[2] = {Fp12::one(), Fp12::one()};                              // the device's share of each value
+                if (dev[0] && dev[1]) pairing_values(rows, 2, zd);
+                else if (dev[0]) pairing_values(rows, 1, &zd[0]);
+                else if (dev[1]) pairing_values(rows + N_LINES, 1, &zd[1]);
+                if (j->bs_on && (dev[0] || dev[1])) {      // the device holds bs * b: what it evaluated is z^bs (look-ahead values came from the plain round-0 blocks)
                     const GlsDigits gsi = gls_digits(inv(j->bs));                     // two tasks of two digit strings per value
-                    Fp12* zz[2] = {&zl, &zr}; Fp12 part[4];
-                    const bool skip_l = lk_l != nullptr;
-                    host_pool().parallel(4, [&](int t) { if ((t >> 1) == 0 && skip_l) return; part[t] = gt_pow_gls_strings(*zz[t >> 1], gsi, (t & 1) ? 12u : 3u); });
-                    for (int k = 0; k < 2; ++k) if (!(k == 0 && skip_l)) *zz[k] = mul(part[2 * k], part[2 * k + 1]);
+                    Fp12 part[4];
+                    host_pool().parallel(4, [&](int t) { if (!dev[t >> 1]) return; part[t] = gt_pow_gls_strings(zd[t >> 1], gsi, (t & 1) ? 12u : 3u); });
+                    for (int k = 0; k < 2; ++k) if (dev[k]) zd[k] = mul(part[2 * k], part[2 * k + 1]);
                 }
+                zl = zd[0]; zr = zd[1];
+                if (lk_l) { look_finish_level(*lk_l); zl = dev[0] ? mul(lk_l->Z[0], zd[0]) : lk_l->Z[0]; }
+                if (lk_r) { look_finish_level(*lk_r); zr = dev[1] ? mul(lk_r->Z[0], zd[1]) : lk_r->Z[0]; }
             }
             if (round == 0 && !j->seeded && (rc = job_lookahead(e, j, look_items, look_forced))) return rc;      // blocks on the GPU while the hash thread is still busy
             return RIPP_OK;
@@ -1796,7 +1819,7 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
         const double tf0 = now_ms();
         // nobody waits for this fold when the next round's values are already on their way (pipelined tail) or known (look-ahead)
         const bool pipelined = j->tp_round[(round + 1) & 1] == round + 1;
-        const bool known = look_find(j, round + 1, 0) && look_find(j, round + 1, 1);
+        const bool known = look_full(j, round + 1);
         if (!sharded && len == 2) { j->len = 0; j->pre_vm_ready = false; }      // the one-element vectors of the LAST fold are discarded by the prover (sipp/src/lib.rs:87-104 ends the loop): not computed
         else {
             if (!lrc) lrc = job_fold(e, j, x, true, pipelined || known);

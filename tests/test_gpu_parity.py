@@ -270,8 +270,12 @@ def test_sipp_prove_2p17_vs_oracle_with_precomputed_round0(engine, orc):
     #   RIPP_NO_FOLD_TABLES  two-base NAF kernels            RIPP_NO_XSCALE   G2 folds on the plain vector with the full-width x^-1
     #   RIPP_FQ_MIN=4096     the carry-free (14 x 28-bit) fold kernels and k_line_products_q already at this size -- with the degenerate
     #                        rows above, so their exceptional-case fallback runs         RIPP_NO_FQ   the 12 x 32-bit kernels everywhere
+    #   RIPP_LP_FQ_MIN / RIPP_ML_FQ_MIN = 2^32 - 1: the 12 x 32-bit pairing kernels (k_line_products, k_miller_lines) under the carry-free folds, one at a time
+    #   RIPP_LOOK_EIGHTHS    the hash-window look-ahead cut to a fraction of an item: (1,l) in full + 3/8 of (1,r); 5/8 of (1,l) alone
+    big = str((1 << 32) - 1)
     for env in ({"RIPP_NO_FOLD_TABLES": "1"}, {"RIPP_NO_XSCALE": "1"}, {"RIPP_FQ_MIN": "4096", "RIPP_LP_FQ_MIN": "1"},
-                {"RIPP_FQ_MIN": "4096", "RIPP_NO_XSCALE": "1"}, {"RIPP_NO_FQ": "1"}):
+                {"RIPP_FQ_MIN": "4096", "RIPP_NO_XSCALE": "1"}, {"RIPP_NO_FQ": "1"}, {"RIPP_LP_FQ_MIN": big}, {"RIPP_ML_FQ_MIN": big},
+                {"RIPP_LOOK_EIGHTHS": "11"}, {"RIPP_LOOK_EIGHTHS": "5"}, {"RIPP_LOOK_EIGHTHS": "20", "RIPP_NO_XSCALE": "1"}):
         os.environ.update(env)
         try:
             assert np.array_equal(engine.SIPP.prove(a, b, r, value), eproof), env
@@ -451,6 +455,26 @@ def test_pipelined_tail_rounds_and_job_reuse(engine, orc, n):
             assert np.array_equal(ch, ech), (n, rep)
     finally:
         job.close()
+
+
+@pytest.mark.parametrize("n,eighths", [(1 << 13, 12), (1 << 13, 3), (1 << 13, 21), (1 << 14, 38), (1 << 12, 47)])
+def test_partial_lookahead_items_vs_oracle(engine, orc, n, eighths):
+    """A look-ahead item cut to f/8 of every block's pairs (what is left of the hash window after the whole items): pairs [0, f q / 8) of that
+    round's product come from the round-0 blocks, the rest from the folded vectors on the device, and the two GT values are multiplied.
+    RIPP_LOOK_EIGHTHS = 8 k + f: k whole items and f/8 of the next.  Same proof bytes as the oracle."""
+    import os
+    a, b, r = orc.gen_g1(51, n), orc.gen_g2(52, n), orc.gen_scalars(53, n)
+    a[3] = 0; b[n // 2 + 70] = 0; a[n // 4 + 65] = 0
+    v = orc.product_of_pairings_with_coeffs(a, b, r)
+    rc, eproof, ech = orc.sipp_prove(a, b, r, v)
+    assert rc == 0
+    os.environ["RIPP_LOOK_EIGHTHS"] = str(eighths)
+    try:
+        proof, ch, st = engine.SippJob(a, b, r).prove(v)
+    finally:
+        del os.environ["RIPP_LOOK_EIGHTHS"]
+    assert np.array_equal(proof, eproof) and np.array_equal(ch, ech)
+    assert st["look_items"] == (eighths + 7) // 8 and st["look_pairs"] > 0
 
 
 @pytest.mark.parametrize("n,items", [(8, 6), (64, 6), (1 << 12, 2), (1 << 13, 6), (1 << 15, 3)])
