@@ -1549,7 +1549,7 @@ static int look_plan(const Engine* e, size_t n_local, int world, bool window) {
     if (n < (double)((size_t)1 << 17)) return 0;                    // small statements: the hash is done long before the GPU is
     const double ms_per_pair = 7.7e-5;                              // 2^20 pairs through lines + products: ~80 ms with the carry-free kernels (profiles/r03_*)
     const double hash_ms = n * 336.0 / 1.12e6;                      // the statement hash: 313-317 ms at n = 2^20 (1.06 GB/s of Blake2s in situ + serialisation hidden)
-    double budget = hash_ms - (nl * (4.1e-5 + ms_per_pair + 6.2e-5) + 1.0);      // scaling, round 0, fold tables
+    double budget = hash_ms - (nl * (4.1e-5 + ms_per_pair + 5.3e-5) + 1.0);      // scaling, round 0, fold tables (measured at n = 2^20: 42.6 + 80 + 55 ms)
     int items = 0;
     for (int it = 0; it < 2 * LOOK_MAX_R; ++it) {
         const int R = it / 2 + 1;
