@@ -224,6 +224,14 @@ struct Engine {
     size_t gls_split_max = (size_t)1 << 14;                               // rounds with <= this many outputs use the 4-lane GLS fold
     size_t max_pairs_per_batch = (size_t)1 << 19;                        // lines buffer cap: 2^19 pairs * 19.6 KB = 10.3 GB
     ripp_stats stats{};
+    // A second set of streams and scratch on the SAME device: two independent latency-bound provers of one call (aggregate_proofs' TIPP and
+    // TIPAWithSSM sub-proofs) run side by side, each driven by its own host thread, instead of taking turns waiting for host and device.
+    Engine* aux = nullptr;
+    Engine* aux_engine() {
+        if (!aux) { Engine* a = new Engine(); if (a->init(device) != RIPP_OK) { delete a; return nullptr; } aux = a; }
+        aux->refresh_switches(); aux->stats = ripp_stats{};
+        return aux;
+    }
     // run-time switches: read from the environment ONCE per C-ABI call (get_engine), never inside round loops
     struct Switches { bool no_vm = false, no_precompute = false, no_fold_tables = false, no_msm_glv = false, lp_one_lane = false, no_endo = false, no_fq = false, no_xscale = false; } sw;
     // crossover sizes: the member initialisers above are the defaults, the environment overrides them PER CALL (a test or
@@ -268,6 +276,7 @@ struct Engine {
         return RIPP_OK;
     }
     void destroy() {
+        if (aux) { aux->destroy(); delete aux; aux = nullptr; }
         for (DevBuf* b : {&lines, &partA, &partB, &jacG1, &jacG2, &tmpA, &tmpB, &tmpR, &affG1, &affG2, &qtab, &vm_flag, &scale_tab, &fold_tab1, &fold_mult, &fold_tab, &fold_jac1, &fold_jac2}) b->release();
         msm_scratch[0].release(); msm_scratch[1].release(); kzg_q[0].release(); kzg_q[1].release(); kzg_bases[0].release(); kzg_bases[1].release();
         if (stream3) (void)hipStreamDestroy(stream3);
@@ -1074,6 +1083,7 @@ API int32_t ripp_release_scratch(void) {
     e->msm_scratch[0].release(); e->msm_scratch[1].release(); e->kzg_q[0].release(); e->kzg_q[1].release(); e->kzg_bases[0].release(); e->kzg_bases[1].release();
     for (PinBuf& pb : e->stage) pb.release();             // pinned host staging (up to 2 x 32 MB after a verifier call at n = 2^20)
     e->tab_owner = nullptr;
+    if (e->aux) { e->aux->destroy(); delete e->aux; e->aux = nullptr; }
     return RIPP_OK;
 }
 

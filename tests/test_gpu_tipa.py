@@ -152,6 +152,22 @@ def test_aggregate_proofs_vs_oracle(engine, orc, n):
     c2 = c.copy(); c2[0] = c[1]                       # one invalid Groth16 proof among the n
     bad, _ = engine.aggregate_proofs(srs, a, b, c2)
     assert not engine.verify_aggregate_proof(vs, vk, pub, bad) and orc.verify_aggregate_proof(h.verifier_srs(osrs), vk, pub, bad) == 0
+    # by default the TIPP and TIPAWithSSM sub-proofs run side by side (second host thread, the engine's auxiliary streams and scratch);
+    # RIPP_AGG_SEQUENTIAL=1 runs them one after the other on the main engine: the same AggregateProof, member for member
+    import os
+    os.environ["RIPP_AGG_SEQUENTIAL"] = "1"
+    try:
+        seq, _ = engine.aggregate_proofs(srs, a, b, c)
+    finally:
+        del os.environ["RIPP_AGG_SEQUENTIAL"]
+    for k in ("com_a", "com_b", "com_c", "ip_ab", "r", "ab_kzg_c", "c_base_b", "c_kzg_c"):
+        assert np.array_equal(seq.field(k), got.field(k)), k
+    for k in ("agg_c", "ab_base_a", "ab_final_ck_b", "ab_opening_b", "c_base_a"):          # projective members: the same POINT (an MSM's bucket order, hence its Z, varies run to run)
+        assert same_g1(engine, orc, seq.field(k), got.field(k)), k
+    for k in ("ab_base_b", "ab_final_ck_a", "ab_opening_a", "c_final_ck_a", "c_opening_a"):
+        assert same_g2(engine, orc, seq.field(k), got.field(k)), k
+    for k in ("ab_com_steps", "ab_transcript", "c_com_gt", "c_transcript"):
+        assert np.array_equal(getattr(seq, k), getattr(got, k)), k
     srs.close()
 
 
