@@ -12,9 +12,8 @@
 #include <stdint.h>
 #if defined(RIPP_BLS12_377)
 // BLS12-377 build (libripp_hip_377.so; the curve of the reference's own SIPP test, sipp/src/lib.rs:229): the same 12 x u32 / 8 x u32 limb
-// layouts and code, other constants.  Endomorphism-accelerated paths and the field VM are disabled in that build (engine.hip).
+// layouts and code, other constants (GLV / GLS endomorphism constants included: tools/gen_params.py derives and checks them).
 #include "../bls12_377/params.hpp"
-#include "../bls12_377/endo_stub.hpp"
 #else
 #include "params.hpp"
 #endif

@@ -252,8 +252,9 @@ struct Engine {
         sw.no_xscale = std::getenv("RIPP_NO_XSCALE") != nullptr;        // G2 folds always on the plain vector with the full-width x^-1
         sw.no_fq = std::getenv("RIPP_NO_FQ") != nullptr;                // the 12 x 32-bit forms of the kernels that have a carry-free twin (fq_curve.hpp)
 #if defined(RIPP_BLS12_377)
-        // this build carries no endomorphism constants and no VM programs for its tower: plain paths only
-        sw.no_vm = sw.no_precompute = sw.no_fold_tables = sw.no_msm_glv = sw.no_endo = sw.no_fq = sw.no_xscale = true; sw.lp_one_lane = false;
+        // this build has the GLV / GLS constants of its curve (bls12_377/params.hpp) but no VM programs and no carry-free kernels for its tower
+        // (Fp2 = Fp[u]/(u^2 + 5), xi = u, D-type twist): the endomorphism-accelerated 12 x 32-bit kernels, no field VM
+        sw.no_vm = sw.no_fq = true; sw.lp_one_lane = false;
 #endif
     }
 
@@ -1550,7 +1551,7 @@ static HostPool& look_pool() { static HostPool pool(3); return pool; }      // o
 // Returned in EIGHTHS of an item: 8 k + f = the first k items in full and f/8 of the pairs of the next one (the window is a fixed budget; a
 // whole item of round R costs 2^(R-1) n pairs, so the last one is cut to what is left).
 static int look_plan(const Engine* e, size_t n_local, int world, bool window) {
-    if (!window || e->sw.no_precompute || e->sw.no_endo || e->sw.no_vm) return 0;
+    if (!window || e->sw.no_precompute || e->sw.no_endo) return 0;
     if (const char* s = std::getenv("RIPP_LOOK_EIGHTHS")) return std::max(0, std::min(16 * LOOK_MAX_R, std::atoi(s)));
     if (const char* s = std::getenv("RIPP_LOOK_ITEMS")) return 8 * std::max(0, std::min(2 * LOOK_MAX_R, std::atoi(s)));
     double share = 1.0;                                             // ranks sharing this rank's GPU (test rigs: several ranks on one device): their work adds up in the same window

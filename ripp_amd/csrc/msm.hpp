@@ -117,15 +117,15 @@ __global__ void __launch_bounds__(256) k_msm_digits(const Fr* __restrict__ scala
     if (p.n == p.nreal) { msm_emit_digits(k.l, 8, i, p, digits, hist); return; }
     if (p.n == 2 * p.nreal) {                                                        // GLV (G1): k = q * lambda + rem, both < 2^128
         const uint32_t lam[8] = RIPP_GLV_LAMBDA;
-        const uint32_t lam_mu[5] = {0xf6cfee30u, 0x63f6e522u, 0xe01faaddu, 0x7c6becf1u, 0x00000001u};     // floor(2^256 / lambda)
+        const uint32_t lam_mu[5] = RIPP_GLV_LAMBDA_MU;                  // floor(2^256 / lambda)
         uint32_t rem[5];
         msm_divmod<4, 5>(k.l, lam, lam_mu, rem);
         msm_emit_digits(rem, 5, i, p, digits, hist);
         msm_emit_digits(k.l, 8, p.nreal + i, p, digits, hist);
         return;
     }
-    const uint32_t u[2] = {0x00010000u, 0xd2010000u};                                // GLS (G2): base-|x| digits
-    const uint32_t u_mu[7] = {0x8573b29cu, 0x92078a5eu, 0x3e76ec28u, 0x33cfcc0du, 0x56cd56b5u, 0x381204cau, 0x00000001u};   // floor(2^256 / |x|)
+    const uint32_t u[2] = RIPP_X_ABS_LIMBS;                                          // GLS (G2): base-|x| digits
+    const uint32_t u_mu[7] = RIPP_X_ABS_MU;                                          // floor(2^256 / |x|)
 #pragma unroll 1
     for (int j = 0; j < 3; ++j) {
         uint32_t rem[3];

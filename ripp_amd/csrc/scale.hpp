@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(256, 2) k_scale_g1_glv(const G1A* __restrict__
     {
         Fr k = from_mont(k_mont[i]);
         const uint32_t lam[8] = RIPP_GLV_LAMBDA;
-        const uint32_t lam_mu[5] = {0xf6cfee30u, 0x63f6e522u, 0xe01faaddu, 0x7c6becf1u, 0x00000001u};     // floor(2^256 / lambda)
+        const uint32_t lam_mu[5] = RIPP_GLV_LAMBDA_MU;                  // floor(2^256 / lambda)
         uint32_t rem[5];
         msm_divmod<4, 5>(k.l, lam, lam_mu, rem);                      // k = q * lambda + rem
         scale_bias(rem, d1); scale_bias(k.l, d2);

@@ -133,3 +133,49 @@ def test_scaling_ipp_inputs_verbatim(E, o, n):
     proof = E.SIPP.prove(a, b, r, value)
     rc, eproof, _ = o.sipp_prove(a, b, r, value)
     assert rc == 0 and np.array_equal(proof, eproof) and E.SIPP.verify(a, b, r, value, proof)
+
+
+def test_sipp_2p17_endomorphism_paths_vs_oracle(E, o):
+    """The BLS12-377 build now carries the GLV (beta, lambda = x^2 - 1) and GLS (psi on the D-type twist, x > 0: no sign flip) constants of ITS
+    curve (tools/gen_params.py derives and checks them): round-0 fold tables in the hash window, the x-scaled G2 vector, the look-ahead and
+    the GLV / GLS scalar splits of the folds, the per-element scaling and the MSMs all run here.  n = 2^17 is the smallest statement that
+    takes the table folds; degenerate rows included.  Every switch that selects another implementation of the same step stays pinned to
+    the oracle: RIPP_NO_ENDO is the former plain double-and-add build."""
+    n = 1 << 17
+    a, b, r = E.synth_g1(1000, n), E.synth_g2(2000, n), E.synth_fr(0, n)
+    h = n // 2
+    a[h + 3] = 0; b[h + 5] = 0; b[7] = 0; r[h + 9] = 0
+    a[h + 11] = a[11]; b[h + 11] = b[11]; r[h + 11] = r[11]
+    value = E.product_of_pairings_with_coeffs(a, b, r)
+    assert np.array_equal(value, o.product_of_pairings_with_coeffs(a, b, r))
+    rc, eproof, ech = o.sipp_prove(a, b, r, value)
+    assert rc == 0
+    proof, ch, st = E.SIPP.prove_with_stats(a, b, r, value)
+    assert np.array_equal(proof, eproof) and np.array_equal(ch, ech)
+    assert E.SIPP.verify(a, b, r, value, proof) and o.sipp_verify(a, b, r, value, proof) == 1
+    for env in ({"RIPP_NO_ENDO": "1"}, {"RIPP_NO_FOLD_TABLES": "1"}, {"RIPP_NO_XSCALE": "1"}, {"RIPP_NO_PRECOMPUTE": "1"}, {"RIPP_LOOK_EIGHTHS": "12"}, {"RIPP_NO_MSM_GLV": "1"}):
+        os.environ.update(env)
+        try:
+            assert np.array_equal(E.SIPP.prove(a, b, r, value), eproof), env
+            assert E.SIPP.verify(a, b, r, value, eproof), env
+        finally:
+            for k in env: del os.environ[k]
+
+
+@pytest.mark.parametrize("n", [64, 1 << 12, 1 << 16])
+def test_msm_glv_gls_split_vs_oracle(E, o, n):
+    """GLV (G1) / GLS (G2) scalar splits of the Pippenger MSM on BLS12-377 with adversarial scalars: 0, 1, r - 1, lambda, lambda +- 1, x, x^2, x^3,
+    2^128 - 1 and values around the Barrett quotient's correction range; also against the unsplit 253-bit windows (RIPP_NO_MSM_GLV)."""
+    x = 0x8508C00000000001; lam = x * x - 1
+    a, b, s = o.gen_g1(31, n), o.gen_g2(41, n), o.gen_scalars(9, n)
+    special = [0, 1, o.R - 1, lam, lam + 1, lam - 1, x, x * x, x ** 3, 2**128 - 1, 2**128, o.R - lam, (o.R - 1) // 2, lam * lam % o.R, x ** 3 - 1, 2 * lam]
+    s[:len(special)] = o.fr_array([v % o.R for v in special])[: min(n, len(special))] if n >= len(special) else s[:len(special)]
+    e1, e2 = o.g1_to_affine(o.msm_g1_a(a, s)).reshape(1, 12), o.g2_to_affine(o.msm_g2_a(b, s)).reshape(1, 24)
+    for env in ({}, {"RIPP_NO_MSM_GLV": "1"}):
+        os.environ.update(env)
+        try:
+            assert np.array_equal(E.normalize_batch_g1(E.MultiexponentiationInnerProductG1.inner_product(o.to_jac_g1(a), s)), e1), env
+            assert np.array_equal(E.normalize_batch_g2(E.MultiexponentiationInnerProductG2.inner_product(o.to_jac_g2(b), s)), e2), env
+        finally:
+            for k in env: del os.environ[k]
+    assert np.array_equal(E.scale_g1_affine(a, s), o.scale_g1_a(a, s))
