@@ -252,9 +252,9 @@ struct Engine {
         sw.no_xscale = std::getenv("RIPP_NO_XSCALE") != nullptr;        // G2 folds always on the plain vector with the full-width x^-1
         sw.no_fq = std::getenv("RIPP_NO_FQ") != nullptr;                // the 12 x 32-bit forms of the kernels that have a carry-free twin (fq_curve.hpp)
 #if defined(RIPP_BLS12_377)
-        // this build has the GLV / GLS constants of its curve (bls12_377/params.hpp) but no VM programs and no carry-free kernels for its tower
-        // (Fp2 = Fp[u]/(u^2 + 5), xi = u, D-type twist): the endomorphism-accelerated 12 x 32-bit kernels, no field VM
-        sw.no_vm = sw.no_fq = true; sw.lp_one_lane = false;
+        // this build has the GLV / GLS constants (bls12_377/params.hpp) and the VM programs (bls12_377/vm_programs.inc) of its curve; the carry-free
+        // THROUGHPUT kernels (fq_curve*.hpp, fq_line_products.hpp, fq_miller.hpp) are written for u^2 = -1 and the M-type twist: 12 x 32-bit forms here
+        sw.no_fq = true; sw.lp_one_lane = false;
 #endif
     }
 

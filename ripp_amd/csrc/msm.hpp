@@ -169,8 +169,14 @@ __global__ void __launch_bounds__(256) k_msm_scatter(const uint16_t* __restrict_
 // Everything after the gathered mixed additions is kept in this form so that the latency-bound stages can use the field VM's complete
 // addition (vm.hpp, 16 lanes per point, ~8x shorter latency than one lane); add_h is the one-lane twin of that program
 // (Renes-Costello-Batina 2015, Alg. 7, a = 0: 12 products, no exceptional case), used where a stage has lanes to spare instead.
+#if defined(RIPP_BLS12_377)
+__device__ __forceinline__ Fp msm_mul_b3(const Fp& t) { return add(dbl(t), t); }                                                      // 3b = 3
+// 3b' = 3 / u: (c0 + c1 u) / u = c1 + (c0 / u^2) u = (c1, c0 * (-1/5)) -- RIPP_FP_TWIST_B1 is -1/5
+__device__ __forceinline__ Fp2 msm_mul_b3(const Fp2& t) { const Fp2 x = {t.c1, fmul(t.c0, fp_const(RIPP_FP_TWIST_B1))}; return add(dbl(x), x); }
+#else
 __device__ __forceinline__ Fp msm_mul_b3(const Fp& t) { const Fp t4 = dbl(dbl(t)); return add(dbl(t4), t4); }                     // 3b = 12
 __device__ __forceinline__ Fp2 msm_mul_b3(const Fp2& t) { const Fp2 x = mul_xi(t), x4 = dbl(dbl(x)); return add(dbl(x4), x4); }     // 3b' = 12 (1 + u)
+#endif
 template <class F> __device__ __forceinline__ Jac<F> msm_id_h() { return {F::zero(), F::one(), F::zero()}; }
 template <class F> __device__ __forceinline__ Jac<F> msm_jac_to_h(const Jac<F>& a) {                                                // (X/Z^2, Y/Z^3) -> (X Z : Y : Z^3)
     if (a.z.is_zero()) return msm_id_h<F>();

@@ -32,7 +32,11 @@ namespace ripp {
 struct VmOp { unsigned char dst, flags; unsigned short nbias; unsigned char s[16]; signed char c[16]; };   // 36 bytes
 struct alignas(16) VmSlot { uint32_t l[16]; };          // 14 limbs + padding: four 16-byte LDS accesses
 }  // namespace ripp
+#if defined(RIPP_BLS12_377)
+#include "bls12_377/vm_programs.inc"      // the same programs for Fp2 = Fp[u]/(u^2 + 5), xi = u, the D-type twist and b = 1 (tools/vmgen.py, curve "bls12_377")
+#else
 #include "vm_programs.inc"
+#endif
 namespace ripp {
 
 constexpr int VM_G = 16;                 // lanes per element

@@ -9,17 +9,29 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
-def test_vm_schedules_validate_and_header_is_current(tmp_path):
+import pytest
+
+
+@pytest.fixture(params=["bls12_381", "bls12_377"])
+def curve(request):
+    import vmgen
+    vmgen.set_curve(request.param)
+    yield request.param
+    vmgen.set_curve("bls12_381")
+
+
+def test_vm_schedules_validate_and_header_is_current(tmp_path, curve):
+    """both curves: BLS12-377 has its own tables (u^2 = -5, xi = u, D-type twist with b' = 1/u carried times 5, b = 1)"""
     import vmgen
     progs = vmgen.validate()                       # asserts inside compare each schedule with the reference formulas
     assert {name for name, _ in progs} >= {"line_double", "line_add", "fp12_mul", "g1_hdbl", "g1_cadd", "g2_hdbl", "g2_cadd"}
     out = tmp_path / "vm_programs.inc"
     vmgen.emit(progs, str(out))
-    committed = open(os.path.join(ROOT, "ripp_amd", "csrc", "vm_programs.inc")).read()
-    assert out.read_text() == committed, "vm_programs.inc is stale: run python tools/vmgen.py"
+    committed = open(os.path.join(ROOT, vmgen.CURVE["header"])).read()
+    assert out.read_text() == committed, vmgen.CURVE["header"] + " is stale: run python tools/vmgen.py"
 
 
-def test_vm_layers_are_homogeneous_and_in_bounds():
+def test_vm_layers_are_homogeneous_and_in_bounds(curve):
     """What vm.hpp::vm_run assumes about the tables: slot indices are bytes, a LIN op has at most 16 terms with |coefficient| <= 127 and a
     bias that fits 16 bits and covers its negative terms (values < 2p for program inputs and products, < 16p for unreduced LIN results),
     and a light LIN result stays below 16 p."""

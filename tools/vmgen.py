@@ -27,7 +27,39 @@ import os
 import random
 import sys
 
-P = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+# ---- curve parameters: the formulas below are written once and specialised by these ----------------------------------------------------
+#   beta: u^2 in Fp2;  xi: the Fp6 non-residue (w^6 = xi);  twist: M (b' = b xi) or D (b' = b / xi);  b: the G1 curve coefficient;
+#   s: projective rescaling that keeps 3 b' times a value a SMALL-INTEGER linear form (BLS12-377: b' = 1/u = -u/5, so everything that meets
+#      3 b' c is carried times 5 -- the same projective point, lines scaled by an element of Fp)
+_X377 = 0x8508C00000000001
+_R377 = _X377**4 - _X377**2 + 1
+CURVES = {
+    "bls12_381": dict(P=0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB, beta=-1, xi=(1, 1), twist="M", b=4, s=1,
+                      header=os.path.join("ripp_amd", "csrc", "vm_programs.inc"),
+                      g1=(0x17F1D3A73197D7942695638C4FA9AC0FC3688C4F9774B905A14E3A3F171BAC586C55E83FF97A1AEFFB3AF00ADB22C6BB,
+                          0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC744A2888AE40CAA232946C5E7E1),
+                      g2=((0x024AA2B2F08F0A91260805272DC51051C6E47AD4FA403B02B4510B647AE3D1770BAC0326A805BBEFD48056C8C121BDB8,
+                           0x13E02B6052719F607DACD3A088274F65596BD0D09920B61AB5DA61BBDC7F5049334CF11213945D57E5AC7D055D042B7E),
+                          (0x0CE5D527727D6E118CC9CDC6DA2E351AADFD9BAA8CBDD3A76D429A695160D12C923AC9CC3BACA289E193548608B82801,
+                           0x0606C4A02EA734CC32ACD2B02BC28B99CB3E287E85A763AF267492AB572E99AB3F370D275CEC1DA1AAA9075FF05F79BE))),
+    "bls12_377": dict(P=(_X377 - 1) ** 2 * _R377 // 3 + _X377, beta=-5, xi=(0, 1), twist="D", b=1, s=5,
+                      header=os.path.join("ripp_amd", "csrc", "bls12_377", "vm_programs.inc"),
+                      g1=(81937999373150964239938255573465948239988671502647976594219695644855304257327692006745978603320413799295628339695,
+                          241266749859715473739788878240585681733927191168601896383759122102112907357779751001206799952863815012735208165030),
+                      g2=((233578398248691099356572568220835526895379068987715365179118596935057653620464273615301663571204657964920925606294,
+                           140913150380207355837477652521042157274541796891053068589147167627541651775299824604154852141315666357241556069118),
+                          (63160294768292073209381361943935198908131692476676907196754037919244929611450776219210369229519898517858833747423,
+                           149157405641012693445398062341192467754805999074082136895788947234480009303640899064710353187729182149407503257491))),
+}
+CURVE = CURVES["bls12_381"]
+P = CURVE["P"]
+
+
+def set_curve(name):
+    global CURVE, P
+    CURVE = CURVES[name]; P = CURVE["P"]
+
+
 MUL, LIN = 0, 1
 ZERO_SLOT = 0          # workspace slot 0 always holds 0; slot 1 is a write-only dump for idle lanes
 DUMP_SLOT = 1
@@ -141,14 +173,22 @@ class Prog:
 
 
 class F2:
-    """Fp2 = Fp[u]/(u^2+1) over lazy linear forms."""
+    """Fp2 = Fp[u]/(u^2 - beta) over lazy linear forms (beta = -1 on BLS12-381, -5 on BLS12-377)."""
 
     def __init__(self, p, c0, c1): self.p, self.c0, self.c1 = p, Lin.of(c0), Lin.of(c1)
     def __add__(self, o): return F2(self.p, self.c0 + o.c0, self.c1 + o.c1)
     def __sub__(self, o): return F2(self.p, self.c0 - o.c0, self.c1 - o.c1)
     def __neg__(self): return F2(self.p, -self.c0, -self.c1)
     def scale(self, c): return F2(self.p, self.c0 * c, self.c1 * c)
-    def mul_xi(self): return F2(self.p, self.c0 - self.c1, self.c0 + self.c1)           # * (1 + u)
+    def mul_xi(self):
+        if CURVE["xi"] == (1, 1): return F2(self.p, self.c0 - self.c1, self.c0 + self.c1)           # * (1 + u), u^2 = -1
+        return F2(self.p, self.c1 * CURVE["beta"], self.c0)                                          # * u
+    def mul_3b(self):
+        """s * 3 b' * self with b' the twist's curve coefficient: 12 (1 + u) * self (s = 1); on the D-type twist b' = 1/u = u / beta, so
+        5 * 3 * (c0 + c1 u) u / beta = 15 (c1 + c0 u / beta) = (15 c1, -3 c0)"""
+        if CURVE["twist"] == "M": return self.mul_xi().scale(3 * CURVE["b"])
+        assert CURVE["xi"] == (0, 1) and CURVE["s"] == -CURVE["beta"] and CURVE["b"] == 1
+        return F2(self.p, self.c1 * (3 * CURVE["s"]), self.c0 * -3)
     def opnd(self):
         """Components usable inside Karatsuba sums: each a single value or a +-1 pair that stays simple when the two are added."""
         a = self
@@ -158,9 +198,12 @@ class F2:
         a, b = self.opnd(), o.opnd()
         t0, t1 = self.p.mul(a.c0, b.c0), self.p.mul(a.c1, b.c1)
         m = self.p.mul(a.c0 + a.c1, b.c0 + b.c1)
-        return F2(self.p, t0 - t1, m - t0 - t1)
+        return F2(self.p, t0 + t1 * CURVE["beta"], m - t0 - t1)
     def sqr(self):                                                                       # (a0+a1)(a0-a1), 2 a0 a1
         a = self.opnd()
+        if CURVE["beta"] != -1:      # a0^2 + beta a1^2 as two squares: (a0 + a1)(a0 + beta a1) would need a materialised operand, i.e. one more layer
+            t0, t1 = self.p.mul(a.c0, a.c0), self.p.mul(a.c1, a.c1)
+            return F2(self.p, t0 + t1 * CURVE["beta"], self.p.mul(a.c0, a.c1) * 2)
         m = self.p.mul(a.c0, a.c1)
         return F2(self.p, self.p.mul(a.c0 + a.c1, a.c0 - a.c1), m * 2)
     def mul_fp(self, s): return F2(self.p, self.p.mul(self.c0, s), self.p.mul(self.c1, s))
@@ -175,7 +218,8 @@ class F1:
     def __sub__(self, o): return F1(self.p, self.c0 - o.c0)
     def __neg__(self): return F1(self.p, -self.c0)
     def scale(self, c): return F1(self.p, self.c0 * c)
-    def mul_xi(self): return self                               # G1: b = 4, no twist factor
+    def mul_xi(self): return self                               # G1: no twist factor
+    def mul_3b(self): return self.scale(3 * CURVE["b"])        # G1: 3 b (no rescaling needed there: s enters the G1 formulas as 1)
     def mul(self, o): return F1(self.p, self.p.mul(self.c0, o.c0))
     def sqr(self): return F1(self.p, self.p.mul(self.c0, self.c0))
     def mat(self): return F1(self.p, self.p.materialise(self.c0))
@@ -318,17 +362,22 @@ def prog_line_double():
     p = Prog("line_double")
     X, Y, Z = f2in(p, "X"), f2in(p, "Y"), f2in(p, "Z")
     xP, yP = p.inp("xP"), p.inp("yP")
+    s = CURVE["s"]                                     # everything that meets e = 3 b' c is carried times s (s = 1: the formulas as written above)
     b, c = Y.sqr(), Z.sqr()
-    e = c.mul_xi().scale(12)                           # 4(1+u) * 3c
+    e = c.mul_3b()                                     # s * 3 b' c   (BLS12-381: 4(1+u) * 3c)
     f = e.scale(3)
     h = Y.mul(Z).scale(2)                              # (Y + Z)^2 - (b + c)
-    i = e - b
+    bs = b.scale(s)
+    i = e - bs
     j = X.sqr()
-    X3 = X.mul(Y).scale(2).mul(b - f)
-    Y3 = (b + f).sqr() - e.sqr().scale(12)
-    Z3 = b.mul(h).scale(4)
+    X3 = X.mul(Y).scale(2 * s).mul(bs - f)             # s^2 x the textbook point
+    Y3 = (bs + f).sqr() - e.sqr().scale(12)
+    Z3 = b.mul(h).scale(4) if s == 1 else bs.mul(h.scale(4)).scale(s)      # 4 s^2 b h with every coefficient <= COEF_MAX
     f2out(p, "X", X3, into="X"); f2out(p, "Y", Y3, into="Y"); f2out(p, "Z", Z3, into="Z")
-    f2out(p, "L0", i); f2out(p, "L1", j.mul_fp(xP).scale(3)); f2out(p, "L2", (-h.mat()).mul_fp(yP))
+    # s x the textbook line (free, xP, yP) = (e - b, 3 X^2 xP, -h yP); line slots: M-type twist (free, xP, yP) at w^0, w^2, w^3,
+    # D-type twist (yP, xP, free) at w^0, w^1, w^3
+    if CURVE["twist"] == "M": f2out(p, "L0", i); f2out(p, "L1", j.mul_fp(xP).scale(3 * s)); f2out(p, "L2", (-h.mat()).mul_fp(yP).scale(s))
+    else: f2out(p, "L0", (-h.mat()).mul_fp(yP).scale(s)); f2out(p, "L1", j.mul_fp(xP).scale(3 * s)); f2out(p, "L2", i)
     return p
 
 
@@ -347,7 +396,8 @@ def prog_line_add():
     Z3 = Z.mul(e)
     j = theta.mul(qx) - lam.mul(qy)
     f2out(p, "X", X3, into="X"); f2out(p, "Y", Y3, into="Y"); f2out(p, "Z", Z3, into="Z")
-    f2out(p, "L0", j); f2out(p, "L1", (-theta).mul_fp(xP)); f2out(p, "L2", lam.mul_fp(yP))
+    if CURVE["twist"] == "M": f2out(p, "L0", j); f2out(p, "L1", (-theta).mul_fp(xP)); f2out(p, "L2", lam.mul_fp(yP))
+    else: f2out(p, "L0", lam.mul_fp(yP)); f2out(p, "L1", (-theta).mul_fp(xP)); f2out(p, "L2", j)
     return p
 
 
@@ -363,11 +413,13 @@ def prog_hom_double(deg):
     p = Prog("g%d_hdbl" % deg)
     X, Y, Z = fin(p, "X", deg), fin(p, "Y", deg), fin(p, "Z", deg)
     fin(p, "qx", deg); fin(p, "qy", deg)                       # resident affine addend: slots reserved, not used here
+    s = CURVE["s"] if deg == 2 else 1
     b, c = Y.sqr(), Z.sqr()
-    e = c.mul_xi().scale(12)
+    e = c.mul_3b()
     f = e.scale(3)
     h = Y.mul(Z).scale(2)
-    fout(p, "X", X.mul(Y).scale(2).mul(b - f), into="X"); fout(p, "Y", (b + f).sqr() - e.sqr().scale(12), into="Y"); fout(p, "Z", b.mul(h).scale(4), into="Z")
+    bs = b.scale(s)
+    fout(p, "X", X.mul(Y).scale(2 * s).mul(bs - f), into="X"); fout(p, "Y", (bs + f).sqr() - e.sqr().scale(12), into="Y"); fout(p, "Z", b.mul(h).scale(4) if s == 1 else bs.mul(h.scale(4)).scale(s), into="Z")
     return p
 
 
@@ -383,9 +435,11 @@ def prog_hom_cadd(deg):
     t3 = X1.mul(Y2) + X2.mul(Y1)
     t4 = Y1.mul(Z2) + Y2.mul(Z1)
     t5 = X1.mul(Z2) + X2.mul(Z1)
-    b3t2, b3t5 = t2.mul_xi().scale(12), t5.mul_xi().scale(12)
-    m, pl, t03 = t1 - b3t2, t1 + b3t2, t0.scale(3)
-    fout(p, "X", t3.mul(m) - t4.mul(b3t5), into="X"); fout(p, "Y", m.mul(pl) + b3t5.mul(t03), into="Y"); fout(p, "Z", pl.mul(t4) + t03.mul(t3), into="Z")
+    s = CURVE["s"] if deg == 2 else 1                         # with B = s b3: (X3, Y3, Z3) s^2 = (s t3 (s t1 - B t2) - s t4 B t5, (s t1 - B t2)(s t1 + B t2) + B t5 3 s t0, ...)
+    b3t2, b3t5 = t2.mul_3b(), t5.mul_3b()
+    t1s, t3s, t4s = t1.scale(s), t3.scale(s), t4.scale(s)
+    m, pl, t03 = t1s - b3t2, t1s + b3t2, t0.scale(3 * s)
+    fout(p, "X", t3s.mul(m) - t4s.mul(b3t5), into="X"); fout(p, "Y", m.mul(pl) + b3t5.mul(t03), into="Y"); fout(p, "Z", pl.mul(t4s) + t03.mul(t3s), into="Z")
     return p
 
 
@@ -421,26 +475,32 @@ def prog_fp12_mul():
 
 
 # ------------------------------------------------------------------------------------------------ reference formulas (ints) for validation
-def f2m(a, b): return ((a[0] * b[0] - a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
+def f2m(a, b): return ((a[0] * b[0] + CURVE["beta"] * a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
 def f2a(a, b): return ((a[0] + b[0]) % P, (a[1] + b[1]) % P)
 def f2s(a, b): return ((a[0] - b[0]) % P, (a[1] - b[1]) % P)
 def f2k(a, k): return (a[0] * k % P, a[1] * k % P)
-def f2xi(a): return ((a[0] - a[1]) % P, (a[0] + a[1]) % P)
+def f2xi(a): return f2m(a, CURVE["xi"])
+def f2inv(a):
+    d = pow(a[0] * a[0] - CURVE["beta"] * a[1] * a[1], -1, P); return (a[0] * d % P, (-a[1]) * d % P)
+def twist_b(): return f2k(f2xi((1, 0)), CURVE["b"]) if CURVE["twist"] == "M" else f2k(f2inv(CURVE["xi"]), CURVE["b"])
 
 
 def ref_line_double(X, Y, Z, xP, yP):
     """pairing.hpp line_double, the new point scaled by 4 (same point; the VM avoids the two halvings that way)"""
-    i2 = pow(2, -1, P)
-    a = f2k(f2m(X, Y), i2); b = f2m(Y, Y); c = f2m(Z, Z); e = f2xi(f2k(c, 12)); f = f2k(e, 3); g = f2k(f2a(b, f), i2)
+    i2 = pow(2, -1, P); s = CURVE["s"]
+    a = f2k(f2m(X, Y), i2); b = f2m(Y, Y); c = f2m(Z, Z); e = f2m(f2k(c, 3), twist_b()); f = f2k(e, 3); g = f2k(f2a(b, f), i2)
     h = f2s(f2m(f2a(Y, Z), f2a(Y, Z)), f2a(b, c)); i = f2s(e, b); j = f2m(X, X); e2 = f2m(e, e)
-    return dict(X=f2k(f2m(a, f2s(b, f)), 4), Y=f2k(f2s(f2m(g, g), f2k(e2, 3)), 4), Z=f2k(f2m(b, h), 4), L0=i, L1=f2k(f2k(j, 3), xP), L2=f2k(f2k(h, -1), yP))
+    lfree, lx, ly = f2k(i, s), f2k(f2k(j, 3 * s), xP), f2k(f2k(h, -s), yP)                  # the VM carries the point times 4 s^2, the line times s
+    L = dict(L0=lfree, L1=lx, L2=ly) if CURVE["twist"] == "M" else dict(L0=ly, L1=lx, L2=lfree)
+    return dict(X=f2k(f2m(a, f2s(b, f)), 4 * s * s), Y=f2k(f2s(f2m(g, g), f2k(e2, 3)), 4 * s * s), Z=f2k(f2m(b, h), 4 * s * s), **L)
 
 
 def ref_line_add(X, Y, Z, qx, qy, xP, yP):
     theta = f2s(Y, f2m(qy, Z)); lam = f2s(X, f2m(qx, Z)); c = f2m(theta, theta); d = f2m(lam, lam)
     e = f2m(lam, d); f = f2m(Z, c); g = f2m(X, d); h = f2s(f2a(e, f), f2k(g, 2))
-    return dict(X=f2m(lam, h), Y=f2s(f2m(theta, f2s(g, h)), f2m(e, Y)), Z=f2m(Z, e), L0=f2s(f2m(theta, qx), f2m(lam, qy)),
-                L1=f2k(f2k(theta, -1), xP), L2=f2k(lam, yP))
+    lfree, lx, ly = f2s(f2m(theta, qx), f2m(lam, qy)), f2k(f2k(theta, -1), xP), f2k(lam, yP)
+    L = dict(L0=lfree, L1=lx, L2=ly) if CURVE["twist"] == "M" else dict(L0=ly, L1=lx, L2=lfree)
+    return dict(X=f2m(lam, h), Y=f2s(f2m(theta, f2s(g, h)), f2m(e, Y)), Z=f2m(Z, e), **L)
 
 
 def f12_to_poly(c):   # tower (c00,c01,c02,c10,c11,c12) -> coefficients of w^0..w^5  (v = w^2)
@@ -483,32 +543,20 @@ def validate():
         for deg in (1, 2):
             if deg == 1:
                 fm = lambda a, b: a * b % P; fi = lambda a: pow(a, -1, P); fs = lambda a, b: (a - b) % P; fk = lambda a, k: a * k % P
-                bcoef = 4
             else:
-                fm, fs, fk = f2m, f2s, f2k
-                fi = lambda a: (lambda d: (a[0] * d % P, (-a[1]) * d % P))(pow(a[0] * a[0] + a[1] * a[1], -1, P))
-                bcoef = (4, 4)
+                fm, fs, fk, fi = f2m, f2s, f2k, f2inv
             fa = (lambda a, b: (a + b) % P) if deg == 1 else f2a
-            def rnd_pt():
-                while True:   # random affine point on the curve
-                    x = rf() if deg == 1 else rf2()
-                    y2 = fa(fm(fm(x, x), x), bcoef)
-                    if deg == 1:
-                        y = pow(y2, (P + 1) // 4, P)
-                        if y * y % P == y2: return x, y
-                    else:     # sqrt in Fp2 via the norm method (p = 3 mod 4)
-                        a0, a1 = y2
-                        n = (a0 * a0 + a1 * a1) % P; sn = pow(n, (P + 1) // 4, P)
-                        if sn * sn % P != n: continue
-                        for sgn in (1, -1):
-                            t = (a0 + sgn * sn) * pow(2, -1, P) % P; x0 = pow(t, (P + 1) // 4, P)
-                            if x0 * x0 % P == t and x0:
-                                x1 = a1 * pow(2 * x0, -1, P) % P
-                                if f2m((x0, x1), (x0, x1)) == y2: return x, (x0, x1)
             def aff_add(p1, p2):
                 (x1, y1), (x2, y2) = p1, p2
                 lam = fm(fk(fm(x1, x1), 3), fi(fk(y1, 2))) if p1 == p2 else fm(fs(y2, y1), fi(fs(x2, x1)))
                 x3 = fs(fs(fm(lam, lam), x1), x2); return x3, fs(fm(lam, fs(x1, x3)), y1)
+            def rnd_pt():         # a random multiple of the generator (no square roots: p = 1 mod 4 on BLS12-377)
+                gen = CURVE["g1"] if deg == 1 else CURVE["g2"]
+                acc = None
+                for bit in bin(rnd.randrange(2, 1 << 40))[2:]:
+                    if acc is not None: acc = aff_add(acc, acc)
+                    if bit == "1": acc = gen if acc is None else aff_add(acc, gen)
+                return acc
             T, Q = rnd_pt(), rnd_pt()
             z = rf() if deg == 1 else rf2()
             Th = (fm(T[0], z), fm(T[1], z), z)                # homogeneous representative of T
@@ -549,7 +597,7 @@ def validate():
 
 def emit(progs, path):
     w = []
-    w.append("// GENERATED by tools/vmgen.py -- do not edit.  Layer tables of the lane-parallel field VM (vm.hpp).")
+    w.append("// GENERATED by tools/vmgen.py -- do not edit.  Layer tables of the lane-parallel field VM (vm.hpp), %s." % [k for k, v in CURVES.items() if v is CURVE][0].upper().replace("_", "-"))
     w.append("// kind[l]: 0 = MUL layer; otherwise LIN layer: bits 0-4 = terms walked by the layer (max over its ops), bit 6 = heavy (results reduced below 2p).")
     w.append("// op = {dst, flags, nbias, s[16], c[16]}: MUL uses s[0..3] (second term of an operand absent <=> slot 0) and flags bits 0-3 = negate term i;")
     w.append("// LIN: dst = sum_t c[t] * slot[s[t]] + nbias * p  (unused terms: slot 0, coefficient 0).")
@@ -581,8 +629,12 @@ def emit(progs, path):
 
 
 if __name__ == "__main__":
-    progs = validate()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    emit(progs, os.path.join(root, "ripp_amd", "csrc", "vm_programs.inc"))
-    for (name, G), c in sorted(progs.items()):
-        print(f"{name:12s} G={G:2d}: {c['mul_ops']:3d} products in {c['nmul']:2d} MUL layers, {c['lin_ops']:3d} linear ops in {c['nlin']:2d} LIN layers, {c['nslots']:3d} slots, mul util {c['mul_ops'] / max(1, c['nmul'] * G):.0%}")
+    for curve in CURVES:
+        set_curve(curve)
+        progs = validate()
+        emit(progs, os.path.join(root, CURVE["header"]))
+        print(curve)
+        for (name, G), c in sorted(progs.items()):
+            print(f"  {name:12s} G={G:2d}: {c['mul_ops']:3d} products in {c['nmul']:2d} MUL layers, {c['lin_ops']:3d} linear ops in {c['nlin']:2d} LIN layers, {c['nslots']:3d} slots, mul util {c['mul_ops'] / max(1, c['nmul'] * G):.0%}")
+    set_curve("bls12_381")
