@@ -503,6 +503,4 @@ ORC_API int orc_gipa_tipp_verify(const g2j_t *ck_a, const g1j_t *ck_b, size_t n,
     return ok;
 }
 
-#ifndef ORC_BLS12_377
-#include "tipa.h"       /* TIPA / aggregation restatements: BLS12-381 only (Fr::from_random_bytes masks, GLS-free but 381-tested) */
-#endif
+#include "tipa.h"       /* TIPA / aggregation restatements (both curves: nothing in them depends on the curve beyond field.h / curve.h / pairing.h and the point encodings above) */

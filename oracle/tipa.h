@@ -34,7 +34,9 @@ typedef struct {
 } orc_aggregate_proof_t;
 
 static int fr_from_random_bytes(const uint8_t dig[64], fr_t *out) {
-    fr_t t; memcpy(t.l, dig, 32); t.l[3] &= 0x7fffffffffffffffull;
+    /* bits above MODULUS_BIT_SIZE are cleared (ark-ff 0.4 from_random_bytes_with_flags: `shave_bits` = 64 N - MODULUS_BIT_SIZE): 1 bit on BLS12-381 (255-bit r), 3 on BLS12-377 (253-bit r) */
+    int top = 63; while (top > 0 && !((FR_R[3] >> top) & 1)) --top;
+    fr_t t; memcpy(t.l, dig, 32); t.l[3] &= (top == 63) ? ~0ull : (((uint64_t)1 << (top + 1)) - 1);
     uint64_t bo = 0; for (int i = 0; i < 4; ++i) (void)sbb64(t.l[i], FR_R[i], &bo);
     if (!bo) return 0;
     fr_to_mont(out, &t); return 1;

@@ -247,9 +247,10 @@ inline Fr gipa_tipp_challenge(const Fr* prev, const Fp12 com[6], Fr& c_inv) {
 }
 
 // Fr::from_random_bytes(&digest) of ark-ff 0.4 (Fp::from_random_bytes_with_flags::<EmptyFlags>): the first 32 bytes are
-// read little-endian, the bits above MODULUS_BIT_SIZE = 255 are cleared, and the value is rejected when it is >= r.
+// read little-endian, the bits above MODULUS_BIT_SIZE (255 on BLS12-381, 253 on BLS12-377) are cleared, and the value is rejected when it is >= r.
 inline bool fr_from_random_bytes(const uint8_t dig[64], Fr& out) {
-    Fr t; std::memcpy(t.l, dig, 32); t.l[7] &= 0x7fffffffu;
+    int top = 31; while (top > 0 && !((FrParams::mod(7) >> top) & 1u)) --top;                 // MODULUS_BIT_SIZE - 225: 30 on BLS12-381 (255-bit r), 28 on BLS12-377 (253-bit r)
+    Fr t; std::memcpy(t.l, dig, 32); t.l[7] &= (top == 31) ? ~0u : ((1u << (top + 1)) - 1u);
     uint32_t borrow = 0; for (int i = 0; i < 8; ++i) (void)subb32(t.l[i], FrParams::mod(i), borrow);
     if (!borrow) return false;
     out = to_mont(t); return true;

@@ -20,7 +20,7 @@ def gt_from_bytes(hexstr):
 
 
 # ---------------------------------------------------------------- TIPA SRS and synthetic Groth16 instances (oracle-side, test infrastructure)
-def make_srs(n, alpha, beta):
+def make_srs(n, alpha, beta, o=o):
     """SRS of TIPA::setup (tipa/mod.rs:150-165) for fixed trapdoors: (g_alpha_powers[2n-1], h_beta_powers[2n-1], g_beta, h_alpha), all Jacobian."""
     fa, fb = o.fr_array([alpha]), o.fr_array([beta])
     gap = o.srs_powers_g1(fa[0], 2 * n - 1); hbp = o.srs_powers_g2(fb[0], 2 * n - 1)
@@ -38,7 +38,7 @@ def commitment_keys(srs):
     return np.ascontiguousarray(srs[1][::2]), np.ascontiguousarray(srs[0][::2])
 
 
-def fake_groth16(n, m, seed):
+def fake_groth16(n, m, seed, o=o):
     """n Groth16 (A, B, C) triples over m public inputs that SATISFY e(A,B) = e(alpha,beta) e(sum x_k abc_k, gamma) e(C, delta) for a
     verifying key with known discrete logs (no circuit needed).  Returns vk = (alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1[m+1]),
     public_inputs (n, m, 4), a (n,12), b (n,24), c (n,12)."""

@@ -179,3 +179,32 @@ def test_msm_glv_gls_split_vs_oracle(E, o, n):
         finally:
             for k in env: del os.environ[k]
     assert np.array_equal(E.scale_g1_affine(a, s), o.scale_g1_a(a, s))
+
+
+@pytest.mark.parametrize("n", [2, 8, 256, 1 << 12])
+def test_aggregate_proofs_bls12_377_vs_oracle(E, o, n):
+    """aggregate_proofs (TIPA with SRS shift + TIPAWithSSM, KZG openings, Fr::from_random_bytes with THIS field's 253-bit mask) on the curve of the
+    reference's aggregation bench (benches/benches/groth16_aggregation/bench.rs): every member of the AggregateProof equals the BLS12-377
+    oracle's, both verifiers accept it, and both reject it against other public inputs."""
+    import helpers as h
+    osrs = h.make_srs(n, 0xa1fa + n, 0xbe7a + n, o=o); srs = E.SRS(osrs[0], osrs[1], osrs[2], osrs[3])
+    vk, pub, a, b, c = h.fake_groth16(n, 2, seed=n, o=o)
+    got, _ = E.aggregate_proofs(srs, a, b, c)
+    rc, exp = o.aggregate_proofs(osrs[0], osrs[1], a, b, c); assert rc == 0
+    rounds = n.bit_length() - 1
+    for k in ("com_a", "com_b", "com_c", "ip_ab", "r", "ab_kzg_c", "c_base_b", "c_kzg_c"):
+        assert np.array_equal(got.field(k), exp.field(k)), k
+    for k in ("ab_com_steps", "ab_transcript", "c_com_gt", "c_transcript"):
+        assert np.array_equal(getattr(got, k), getattr(exp, k)), k
+    n1 = lambda p: E.normalize_batch_g1(np.ascontiguousarray(p).reshape(-1, 18)); n2 = lambda p: E.normalize_batch_g2(np.ascontiguousarray(p).reshape(-1, 36))
+    for k in ("agg_c", "ab_base_a", "ab_final_ck_b", "ab_opening_b", "c_base_a"):
+        assert np.array_equal(n1(got.field(k)), o.normalize_g1(np.ascontiguousarray(exp.field(k)).reshape(-1, 18))), k
+    for k in ("ab_base_b", "ab_final_ck_a", "ab_opening_a", "c_final_ck_a", "c_opening_a"):
+        assert np.array_equal(n2(got.field(k)), o.normalize_g2(np.ascontiguousarray(exp.field(k)).reshape(-1, 36))), k
+    assert np.array_equal(n1(got.c_com_g1[: 2 * rounds]), o.normalize_g1(exp.c_com_g1[: 2 * rounds]))
+    assert o.verify_aggregate_proof(h.verifier_srs(osrs), vk, pub, got) == 1
+    vs = srs.get_verifier_key()
+    assert E.verify_aggregate_proof(vs, vk, pub, got)
+    pub2 = pub.copy(); pub2[0, 0] = pub[1, 0]
+    assert o.verify_aggregate_proof(h.verifier_srs(osrs), vk, pub2, got) == 0 and not E.verify_aggregate_proof(vs, vk, pub2, got)
+    srs.close()

@@ -93,3 +93,21 @@ def test_reference_prove_and_verify_base_case(o):
     assert rc == 0 and o.sipp_verify(a, b, r, z, proof) == 1
     bad = proof.copy(); bad[3] = proof[2]
     assert o.sipp_verify(a, b, r, z, bad) == 0
+
+
+def test_aggregate_proofs_round_trip_bls12_377(o):
+    """the TIPA / aggregation restatement (oracle/tipa.h) on BLS12-377 -- the curve of the reference's aggregation bench: prove -> verify accepts,
+    other public inputs are rejected; Fr::from_random_bytes clears the THREE bits above this field's 253-bit modulus [ark-mem]"""
+    import helpers as h
+    n = 8
+    osrs = h.make_srs(n, 0xa1fa + n, 0xbe7a + n, o=o)
+    vk, pub, a, b, c = h.fake_groth16(n, 2, seed=n, o=o)
+    rc, pf = o.aggregate_proofs(osrs[0], osrs[1], a, b, c)
+    assert rc == 0 and o.verify_aggregate_proof(h.verifier_srs(osrs), vk, pub, pf) == 1
+    pub2 = pub.copy(); pub2[0, 0] = pub[1, 0]
+    assert o.verify_aggregate_proof(h.verifier_srs(osrs), vk, pub2, pf) == 0
+    import ctypes
+    dig = (ctypes.c_uint8 * 64)(*([0xff] * 64)); out = np.zeros(4, dtype=np.uint64)
+    assert o.lib().orc_fr_from_random_bytes(dig, out.ctypes.data_as(ctypes.c_void_p)) == 0        # 2^253 - 1 >= r: rejected
+    dig = (ctypes.c_uint8 * 64)(*([0xff] * 31 + [0xe0] + [0] * 32))                                  # the three top bits set, the rest of the top byte clear
+    assert o.lib().orc_fr_from_random_bytes(dig, out.ctypes.data_as(ctypes.c_void_p)) == 1 and o.limbs_to_fr(out) == (1 << 248) - 1
