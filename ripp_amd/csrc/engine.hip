@@ -30,6 +30,7 @@
 #include "fq_curve2.hpp"
 #include "fq_line_products.hpp"
 #include "fq_miller.hpp"
+#include "fq_scale.hpp"
 #include "vm_fold2.hpp"
 #include "host_fs.hpp"
 #include "wire.hpp"
@@ -332,6 +333,9 @@ struct Engine {
             return RIPP_OK;
         }
         int32_t rc = scale_tab.reserve((size_t)SCALE_TAB * G1J_CHUNKS * n * sizeof(uint4)); if (rc) return rc;
+        if (!sw.no_fq && !std::getenv("RIPP_SCALE_NO_FQ"))      // the carry-free twin (fq_scale.hpp)
+            hipLaunchKernelGGL(k_scale_g1_glv_q, dim3(nblk(n, 256)), dim3(256), 0, st, base, base_stride, k, (uint32_t)n, scale_tab.as<uint4>(), out);
+        else
         hipLaunchKernelGGL(k_scale_g1_glv, dim3(nblk(n, 256)), dim3(256), 0, st, base, base_stride, k, (uint32_t)n, scale_tab.as<uint4>(), out);
         HIPCHK(hipGetLastError());
         return RIPP_OK;
@@ -1560,7 +1564,7 @@ static int look_plan(const Engine* e, size_t n_local, int world, bool window) {
     if (n < (double)((size_t)1 << 17)) return 0;                    // small statements: the hash is done long before the GPU is
     const double ms_per_pair = 7.7e-5;                              // 2^20 pairs through lines + products: ~80 ms with the carry-free kernels (profiles/r03_*)
     const double hash_ms = n * 336.0 / 1.12e6;                      // the statement hash: 313-317 ms at n = 2^20 (1.06 GB/s of Blake2s in situ + serialisation hidden)
-    double budget = hash_ms - (nl * (4.1e-5 + ms_per_pair + 5.3e-5) + 1.0);      // scaling, round 0, fold tables (measured at n = 2^20: 42.6 + 80 + 55 ms)
+    double budget = hash_ms - (nl * (3.2e-5 + ms_per_pair + 5.3e-5) + 1.0);      // scaling, round 0, fold tables (measured at n = 2^20: 33 + 80 + 55 ms)
     int items = 0;
     for (int it = 0; it < 2 * LOOK_MAX_R; ++it) {
         const int R = it / 2 + 1;
