@@ -31,6 +31,7 @@
 #include "fq_line_products.hpp"
 #include "fq_miller.hpp"
 #include "fq_scale.hpp"
+#include "fq_msm.hpp"
 #include "vm_fold2.hpp"
 #include "host_fs.hpp"
 #include "wire.hpp"
@@ -172,8 +173,9 @@ struct PinBuf {
 // scratch of ONE in-flight MSM (two MSMs of a GIPA-with-SSM round run side by side on two streams)
 struct MsmScratch {
     DevBuf digits, hist, offs, cursor, slotoffs, spw, sorted, slots, buckets, seg, seg2, win, out;
+    DevBuf ext;                          // bases and their endomorphism images in the carry-free form (fq_msm.hpp)
     void* host_out = nullptr;            // pinned landing zone for the result
-    void release() { for (DevBuf* b : {&digits, &hist, &offs, &cursor, &slotoffs, &spw, &sorted, &slots, &buckets, &seg, &seg2, &win, &out}) b->release(); if (host_out) (void)hipHostFree(host_out); host_out = nullptr; }
+    void release() { for (DevBuf* b : {&digits, &hist, &offs, &cursor, &slotoffs, &spw, &sorted, &slots, &buckets, &seg, &seg2, &win, &out, &ext}) b->release(); if (host_out) (void)hipHostFree(host_out); host_out = nullptr; }
 };
 
 struct Timer {   // HIP-event stopwatch on the engine stream
@@ -382,6 +384,15 @@ struct Engine {
         // the gather work on homogeneous coordinates and the ones with few points run on the field VM (msm.hpp)
         const bool hom = !sw.no_vm;
         const size_t vm_lds = 4 * VM_EPW * VmCurve<F>::SLOTS * sizeof(VmSlot);
+#if !defined(RIPP_BLS12_377)
+        if (!sw.no_fq) {        // gathered additions on the carry-free form over the extended base array (fq_msm.hpp)
+            const int split = (int)(n / nreal);
+            if ((rc = ms.ext.reserve(n * sizeof(Affine<F>)))) return rc;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_extend_q<F>), dim3(nblk(nreal, 256), split), dim3(256), 0, st, bases, (uint32_t)nreal, split, ms.ext.as<QAff<F>>());
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_slot_sum_q<F>), dim3(nblk(max_slots, 64), p.nwin), dim3(64), 0, st, bases, ms.ext.as<QAff<F>>(), p, ms.hist.as<uint32_t>(), ms.offs.as<uint32_t>(),
+                               ms.slotoffs.as<uint32_t>(), ms.spw.as<uint32_t>(), ms.sorted.as<uint32_t>(), ms.slots.as<Jac<F>>(), max_slots, hom);
+        } else
+#endif
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_slot_sum<F>), dim3(nblk(max_slots, 64), p.nwin), dim3(64), 0, st, bases, p, ms.hist.as<uint32_t>(), ms.offs.as<uint32_t>(),
                            ms.slotoffs.as<uint32_t>(), ms.spw.as<uint32_t>(), ms.sorted.as<uint32_t>(), ms.slots.as<Jac<F>>(), max_slots, hom);
         uint32_t passes = 0;                                                       // a bucket holds at most n / ch + 1 slots

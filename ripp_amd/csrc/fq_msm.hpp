@@ -1,0 +1,137 @@
+// The gathered mixed additions of the Pippenger MSM (msm.hpp k_msm_slot_sum: ~2/3 of an MSM's device time) on the carry-free field form.
+//   * k_msm_extend_q: once per MSM, the `split` endomorphism images of every base (G1: P, phi(P); G2: Q, psi(Q), psi^2(Q), psi^3(Q)) are written
+//     to an EXTENDED base array -- a term's base is then one load (k_msm_slot_sum formed phi / psi of a re-loaded base inside every addition:
+//     1 resp. 6 extra Fp products per addition, and on G2 the operands of those products pushed the kernel into scratch).  The array holds
+//     the coordinates already in the carry-free form (12 words of the canonical Montgomery-392 integer), so a gathered point is only re-sliced.
+//   * k_msm_slot_sum_q: the slot loop with madd-2007-bl on 14 x 28-bit limbs (G1: fq_curve.hpp's jmadd_q; G2: the same formulas over Fp2
+//     products written as two lazily reduced sums of two products, fq_miller.hpp) -- fewer instructions on an issue-bound kernel, no scratch
+//     for G1.  Exceptional additions (T = +-Q) are DETECTED and that slot is redone with the complete formulas (msm_slot_sum_complete), like
+//     everywhere the low-liveness additions are used.  BLS12-381 only.
+#pragma once
+#include "fq_miller.hpp"
+#include "msm.hpp"
+
+namespace ripp {
+
+// an Fp / Fp2 coordinate of the extended array: 12 words per Fp (canonical integer of the Montgomery-392 form)
+struct QFp { uint32_t w[12]; };
+template <class F> struct QAff;
+template <> struct alignas(16) QAff<Fp> { QFp x, y; };
+template <> struct alignas(16) QAff<Fp2> { QFp x0, x1, y0, y1; };
+static_assert(sizeof(QAff<Fp>) == sizeof(G1A) && sizeof(QAff<Fp2>) == sizeof(G2A), "the extended array has the footprint of split * n affine points");
+
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RIPP_BLS12_377)
+__device__ __forceinline__ QFp qfp_from(const Fp& v) { QFp r; fq_pack(fq_canon(fq_from_fp_fast(v)), r.w); return r; }
+__device__ __forceinline__ Fqn qfp_get(const QFp& v) { return fq_unpack(v.w); }
+__device__ __forceinline__ bool qfp_zero(const QFp& v) { uint32_t z = 0; for (int k = 0; k < 12; ++k) z |= v.w[k]; return z == 0; }
+
+#define SBX() __builtin_amdgcn_sched_barrier(0)
+// madd-2007-bl over Fp2 in the order of fq_curve2.hpp's jmadd2_q; products in the two-sums form (no out-of-line calls, no Karatsuba temporaries).
+// park: this lane's LDS column (7 x 16 B, stride 64 lanes).  Returns true when the result is NOT valid (H = 0: T = +-Q).
+template <class LOADX, class LOADY>
+__device__ __forceinline__ bool jmadd2_qd(JacQ2& p, LOADX loadx, LOADY loady, uint4* park) {
+    const Fq2n Z1Z1 = f2_sqrd(p.z); SBX();
+    const Fq2n H = f2_reduce(f2_sub(f2_muld(loadx(), Z1Z1), p.x)); SBX();
+    const Fq2n t = f2_muld(Z1Z1, p.z); SBX();
+    const Fq2n r = f2_reduce(f2_dbl(f2_sub(f2_muld(loady(), t), p.y))); SBX();
+    const bool special = f2_is_zero(H);
+    { uint32_t w[28];                                                      // Y1 rests in LDS until the last product
+#pragma unroll
+      for (int k = 0; k < 14; ++k) { w[k] = p.y.c0.l[k]; w[14 + k] = p.y.c1.l[k]; }
+      const uint4* src = reinterpret_cast<const uint4*>(w);
+#pragma unroll
+      for (int k = 0; k < 7; ++k) park[k * 64] = src[k]; } SBX();
+    const Fq2n HH = f2_sqrd(H); SBX();
+    p.z = f2_to_coord(f2_sub(f2_sub(f2_sqrd(f2_norm(f2_add(p.z, H))), Z1Z1), HH)); SBX();
+    const auto I = f2_dbl(f2_dbl(HH));                                     // 4 HH, lazy
+    const Fq2n J = f2_muld(H, I); SBX();
+    const Fq2n V = f2_muld(p.x, I); SBX();
+    const Fq2n X3 = f2_reduce(f2_sub(f2_sub(f2_sub(f2_sqrd(r), J), V), V)); SBX();
+    Fq2n t2;
+    { uint4 q[7];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) q[k] = park[k * 64];
+      const uint32_t* w = reinterpret_cast<const uint32_t*>(q);
+      Fq2C y1;
+#pragma unroll
+      for (int k = 0; k < 14; ++k) { y1.c0.l[k] = w[k]; y1.c1.l[k] = w[14 + k]; }
+      t2 = f2_muld(J, y1); } SBX();
+    p.y = f2_to_coord(f2_sub(f2_muld(r, f2_norm(f2_sub(V, X3))), f2_dbl(t2)));
+    p.x = f2_to_coord(X3);
+    return special;
+}
+#undef SBX
+#endif
+
+// ext[j * n + i] = image j of bases[i] in the carry-free form, j < split (1: the bases themselves; 2: + phi; 4: + psi, psi^2, psi^3); the identity (0, 0) stays (0, 0)
+template <class F>
+__global__ void __launch_bounds__(256) k_msm_extend_q(const Affine<F>* __restrict__ bases, uint32_t n, int split, QAff<F>* __restrict__ ext) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (i >= n || j >= split) return;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RIPP_BLS12_377)
+    if constexpr (std::is_same<F, Fp>::value) {
+        G1A q = bases[i];
+        if (j == 1) q.x = fmul(q.x, fp_const(RIPP_GLV_BETA));
+        QAff<Fp> o; o.x = qfp_from(q.x); o.y = qfp_from(q.y);
+        ext[(size_t)j * n + i] = o;
+    } else {
+        const G2A q = gls_image(bases[i], j);
+        QAff<Fp2> o; o.x0 = qfp_from(q.x.c0); o.x1 = qfp_from(q.x.c1); o.y0 = qfp_from(q.y.c0); o.y1 = qfp_from(q.y.c1);
+        ext[(size_t)j * n + i] = o;
+    }
+#endif
+}
+
+// k_msm_slot_sum with the gathered additions on the carry-free form; `ext` from k_msm_extend_q (term t <-> ext[t]); same grid, outputs and slot layout
+template <class F>
+__global__ void __launch_bounds__(64, 2) k_msm_slot_sum_q(const Affine<F>* __restrict__ bases, const QAff<F>* __restrict__ ext, MsmPlan p, const uint32_t* __restrict__ hist,
+                                                        const uint32_t* __restrict__ offs, const uint32_t* __restrict__ slot_offs, const uint32_t* __restrict__ slots_per_window,
+                                                        const uint32_t* __restrict__ sorted, Jac<F>* __restrict__ slot_sums, uint32_t max_slots, bool hom) {
+    __shared__ uint4 park_[7 * 64];
+    const int w = blockIdx.y;
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= slots_per_window[w]) return;
+    const uint32_t* so = slot_offs + (size_t)w * p.nb;
+    uint32_t lo = 0, hi = p.nb - 1;
+    while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (so[mid] <= s) lo = mid; else hi = mid - 1; }
+    uint32_t d = lo;
+    while (d > 0 && (hist[(size_t)w * p.nb + d] + p.ch - 1) / p.ch + so[d] <= s) --d;
+    const uint32_t part = s - so[d];
+    const uint32_t cnt = hist[(size_t)w * p.nb + d];
+    const uint32_t begin = offs[(size_t)w * p.nb + d] + part * p.ch;
+    const uint32_t end = min(offs[(size_t)w * p.nb + d] + cnt, begin + p.ch);
+    Jac<F> acc = jac_inf<F>();
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RIPP_BLS12_377)
+    bool inf = true, bad = false;
+    if constexpr (std::is_same<F, Fp>::value) {
+        JacQ a; a.x = a.y = fq_widen<FQ_LN, 4>(fq_one()); a.z = fq_widen<FQ_LN, 4>(fq_zero());
+#pragma unroll 1
+        for (uint32_t k = begin; k < end; ++k) {
+            const QAff<Fp> q = ext[sorted[(size_t)w * p.n + k]];
+            if (qfp_zero(q.x) && qfp_zero(q.y)) continue;                                 // the identity among the bases
+            const Fqn x = qfp_get(q.x), y = qfp_get(q.y);
+            if (inf) { a.x = fq_widen<FQ_LN, 4>(x); a.y = fq_widen<FQ_LN, 4>(y); a.z = fq_widen<FQ_LN, 4>(fq_one()); inf = false; }
+            else bad |= jmadd_q(a, x, y);
+        }
+        if (!inf && !bad) acc = jacq_to_g1j(a);
+    } else {
+        uint4* park = park_ + threadIdx.x;
+        JacQ2 a; a.x = a.y = f2_to_coord(Fq2n{fq_one(), fq_zero()}); a.z = f2_to_coord(Fq2n{fq_zero(), fq_zero()});
+#pragma unroll 1
+        for (uint32_t k = begin; k < end; ++k) {
+            const QAff<Fp2>* qp = ext + sorted[(size_t)w * p.n + k];
+            { const QAff<Fp2> q = *qp; if (qfp_zero(q.x0) && qfp_zero(q.x1) && qfp_zero(q.y0) && qfp_zero(q.y1)) continue; }
+            auto lx = [&]() { const QAff<Fp2>* o = opaque(qp); return Fq2n{qfp_get(o->x0), qfp_get(o->x1)}; };
+            auto ly = [&]() { const QAff<Fp2>* o = opaque(qp); return Fq2n{qfp_get(o->y0), qfp_get(o->y1)}; };
+            if (inf) { a.x = f2_to_coord(lx()); a.y = f2_to_coord(ly()); a.z = f2_to_coord(Fq2n{fq_one(), fq_zero()}); inf = false; }
+            else bad |= jmadd2_qd(a, lx, ly, park);
+        }
+        if (!inf && !bad) acc = G2J{f2_to(a.x), f2_to(a.y), f2_to(a.z)};
+    }
+    if (bad) msm_slot_sum_complete<F>(bases, sorted + (size_t)w * p.n, begin, end, p.nreal, &acc);
+#endif
+    slot_sums[(size_t)w * max_slots + s] = hom ? msm_jac_to_h(acc) : acc;
+}
+
+}  // namespace ripp
