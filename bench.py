@@ -251,6 +251,9 @@ def main():
         out["phase_ms"]["statement_hash_ms"] = round(hd[0] + hd[1], 3)
         out["gpu_phase_ms"] = ms_per_step - stats["hash_ms"]
         out["value_excl_hash"] = n / ((ms_per_step - stats["hash_ms"]) * 1e-3)
+        # The look-ahead FILLS the window (hash_wait_ms -> 0 by design), so the figure that shows what more GPUs buy is the time the proof needs
+        # AFTER the digest exists: post_hash_ms = step - duration of the statement hash (last step's hash; DESIGN.md section 6 has the model).
+        out["post_hash_ms"] = ms_per_step - (hd[0] + hd[1])
         out["look_ahead"] = {"items": int(stats["look_items"]), "pairs": int(stats["look_pairs"]), "order": "(1,l) (1,r) (2,l) (2,r) (3,l) (3,r)"}
         if host_slices_ms is not None:
             out["host_slices_ms"] = host_slices_ms

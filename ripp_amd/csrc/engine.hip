@@ -1936,12 +1936,7 @@ API int32_t ripp_sipp_challenge(uint8_t seed[32], const ripp_gt* z_l, const ripp
 
 #include "vec_api.inc"       // device-resident vectors (ripp_vec_*)
 
-#if !defined(RIPP_BLS12_377)
-// BLS12-381 only: wire.hpp's COMPRESSED point encodings and square roots are the zcash layout of ark-bls12-381 (p = 3 mod 4); ark-bls12-377
-// keeps the generic SWFlags layout and needs Tonelli-Shanks (p = 1 mod 2^46).  The 377 library does not export these entry points
-// (tests/test_abi_cpu.py asserts their absence) rather than exporting ones that would give wrong bytes.
-#include "wire_api.inc"      // CanonicalSerialize / CanonicalDeserialize images of the proof structs
-#endif
+#include "wire_api.inc"      // CanonicalSerialize / CanonicalDeserialize images of the proof structs (zcash layout on BLS12-381, generic SWFlags layout on BLS12-377: wire.hpp)
 
 #include "comm_api.inc"      // RCCL / callback communicator, sharded inner products and the sharded SIPP prover
 

@@ -33,6 +33,7 @@ fn g2(v: &Value) -> G2Affine {
     G2Affine::new(c(&v[0]), c(&v[1]))
 }
 fn ser<T: CanonicalSerialize>(x: &T) -> String { let mut b = Vec::new(); x.serialize_uncompressed(&mut b).unwrap(); hex::encode(b) }
+fn ser_c<T: CanonicalSerialize>(x: &T) -> String { let mut b = Vec::new(); x.serialize_compressed(&mut b).unwrap(); hex::encode(b) }
 fn hexint<F: PrimeField>(x: &F) -> String { let mut b = x.into_bigint().to_bytes_be(); while b.len() > 1 && b[0] == 0 { b.remove(0); } format!("0x{}", hex::encode(b).trim_start_matches('0')) }
 fn pg1(p: &G1Affine) -> Value { if p.infinity { Value::Null } else { json!([hexint(&p.x), hexint(&p.y)]) } }
 fn pg2(p: &G2Affine) -> Value { if p.infinity { Value::Null } else { json!([[hexint(&p.x.c0), hexint(&p.x.c1)], [hexint(&p.y.c0), hexint(&p.y.c1)]]) } }
@@ -62,7 +63,9 @@ fn main() {
     // ---- generators and the generic short-Weierstrass encoding (flags in the LAST byte; the y-sign bit also in the uncompressed form)
     let (g, h) = (G1Affine::generator(), G2Affine::generator());
     out.insert("generators".into(), json!({"g1": pg1(&g), "g2": pg2(&h), "ser_g1": ser(&g), "ser_g2": ser(&h),
-        "ser_g1_neg": ser(&(-g)), "ser_g2_neg": ser(&(-h)), "ser_g1_inf": ser(&G1Affine::identity()), "ser_g2_inf": ser(&G2Affine::identity())}));
+        "ser_g1_neg": ser(&(-g)), "ser_g2_neg": ser(&(-h)), "ser_g1_inf": ser(&G1Affine::identity()), "ser_g2_inf": ser(&G2Affine::identity()),
+        "ser_g1_compressed": ser_c(&g), "ser_g2_compressed": ser_c(&h), "ser_g1_neg_compressed": ser_c(&(-g)), "ser_g2_neg_compressed": ser_c(&(-h)),
+        "ser_g1_inf_compressed": ser_c(&G1Affine::identity()), "ser_g2_inf_compressed": ser_c(&G2Affine::identity())}));
     // ---- e(G1, G2) and bilinearity
     let e = Bls12_377::pairing(g, h);
     out.insert("pairing_generators".into(), json!({"gt": ser(&e)}));

@@ -24,7 +24,10 @@ def main():
     neg1 = (m.G1[0], (-m.G1[1]) % m.P); neg2 = (m.G2[0], m.f2neg(m.G2[1]))
     fx["generators"] = {"g1": pg1(m.G1), "g2": pg2(m.G2), "ser_g1": m.ser_g1(m.G1).hex(), "ser_g2": m.ser_g2(m.G2).hex(),
                         "ser_g1_neg": m.ser_g1(neg1).hex(), "ser_g2_neg": m.ser_g2(neg2).hex(),
-                        "ser_g1_inf": m.ser_g1(None).hex(), "ser_g2_inf": m.ser_g2(None).hex()}
+                        "ser_g1_inf": m.ser_g1(None).hex(), "ser_g2_inf": m.ser_g2(None).hex(),
+                        "ser_g1_compressed": m.ser_g1_compressed(m.G1).hex(), "ser_g2_compressed": m.ser_g2_compressed(m.G2).hex(),
+                        "ser_g1_neg_compressed": m.ser_g1_compressed(neg1).hex(), "ser_g2_neg_compressed": m.ser_g2_compressed(neg2).hex(),
+                        "ser_g1_inf_compressed": m.ser_g1_compressed(None).hex(), "ser_g2_inf_compressed": m.ser_g2_compressed(None).hex()}
     e = m.pairing(m.G1, m.G2)
     fx["pairing_generators"] = {"gt": m.ser_gt(e).hex()}
     a, b = 0x1234567, 0xABCDEF987

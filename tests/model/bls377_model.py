@@ -146,6 +146,12 @@ def ser_g2(q):
     if q is None: return bytes(96) + bytes(48) + _flag(bytes(48), 0x40)
     neg = _f2_gt(q[1], f2neg(q[1]))
     return ser_fp_le(q[0][0]) + ser_fp_le(q[0][1]) + ser_fp_le(q[1][0]) + _flag(ser_fp_le(q[1][1]), 0x80 if neg else 0)
+def ser_g1_compressed(p):
+    if p is None: return _flag(bytes(48), 0x40)
+    return _flag(ser_fp_le(p[0]), 0x80 if p[1] > (P - p[1]) % P else 0)
+def ser_g2_compressed(q):
+    if q is None: return bytes(48) + _flag(bytes(48), 0x40)
+    return ser_fp_le(q[0][0]) + _flag(ser_fp_le(q[0][1]), 0x80 if _f2_gt(q[1], f2neg(q[1])) else 0)
 def ser_vec(items, f): return struct.pack("<Q", len(items)) + b"".join(f(i) for i in items)
 
 def sipp_prove(a, b, r, value):

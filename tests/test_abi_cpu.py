@@ -30,18 +30,24 @@ def test_every_declared_symbol_is_exported(hiplib):
     assert not missing, f"declared in include/ripp_hip.h but not exported: {missing}"
 
 
-WIRE_381_ONLY = ("ripp_ser_tipa_tipp_proof", "ripp_de_tipa_tipp_proof", "ripp_ser_tipa_ssm_proof", "ripp_de_tipa_ssm_proof", "ripp_ser_g1_compressed", "ripp_ser_g2_compressed")
-
-
-def test_bls12_377_library_exports_the_same_abi_minus_the_381_wire_format():
-    """libripp_hip_377.so is the same engine: every declared symbol except the proof-struct wire format, whose compressed encodings are the
-    zcash layout of ark-bls12-381 (ark-bls12-377 uses the generic SWFlags layout) -- those must be ABSENT, not silently wrong."""
+def test_bls12_377_library_exports_the_same_abi_and_its_own_point_encodings():
+    """libripp_hip_377.so is the same engine: every declared symbol, the proof-struct wire format included -- with ark-ec's GENERIC
+    short-Weierstrass encodings (flags in the LAST byte; compressed = x alone) instead of ark-bls12-381's zcash layout.  The compressed images
+    of the generators, their negatives and the identities equal the model's (tests/golden/bls12_377_vectors.json); device-free."""
+    import json
     import ripp_amd.bls12_377 as R7
+    import orclib377 as o7
     L = R7.lib()
-    missing = [n for n in declared_symbols() if n not in WIRE_381_ONLY and not hasattr(L, n)]
+    missing = [n for n in declared_symbols() if not hasattr(L, n)]
     assert not missing, missing
-    present = [n for n in WIRE_381_ONLY if hasattr(L, n)]
-    assert not present, f"BLS12-381-only wire entry points exported by the BLS12-377 build: {present}"
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "bls12_377_vectors.json")))["generators"]
+    g1 = o7.g1_array([(int(g["g1"][0], 16), int(g["g1"][1], 16))]); g2 = o7.g2_array([((int(g["g2"][0][0], 16), int(g["g2"][0][1], 16)), (int(g["g2"][1][0], 16), int(g["g2"][1][1], 16)))])
+    n1 = g1.copy(); n1[0, 6:] = o7.fp_to_limbs((o7.P - o7.limbs_to_fp(g1[0, 6:])) % o7.P)
+    n2 = g2.copy()
+    for k in (12, 18): n2[0, k:k + 6] = o7.fp_to_limbs((o7.P - o7.limbs_to_fp(g2[0, k:k + 6])) % o7.P)
+    assert R7.ser_g1_compressed(g1[0]).hex() == g["ser_g1_compressed"] and R7.ser_g2_compressed(g2[0]).hex() == g["ser_g2_compressed"]
+    assert R7.ser_g1_compressed(n1[0]).hex() == g["ser_g1_neg_compressed"] and R7.ser_g2_compressed(n2[0]).hex() == g["ser_g2_neg_compressed"]
+    assert R7.ser_g1_compressed(np.zeros(12, dtype=np.uint64)).hex() == g["ser_g1_inf_compressed"] and R7.ser_g2_compressed(np.zeros(24, dtype=np.uint64)).hex() == g["ser_g2_inf_compressed"]
 
 
 def test_no_cpu_fallback_without_device(hiplib):

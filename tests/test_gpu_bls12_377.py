@@ -208,3 +208,44 @@ def test_aggregate_proofs_bls12_377_vs_oracle(E, o, n):
     pub2 = pub.copy(); pub2[0, 0] = pub[1, 0]
     assert o.verify_aggregate_proof(h.verifier_srs(osrs), vk, pub2, got) == 0 and not E.verify_aggregate_proof(vs, vk, pub2, got)
     srs.close()
+
+
+def test_wire_format_round_trip_bls12_377(E, o):
+    """CanonicalSerialize / CanonicalDeserialize images of a TIPA proof and a TIPAWithSSM proof on BLS12-377, in ark-ec's generic SWFlags layout
+    (flags in the last byte, compressed = x alone, square roots by Tonelli-Shanks): serialise -> deserialise gives the same members in both
+    modes, the deserialised proof still verifies, and a flipped flag / an x that is not on the curve / a point outside the subgroup is rejected."""
+    import helpers as h
+    n = 8
+    osrs = h.make_srs(n, 0xa1fa + n, 0xbe7a + n, o=o); srs = E.SRS(osrs[0], osrs[1], osrs[2], osrs[3])
+    vk, pub, a, b, c = h.fake_groth16(n, 2, seed=n, o=o)
+    got, _ = E.aggregate_proofs(srs, a, b, c)
+    ab, cc = h.aggregate_subproofs(got)
+    n1 = lambda p: E.normalize_batch_g1(np.ascontiguousarray(p).reshape(-1, 18)); n2 = lambda p: E.normalize_batch_g2(np.ascontiguousarray(p).reshape(-1, 36))
+    for compress in (False, True):
+        img = E.ser_tipa_tipp_proof(ab, compress=compress)
+        back = E.de_tipa_tipp_proof(img, compress=compress)
+        assert np.array_equal(back["steps"], ab["steps"])
+        for k in ("base_a", "final_ck_b", "opening_b"): assert np.array_equal(n1(back[k]), n1(ab[k])), k
+        for k in ("base_b", "final_ck_a", "opening_a"): assert np.array_equal(n2(back[k]), n2(ab[k])), k
+        assert E.ser_tipa_tipp_proof(back, compress=compress) == img
+        img2 = E.ser_tipa_ssm_proof(cc, compress=compress)
+        back2 = E.de_tipa_ssm_proof(img2, compress=compress)
+        assert np.array_equal(back2["com_gt"], cc["com_gt"]) and np.array_equal(back2["base_b"], cc["base_b"])
+        assert np.array_equal(n1(back2["com_g1"]), n1(cc["com_g1"])) and np.array_equal(n2(back2["opening_a"]), n2(cc["opening_a"]))
+        assert E.ser_tipa_ssm_proof(back2, compress=compress) == img2
+        # tampering: flip the y-sign flag of the last G1 member (another valid point: members differ), set both flags (invalid), break x
+        bad = bytearray(img); bad[-1] ^= 0x80
+        if compress:
+            assert not np.array_equal(n1(E.de_tipa_tipp_proof(bytes(bad), compress=True)["opening_b"]), n1(ab["opening_b"]))
+        bad = bytearray(img); bad[-1] |= 0xC0
+        with pytest.raises(ValueError): E.de_tipa_tipp_proof(bytes(bad), compress=compress)
+    # the last member of the compressed TIPP image is opening_b (G1, 48 bytes): an x with no point on the curve, and a point of the curve that is
+    # not in the prime-order subgroup (x = 0: y^2 = 1, the point (0, 1) has order 3 on y^2 = x^3 + 1 -- G1's cofactor is divisible by 3)
+    img = bytearray(E.ser_tipa_tipp_proof(ab, compress=True))
+    x = 5
+    while pow((x ** 3 + 1) % o.P, (o.P - 1) // 2, o.P) == 1: x += 1
+    bad = bytearray(img); bad[-48:] = x.to_bytes(48, "little")
+    with pytest.raises(ValueError): E.de_tipa_tipp_proof(bytes(bad), compress=True)
+    bad = bytearray(img); bad[-48:] = (0).to_bytes(48, "little")
+    with pytest.raises(ValueError): E.de_tipa_tipp_proof(bytes(bad), compress=True)
+    srs.close()

@@ -375,5 +375,6 @@ def test_bench_two_ranks_on_one_device_reports_the_hash_excluded_figures(engine)
     assert out["gpu_phase_ms"] > 0 and abs(out["gpu_phase_ms"] - (out["ms_per_step"] - out["phase_ms"]["hash_wait_ms"])) < 1e-3
     assert abs(out["value_excl_hash"] - out["config"]["n"] / (out["gpu_phase_ms"] * 1e-3)) < 1e-6 * out["value_excl_hash"]
     assert out["value"] <= out["value_excl_hash"] * (1 + 1e-9)
+    assert abs(out["post_hash_ms"] - (out["ms_per_step"] - out["phase_ms"]["statement_hash_ms"])) < 2e-3
     assert set(out["look_ahead"]) >= {"items", "pairs"}
     assert "cpu_baseline" not in out                                  # rank 0 at N = 1 only
