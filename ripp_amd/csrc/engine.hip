@@ -154,10 +154,11 @@ struct DevBuf {
 // steps of 10 ms (measured on the n = 2^13..2^14 SIPP verifier: 13.7 ms became 30-50 ms; tools/kdev/verify_lat2.py).
 struct PinBuf {
     void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool pending = false;
+    bool blocking = false;               // set before the first reserve(): waits SLEEP instead of spinning (buffers that are only waited for while the statement hash runs)
     int32_t wait() { if (pending) { HIPCHK(hipEventSynchronize(ev)); pending = false; } return RIPP_OK; }      // the previous copy out of this buffer has landed
     int32_t reserve(size_t bytes) {
         int32_t rc = wait(); if (rc) return rc;
-        if (!ev) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        if (!ev) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming | (blocking ? hipEventBlockingSync : 0)));
         if (bytes <= cap) return RIPP_OK;
         if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
         HIPCHK(hipHostMalloc(&p, bytes, hipHostMallocDefault)); cap = bytes; return RIPP_OK;
@@ -295,6 +296,7 @@ struct Engine {
         if (stream2) (void)hipStreamDestroy(stream2);
         if (ev_fork) (void)hipEventDestroy(ev_fork); if (ev_join) (void)hipEventDestroy(ev_join); if (ev_join3) (void)hipEventDestroy(ev_join3);
         if (ev_t0) (void)hipEventDestroy(ev_t0); if (ev_t1) (void)hipEventDestroy(ev_t1);
+        if (ev_quiet) (void)hipEventDestroy(ev_quiet);
     }
     int32_t ensure_pinned_rows(size_t rows) {
         if (rows <= pinned_rows_cap) return RIPP_OK;
@@ -302,7 +304,16 @@ struct Engine {
         HIPCHK(hipHostMalloc((void**)&pinned_rows, rows * sizeof(Fp12), hipHostMallocDefault));
         pinned_rows_cap = rows; return RIPP_OK;
     }
-    int32_t sync() { HIPCHK(hipStreamSynchronize(stream)); return RIPP_OK; }
+    // quiet_waits (RIPP_QUIET_WAITS, an experiment kept for A/B): stream waits go through an event created with hipEventBlockingSync, so the
+    // prover's thread sleeps instead of spinning next to the hashing core while the statement hash runs.
+    bool quiet_waits = false; hipEvent_t ev_quiet = nullptr;
+    int32_t sync() {
+        if (quiet_waits) {
+            if (!ev_quiet) HIPCHK(hipEventCreateWithFlags(&ev_quiet, hipEventDisableTiming | hipEventBlockingSync));
+            HIPCHK(hipEventRecord(ev_quiet, stream)); HIPCHK(hipEventSynchronize(ev_quiet)); return RIPP_OK;
+        }
+        HIPCHK(hipStreamSynchronize(stream)); return RIPP_OK;
+    }
 
     // ---- event bookkeeping for the roofline figures -----------------------------------------------------
     int32_t mark(std::vector<std::pair<hipEvent_t, hipEvent_t>>& v, bool begin) {
@@ -704,7 +715,7 @@ template <class T> int32_t upload(Engine* e, DevBuf& buf, const void* host, size
 // Blake2s of (a, b, r, value).serialize_uncompressed (sipp/src/lib.rs:56-59).  Serialisation (Montgomery -> canonical
 // big-endian) is spread over worker threads in blocks; the hash itself is inherently sequential.
 double g_digest_hash_ms = 0, g_digest_wait_ms = 0;
-void statement_digest(const G1A* a, const G2A* b, const Fr* r, size_t n, const Fp12& value, uint8_t digest[32]) {
+void statement_digest(const G1A* a, const G2A* b, const Fr* r, size_t n, const Fp12& value, uint8_t digest[32], std::atomic<uint64_t>* progress = nullptr) {
     fs::Blake2s h;
     g_digest_hash_ms = g_digest_wait_ms = 0;
     const uint64_t len = (uint64_t)n;
@@ -747,6 +758,7 @@ void statement_digest(const G1A* a, const G2A* b, const Fr* r, size_t n, const F
         fut[j].get();
         const double t1 = now_ms();
         h.update(buf[j % RING].data(), (segs[j].e - segs[j].s) * item[segs[j].kind]);
+        if (progress) progress->fetch_add((segs[j].e - segs[j].s) * item[segs[j].kind], std::memory_order_relaxed);
         g_digest_wait_ms += t1 - t0; g_digest_hash_ms += now_ms() - t1;
         if (j + RING - 1 < segs.size()) launch(j + RING - 1);          // its buffer was released by the segment just hashed... one slot later
     }
@@ -777,6 +789,7 @@ struct ripp_sipp_job {
         std::vector<std::future<Fp12>> fe, pend;    // final exponentiations still running; GT powers of the level being applied (3 per output)
     };
     std::vector<LookItem> look; PinBuf look_rows[2];
+    std::atomic<uint64_t> hash_done{0}; uint64_t hash_total = 0; double hash_t0 = 0;      // progress of the statement hash (bytes), for the adaptive look-ahead
     bool no_window = false;                         // sharded proofs: rank 0 was handed the digest, nobody hashes, nothing to hide work behind
     size_t hash_n = 0;                              // length of the statement ha_ext / hb_ext / hr_ext point to (the FULL statement on rank 0 of a sharded proof)
     DevBuf a_pow_h, b_pow_h, parts1, parts2; bool pre_vm_ready = false, pre_vm_side = false;   // the same for the small rounds, on the field VM (vm_fold2.hpp); side: b_pow_h comes from stream3 (ev_join3)
@@ -1055,7 +1068,8 @@ void job_start_hash(ripp_sipp_job* j, const Fp12& value) {
     j->digest_ready = false;
     const G1A* pa = j->ha_ext ? j->ha_ext : j->ha.data(); const G2A* pb = j->ha_ext ? j->hb_ext : j->hb.data(); const Fr* pr = j->ha_ext ? j->hr_ext : j->hr.data();
     const size_t pn = j->ha_ext ? j->hash_n : j->ha.size();
-    j->hash_thread = std::thread([j, value, pa, pb, pr, pn]() { statement_digest(pa, pb, pr, pn, value, j->digest); j->digest_ready = true; });
+    j->hash_done = 0; j->hash_total = (uint64_t)pn * (96 + 192 + 32); j->hash_t0 = now_ms();
+    j->hash_thread = std::thread([j, value, pa, pb, pr, pn]() { statement_digest(pa, pb, pr, pn, value, j->digest, &j->hash_done); j->digest_ready = true; });
 }
 
 }  // namespace
@@ -1589,9 +1603,14 @@ static int look_plan(const Engine* e, size_t n_local, int world, bool window) {
     }
     return 8 * items;
 }
-static int32_t job_lookahead(Engine* e, ripp_sipp_job* j, int eighths, bool forced) {
+// ms_per_pair: what round 0's products cost on THIS device a moment ago.  A rank that hashes the statement itself (rank 0, unless the plan is forced)
+// sizes every item ADAPTIVELY: the hash thread counts the bytes it has consumed, so the time the window still has is known to a few per cent,
+// the device queue is drained before an item is sized, and the item takes the whole / the fraction of its pairs that still fits -- boxes differ
+// by +-3 % in hash speed and +-5 % in GPU speed, more than the static plan's margin.  Other ranks follow the plan rank 0 sent.
+static int32_t job_lookahead(Engine* e, ripp_sipp_job* j, int eighths, bool forced, double ms_per_pair) {
     j->look.clear();
-    const int items = (eighths + 7) / 8;
+    const bool adaptive = !forced && j->hash_total > 0 && !j->no_window && eighths > 0 && !std::getenv("RIPP_LOOK_STATIC");
+    const int items = adaptive ? 2 * LOOK_MAX_R : (eighths + 7) / 8;
     if (items <= 0 || (j->digest_ready.load() && !forced)) return RIPP_OK;      // the hash is already done: nothing to hide the work behind (forced: RIPP_LOOK_ITEMS, tests)
     const double t0 = now_ms();
     const size_t len = j->len;
@@ -1601,8 +1620,19 @@ static int32_t job_lookahead(Engine* e, ripp_sipp_job* j, int eighths, bool forc
         const int R = it / 2 + 1, side = it & 1;
         const size_t qblk = len >> (R + 1);
         if (qblk == 0 || qblk > e->max_pairs_per_batch) break;
-        const int frac = std::min(8, eighths - 8 * it);                  // the last item may be partial: the first frac/8 of every block's pairs
-        const size_t q = frac >= 8 ? qblk : (qblk * (size_t)frac / 8) & ~(size_t)63;
+        int frac = std::min(8, eighths - 8 * it);                        // static plan: the last item may be partial (the first frac/8 of every block's pairs)
+        if (adaptive) {
+            if (qblk < 1024) break;
+            if ((rc = e->sync())) return rc;                             // the fold tables / the previous item have left the device: what follows starts now
+            const uint64_t done = j->hash_done.load(std::memory_order_relaxed);
+            if (j->digest_ready.load() || done == 0) break;
+            const double elapsed = now_ms() - j->hash_t0;
+            const double room = elapsed * (double)(j->hash_total - std::min(done, j->hash_total)) / (double)done - 3.0;      // ms the hash still needs, minus the item's host work
+            const double cost = (double)qblk * (double)((size_t)1 << (2 * R)) * ms_per_pair;
+            frac = room >= cost ? 8 : -(int)(32.0 * room / cost);        // adaptive: 32nds (negative = in 32nds)
+            if (frac < 0 && frac > -6) break;
+        }
+        const size_t q = frac >= 8 ? qblk : frac < 0 ? (qblk * (size_t)(-frac) / 32) & ~(size_t)63 : (qblk * (size_t)frac / 8) & ~(size_t)63;
         if (q == 0) break;
         const int ngroups = pow3(R);
         struct Prod { const G1A* a; const G2A* b; int g; };
@@ -1716,6 +1746,12 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
         look_items = all[0].look_items; j->no_window = !all[0].window;
     }
     struct HotOff { ~HotOff() { host_pool().set_hot(false); } } hot_off;       // whatever the exit path, the workers go back to sleeping waits
+    struct QuietOff { Engine* e; ~QuietOff() { e->quiet_waits = false; } } quiet_off{e};
+    // RIPP_QUIET_WAITS=1: sleeping instead of spinning waits while this rank hashes.  Measured A/B on four boxes (profiles/r03_quiet_vs_spin_waits.txt):
+    // the hash is not faster for it (313-322 vs 312-330 ms) and the wake-up latencies make the adaptive look-ahead overrun the window: 460-470 ms
+    // against 458-465 ms with spinning waits.  Off by default.
+    e->quiet_waits = window && std::getenv("RIPP_QUIET_WAITS");
+    j->look_rows[0].blocking = j->look_rows[1].blocking = e->quiet_waits;
     struct XsOff { ripp_sipp_job* j; ~XsOff() { j->xs_enabled = false; } } xs_off{j};
     // whatever the exit path: nothing enqueued by this proof may still be running when the caller gets control back (engine scratch, tp_rows and
     // the job's vectors are reused by the next call), and no prepared state may leak into the next proof
@@ -1771,6 +1807,7 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
         ripp_sipp_job::LookItem* lk_r = lrc ? nullptr : look_find(j, round, 1);
         const bool tp_round = !lrc && j->tp_round[round & 1] == round;                       // pipelined tail: this round's products were enqueued a round ago
         double t0 = tr0;
+        double round0_ms_per_pair = 7.7e-5;                                                     // measured below in round 0 (lines + products + tree + copy per pair)
         Fp12 zl = Fp12::one(), zr = Fp12::one();
         auto local_values = [&]() -> int32_t {
             int32_t rc;
@@ -1778,7 +1815,11 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
             const size_t half = j->len / 2;
             const size_t start[2] = {lk_l ? std::min(lk_l->npairs, half) : 0, lk_r ? std::min(lk_r->npairs, half) : 0};
             const bool dev[2] = {!tp_round && start[0] < half, !tp_round && start[1] < half};
-            if (dev[0] && dev[1] && start[0] == 0 && start[1] == 0) { if ((rc = job_round_partials(e, j, rows))) return rc; }
+            if (dev[0] && dev[1] && start[0] == 0 && start[1] == 0) {
+                const double tp = now_ms();
+                if ((rc = job_round_partials(e, j, rows))) return rc;
+                if (round == 0 && j->len >= ((size_t)1 << 16)) round0_ms_per_pair = (now_ms() - tp) / (double)j->len;      // 2 products x len / 2 pairs
+            }
             else for (int sd = 0; sd < 2; ++sd) {
                 if (!dev[sd]) continue;
                 const G1A* as[1] = {j->a.as<G1A>() + (sd == 0 ? half : 0) + start[sd]}; const G2A* bs[1] = {j->b.as<G2A>() + (sd == 0 ? 0 : half) + start[sd]};
@@ -1808,7 +1849,7 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
                 if (lk_l) { look_finish_level(*lk_l); zl = dev[0] ? mul(lk_l->Z[0], zd[0]) : lk_l->Z[0]; }
                 if (lk_r) { look_finish_level(*lk_r); zr = dev[1] ? mul(lk_r->Z[0], zd[1]) : lk_r->Z[0]; }
             }
-            if (round == 0 && !j->seeded && (rc = job_lookahead(e, j, look_items, look_forced))) return rc;      // blocks on the GPU while the hash thread is still busy
+            if (round == 0 && !j->seeded && (rc = job_lookahead(e, j, look_items, look_forced, round0_ms_per_pair))) return rc;      // blocks on the GPU while the hash thread is still busy
             return RIPP_OK;
         };
         if (!lrc) lrc = local_values();
@@ -1834,6 +1875,7 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
         }
         if (!j->seeded) {
             j->rng.from_digest(j->digest); j->seeded = true;
+            e->quiet_waits = false;
             host_pool().set_hot(true);                       // the remaining rounds hand 0.1-0.6 ms tasks to the workers every ~2 ms
         }
         const Fr x = fs::sipp_challenge(j->rng, zl, zr);
