@@ -17,10 +17,14 @@ namespace ripp {
 
 constexpr int LQ_SLOT_DW = 16;                                     // an Fq in LDS: 14 limbs + 2 (four 16-byte accesses)
 constexpr int LQ_ACC_DW = 6 * 2 * LQ_SLOT_DW;                      // f_0 .. f_5 in Fp2: 768 B per accumulator
+// The 21 accumulators of a wave are laid out with a stride of 49 chunks (784 B), not 48: 768 B is a multiple of the 128-byte bank row, so every
+// group's slot k sat in the SAME banks and the 16-byte accumulator reads of the 21 groups serialised -- SQ_LDS_BANK_CONFLICT was 20 % of the kernel's
+// wave-cycles (profiles/r03_sq_counters_pmc.csv, first pass).  With the odd stride consecutive groups are 16 bytes apart modulo a bank row.
+constexpr int LQ_ACC_STRIDE = LQ_ACC_DW / 4 + 1;                   // in 16-byte chunks
 
 // grid = (ceil(T / 21), rows), block = 64 (one wave); same arguments and output layout as k_line_products
 __global__ void __launch_bounds__(64, 2) k_line_products_q(const uint4* __restrict__ lines, size_t stride, uint32_t M, uint4* __restrict__ partials, uint32_t T) {
-    __shared__ uint4 lds[LP_GROUPS_PER_WAVE * LQ_ACC_DW / 4];
+    __shared__ uint4 lds[LP_GROUPS_PER_WAVE * LQ_ACC_STRIDE];
 #if defined(__HIP_DEVICE_COMPILE__)
     using namespace fq28;
     const uint32_t lane = threadIdx.x;
@@ -31,7 +35,7 @@ __global__ void __launch_bounds__(64, 2) k_line_products_q(const uint4* __restri
     const uint32_t t = blockIdx.x * LP_GROUPS_PER_WAVE + g;
     const bool active = g < (uint32_t)LP_GROUPS_PER_WAVE && t < T;
     const size_t row = blockIdx.y;
-    uint4* acc = lds + (active ? g : 0) * (LQ_ACC_DW / 4);
+    uint4* acc = lds + (active ? g : 0) * LQ_ACC_STRIDE;
     auto ld_fq = [&](int slot, int part) { Fqn v; uint4 q[4];                    // slot = w-index 0..5, part = 0 (real) / 1 (imaginary)
 #pragma unroll
         for (int c = 0; c < 4; ++c) q[c] = acc[(slot * 2 + part) * 4 + c];

@@ -84,12 +84,13 @@ constexpr int LP_GROUP = 3;                       // lanes per accumulator
 constexpr int LP_GROUPS_PER_WAVE = 21;            // 63 of 64 lanes
 constexpr int LP_SLOTS = 9;                       // f_0..f_5, xi f_3, xi f_4, xi f_5
 constexpr int LP_ACC_BYTES = LP_SLOTS * 96;       // 864 B of LDS per accumulator
+constexpr int LP_ACC_STRIDE = LP_SLOTS * 6 + 1;   // laid out 55 chunks (880 B) apart: 864 B repeats its bank pattern every 4 groups, 880 B every 8 (fq_line_products.hpp has the measurement)
 
 // grid = (ceil(T / 21), rows), block = 64 (one wave).  Group t of row r multiplies lines r[t], r[t + T], ... (< M) and writes ONE dense
 // partial to partials[r][36][T] (the layout k_fp12_tree consumes).  lines: [rows][18][stride] 16-byte chunks (kernels.hpp).
 __global__ void __launch_bounds__(64, 2) k_line_products(const uint4* __restrict__ lines, size_t stride, uint32_t M,
                                                          uint4* __restrict__ partials, uint32_t T) {
-    __shared__ uint4 lds[LP_GROUPS_PER_WAVE * LP_SLOTS * 6];
+    __shared__ uint4 lds[LP_GROUPS_PER_WAVE * LP_ACC_STRIDE];
     const uint32_t lane = threadIdx.x;
     const uint32_t g = lane / LP_GROUP, j = lane - g * LP_GROUP;               // group in wave, lane in group (lane 63: g = 21, idle)
     // t = accumulator index within the row; cheap to recompute from the lane id, so it is NOT kept live across the 8 000-instruction
@@ -100,7 +101,7 @@ __global__ void __launch_bounds__(64, 2) k_line_products(const uint4* __restrict
     const uint32_t t = blockIdx.x * LP_GROUPS_PER_WAVE + g;
     const bool active = g < (uint32_t)LP_GROUPS_PER_WAVE && t < T;
     const size_t row = blockIdx.y;
-    uint4* acc = lds + (active ? g : 0) * (LP_SLOTS * 6);                        // 6 chunks (96 B) per Fp2 slot
+    uint4* acc = lds + (active ? g : 0) * LP_ACC_STRIDE;                         // 6 chunks (96 B) per Fp2 slot
     auto ld_slot = [&](int s) { Fp2 v; uint4* d = reinterpret_cast<uint4*>(&v);
 #pragma unroll
         for (int q = 0; q < 6; ++q) d[q] = acc[s * 6 + q]; return v; };
