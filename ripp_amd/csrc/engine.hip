@@ -1610,7 +1610,7 @@ static int look_plan(const Engine* e, size_t n_local, int world, bool window) {
 static int32_t job_lookahead(Engine* e, ripp_sipp_job* j, int eighths, bool forced, double ms_per_pair) {
     j->look.clear();
     const bool adaptive = !forced && j->hash_total > 0 && !j->no_window && eighths > 0 && !std::getenv("RIPP_LOOK_STATIC");
-    const int items = adaptive ? 2 * LOOK_MAX_R : (eighths + 7) / 8;
+    const int items = adaptive ? std::min(2 * LOOK_MAX_R, eighths / 8 + 2) : (eighths + 7) / 8;      // adaptive: at most one whole item beyond what the static model expects
     if (items <= 0 || (j->digest_ready.load() && !forced)) return RIPP_OK;      // the hash is already done: nothing to hide the work behind (forced: RIPP_LOOK_ITEMS, tests)
     const double t0 = now_ms();
     const size_t len = j->len;
@@ -1627,8 +1627,12 @@ static int32_t job_lookahead(Engine* e, ripp_sipp_job* j, int eighths, bool forc
             const uint64_t done = j->hash_done.load(std::memory_order_relaxed);
             if (j->digest_ready.load() || done == 0) break;
             const double elapsed = now_ms() - j->hash_t0;
-            const double room = elapsed * (double)(j->hash_total - std::min(done, j->hash_total)) / (double)done - 3.0;      // ms the hash still needs, minus the item's host work
-            const double cost = (double)qblk * (double)((size_t)1 << (2 * R)) * ms_per_pair;
+            double room = elapsed * (double)(j->hash_total - std::min(done, j->hash_total)) / (double)done - 3.0;      // ms the hash still needs, minus the item's host work
+            // the extrapolation is only trusted inside what a sequential Blake2s can plausibly need in total (0.9 - 1.25 GB/s): a progress counter that
+            // lags (the hash thread descheduled, a burst of serialisation waits) must not make the window look longer than it can be
+            room = std::min(room, (double)j->hash_total / 0.9e6 - elapsed);
+            const double cost = (double)qblk * (double)((size_t)1 << (2 * R)) * std::max(ms_per_pair, 5.0e-5);
+            if (trace_on()) fprintf(stderr, "[ripp] look-ahead item (%d,%c): hash %.0f %% after %.1f ms, room %.1f ms, item %.1f ms\n", R, side ? 'r' : 'l', 100.0 * (double)done / (double)j->hash_total, elapsed, room, cost);
             frac = room >= cost ? 8 : -(int)(32.0 * room / cost);        // adaptive: 32nds (negative = in 32nds)
             if (frac < 0 && frac > -6) break;
         }

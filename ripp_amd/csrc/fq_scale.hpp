@@ -4,7 +4,9 @@
 // both halves walked jointly (132 doublings + <= 66 additions, uniform control flow) -- with the group law of fq_curve.hpp: every Fp product
 // is 196 + 196 multiply-adds without carry instructions, additions are limb-wise.  k_scale_g1_glv runs at the VALU issue roof (2^20 elements x
 // ~2 000 products / 50 G products/s = 42 ms), so the gain is the instruction count: ~30 %.
-// The table holds JACOBIAN multiples (no inversion), 3 x 12 packed words per entry, in the layout of scale.hpp (lane-coalesced rows).
+// The table holds JACOBIAN multiples (no inversion), 3 x 12 packed words per entry; an element's 8 multiples are CONTIGUOUS (1 152 B): every lane picks
+// its own digit row, so in the lane-interleaved layout of scale.hpp a 128-byte line served one or two lanes (49.5 GB of HBM traffic per 2^20-element
+// launch, 174 x the algorithmic bytes); here a lookup reads one 144-byte run.
 // Exceptional additions (acc = +-T: H = 0) cannot occur for the digit patterns of a proper GLV split, but they are DETECTED and such a lane
 // is recomputed by plain double-and-add with the complete formulas of curve.hpp.  BLS12-381 only (the 377 build keeps the 12 x 32-bit kernel).
 #pragma once
@@ -46,12 +48,12 @@ __device__ __forceinline__ void st_tab_q(uint4* tab, int e, uint32_t n, uint32_t
     { uint32_t x[12]; fq_pack_c(t.y, x); for (int k = 0; k < 12; ++k) w[12 + k] = x[k]; }
     { uint32_t x[12]; fq_pack_c(t.z, x); for (int k = 0; k < 12; ++k) w[24 + k] = x[k]; }
 #pragma unroll
-    for (int q = 0; q < G1J_CHUNKS; ++q) tab[((size_t)e * G1J_CHUNKS + q) * n + i] = uint4{w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
+    for (int q = 0; q < G1J_CHUNKS; ++q) tab[((size_t)i * SCALE_TAB + e) * G1J_CHUNKS + q] = uint4{w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
 }
 __device__ __forceinline__ JacQ ld_tab_q(const uint4* tab, int e, uint32_t n, uint32_t i) {
     uint32_t w[36];
 #pragma unroll
-    for (int q = 0; q < G1J_CHUNKS; ++q) { const uint4 v = tab[((size_t)e * G1J_CHUNKS + q) * n + i]; w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w; }
+    for (int q = 0; q < G1J_CHUNKS; ++q) { const uint4 v = tab[((size_t)i * SCALE_TAB + e) * G1J_CHUNKS + q]; w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w; }
     uint32_t a[12], b[12], c[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) { a[k] = w[k]; b[k] = w[12 + k]; c[k] = w[24 + k]; }
