@@ -7,7 +7,7 @@ import ctypes
 import os
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "lib", "libripp_hip.so")
+LIB_PATH = os.environ.get("RIPP_HIP_LIB") or os.path.join(PKG_DIR, "lib", "libripp_hip.so")      # RIPP_HIP_LIB: another build of the same library (A/B runs)
 
 RIPP_OK, RIPP_ERR_LENGTH, RIPP_ERR_POW2, RIPP_ERR_DEVICE, RIPP_ERR_ARG = 0, 1, 2, 3, 4
 

@@ -55,11 +55,21 @@ static_assert((uint64_t)K17.l[NL - 1] >= (uint64_t)VM_SLOT_VB * (P_TOP + 1), "K1
 constexpr float INV_PTOP = (1.0f - 1.0f / 1048576.0f) / (float)(P_TOP + 1);     // quotient estimate of a heavy LIN: never above the true quotient
 }  // namespace fq28
 
+// Bank layout.  A slot is 64 B, half a 128-byte bank row: in a layer the 16 lanes of a group read 16 DIFFERENT slots at the same chunk index, so
+// with the chunks in their natural places all even slots hit one quarter of the banks and all odd slots another -- SQ_LDS_BANK_CONFLICT was 11-31 %
+// of the wave-cycles of the VM kernels (profiles/r03_sq_counters_pmc.csv), pure latency on a lone wave.  Chunk c of slot s therefore sits at
+// position (c + s / 2) mod 4: eight consecutive slots cover the eight 16-byte positions of a bank row.  Every access goes through vm_ld / vm_st.
+#if defined(RIPP_VM_NO_SWIZZLE)
+__device__ __forceinline__ unsigned vm_rot(unsigned) { return 0u; }            // natural chunk order (A/B builds)
+#else
+__device__ __forceinline__ unsigned vm_rot(unsigned s) { return (s >> 1) & 3u; }
+#endif
 __device__ __forceinline__ VmVal vm_ld(const VmSlot* ws, unsigned s) {
     VmVal r; uint4 q[4];
     const uint4* p = reinterpret_cast<const uint4*>(ws[s].l);
+    const unsigned rot = vm_rot(s);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) q[i] = p[i];
+    for (int i = 0; i < 4; ++i) q[i] = p[(i + rot) & 3u];
     const uint32_t* w = reinterpret_cast<const uint32_t*>(q);
 #pragma unroll
     for (int i = 0; i < fq28::NL; ++i) r.l[i] = w[i];
@@ -73,8 +83,9 @@ __device__ __forceinline__ void vm_st(VmSlot* ws, unsigned s, const Fq<LM, VB>& 
     for (int i = 0; i < fq28::NL; ++i) w[i] = v.l[i];
     w[14] = 0; w[15] = 0;
     uint4* p = reinterpret_cast<uint4*>(ws[s].l);
+    const unsigned rot = vm_rot(s);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) p[i] = q[i];
+    for (int i = 0; i < 4; ++i) p[(i + rot) & 3u] = q[i];
 }
 // kernel-side access to the workspace: engine values are RE-SLICED, not converted (see the header note)
 __device__ __forceinline__ void vm_put(VmSlot* ws, int slot, const Fp& v) { vm_st(ws, slot, fq_unpack(v.l)); }
