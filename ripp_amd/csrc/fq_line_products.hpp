@@ -19,8 +19,13 @@ constexpr int LQ_SLOT_DW = 16;                                     // an Fq in L
 constexpr int LQ_ACC_DW = 6 * 2 * LQ_SLOT_DW;                      // f_0 .. f_5 in Fp2: 768 B per accumulator
 // The 21 accumulators of a wave are laid out with a stride of 49 chunks (784 B), not 48: 768 B is a multiple of the 128-byte bank row, so every
 // group's slot k sat in the SAME banks and the 16-byte accumulator reads of the 21 groups serialised -- SQ_LDS_BANK_CONFLICT was 20 % of the kernel's
-// wave-cycles (profiles/r03_sq_counters_pmc.csv, first pass).  With the odd stride consecutive groups are 16 bytes apart modulo a bank row.
+// wave-cycles (first r03 PMC pass; 4.7 % now: profiles/r03_sq_counters_pmc.csv).  With the odd stride consecutive groups are 16 bytes apart modulo a bank
+// row.  Same-box A/B (-DRIPP_LP_NO_PAD): 452.0 against 454.8 ms per proof -- most of those cycles were hidden behind the SIMD's other wave.
+#if defined(RIPP_LP_NO_PAD)
+constexpr int LQ_ACC_STRIDE = LQ_ACC_DW / 4;                       // (A/B builds: the conflicting layout)
+#else
 constexpr int LQ_ACC_STRIDE = LQ_ACC_DW / 4 + 1;                   // in 16-byte chunks
+#endif
 
 // grid = (ceil(T / 21), rows), block = 64 (one wave); same arguments and output layout as k_line_products
 __global__ void __launch_bounds__(64, 2) k_line_products_q(const uint4* __restrict__ lines, size_t stride, uint32_t M, uint4* __restrict__ partials, uint32_t T) {
