@@ -1440,7 +1440,7 @@ API void ripp_sipp_job_destroy(ripp_sipp_job* j) {
     if (!j) return; LOCK;
     if (j->hash_thread.joinable()) j->hash_thread.join();
     for (DevBuf* b : {&j->a0, &j->b0, &j->r0, &j->a, &j->b, &j->a_next, &j->b_next, &j->jac1, &j->jac2, &j->a_pow, &j->b_pow, &j->a_pow_h, &j->b_pow_h, &j->parts1, &j->parts2}) b->release();
-    j->tp_rows[0].release(); j->tp_rows[1].release();
+    j->tp_rows[0].release(); j->tp_rows[1].release(); j->look_rows[0].release(); j->look_rows[1].release();
     if (g_engine && g_engine->tab_owner == j) g_engine->tab_owner = nullptr;
     delete j; --g_live_handles;
 }
