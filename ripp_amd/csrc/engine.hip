@@ -918,7 +918,8 @@ int32_t job_precompute_round0(Engine* e, ripp_sipp_job* j) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_odd_multiples<Fp>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, base1, (uint32_t)half, (int)M, sj1);
         HIPCHK(hipGetLastError());
         if ((rc = e->normalize_dev<Fp>(sj1, njt, base1 + half))) return rc;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_odd_multiples<Fp2>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, base2, (uint32_t)half, (int)M, sj2);
+        if (!e->sw.no_fq) hipLaunchKernelGGL(k_odd_multiples_q, dim3(nblk(half, 64)), dim3(64), 0, e->stream, base2, (uint32_t)half, (int)M, sj2);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_odd_multiples<Fp2>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, base2, (uint32_t)half, (int)M, sj2);
         HIPCHK(hipGetLastError());
         if ((rc = e->normalize_dev<Fp2>(sj2, njt, base2 + half))) return rc;
     }
@@ -940,7 +941,8 @@ int32_t fold_g2_table(Engine* e, hipStream_t st, const G2A* hi, const G2A* lo, s
     e->tab_owner = nullptr;                                     // whatever round-0 tables were there are overwritten
     G2A* mult = e->fold_mult.as<G2A>();
     HIPCHK(hipMemcpyAsync(mult, hi, half * sizeof(G2A), hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_odd_multiples<Fp2>), dim3(nblk(half, 64)), dim3(64), 0, st, hi, (uint32_t)half, M, e->fold_jac2.as<G2J>());
+    if (!e->sw.no_fq) hipLaunchKernelGGL(k_odd_multiples_q, dim3(nblk(half, 64)), dim3(64), 0, st, hi, (uint32_t)half, M, e->fold_jac2.as<G2J>());
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_odd_multiples<Fp2>), dim3(nblk(half, 64)), dim3(64), 0, st, hi, (uint32_t)half, M, e->fold_jac2.as<G2J>());
     HIPCHK(hipGetLastError());
     if ((rc = e->normalize_dev<Fp2>(e->fold_jac2.as<G2J>(), (size_t)(M - 1) * half, mult + half, st)) != RIPP_OK) return rc;
     hipLaunchKernelGGL(k_g2_tab_images, dim3(nblk(half, 64), M), dim3(64), 0, st, mult, (uint32_t)half, M, e->fold_tab.as<uint4>(), qstride);

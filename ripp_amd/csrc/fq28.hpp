@@ -91,6 +91,13 @@ __device__ __forceinline__ Fq<LM2, VB2> fq_widen(const Fq<LM, VB>& a) {
     return r;
 }
 
+// Pins a value where it is written: an empty asm over its 14 limbs.  The compiler is otherwise free to sink a product below later loads (or hoist
+// loads above it) and then keeps BOTH alive -- __builtin_amdgcn_sched_barrier only binds the machine scheduler, the order is already lost in the
+// DAG.  A data dependence through a volatile asm is honoured everywhere (fq_line_products.hpp: 48 spilled dwords -> 0 with this alone).
+template <uint64_t LM, int VB> __device__ __forceinline__ void fq_pin(Fq<LM, VB>& a) {
+    asm volatile("" : "+v"(a.l[0]), "+v"(a.l[1]), "+v"(a.l[2]), "+v"(a.l[3]), "+v"(a.l[4]), "+v"(a.l[5]), "+v"(a.l[6]), "+v"(a.l[7]), "+v"(a.l[8]), "+v"(a.l[9]), "+v"(a.l[10]), "+v"(a.l[11]), "+v"(a.l[12]), "+v"(a.l[13]));
+}
+
 namespace fq28 {
 // column bound of a lazily reduced sum of NT products: NT * 14 * (L1-1)(L2-1) + 14 * 2^56 (the m p terms) + carry-in (< 2^37) < 2^64
 constexpr bool dot_fits(int NT, uint64_t L1, uint64_t L2) {

@@ -18,6 +18,7 @@ template <uint64_t L1, int V1> __device__ __forceinline__ auto f2_dbl(const Fq2T
 template <uint64_t L1, int V1> __device__ __forceinline__ auto f2_norm(const Fq2T<L1, V1>& a) { return Fq2T<FQ_LN, V1>{fq_norm(a.c0), fq_norm(a.c1)}; }
 template <uint64_t L1, int V1> __device__ __forceinline__ Fq2n f2_reduce(const Fq2T<L1, V1>& a) { return {fq_reduce(a.c0), fq_reduce(a.c1)}; }
 template <uint64_t L1, int V1> __device__ __forceinline__ Fq2C f2_coord(const Fq2T<L1, V1>& a) { return {fq_coord(a.c0), fq_coord(a.c1)}; }
+template <uint64_t L1, int V1> __device__ __forceinline__ void f2_pin(Fq2T<L1, V1>& a) { fq_pin(a.c0); fq_pin(a.c1); }
 __device__ __forceinline__ bool f2_is_zero(const Fq2n& a) { return fq_is_zero(a.c0) && fq_is_zero(a.c1); }
 // THE call boundary of the G2 kernels: one out-of-line Fq product with vector-typed register arguments (28 VGPRs in, 14 out -- within the
 // 32 argument registers of the AMDGPU convention, nothing on the stack).  Inlining the ~550-instruction product 20 times per group
@@ -65,46 +66,71 @@ __device__ __forceinline__ Fq2n f2_sqr(const Fq2T<L1, V1>& a_) {
     return {fq_mulc(fq_add(a.c0, a.c1), fq_sub(a.c0, a.c1)), fq_mulc(fq_dbl(a.c0), a.c1)};
 }
 
+// ---- the inlined forms (no call, no Karatsuba temporaries): what the throughput kernels use.  The first half of a product is PINNED (fq28.hpp
+// fq_pin) so that the two column sets are never alive together.
+// (a0 + a1 u)(b0 + b1 u), u^2 = -1: two lazily reduced sums of two products, inlined; the result is reduced (< 2p, normalised limbs)
+template <uint64_t L1, int V1, uint64_t L2, int V2>
+__device__ __forceinline__ Fq2n f2_muld(const Fq2T<L1, V1>& a, const Fq2T<L2, V2>& b) {
+    const auto na1 = fq_neg(a.c1);                                     // K - a1, K = (V1 + 1) p with dominating limbs
+    using TA = decltype(na1);
+    Fq2n r;
+    { const TA aa[2] = {fq_widen<fq28::sub_lm(1, L1), V1 + 2>(a.c0), na1}; const Fq<L2, V2> bb[2] = {b.c0, b.c1}; r.c0 = fq_dot<2>(aa, bb); } fq_pin(r.c0);
+    { const Fq<L1, V1> aa[2] = {a.c0, a.c1}; const Fq<L2, V2> bb[2] = {b.c1, b.c0}; r.c1 = fq_dot<2>(aa, bb); }
+    return r;
+}
+template <uint64_t L1, int V1>
+__device__ __forceinline__ Fq2n f2_sqrd(const Fq2T<L1, V1>& a) {
+    Fq2n r;
+    r.c0 = fq_mul(fq_add(a.c0, a.c1), fq_sub(a.c0, a.c1)); fq_pin(r.c0);
+    r.c1 = fq_mul(fq_dbl(a.c0), a.c1);
+    return r;
+}
+template <uint64_t L1, int V1, uint64_t L2, int V2>
+__device__ __forceinline__ Fq2n f2_mul_fq(const Fq2T<L1, V1>& a, const Fq<L2, V2>& s) { Fq2n r; r.c0 = fq_mul(a.c0, s); fq_pin(r.c0); r.c1 = fq_mul(a.c1, s); return r; }
+template <uint64_t L1, int V1> __device__ __forceinline__ Fq2C f2_to_coord(const Fq2T<L1, V1>& a) { return {fq_coord(a.c0), fq_coord(a.c1)}; }
+
 // engine Fp2 (Mont-384) -> carry-free form: times 2^8 is a re-slicing, then one quotient estimate (no Montgomery product)
 __device__ __forceinline__ Fqn fq_from_fp_fast(const Fp& x) { return fq_reduce(fq_unpack_shl8(x.l)); }
 __device__ __forceinline__ Fq2n f2_from(const Fp2& x) { return {fq_from_fp_fast(x.c0), fq_from_fp_fast(x.c1)}; }
 __device__ __forceinline__ Fp2 f2_to(const Fq2C& a) { return {fq_to_fp(fq_reduce(a.c0)), fq_to_fp(fq_reduce(a.c1))}; }
 
 struct JacQ2 { Fq2C x, y, z; };
-#define SBQ() __builtin_amdgcn_sched_barrier(0)
-__device__ __forceinline__ void jdbl2_q(JacQ2& p) {            // dbl-2009-l in the order of kernels.hpp::jdbl_lo
-    p.z = f2_coord(f2_dbl(f2_mul(p.y, p.z))); SBQ();
-    const Fq2n A = f2_sqr(p.x); SBQ();
-    const Fq2n B = f2_sqr(p.y); SBQ();
-    const Fq2n t = f2_sqr(f2_add(p.x, B)); SBQ();
-    const Fq2n C = f2_sqr(B); SBQ();
-    const auto D = f2_norm(f2_dbl(f2_sub(f2_sub(t, A), C))); SBQ();
-    const auto E = f2_add(f2_dbl(A), A); SBQ();
-    const Fq2n X3 = f2_reduce(f2_sub(f2_sub(f2_sqr(E), D), D)); SBQ();
-    p.y = f2_coord(f2_sub(f2_mul(E, f2_sub(D, X3)), f2_dbl(f2_dbl(f2_dbl(C)))));
-    p.x = f2_coord(X3);
+// dbl-2009-l / madd-2007-bl in the low-liveness order of kernels.hpp (jdbl_lo / jmadd_lo), every product inlined and PINNED where it is written:
+// with the out-of-line Karatsuba products (f2_mul above) these two kept ~340 dwords per lane in scratch, with inlined products and
+// sched_barriers between them 84 -- the barriers bind only the machine scheduler, the DAG had already interleaved the products.
+__device__ __forceinline__ void jdbl2_q(JacQ2& p) {
+    p.z = f2_to_coord(f2_dbl(f2_muld(p.y, p.z))); f2_pin(p.z);
+    Fq2n A = f2_sqrd(p.x); f2_pin(A);
+    Fq2n B = f2_sqrd(p.y); f2_pin(B);
+    Fq2n t = f2_sqrd(f2_norm(f2_add(p.x, B))); f2_pin(t);
+    Fq2n C = f2_sqrd(B); f2_pin(C);
+    auto D = f2_norm(f2_dbl(f2_sub(f2_sub(t, A), C))); f2_pin(D);
+    auto E = f2_norm(f2_add(f2_dbl(A), A)); f2_pin(E);
+    Fq2n X3 = f2_reduce(f2_sub(f2_sub(f2_sqrd(E), D), D)); f2_pin(X3);
+    p.y = f2_to_coord(f2_sub(f2_muld(E, f2_norm(f2_sub(D, X3))), f2_dbl(f2_dbl(f2_dbl(C))))); f2_pin(p.y);
+    p.x = f2_to_coord(X3);
 }
-// madd-2007-bl; loadx / loady fetch the affine addend (Fq2n); park: this lane's LDS column (stride 64 lanes, 7 x 16 B).
+// loadx / loady fetch the affine addend (Fq2n); park: this lane's LDS column (stride 64 lanes, 7 x 16 B).
 // Returns true when the result is NOT valid (H = 0: T = +-Q).
 template <class LOADX, class LOADY>
 __device__ __forceinline__ bool jmadd2_q(JacQ2& p, LOADX loadx, LOADY loady, uint4* park) {
-    const Fq2n Z1Z1 = f2_sqr(p.z); SBQ();
-    const Fq2n H = f2_reduce(f2_sub(f2_mul(loadx(), Z1Z1), p.x)); SBQ();
-    const auto t = f2_mul(p.z, Z1Z1); SBQ();
-    const Fq2n r = f2_reduce(f2_dbl(f2_sub(f2_mul(loady(), t), p.y))); SBQ();
+    Fq2n Z1Z1 = f2_sqrd(p.z); f2_pin(Z1Z1);
+    Fq2n H = f2_reduce(f2_sub(f2_muld(loadx(), Z1Z1), p.x)); f2_pin(H);
+    Fq2n t = f2_muld(Z1Z1, p.z); f2_pin(t);
+    Fq2n r = f2_reduce(f2_dbl(f2_sub(f2_muld(loady(), t), p.y))); f2_pin(r);
     const bool special = f2_is_zero(H);
     { uint32_t w[28];                                                      // Y1 rests in LDS until the last product
 #pragma unroll
       for (int k = 0; k < 14; ++k) { w[k] = p.y.c0.l[k]; w[14 + k] = p.y.c1.l[k]; }
       const uint4* src = reinterpret_cast<const uint4*>(w);
 #pragma unroll
-      for (int k = 0; k < 7; ++k) park[k * 64] = src[k]; } SBQ();
-    const Fq2n HH = f2_sqr(H); SBQ();
-    p.z = f2_coord(f2_sub(f2_sub(f2_sqr(f2_add(p.z, H)), Z1Z1), HH)); SBQ();
-    const auto I = f2_dbl(f2_dbl(HH));
-    const auto J = f2_norm(f2_mul(H, I)); SBQ();
-    const auto V = f2_norm(f2_mul(p.x, I)); SBQ();
-    const Fq2n X3 = f2_reduce(f2_sub(f2_sub(f2_sub(f2_sqr(r), J), V), V)); SBQ();
+      for (int k = 0; k < 7; ++k) park[k * 64] = src[k]; }
+    Fq2n HH = f2_sqrd(H); f2_pin(HH);
+    p.z = f2_to_coord(f2_sub(f2_sub(f2_sqrd(f2_norm(f2_add(p.z, H))), Z1Z1), HH)); f2_pin(p.z);
+    const auto I = f2_dbl(f2_dbl(HH));                                     // 4 HH, lazy
+    Fq2n J = f2_muld(H, I); f2_pin(J);
+    Fq2n V = f2_muld(p.x, I); f2_pin(V);
+    Fq2n X3 = f2_reduce(f2_sub(f2_sub(f2_sub(f2_sqrd(r), J), V), V)); f2_pin(X3);
     Fq2n t2;
     { uint4 q[7];
 #pragma unroll
@@ -113,12 +139,11 @@ __device__ __forceinline__ bool jmadd2_q(JacQ2& p, LOADX loadx, LOADY loady, uin
       Fq2C y1;
 #pragma unroll
       for (int k = 0; k < 14; ++k) { y1.c0.l[k] = w[k]; y1.c1.l[k] = w[14 + k]; }
-      t2 = f2_reduce(f2_mul(y1, J)); } SBQ();
-    p.y = f2_coord(f2_sub(f2_mul(r, f2_sub(V, X3)), f2_dbl(t2)));
-    p.x = f2_coord(X3);
+      t2 = f2_muld(J, y1); f2_pin(t2); }
+    p.y = f2_to_coord(f2_sub(f2_muld(r, f2_norm(f2_sub(V, X3))), f2_dbl(t2))); f2_pin(p.y);
+    p.x = f2_to_coord(X3);
     return special;
 }
-#undef SBQ
 #endif
 
 // NS digit strings; string t works on table rows t M .. t M + M - 1 (kernels.hpp k_fold_g2_tab).  Exceptional lanes are recomputed with the
@@ -160,6 +185,71 @@ __global__ void __launch_bounds__(64, 2) k_fold_g2_tab_q(const uint4* __restrict
     if (!is_inf(l)) bad |= jmadd2_q(acc, [&]() { return f2_from(l.x); }, [&]() { return f2_from(l.y); }, park);
     if (bad) fold_g2_tab_complete<D, NS>(qtab, stride, M, lo, i, dg, out);
     else out[i] = G2J{f2_to(acc.x), f2_to(acc.y), f2_to(acc.z)};
+#endif
+}
+
+// Odd multiples 3 Q, 5 Q, .., (2 M - 1) Q of the fold tables (kernels.hpp k_odd_multiples: out[m][i] = (2m + 3) base[i], Jacobian, batch-normalised
+// by the caller) on the carry-free form.  k_odd_multiples<Fp2> chains M - 2 GENERAL Jacobian additions t += 2Q (16 Fp2 products each, out-of-line
+// 12-word products: 1 448 B of scratch per lane, 63 % of its own issue roof).  Here the chain runs on the isomorphic curve on which 2Q = (X2, Y2, Z2)
+// is AFFINE -- (x, y) -> (x Z2^2, y Z2^3) -- so every step is a mixed addition with the same affine addend (X2, Y2) (11 products), and a result
+// (X', Y', Z') is the point (X', Y', Z' Z2) of the original curve (one more product).  (X2, Y2) rest in the element's LAST output slot until the
+// last addition has read them, Z2 and the idle Y1 in LDS.  Exceptional elements (infinity, small order) are redone with the complete formulas.
+template <class F>
+__device__ __noinline__ void odd_multiples_complete(const Affine<F>* __restrict__ base, uint32_t n, int M, uint32_t i, Jac<F>* __restrict__ out) {
+    const Affine<F> b = base[i];
+    const Jac<F> b2 = dbl(to_jac(b));
+    Jac<F> t = add_mixed(b2, b);
+    out[i] = t;
+#pragma unroll 1
+    for (int m = 1; m < M - 1; ++m) { t = add(t, b2); out[(size_t)m * n + i] = t; }
+}
+__global__ void __launch_bounds__(64, 2) k_odd_multiples_q(const G2A* __restrict__ base, uint32_t n, int M, G2J* __restrict__ out) {
+    __shared__ uint4 park_[14 * 64];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || M < 2) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint4* park = park_ + threadIdx.x;
+    uint4* zpark = park + 7 * 64;
+    auto st7 = [](uint4* dst, size_t stride, const Fq2n& v) { uint32_t w[28];
+#pragma unroll
+        for (int k = 0; k < 14; ++k) { w[k] = v.c0.l[k]; w[14 + k] = v.c1.l[k]; }
+        const uint4* src = reinterpret_cast<const uint4*>(w);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) dst[k * stride] = src[k]; };
+    auto ld7 = [](const uint4* src, size_t stride) { uint4 q[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) q[k] = src[k * stride];
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(q);
+        Fq2n v;
+#pragma unroll
+        for (int k = 0; k < 14; ++k) { v.c0.l[k] = w[k]; v.c1.l[k] = w[14 + k]; }
+        return v; };
+    const G2A* bp = base + i;
+    bool bad;
+    { const G2A b = *bp; bad = is_inf(b); }
+    uint4* tmp = reinterpret_cast<uint4*>(out + (size_t)(M - 2) * n + i);       // 14 of the slot's 18 chunks: X2, Y2
+    JacQ2 t;
+    {
+        JacQ2 d; d.x = f2_to_coord(f2_from(opaque(bp)->x)); d.y = f2_to_coord(f2_from(opaque(bp)->y)); d.z = f2_to_coord(Fq2n{fq_one(), fq_zero()});
+        f2_pin(d.z);
+        jdbl2_q(d);
+        Fq2n Z2 = f2_reduce(d.z); f2_pin(Z2);
+        bad |= f2_is_zero(Z2);
+        st7(zpark, 64, Z2);
+        st7(tmp, 1, f2_reduce(d.x)); st7(tmp + 7, 1, f2_reduce(d.y));
+        Fq2n zz = f2_sqrd(Z2); f2_pin(zz);
+        { Fq2n px = f2_muld(f2_from(opaque(bp)->x), zz); f2_pin(px); t.x = f2_to_coord(px); }
+        Fq2n zzz = f2_muld(zz, Z2); f2_pin(zzz);
+        { Fq2n py = f2_muld(f2_from(opaque(bp)->y), zzz); f2_pin(py); t.y = f2_to_coord(py); }
+        t.z = f2_to_coord(Fq2n{fq_one(), fq_zero()}); f2_pin(t.z);
+    }
+#pragma unroll 1
+    for (int m = 0; m < M - 1; ++m) {
+        bad |= jmadd2_q(t, [&]() { return ld7(opaque(tmp), 1); }, [&]() { return ld7(opaque(tmp) + 7, 1); }, park);
+        Fq2n zo = f2_muld(t.z, ld7(zpark, 64)); f2_pin(zo);
+        out[(size_t)m * n + i] = G2J{f2_to(t.x), f2_to(t.y), f2_to(f2_to_coord(zo))};
+    }
+    if (bad) odd_multiples_complete<Fp2>(base, n, M, i, out);
 #endif
 }
 

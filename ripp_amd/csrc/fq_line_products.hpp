@@ -15,6 +15,14 @@
 
 namespace ripp {
 
+// pins the multiply-adds of one operand pass BEFORE the next pass's LDS reads are laundered (an empty asm over all 27 columns): without it the
+// compiler sinks the arithmetic below every read and keeps the fetched operands -- all of them -- live
+#define TIE(c) asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(c[8]), "+v"(c[9]), "+v"(c[10]), "+v"(c[11]), "+v"(c[12]), "+v"(c[13]), \
+                                "+v"(c[14]), "+v"(c[15]), "+v"(c[16]), "+v"(c[17]), "+v"(c[18]), "+v"(c[19]), "+v"(c[20]), "+v"(c[21]), "+v"(c[22]), "+v"(c[23]), "+v"(c[24]), "+v"(c[25]), "+v"(c[26]))
+// the same for a reduced sum: the reduction happens HERE (14 live registers), not where the value is stored (54)
+#define TIE14(c) asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(c[8]), "+v"(c[9]), "+v"(c[10]), "+v"(c[11]), "+v"(c[12]), "+v"(c[13]))
+typedef uint32_t lq_v4u __attribute__((ext_vector_type(4)));
+struct LqBuf { lq_v4u q[4]; };                                    // one accumulator coefficient as fetched: 14 limbs + 2
 constexpr int LQ_SLOT_DW = 16;                                     // an Fq in LDS: 14 limbs + 2 (four 16-byte accesses)
 constexpr int LQ_ACC_DW = 6 * 2 * LQ_SLOT_DW;                      // f_0 .. f_5 in Fp2: 768 B per accumulator
 // The 21 accumulators of a wave are laid out with a stride of 49 chunks (784 B), not 48: 768 B is a multiple of the 128-byte bank row, so every
@@ -40,7 +48,9 @@ __global__ void __launch_bounds__(64, 2) k_line_products_q(const uint4* __restri
     const uint32_t t = blockIdx.x * LP_GROUPS_PER_WAVE + g;
     const bool active = g < (uint32_t)LP_GROUPS_PER_WAVE && t < T;
     const size_t row = blockIdx.y;
-    uint4* acc = lds + (active ? g : 0) * LQ_ACC_STRIDE;
+    const uint32_t acc_chunk = (active ? g : 0) * LQ_ACC_STRIDE;
+    const uint32_t lds_base = (uint32_t)(size_t)lds;                            // LDS byte offset of the array (the low half of its flat address)
+    uint4* acc = lds + acc_chunk;
     auto ld_fq = [&](int slot, int part) { Fqn v; uint4 q[4];                    // slot = w-index 0..5, part = 0 (real) / 1 (imaginary)
 #pragma unroll
         for (int c = 0; c < 4; ++c) q[c] = acc[(slot * 2 + part) * 4 + c];
@@ -90,12 +100,22 @@ __global__ void __launch_bounds__(64, 2) k_line_products_q(const uint4* __restri
         // (K = 3p with limbs that dominate a reduced value's: fq28::sub_bias), ysel[t]: index of the line-side operand.
         static_assert(dot_fits(6, (uint64_t)1 << 29, FQ_LN) && 6 * 4 * 3 <= VMAX, "six products of (x or K - x) by a line coefficient fit the 64-bit columns");
         constexpr Limbs KN = sub_bias<FQ_LN, 2>();
-        // col += (x or K - x) * yt, x = accumulator coefficient (slot, part) streamed from LDS
-        auto rows = [&](uint64_t (&col)[2 * NL - 1], int slot, int part, bool neg, const FY& yt) {
+        // One accumulator coefficient (slot, part) = four 16-byte LDS reads, issued by hand one operand pass AHEAD of their use (asm: the
+        // compiler merged the repeated reads of a coefficient -- each is an operand of two sums, slots j and j + 3 of four -- into one and kept all
+        // 8 coefficients, 112 registers, live across the iteration, which pushed 48 dwords of the outputs into scratch; left to schedule plain
+        // re-reads it placed every one directly before its use).  Streaming costs 64 more ds_read_b128 per line; the kernel has no scratch.
+        // `pin`: a column the current pass accumulates into -- orders the reads BEFORE that pass's multiply-adds.
+        auto fetch = [&](LqBuf& b, int slot, int part, uint64_t& pin) {
+            const uint32_t addr = lds_base + (acc_chunk + (uint32_t)(slot * 2 + part) * 4) * 16;
+            asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:16\n\tds_read_b128 %2, %5 offset:32\n\tds_read_b128 %3, %5 offset:48"
+                         : "=&v"(b.q[0]), "=&v"(b.q[1]), "=&v"(b.q[2]), "=&v"(b.q[3]), "+v"(pin) : "v"(addr));
+        };
+        auto arrived = [&](LqBuf& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b.q[0]), "+v"(b.q[1]), "+v"(b.q[2]), "+v"(b.q[3])); };
+        // col += (x or K - x) * yt, x = the fetched coefficient
+        auto mads = [&](uint64_t (&col)[2 * NL - 1], const LqBuf& b, bool neg, const FY& yt) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const uint4 xv = acc[(slot * 2 + part) * 4 + q];
-                const uint32_t xl[4] = {xv.x, xv.y, xv.z, xv.w};
+                const uint32_t xl[4] = {b.q[q].x, b.q[q].y, b.q[q].z, b.q[q].w};
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int i = 4 * q + u;
@@ -124,19 +144,32 @@ __global__ void __launch_bounds__(64, 2) k_line_products_q(const uint4* __restri
         };
         // (s0, s1, s2) against (l0, l1, l2):  im = sum x.c0 y.c1 + x.c1 y.c0,  re = sum x.c0 y.c0 + (K - x.c1) y.c1
         auto two_dots = [&](int s0, int s1, int s2, Fqn& re, Fqn& im) {
+            const int sl[3] = {s0, s1, s2};
+            LqBuf b0, b1;
             {
                 uint64_t col[2 * NL - 1];
 #pragma unroll
                 for (int c = 0; c < 2 * NL - 1; ++c) col[c] = 0;
-                rows(col, s0, 0, false, y[1]); rows(col, s0, 1, false, y[0]); rows(col, s1, 0, false, y[3]); rows(col, s1, 1, false, y[2]); rows(col, s2, 0, false, y[5]); rows(col, s2, 1, false, y[4]);
-                im = reduce_cols(col);
+                fetch(b0, s0, 0, col[NL - 1]); arrived(b0);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {                                    // x.c0 y.c1 + x.c1 y.c0
+                    fetch(b1, sl[t], 1, col[NL - 1]); mads(col, b0, false, y[2 * t + 1]); TIE(col); arrived(b1);
+                    fetch(b0, sl[(t + 1) % 3], 0, col[NL - 1]); mads(col, b1, false, y[2 * t]); TIE(col); arrived(b0);      // (t = 2: x.c0 of s0 again, for the real part)
+                }
+                im = reduce_cols(col); TIE14(im.l);
             }
             {
                 uint64_t col[2 * NL - 1];
 #pragma unroll
                 for (int c = 0; c < 2 * NL - 1; ++c) col[c] = 0;
-                rows(col, s0, 0, false, y[0]); rows(col, s0, 1, true, y[1]); rows(col, s1, 0, false, y[2]); rows(col, s1, 1, true, y[3]); rows(col, s2, 0, false, y[4]); rows(col, s2, 1, true, y[5]);
-                re = reduce_cols(col);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {                                    // x.c0 y.c0 + (K - x.c1) y.c1
+                    fetch(b1, sl[t], 1, col[NL - 1]); mads(col, b0, false, y[2 * t]); TIE(col); arrived(b1);
+                    if (t < 2) fetch(b0, sl[t + 1], 0, col[NL - 1]);
+                    mads(col, b1, true, y[2 * t + 1]); TIE(col);
+                    if (t < 2) arrived(b0);
+                }
+                re = reduce_cols(col); TIE14(re.l);
             }
         };
         two_dots((int)j + 3, (int)j + 1, (int)j, o1r, o1i);                      // k = j + 3: plain line
@@ -172,5 +205,7 @@ __global__ void __launch_bounds__(64, 2) k_line_products_q(const uint4* __restri
     }
 #endif
 }
+#undef TIE
+#undef TIE14
 
 }  // namespace ripp

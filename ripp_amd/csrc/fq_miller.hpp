@@ -20,26 +20,6 @@
 namespace ripp {
 
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(RIPP_BLS12_377)
-#define SBM() __builtin_amdgcn_sched_barrier(0)
-// (a0 + a1 u)(b0 + b1 u), u^2 = -1: two lazily reduced sums of two products, inlined; the result is reduced (< 2p, normalised limbs)
-template <uint64_t L1, int V1, uint64_t L2, int V2>
-__device__ __forceinline__ Fq2n f2_muld(const Fq2T<L1, V1>& a, const Fq2T<L2, V2>& b) {
-    const auto na1 = fq_neg(a.c1);                                     // K - a1, K = (V1 + 1) p with dominating limbs
-    using TA = decltype(na1);
-    Fq2n r;
-    { const TA aa[2] = {fq_widen<fq28::sub_lm(1, L1), V1 + 2>(a.c0), na1}; const Fq<L2, V2> bb[2] = {b.c0, b.c1}; r.c0 = fq_dot<2>(aa, bb); } SBM();
-    { const Fq<L1, V1> aa[2] = {a.c0, a.c1}; const Fq<L2, V2> bb[2] = {b.c1, b.c0}; r.c1 = fq_dot<2>(aa, bb); }
-    return r;
-}
-template <uint64_t L1, int V1>
-__device__ __forceinline__ Fq2n f2_sqrd(const Fq2T<L1, V1>& a) {
-    Fq2n r;
-    r.c0 = fq_mul(fq_add(a.c0, a.c1), fq_sub(a.c0, a.c1)); SBM();
-    r.c1 = fq_mul(fq_dbl(a.c0), a.c1);
-    return r;
-}
-template <uint64_t L1, int V1, uint64_t L2, int V2>
-__device__ __forceinline__ Fq2n f2_mul_fq(const Fq2T<L1, V1>& a, const Fq<L2, V2>& s) { Fq2n r; r.c0 = fq_mul(a.c0, s); SBM(); r.c1 = fq_mul(a.c1, s); return r; }
 // a line coefficient (value < 2p) -> the canonical integer, 12 words, chunked SoA (kernels.hpp store_chunks layout)
 __device__ __forceinline__ void store_line_q(uint4* lines, size_t row, size_t stride, size_t i, const Fq2n& v) {
     uint32_t w[24];
@@ -58,17 +38,17 @@ __device__ __forceinline__ void store_line_raw(uint4* lines, size_t row, size_t 
     for (int q = 0; q < 6; ++q) lines[(row * 6 + q) * stride + i] = src[q];
 }
 // P's coordinates in LDS: 4 chunks each (14 limbs + 2), lane-strided
-__device__ __forceinline__ Fqn ld_park_fq(const uint4* park, int slot) {
+template <class FQ = Fqn> __device__ __forceinline__ FQ ld_park_fq(const uint4* park, int slot) {
     uint4 q[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) q[c] = park[(slot * 4 + c) * 256];
     const uint32_t* w = reinterpret_cast<const uint32_t*>(q);
-    Fqn v;
+    FQ v;
 #pragma unroll
     for (int k = 0; k < fq28::NL; ++k) v.l[k] = w[k];
     return v;
 }
-__device__ __forceinline__ void st_park_fq(uint4* park, int slot, const Fqn& v) {
+template <class FQ> __device__ __forceinline__ void st_park_fq(uint4* park, int slot, const FQ& v) {
     uint32_t w[16];
 #pragma unroll
     for (int k = 0; k < fq28::NL; ++k) w[k] = v.l[k];
@@ -76,74 +56,74 @@ __device__ __forceinline__ void st_park_fq(uint4* park, int slot, const Fqn& v) 
 #pragma unroll
     for (int c = 0; c < 4; ++c) park[(slot * 4 + c) * 256] = uint4{w[4 * c], w[4 * c + 1], w[4 * c + 2], w[4 * c + 3]};
 }
-template <uint64_t L1, int V1> __device__ __forceinline__ Fq2C f2_to_coord(const Fq2T<L1, V1>& a) { return {fq_coord(a.c0), fq_coord(a.c1)}; }
 
-// doubling step + its line; (X, Y, Z) <- -4 x the doubled point.  park: slots 0 (xP), 1 (yP)
+// doubling step + its line; (X, Y, Z) <- -4 x the doubled point.  park: slots 0 (xP), 1 (yP).  Every product is PINNED where it is written
+// (fq28.hpp fq_pin): the compiler otherwise carries un-reduced column sums of one step across the loop's branch into the next.
 __device__ __forceinline__ void line_double_store_q(Fq2C& X, Fq2C& Y, Fq2C& Z, const uint4* park, uint4* lines, size_t s, size_t stride, size_t i, bool skip) {
-    const Fq2n t1 = f2_sqrd(f2_norm(f2_add(Y, Z))); SBM();
-    const Fq2n c = f2_sqrd(Z); SBM();
-    const Fq2n b = f2_sqrd(Y); SBM();
-    const auto nh = f2_norm(f2_sub(f2_add(b, c), t1)); SBM();                    // -h, value < 7p
+    Fq2n t1 = f2_sqrd(f2_norm(f2_add(Y, Z))); f2_pin(t1);
+    Fq2n c = f2_sqrd(Z); f2_pin(c);
+    Fq2n b = f2_sqrd(Y); f2_pin(b);
+    auto nh = f2_norm(f2_sub(f2_add(b, c), t1)); f2_pin(nh);                      // -h, value < 7p
     {
-        const Fq2n l2 = f2_mul_fq(nh, ld_park_fq(park, 1));
+        Fq2n l2 = f2_mul_fq(nh, ld_park_fq(park, 1)); f2_pin(l2);
         if (skip) store_line_raw(lines, s * 3 + 2, stride, i, Fp2::zero()); else store_line_q(lines, s * 3 + 2, stride, i, l2);
-    } SBM();
+    }
     Fq2n e;                                                                       // b' * 3c, b' = 4 (1 + u): 4 (c0 - c1) + 4 (c0 + c1) u
     {
         const auto c3 = f2_add(f2_add(c, c), c);
         e.c0 = fq_reduce(fq_dbl(fq_dbl(fq_norm(fq_sub(c3.c0, c3.c1)))));
         e.c1 = fq_reduce(fq_dbl(fq_dbl(fq_norm(fq_add(c3.c0, c3.c1)))));
-    } SBM();
+    } f2_pin(e);
     if (skip) store_line_raw(lines, s * 3 + 0, stride, i, Fp2::one()); else store_line_q(lines, s * 3 + 0, stride, i, f2_reduce(f2_sub(e, b)));
-    SBM();
-    const Fq2n a2 = f2_muld(X, Y); SBM();                                         // a' = X Y
+    Fq2n a2 = f2_muld(X, Y); f2_pin(a2);                                          // a' = X Y
     {
-        const Fq2n j = f2_sqrd(X); SBM();
-        const Fq2n l1 = f2_mul_fq(f2_add(f2_add(j, j), j), ld_park_fq(park, 0));
+        Fq2n j = f2_sqrd(X); f2_pin(j);
+        Fq2n l1 = f2_mul_fq(f2_add(f2_add(j, j), j), ld_park_fq(park, 0)); f2_pin(l1);
         if (skip) store_line_raw(lines, s * 3 + 1, stride, i, Fp2::zero()); else store_line_q(lines, s * 3 + 1, stride, i, l1);
-    } SBM();
-    Z = f2_to_coord(f2_muld(f2_dbl(b), f2_dbl(nh))); SBM();                       // (2b)(2 nh) = -4 b h
+    }
+    Z = f2_to_coord(f2_muld(f2_dbl(b), f2_dbl(nh))); f2_pin(Z);                   // (2b)(2 nh) = -4 b h
     const auto f = f2_add(f2_add(e, e), e);                                       // 3e, lazy
-    X = f2_to_coord(f2_muld(f2_dbl(a2), f2_norm(f2_sub(f, b)))); SBM();                    // 2 a' (f - b) = -4 a (b - f)
-    const Fq2n g2 = f2_sqrd(f2_norm(f2_add(b, f))); SBM();                                 // g'^2 = 4 g^2
-    const Fq2n e2 = f2_sqrd(e); SBM();
+    X = f2_to_coord(f2_muld(f2_dbl(a2), f2_norm(f2_sub(f, b)))); f2_pin(X);       // 2 a' (f - b) = -4 a (b - f)
+    Fq2n g2 = f2_sqrd(f2_norm(f2_add(b, f))); f2_pin(g2);                         // g'^2 = 4 g^2
+    Fq2n e2 = f2_sqrd(e); f2_pin(e2);
     const auto e12 = f2_dbl(f2_dbl(f2_add(f2_add(e2, e2), e2)));                  // 12 e^2, lazy
-    Y = f2_to_coord(f2_sub(e12, g2));                                             // 12 e^2 - g'^2 = -4 (g^2 - 3 e^2)
+    Y = f2_to_coord(f2_sub(e12, g2)); f2_pin(Y);                                  // 12 e^2 - g'^2 = -4 (g^2 - 3 e^2)
 }
 __device__ __forceinline__ Fq2n f2_load_conv(const Fp2* p) { const Fp2 v = *p; return f2_from(v); }
 // mixed addition step + its line (-j, theta xP, -lambda yP) = -1 x the textbook line
 __device__ __forceinline__ void line_add_store_q(Fq2C& X, Fq2C& Y, Fq2C& Z, const G2A* q, const uint4* park, uint4* lines, size_t s, size_t stride, size_t i, bool skip) {
     Fq2n theta, lambda;
-    { const Fq2n qy = f2_load_conv(&opaque(q)->y); theta = f2_reduce(f2_sub(Y, f2_muld(qy, Z))); } SBM();
-    { const Fq2n qx = f2_load_conv(&opaque(q)->x); lambda = f2_reduce(f2_sub(X, f2_muld(qx, Z))); } SBM();
+    { const Fq2n qy = f2_load_conv(&opaque(q)->y); theta = f2_reduce(f2_sub(Y, f2_muld(qy, Z))); } f2_pin(theta);
+    st_park_fq(const_cast<uint4*>(park), 2, Y.c0); st_park_fq(const_cast<uint4*>(park), 3, Y.c1);      // Y rests in LDS until the step's last product
+    { const Fq2n qx = f2_load_conv(&opaque(q)->x); lambda = f2_reduce(f2_sub(X, f2_muld(qx, Z))); } f2_pin(lambda);
     {
-        Fq2n t; { const Fq2n qy = f2_load_conv(&opaque(q)->y); t = f2_muld(lambda, qy); } SBM();
+        Fq2n t; { const Fq2n qy = f2_load_conv(&opaque(q)->y); t = f2_muld(lambda, qy); } f2_pin(t);
         const Fq2n qx = f2_load_conv(&opaque(q)->x);
-        const Fq2n nj = f2_reduce(f2_sub(t, f2_muld(theta, qx)));                  // lambda qy - theta qx = -j
+        Fq2n nj = f2_reduce(f2_sub(t, f2_muld(theta, qx))); f2_pin(nj);             // lambda qy - theta qx = -j
         if (skip) store_line_raw(lines, s * 3 + 0, stride, i, Fp2::one()); else store_line_q(lines, s * 3 + 0, stride, i, nj);
-    } SBM();
-    { const Fq2n l1 = f2_mul_fq(theta, ld_park_fq(park, 0));
-      if (skip) store_line_raw(lines, s * 3 + 1, stride, i, Fp2::zero()); else store_line_q(lines, s * 3 + 1, stride, i, l1); } SBM();
+    }
+    { Fq2n l1 = f2_mul_fq(theta, ld_park_fq(park, 0)); f2_pin(l1);
+      if (skip) store_line_raw(lines, s * 3 + 1, stride, i, Fp2::zero()); else store_line_q(lines, s * 3 + 1, stride, i, l1); }
     { const auto nl = Fq2T<fq28::sub_lm(1, FQ_LN), 4>{fq_neg(lambda.c0), fq_neg(lambda.c1)};
-      const Fq2n l2 = f2_mul_fq(nl, ld_park_fq(park, 1));
-      if (skip) store_line_raw(lines, s * 3 + 2, stride, i, Fp2::zero()); else store_line_q(lines, s * 3 + 2, stride, i, l2); } SBM();
+      Fq2n l2 = f2_mul_fq(nl, ld_park_fq(park, 1)); f2_pin(l2);
+      if (skip) store_line_raw(lines, s * 3 + 2, stride, i, Fp2::zero()); else store_line_q(lines, s * 3 + 2, stride, i, l2); }
     Fq2n f;
-    { const Fq2n c = f2_sqrd(theta); SBM(); f = f2_muld(c, Z); } SBM();
-    const Fq2n d = f2_sqrd(lambda); SBM();
-    const Fq2n e = f2_muld(lambda, d); SBM();
-    const Fq2n g = f2_muld(d, X); SBM();
-    const Fq2n h = f2_reduce(f2_sub(f2_add(e, f), f2_dbl(g))); SBM();
-    X = f2_to_coord(f2_muld(lambda, h)); SBM();
-    Z = f2_to_coord(f2_muld(e, Z)); SBM();
-    const Fq2n t = f2_muld(theta, f2_norm(f2_sub(g, h))); SBM();
-    Y = f2_to_coord(f2_sub(t, f2_muld(e, Y)));
+    { Fq2n c = f2_sqrd(theta); f2_pin(c); f = f2_muld(c, Z); } f2_pin(f);
+    Fq2n d = f2_sqrd(lambda); f2_pin(d);
+    Fq2n g = f2_muld(d, X); f2_pin(g);                                            // (before e: X dies here, d right after -- one coordinate less alive at the peak)
+    Fq2n e = f2_muld(lambda, d); f2_pin(e);
+    Fq2n h = f2_reduce(f2_sub(f2_add(e, f), f2_dbl(g))); f2_pin(h);
+    X = f2_to_coord(f2_muld(lambda, h)); f2_pin(X);
+    Z = f2_to_coord(f2_muld(e, Z)); f2_pin(Z);
+    Fq2n t = f2_muld(theta, f2_norm(f2_sub(g, h))); f2_pin(t);
+    { Fq2C y1; y1.c0 = ld_park_fq<decltype(y1.c0)>(park, 2); y1.c1 = ld_park_fq<decltype(y1.c1)>(park, 3);
+      Y = f2_to_coord(f2_sub(t, f2_muld(e, y1))); } f2_pin(Y);
 }
-#undef SBM
 #endif
 
 // same arguments, grid and line-buffer layout as k_miller_lines
 __global__ void __launch_bounds__(256, RIPP_OCC) k_miller_lines_q(PairSets ps, uint32_t M, uint4* __restrict__ lines, size_t stride) {
-    __shared__ uint4 park_[8 * 256];
+    __shared__ uint4 park_[16 * 256];                            // per lane: xP, yP and (addition steps) the two halves of Y
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(RIPP_BLS12_377)
@@ -157,6 +137,7 @@ __global__ void __launch_bounds__(256, RIPP_OCC) k_miller_lines_q(PairSets ps, u
         skip = is_inf(P) || (Q.x.is_zero() && Q.y.is_zero());
         X = f2_to_coord(f2_from(Q.x)); Y = f2_to_coord(f2_from(Q.y)); Z = f2_to_coord(Fq2n{fq_one(), fq_zero()});
         st_park_fq(park, 0, fq_from_fp_fast(P.x)); st_park_fq(park, 1, fq_from_fp_fast(P.y));
+        f2_pin(X); f2_pin(Y); f2_pin(Z);                             // (Z = 1 is not to be folded into a peeled first iteration: that copy of the loop body spilled)
     }
     size_t s = (size_t)blockIdx.y * N_LINES;
 #pragma unroll 1
@@ -164,7 +145,8 @@ __global__ void __launch_bounds__(256, RIPP_OCC) k_miller_lines_q(PairSets ps, u
         line_double_store_q(X, Y, Z, park, lines, s, stride, i, skip);
         ++s;
         if ((BLS_X_ABS >> bit) & 1ull) {
-            line_add_store_q(X, Y, Z, b + i, park, lines, s, stride, i, skip);
+            uint32_t iq = i; asm volatile("" : "+v"(iq));                  // Q's address is re-formed here (kept alive across the loop it was the kernel's last spilled register pair)
+            line_add_store_q(X, Y, Z, b + iq, park, lines, s, stride, i, skip);
             ++s;
         }
     }

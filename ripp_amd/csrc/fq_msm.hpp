@@ -25,42 +25,6 @@ __device__ __forceinline__ QFp qfp_from(const Fp& v) { QFp r; fq_pack(fq_canon(f
 __device__ __forceinline__ Fqn qfp_get(const QFp& v) { return fq_unpack(v.w); }
 __device__ __forceinline__ bool qfp_zero(const QFp& v) { uint32_t z = 0; for (int k = 0; k < 12; ++k) z |= v.w[k]; return z == 0; }
 
-#define SBX() __builtin_amdgcn_sched_barrier(0)
-// madd-2007-bl over Fp2 in the order of fq_curve2.hpp's jmadd2_q; products in the two-sums form (no out-of-line calls, no Karatsuba temporaries).
-// park: this lane's LDS column (7 x 16 B, stride 64 lanes).  Returns true when the result is NOT valid (H = 0: T = +-Q).
-template <class LOADX, class LOADY>
-__device__ __forceinline__ bool jmadd2_qd(JacQ2& p, LOADX loadx, LOADY loady, uint4* park) {
-    const Fq2n Z1Z1 = f2_sqrd(p.z); SBX();
-    const Fq2n H = f2_reduce(f2_sub(f2_muld(loadx(), Z1Z1), p.x)); SBX();
-    const Fq2n t = f2_muld(Z1Z1, p.z); SBX();
-    const Fq2n r = f2_reduce(f2_dbl(f2_sub(f2_muld(loady(), t), p.y))); SBX();
-    const bool special = f2_is_zero(H);
-    { uint32_t w[28];                                                      // Y1 rests in LDS until the last product
-#pragma unroll
-      for (int k = 0; k < 14; ++k) { w[k] = p.y.c0.l[k]; w[14 + k] = p.y.c1.l[k]; }
-      const uint4* src = reinterpret_cast<const uint4*>(w);
-#pragma unroll
-      for (int k = 0; k < 7; ++k) park[k * 64] = src[k]; } SBX();
-    const Fq2n HH = f2_sqrd(H); SBX();
-    p.z = f2_to_coord(f2_sub(f2_sub(f2_sqrd(f2_norm(f2_add(p.z, H))), Z1Z1), HH)); SBX();
-    const auto I = f2_dbl(f2_dbl(HH));                                     // 4 HH, lazy
-    const Fq2n J = f2_muld(H, I); SBX();
-    const Fq2n V = f2_muld(p.x, I); SBX();
-    const Fq2n X3 = f2_reduce(f2_sub(f2_sub(f2_sub(f2_sqrd(r), J), V), V)); SBX();
-    Fq2n t2;
-    { uint4 q[7];
-#pragma unroll
-      for (int k = 0; k < 7; ++k) q[k] = park[k * 64];
-      const uint32_t* w = reinterpret_cast<const uint32_t*>(q);
-      Fq2C y1;
-#pragma unroll
-      for (int k = 0; k < 14; ++k) { y1.c0.l[k] = w[k]; y1.c1.l[k] = w[14 + k]; }
-      t2 = f2_muld(J, y1); } SBX();
-    p.y = f2_to_coord(f2_sub(f2_muld(r, f2_norm(f2_sub(V, X3))), f2_dbl(t2)));
-    p.x = f2_to_coord(X3);
-    return special;
-}
-#undef SBX
 #endif
 
 // ext[j * n + i] = image j of bases[i] in the carry-free form, j < split (1: the bases themselves; 2: + phi; 4: + psi, psi^2, psi^3); the identity (0, 0) stays (0, 0)
@@ -125,7 +89,7 @@ __global__ void __launch_bounds__(64, 2) k_msm_slot_sum_q(const Affine<F>* __res
             auto lx = [&]() { const QAff<Fp2>* o = opaque(qp); return Fq2n{qfp_get(o->x0), qfp_get(o->x1)}; };
             auto ly = [&]() { const QAff<Fp2>* o = opaque(qp); return Fq2n{qfp_get(o->y0), qfp_get(o->y1)}; };
             if (inf) { a.x = f2_to_coord(lx()); a.y = f2_to_coord(ly()); a.z = f2_to_coord(Fq2n{fq_one(), fq_zero()}); inf = false; }
-            else bad |= jmadd2_qd(a, lx, ly, park);
+            else bad |= jmadd2_q(a, lx, ly, park);
         }
         if (!inf && !bad) acc = G2J{f2_to(a.x), f2_to(a.y), f2_to(a.z)};
     }
