@@ -211,7 +211,8 @@ struct Engine {
     size_t lp_fq_min = 0;                 // pairs per launch from which k_line_products_q replaces k_line_products: always (11 % faster per launch: 5.8 vs 6.5 ms at the proof's launch
                                           // mix; it keeps ~47 dwords per lane in scratch, which costs HBM traffic, not time -- the kernel is issue-bound).  RIPP_LP_FQ_MIN=4294967295 / RIPP_NO_FQ select k_line_products
     size_t ml_fq_min = 0;                 // pairs per launch from which k_miller_lines_q (fq_miller.hpp) replaces k_miller_lines: every throughput launch (the VM kernel covers the small ones)
-    size_t fq_min = (size_t)1 << 17;      // the carry-free fold kernels (fq_curve.hpp) win on THROUGHPUT: launches with >= 2 waves per SIMD
+    size_t fq_min_g1 = (size_t)1 << 12;   // ... the G1 NAF fold (one 128-step chain per lane either way): the carry-free kernel wherever the lane-per-element form runs at all
+    size_t fq_min = (size_t)1 << 15;      // the carry-free fold kernels (fq_curve.hpp, fq_curve2.hpp): from 2^15 outputs (round 4 of an n = 2^20 proof: 5.4 -> 3.9 ms; below that the 12 x 32-bit forms have the shorter chains)
     size_t fold_tab_min = 32768;          // G2 folds of at least this many elements build in-round odd-multiple tables
     size_t msm_vm_merge_max = 16384;      // buckets (all windows) up to which the bucket merge runs on the field VM
     hipStream_t stream5 = nullptr;        // second G2 fold of a small GIPA round (own scratch there, so it need not queue behind the first)
@@ -240,7 +241,7 @@ struct Engine {
     struct Switches { bool no_vm = false, no_precompute = false, no_fold_tables = false, no_msm_glv = false, lp_one_lane = false, no_endo = false, no_fq = false, no_xscale = false; } sw;
     // crossover sizes: the member initialisers above are the defaults, the environment overrides them PER CALL (a test or
     // an A/B run flips them on a live engine)
-    struct Sizes { size_t vm_lines_max, vm_fold_max, vm_tree_max, gls_split_max, msm_vm_merge_max, fold_tab_min, fq_min, lp_fq_min, vm_joint_max, vm_scale_max, tail_pipe_max, ml_fq_min; } defaults{};
+    struct Sizes { size_t vm_lines_max, vm_fold_max, vm_tree_max, gls_split_max, msm_vm_merge_max, fold_tab_min, fq_min, lp_fq_min, vm_joint_max, vm_scale_max, tail_pipe_max, ml_fq_min, fq_min_g1; } defaults{};
     MsmTune msm_tune;
     void refresh_switches() {
         { const char* s; msm_tune = MsmTune(); if ((s = std::getenv("RIPP_MSM_C"))) msm_tune.c = std::atoi(s); if ((s = std::getenv("RIPP_MSM_CH"))) msm_tune.ch = (uint32_t)std::strtoul(s, nullptr, 10); if ((s = std::getenv("RIPP_MSM_GMIN"))) msm_tune.gmin = (uint32_t)std::strtoul(s, nullptr, 10); }
@@ -248,7 +249,7 @@ struct Engine {
         env_sz("RIPP_VM_LINES_MAX", defaults.vm_lines_max, vm_lines_max); env_sz("RIPP_VM_FOLD_MAX", defaults.vm_fold_max, vm_fold_max); env_sz("RIPP_VM_TREE_MAX", defaults.vm_tree_max, vm_tree_max);
         env_sz("RIPP_GLS_SPLIT_MAX", defaults.gls_split_max, gls_split_max); env_sz("RIPP_MSM_VM_MERGE_MAX", defaults.msm_vm_merge_max, msm_vm_merge_max); env_sz("RIPP_FOLD_TAB_MIN", defaults.fold_tab_min, fold_tab_min);
         env_sz("RIPP_FQ_MIN", defaults.fq_min, fq_min); env_sz("RIPP_LP_FQ_MIN", defaults.lp_fq_min, lp_fq_min); env_sz("RIPP_VM_JOINT_MAX", defaults.vm_joint_max, vm_joint_max);
-        env_sz("RIPP_VM_SCALE_MAX", defaults.vm_scale_max, vm_scale_max); env_sz("RIPP_TAIL_PIPE_MAX", defaults.tail_pipe_max, tail_pipe_max); env_sz("RIPP_ML_FQ_MIN", defaults.ml_fq_min, ml_fq_min);
+        env_sz("RIPP_VM_SCALE_MAX", defaults.vm_scale_max, vm_scale_max); env_sz("RIPP_TAIL_PIPE_MAX", defaults.tail_pipe_max, tail_pipe_max); env_sz("RIPP_ML_FQ_MIN", defaults.ml_fq_min, ml_fq_min); env_sz("RIPP_FQ_MIN_G1", defaults.fq_min_g1, fq_min_g1);
         sw.no_vm = std::getenv("RIPP_NO_VM") != nullptr; sw.no_precompute = std::getenv("RIPP_NO_PRECOMPUTE") != nullptr;
         sw.no_fold_tables = std::getenv("RIPP_NO_FOLD_TABLES") != nullptr; sw.no_msm_glv = std::getenv("RIPP_NO_MSM_GLV") != nullptr;
         sw.lp_one_lane = std::getenv("RIPP_LP_ONE_LANE") != nullptr;
@@ -275,7 +276,7 @@ struct Engine {
         HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_join3, hipEventDisableTiming));
         HIPCHK(hipEventCreate(&ev_t0)); HIPCHK(hipEventCreate(&ev_t1));
         { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n_simd = pr.multiProcessorCount * 4; }
-        defaults = Sizes{vm_lines_max, vm_fold_max, vm_tree_max, gls_split_max, msm_vm_merge_max, fold_tab_min, fq_min, lp_fq_min, vm_joint_max, vm_scale_max, tail_pipe_max, ml_fq_min};
+        defaults = Sizes{vm_lines_max, vm_fold_max, vm_tree_max, gls_split_max, msm_vm_merge_max, fold_tab_min, fq_min, lp_fq_min, vm_joint_max, vm_scale_max, tail_pipe_max, ml_fq_min, fq_min_g1};
         refresh_switches();
         device = dev;
         return RIPP_OK;
@@ -370,9 +371,11 @@ struct Engine {
     // ---- Pippenger MSM over device-resident affine bases and Montgomery scalars; result (Jacobian) to host --------
     // msm_launch enqueues the whole pipeline on `st` with scratch `ms` and leaves the result in ms.host_out (valid after a
     // sync of `st`); msm_dev is the synchronous single-MSM form.
-    template <class F> int32_t msm_launch(MsmScratch& ms, hipStream_t st, const Affine<F>* bases, const Fr* scalars, size_t n) {
+    // bases_arrive (optional): called once the digit sort -- which reads only the scalars -- is enqueued; it brings the bases to the device on another
+    // stream and makes `st` wait for them, so that a host-slice MSM uploads its bases beside the sort instead of in front of it.
+    template <class F> int32_t msm_launch(MsmScratch& ms, hipStream_t st, const Affine<F>* bases, const Fr* scalars, size_t n, const std::function<int32_t()>* bases_arrive = nullptr) {
         if (!ms.host_out) HIPCHK(hipHostMalloc(&ms.host_out, sizeof(G2J), hipHostMallocDefault));
-        if (n == 0) { *reinterpret_cast<Jac<F>*>(ms.host_out) = jac_inf<F>(); return RIPP_OK; }
+        if (n == 0) { *reinterpret_cast<Jac<F>*>(ms.host_out) = jac_inf<F>(); return bases_arrive ? (*bases_arrive)() : RIPP_OK; }
         const bool no_glv = sw.no_msm_glv;
         const size_t nreal = n;
         const MsmPlan p = msm_plan(nreal, no_glv ? 1 : std::is_same<F, Fp>::value ? 2 : 4, msm_tune);
@@ -391,6 +394,7 @@ struct Engine {
         hipLaunchKernelGGL(k_msm_digits, dim3(nblk(nreal, 256)), dim3(256), 0, st, scalars, p, ms.digits.as<uint16_t>(), ms.hist.as<uint32_t>());
         hipLaunchKernelGGL(k_msm_scan, dim3(p.nwin), dim3(1024), 0, st, ms.hist.as<uint32_t>(), p, ms.offs.as<uint32_t>(), ms.cursor.as<uint32_t>(), ms.slotoffs.as<uint32_t>(), ms.spw.as<uint32_t>());
         hipLaunchKernelGGL(k_msm_scatter, dim3(nblk(n, 256)), dim3(256), 0, st, ms.digits.as<uint16_t>(), p, ms.cursor.as<uint32_t>(), ms.sorted.as<uint32_t>());
+        if (bases_arrive && (rc = (*bases_arrive)())) return rc;
         // RIPP_NO_VM keeps every stage on single lanes in Jacobian coordinates (the A/B and fallback form); otherwise the stages after
         // the gather work on homogeneous coordinates and the ones with few points run on the field VM (msm.hpp)
         const bool hom = !sw.no_vm;
@@ -438,8 +442,8 @@ struct Engine {
         HIPCHK(hipMemcpyAsync(ms.host_out, ms.out.p, sizeof(Jac<F>), hipMemcpyDeviceToHost, st));
         return RIPP_OK;
     }
-    template <class F> int32_t msm_dev(const Affine<F>* bases, const Fr* scalars, size_t n, Jac<F>* out_host) {
-        int32_t rc = msm_launch<F>(msm_scratch[0], stream, bases, scalars, n); if (rc) return rc;
+    template <class F> int32_t msm_dev(const Affine<F>* bases, const Fr* scalars, size_t n, Jac<F>* out_host, const std::function<int32_t()>* bases_arrive = nullptr) {
+        int32_t rc = msm_launch<F>(msm_scratch[0], stream, bases, scalars, n, bases_arrive); if (rc) return rc;
         if ((rc = sync())) return rc;
         *out_host = *reinterpret_cast<const Jac<F>*>(msm_scratch[0].host_out);
         return RIPP_OK;
@@ -985,7 +989,7 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true,
     }
     else if (use_vm || mid_vm)
         hipLaunchKernelGGL(k_vm_fold_g1, dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VM_G1_SLOTS * sizeof(VmSlot), e->stream2, a + half, a, (uint32_t)half, naf_digits(x), j->jac1.as<G1J>(), e->vm_flag.as<uint32_t>());
-    else if (!e->sw.no_fq && half >= e->fq_min)
+    else if (!e->sw.no_fq && half >= e->fq_min_g1)
         hipLaunchKernelGGL(k_fold_g1_naf_q, dim3(nblk(half, 256)), dim3(256), 0, e->stream2, a + half, a, (uint32_t)half, naf_digits(x), j->jac1.as<G1J>());
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_affine_naf<Fp>), dim3(nblk(half, 256)), dim3(256), 0, e->stream2, a + half, a, (uint32_t)half, naf_digits(x), j->jac1.as<G1J>());
@@ -1043,7 +1047,8 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true,
     } else
     if (half <= e->gls_split_max) {     // latency-bound round: 4 lanes per element
         if ((rc = e->qtab.reserve(std::max<size_t>(4 * G2A_CHUNKS * qstride * sizeof(uint4), 4 * half * sizeof(G2J)))) != RIPP_OK) return rc;
-        hipLaunchKernelGGL(k_fold_g2_gls_split, dim3(nblk(half, 64), 4), dim3(64), 0, e->stream, g2_hi, (uint32_t)half, gls_digits(g2_s), e->qtab.as<G2J>());
+        if (!e->sw.no_fq) hipLaunchKernelGGL(k_fold_g2_gls_split_q, dim3(nblk(half, 64), 4), dim3(64), 0, e->stream, g2_hi, (uint32_t)half, gls_digits(g2_s), e->qtab.as<G2J>());
+        else hipLaunchKernelGGL(k_fold_g2_gls_split, dim3(nblk(half, 64), 4), dim3(64), 0, e->stream, g2_hi, (uint32_t)half, gls_digits(g2_s), e->qtab.as<G2J>());
         hipLaunchKernelGGL(k_fold_g2_combine, dim3(nblk(half, 64)), dim3(64), 0, e->stream, e->qtab.as<G2J>(), g2_lo, (uint32_t)half, j->jac2.as<G2J>());
     } else if (fold_g2_table_pays(e, half)) {
         if ((rc = fold_g2_table(e, e->stream, g2_hi, g2_lo, half, g2_s, j->jac2)) != RIPP_OK) return rc;
@@ -1274,17 +1279,23 @@ template <class F, bool JAC> static int32_t msm_impl(const void* bases, size_t n
     LOCK; ENGINE; if (!out || (nl && (!bases || !scalars))) return RIPP_ERR_ARG;
     Jac<F> res = jac_inf<F>();
     if (nl) {
-        int32_t rc; Fr* ds; Affine<F>* db;
+        int32_t rc; Fr* ds;
         if ((rc = upload<Fr>(e, e->tmpR, scalars, nl, &ds))) return rc;
         DevBuf& jac = std::is_same<F, Fp>::value ? e->jacG1 : e->jacG2;
         DevBuf& aff = std::is_same<F, Fp>::value ? e->affG1 : e->affG2;
-        if (JAC) {
-            Jac<F>* dj; if ((rc = upload<Jac<F>>(e, jac, bases, nl, &dj))) return rc;
-            if ((rc = aff.reserve(nl * sizeof(Affine<F>)))) return rc;
-            if ((rc = e->normalize_dev<F>(dj, nl, aff.as<Affine<F>>()))) return rc;      // inner_products/src/lib.rs:140
-            db = aff.as<Affine<F>>();
-        } else { if ((rc = upload<Affine<F>>(e, aff, bases, nl, &db))) return rc; }
-        if ((rc = e->msm_dev<F>(db, ds, nl, &res))) return rc;
+        if ((rc = aff.reserve(nl * sizeof(Affine<F>))) || (JAC && (rc = jac.reserve(nl * sizeof(Jac<F>))))) return rc;
+        Affine<F>* db = aff.as<Affine<F>>();
+        // the bases travel on stream2 while the engine stream sorts the digits of the scalars (msm_launch); projective inputs are normalised there too
+        const std::function<int32_t()> bases_arrive = [&]() -> int32_t {
+            if (JAC) {
+                HIPCHK(hipMemcpyAsync(jac.p, bases, nl * sizeof(Jac<F>), hipMemcpyHostToDevice, e->stream2));
+                int32_t r2 = e->normalize_dev<F>(jac.as<Jac<F>>(), nl, db, e->stream2); if (r2) return r2;      // inner_products/src/lib.rs:140
+            } else HIPCHK(hipMemcpyAsync(db, bases, nl * sizeof(Affine<F>), hipMemcpyHostToDevice, e->stream2));
+            HIPCHK(hipEventRecord(e->ev_join, e->stream2));
+            HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
+            return RIPP_OK;
+        };
+        if ((rc = e->msm_dev<F>(db, ds, nl, &res, &bases_arrive))) return rc;
     }
     std::memcpy(out, &res, sizeof(Jac<F>));
     return RIPP_OK;

@@ -253,4 +253,64 @@ __global__ void __launch_bounds__(64, 2) k_odd_multiples_q(const G2A* __restrict
 #endif
 }
 
+// The 4-lane GLS fold of the latency-bound rounds (kernels.hpp k_fold_g2_gls_split: lane (i, j) multiplies psi^j(hi[i]) by digit string j; the
+// combine kernel sums the four parts) on the carry-free form: the chain of 33 doublings + ~11 additions is ~1 150 Fp products per lane at one wave
+// per SIMD, i.e. pure latency -- ~420 instead of ~600 instructions per product and no scratch traffic (the 12-word form spills 262 dwords).
+// The first non-zero digit LOADS the point; an exceptional addition (acc = +-Q) or an identity input redoes the lane with the complete formulas.
+__device__ __noinline__ inline G2J fold_g2_gls_split_complete(const G2A& q, const GlsDigits& dg, int j) {
+    G2J acc = jac_inf<Fp2>();
+#pragma unroll 1
+    for (int pos = dg.len - 1; pos >= 0; --pos) {
+        acc = dbl(acc);
+        const int d = dg.d[j][pos];
+        if (d != 0) { G2A t = q; if (d < 0) t.y = neg(t.y); acc = add_mixed(acc, t); }
+    }
+    return acc;
+}
+__global__ void __launch_bounds__(64, 2) k_fold_g2_gls_split_q(const G2A* __restrict__ hi, uint32_t half, GlsDigits dg, G2J* __restrict__ parts /* [4][half] */) {
+    __shared__ uint4 park_[21 * 64];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= half) return;
+    const int j = blockIdx.y;
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint4* park = park_ + threadIdx.x;
+    uint4* qpark = park + 7 * 64;                                       // psi^j(Q) in the carry-free form: x at chunks 7..13, y at 14..20
+    auto st7 = [](uint4* dst, const Fq2n& v) { uint32_t w[28];
+#pragma unroll
+        for (int k = 0; k < 14; ++k) { w[k] = v.c0.l[k]; w[14 + k] = v.c1.l[k]; }
+        const uint4* src = reinterpret_cast<const uint4*>(w);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) dst[k * 64] = src[k]; };
+    auto ld7 = [](const uint4* src) { uint4 q[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) q[k] = src[k * 64];
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(q);
+        Fq2n v;
+#pragma unroll
+        for (int k = 0; k < 14; ++k) { v.c0.l[k] = w[k]; v.c1.l[k] = w[14 + k]; }
+        return v; };
+    bool bad;
+    {
+        const G2A q = gls_image(hi[i], j);
+        bad = is_inf(q);
+        st7(qpark, f2_from(q.x)); st7(qpark + 7 * 64, f2_from(q.y));
+    }
+    JacQ2 acc; acc.x = acc.y = f2_to_coord(Fq2n{fq_one(), fq_zero()}); acc.z = f2_to_coord(Fq2n{fq_zero(), fq_zero()});
+    bool inf = true;                                                    // wave-uniform: one digit string per wave
+#pragma unroll 1
+    for (int pos = dg.len - 1; pos >= 0; --pos) {
+        if (!inf) jdbl2_q(acc);
+        const int d = dg.d[j][pos];
+        if (d == 0) continue;
+        auto loadx = [&]() { return ld7(qpark); };
+        auto loady = [&]() { const Fq2n y = ld7(qpark + 7 * 64); if (d > 0) return y; return Fq2n{fq_reduce(fq_neg(y.c0)), fq_reduce(fq_neg(y.c1))}; };
+        if (inf) { acc.x = f2_to_coord(loadx()); acc.y = f2_to_coord(loady()); acc.z = f2_to_coord(Fq2n{fq_one(), fq_zero()}); f2_pin(acc.z); inf = false; }
+        else bad |= jmadd2_q(acc, loadx, loady, park);
+    }
+    if (bad) parts[(size_t)j * half + i] = fold_g2_gls_split_complete(gls_image(hi[i], j), dg, j);
+    else if (inf) parts[(size_t)j * half + i] = jac_inf<Fp2>();
+    else parts[(size_t)j * half + i] = G2J{f2_to(acc.x), f2_to(acc.y), f2_to(acc.z)};
+#endif
+}
+
 }  // namespace ripp
