@@ -175,8 +175,9 @@ struct PinBuf {
 struct MsmScratch {
     DevBuf digits, hist, offs, cursor, slotoffs, spw, sorted, slots, buckets, seg, seg2, win, out;
     DevBuf ext;                          // bases and their endomorphism images in the carry-free form (fq_msm.hpp)
+    DevBuf flags;                        // one byte per slot: exceptional additions, redone by k_msm_slot_sum_fix
     void* host_out = nullptr;            // pinned landing zone for the result
-    void release() { for (DevBuf* b : {&digits, &hist, &offs, &cursor, &slotoffs, &spw, &sorted, &slots, &buckets, &seg, &seg2, &win, &out, &ext}) b->release(); if (host_out) (void)hipHostFree(host_out); host_out = nullptr; }
+    void release() { for (DevBuf* b : {&digits, &hist, &offs, &cursor, &slotoffs, &spw, &sorted, &slots, &buckets, &seg, &seg2, &win, &out, &ext, &flags}) b->release(); if (host_out) (void)hipHostFree(host_out); host_out = nullptr; }
 };
 
 struct Timer {   // HIP-event stopwatch on the engine stream
@@ -205,6 +206,7 @@ struct Engine {
     // n = 2^20 and a hipMalloc of that size costs ~100 ms, which a one-shot ripp_sipp_prove would pay on every call.  tab_owner names the
     // job whose round-0 tables they hold; a job that finds another owner falls back to the table-free fold.
     DevBuf fold_tab1, fold_mult, fold_tab, fold_jac1, fold_jac2;
+    DevBuf fix_flags, scale_flags;        // one byte per lane of a carry-free G2 fold / table / scaling kernel: lanes with an exceptional addition, redone by the *_fix kernel behind it
     const void* tab_owner = nullptr;
     size_t vm_scale_max = (size_t)1 << 14;                                // per-element G1 scalings of <= this many elements run on the VM (measured: direct product 6.1 -> 3.8 ms at 2^13, 7.1 -> 6.2 ms at 2^14, level at 2^15)
     size_t vm_joint_max = (size_t)1 << 13;                                // folds with <= this many outputs (and more than vm_fold_max) use the joint one-group-per-element VM forms
@@ -283,7 +285,7 @@ struct Engine {
     }
     void destroy() {
         if (aux) { aux->destroy(); delete aux; aux = nullptr; }
-        for (DevBuf* b : {&lines, &partA, &partB, &jacG1, &jacG2, &tmpA, &tmpB, &tmpR, &affG1, &affG2, &qtab, &vm_flag, &scale_tab, &fold_tab1, &fold_mult, &fold_tab, &fold_jac1, &fold_jac2}) b->release();
+        for (DevBuf* b : {&lines, &partA, &partB, &jacG1, &jacG2, &tmpA, &tmpB, &tmpR, &affG1, &affG2, &qtab, &vm_flag, &scale_tab, &fold_tab1, &fold_mult, &fold_tab, &fold_jac1, &fold_jac2, &fix_flags, &scale_flags}) b->release();
         msm_scratch[0].release(); msm_scratch[1].release(); kzg_q[0].release(); kzg_q[1].release(); kzg_bases[0].release(); kzg_bases[1].release();
         if (stream3) (void)hipStreamDestroy(stream3);
         if (stream4) (void)hipStreamDestroy(stream4); if (ev_join4) (void)hipEventDestroy(ev_join4);
@@ -348,7 +350,11 @@ struct Engine {
         }
         int32_t rc = scale_tab.reserve((size_t)SCALE_TAB * G1J_CHUNKS * n * sizeof(uint4)); if (rc) return rc;
         if (!sw.no_fq && !std::getenv("RIPP_SCALE_NO_FQ"))      // the carry-free twin (fq_scale.hpp)
-            hipLaunchKernelGGL(k_scale_g1_glv_q, dim3(nblk(n, 256)), dim3(256), 0, st, base, base_stride, k, (uint32_t)n, scale_tab.as<uint4>(), out);
+        {
+            if ((rc = scale_flags.reserve(n))) return rc;
+            hipLaunchKernelGGL(k_scale_g1_glv_q, dim3(nblk(n, 256)), dim3(256), 0, st, base, base_stride, k, (uint32_t)n, scale_tab.as<uint4>(), out, scale_flags.as<uint8_t>());
+            hipLaunchKernelGGL(k_scale_g1_fix, dim3(nblk(n, 256)), dim3(256), 0, st, base, base_stride, k, (uint32_t)n, out, scale_flags.as<uint8_t>());
+        }
         else
         hipLaunchKernelGGL(k_scale_g1_glv, dim3(nblk(n, 256)), dim3(256), 0, st, base, base_stride, k, (uint32_t)n, scale_tab.as<uint4>(), out);
         HIPCHK(hipGetLastError());
@@ -402,10 +408,12 @@ struct Engine {
 #if !defined(RIPP_BLS12_377)
         if (!sw.no_fq) {        // gathered additions on the carry-free form over the extended base array (fq_msm.hpp)
             const int split = (int)(n / nreal);
-            if ((rc = ms.ext.reserve(n * sizeof(Affine<F>)))) return rc;
+            if ((rc = ms.ext.reserve(n * sizeof(Affine<F>))) || (rc = ms.flags.reserve((size_t)p.nwin * max_slots))) return rc;
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_extend_q<F>), dim3(nblk(nreal, 256), split), dim3(256), 0, st, bases, (uint32_t)nreal, split, ms.ext.as<QAff<F>>());
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_slot_sum_q<F>), dim3(nblk(max_slots, 64), p.nwin), dim3(64), 0, st, bases, ms.ext.as<QAff<F>>(), p, ms.hist.as<uint32_t>(), ms.offs.as<uint32_t>(),
-                               ms.slotoffs.as<uint32_t>(), ms.spw.as<uint32_t>(), ms.sorted.as<uint32_t>(), ms.slots.as<Jac<F>>(), max_slots, hom);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_slot_sum_q<F>), dim3(nblk(max_slots, 64), p.nwin), dim3(64), 0, st, ms.ext.as<QAff<F>>(), p, ms.hist.as<uint32_t>(), ms.offs.as<uint32_t>(),
+                               ms.slotoffs.as<uint32_t>(), ms.spw.as<uint32_t>(), ms.sorted.as<uint32_t>(), ms.slots.as<Jac<F>>(), max_slots, hom, ms.flags.as<uint8_t>());
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_slot_sum_fix<F>), dim3(nblk(max_slots, 64), p.nwin), dim3(64), 0, st, bases, p, ms.hist.as<uint32_t>(), ms.offs.as<uint32_t>(),
+                               ms.slotoffs.as<uint32_t>(), ms.spw.as<uint32_t>(), ms.sorted.as<uint32_t>(), ms.slots.as<Jac<F>>(), max_slots, hom, ms.flags.as<uint8_t>());
         } else
 #endif
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_slot_sum<F>), dim3(nblk(max_slots, 64), p.nwin), dim3(64), 0, st, bases, p, ms.hist.as<uint32_t>(), ms.offs.as<uint32_t>(),
@@ -902,7 +910,7 @@ int32_t job_precompute_round0(Engine* e, ripp_sipp_job* j) {
     constexpr size_t M = FOLD_TAB_M;
     const size_t njt = (M - 1) * half;
     if ((rc = e->fold_tab1.reserve(4 * M * half * sizeof(G1A))) || (rc = e->fold_mult.reserve(4 * M * half * sizeof(G2A))) || (rc = e->fold_tab.reserve(16 * M * G2A_CHUNKS * qstride * sizeof(uint4))) ||
-        (rc = e->fold_jac1.reserve(njt * sizeof(G1J))) || (rc = e->fold_jac2.reserve(njt * sizeof(G2J)))) return rc;      // all sized BEFORE the first launch: reserve() may reallocate
+        (rc = e->fold_jac1.reserve(njt * sizeof(G1J))) || (rc = e->fold_jac2.reserve(njt * sizeof(G2J))) || (rc = e->fix_flags.reserve(4 * half))) return rc;      // all sized BEFORE the first launch: reserve() may reallocate
     e->tab_owner = j;
     G1A* t1 = e->fold_tab1.as<G1A>(); G2A* t2 = e->fold_mult.as<G2A>();
     G1J* sj1 = e->fold_jac1.as<G1J>(); G2J* sj2 = e->fold_jac2.as<G2J>();
@@ -922,7 +930,10 @@ int32_t job_precompute_round0(Engine* e, ripp_sipp_job* j) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_odd_multiples<Fp>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, base1, (uint32_t)half, (int)M, sj1);
         HIPCHK(hipGetLastError());
         if ((rc = e->normalize_dev<Fp>(sj1, njt, base1 + half))) return rc;
-        if (!e->sw.no_fq) hipLaunchKernelGGL(k_odd_multiples_q, dim3(nblk(half, 64)), dim3(64), 0, e->stream, base2, (uint32_t)half, (int)M, sj2);
+        if (!e->sw.no_fq) {
+            hipLaunchKernelGGL(k_odd_multiples_q, dim3(nblk(half, 64)), dim3(64), 0, e->stream, base2, (uint32_t)half, (int)M, sj2, e->fix_flags.as<uint8_t>());
+            hipLaunchKernelGGL(k_odd_multiples_fix, dim3(nblk(half, 64)), dim3(64), 0, e->stream, base2, (uint32_t)half, (int)M, sj2, e->fix_flags.as<uint8_t>());
+        }
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_odd_multiples<Fp2>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, base2, (uint32_t)half, (int)M, sj2);
         HIPCHK(hipGetLastError());
         if ((rc = e->normalize_dev<Fp2>(sj2, njt, base2 + half))) return rc;
@@ -941,17 +952,23 @@ int32_t fold_g2_table(Engine* e, hipStream_t st, const G2A* hi, const G2A* lo, s
     const size_t qstride = (half + 63) & ~(size_t)63;
     int32_t rc;
     if ((rc = e->fold_mult.reserve((size_t)M * half * sizeof(G2A))) || (rc = e->fold_tab.reserve((size_t)4 * M * G2A_CHUNKS * qstride * sizeof(uint4))) ||
-        (rc = e->fold_jac2.reserve((size_t)(M - 1) * half * sizeof(G2J))) || (rc = jac.reserve(half * sizeof(G2J)))) return rc;
+        (rc = e->fold_jac2.reserve((size_t)(M - 1) * half * sizeof(G2J))) || (rc = jac.reserve(half * sizeof(G2J))) || (rc = e->fix_flags.reserve(4 * half))) return rc;
     e->tab_owner = nullptr;                                     // whatever round-0 tables were there are overwritten
     G2A* mult = e->fold_mult.as<G2A>();
     HIPCHK(hipMemcpyAsync(mult, hi, half * sizeof(G2A), hipMemcpyDeviceToDevice, st));
-    if (!e->sw.no_fq) hipLaunchKernelGGL(k_odd_multiples_q, dim3(nblk(half, 64)), dim3(64), 0, st, hi, (uint32_t)half, M, e->fold_jac2.as<G2J>());
+    if (!e->sw.no_fq) {
+        hipLaunchKernelGGL(k_odd_multiples_q, dim3(nblk(half, 64)), dim3(64), 0, st, hi, (uint32_t)half, M, e->fold_jac2.as<G2J>(), e->fix_flags.as<uint8_t>());
+        hipLaunchKernelGGL(k_odd_multiples_fix, dim3(nblk(half, 64)), dim3(64), 0, st, hi, (uint32_t)half, M, e->fold_jac2.as<G2J>(), e->fix_flags.as<uint8_t>());
+    }
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_odd_multiples<Fp2>), dim3(nblk(half, 64)), dim3(64), 0, st, hi, (uint32_t)half, M, e->fold_jac2.as<G2J>());
     HIPCHK(hipGetLastError());
     if ((rc = e->normalize_dev<Fp2>(e->fold_jac2.as<G2J>(), (size_t)(M - 1) * half, mult + half, st)) != RIPP_OK) return rc;
     hipLaunchKernelGGL(k_g2_tab_images, dim3(nblk(half, 64), M), dim3(64), 0, st, mult, (uint32_t)half, M, e->fold_tab.as<uint4>(), qstride);
     if (!e->sw.no_fq && half >= e->fq_min)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab_q<GlsDigits, 4>), dim3(nblk(half, 64)), dim3(64), 0, st, e->fold_tab.as<uint4>(), qstride, M, lo, (uint32_t)half, gls_wnaf(s, 4), jac.as<G2J>());
+    {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab_q<GlsDigits, 4>), dim3(nblk(half, 64)), dim3(64), 0, st, e->fold_tab.as<uint4>(), qstride, M, lo, (uint32_t)half, gls_wnaf(s, 4), jac.as<G2J>(), e->fix_flags.as<uint8_t>());
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab_fix<GlsDigits, 4>), dim3(nblk(half, 64)), dim3(64), 0, st, e->fold_tab.as<uint4>(), qstride, M, lo, (uint32_t)half, gls_wnaf(s, 4), jac.as<G2J>(), e->fix_flags.as<uint8_t>());
+    }
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab<GlsDigits, 4>), dim3(nblk(half, 64)), dim3(64), 0, st, e->fold_tab.as<uint4>(), qstride, M, lo, (uint32_t)half, gls_wnaf(s, 4), jac.as<G2J>());
     HIPCHK(hipGetLastError());
@@ -1025,7 +1042,9 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true,
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_combine<Fp2>), dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VmCurve<Fp2>::SLOTS * sizeof(VmSlot), e->stream, j->parts2.as<G2J>(), 8, b, (uint32_t)half, j->jac2.as<G2J>());
     } else
     if (tab && !e->sw.no_fq && half >= e->fq_min) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab_q<Wnaf16, 16>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, e->fold_tab.as<uint4>(), j->tab2_stride, (int)FOLD_TAB_M, g2_lo, (uint32_t)half, gls16_wnaf(g2_s), j->jac2.as<G2J>());
+        if ((rc = e->fix_flags.reserve(4 * half))) return rc;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab_q<Wnaf16, 16>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, e->fold_tab.as<uint4>(), j->tab2_stride, (int)FOLD_TAB_M, g2_lo, (uint32_t)half, gls16_wnaf(g2_s), j->jac2.as<G2J>(), e->fix_flags.as<uint8_t>());
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab_fix<Wnaf16, 16>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, e->fold_tab.as<uint4>(), j->tab2_stride, (int)FOLD_TAB_M, g2_lo, (uint32_t)half, gls16_wnaf(g2_s), j->jac2.as<G2J>(), e->fix_flags.as<uint8_t>());
     } else
     if (tab) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab<Wnaf16, 16>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, e->fold_tab.as<uint4>(), j->tab2_stride, (int)FOLD_TAB_M, g2_lo, (uint32_t)half, gls16_wnaf(g2_s), j->jac2.as<G2J>());
@@ -1047,7 +1066,11 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true,
     } else
     if (half <= e->gls_split_max) {     // latency-bound round: 4 lanes per element
         if ((rc = e->qtab.reserve(std::max<size_t>(4 * G2A_CHUNKS * qstride * sizeof(uint4), 4 * half * sizeof(G2J)))) != RIPP_OK) return rc;
-        if (!e->sw.no_fq) hipLaunchKernelGGL(k_fold_g2_gls_split_q, dim3(nblk(half, 64), 4), dim3(64), 0, e->stream, g2_hi, (uint32_t)half, gls_digits(g2_s), e->qtab.as<G2J>());
+        if (!e->sw.no_fq) {
+            if ((rc = e->fix_flags.reserve(4 * half))) return rc;
+            hipLaunchKernelGGL(k_fold_g2_gls_split_q, dim3(nblk(half, 64), 4), dim3(64), 0, e->stream, g2_hi, (uint32_t)half, gls_digits(g2_s), e->qtab.as<G2J>(), e->fix_flags.as<uint8_t>());
+            hipLaunchKernelGGL(k_fold_g2_gls_split_fix, dim3(nblk(half, 64), 4), dim3(64), 0, e->stream, g2_hi, (uint32_t)half, gls_digits(g2_s), e->qtab.as<G2J>(), e->fix_flags.as<uint8_t>());
+        }
         else hipLaunchKernelGGL(k_fold_g2_gls_split, dim3(nblk(half, 64), 4), dim3(64), 0, e->stream, g2_hi, (uint32_t)half, gls_digits(g2_s), e->qtab.as<G2J>());
         hipLaunchKernelGGL(k_fold_g2_combine, dim3(nblk(half, 64)), dim3(64), 0, e->stream, e->qtab.as<G2J>(), g2_lo, (uint32_t)half, j->jac2.as<G2J>());
     } else if (fold_g2_table_pays(e, half)) {
@@ -1116,7 +1139,7 @@ API int32_t ripp_release_scratch(void) {
     LOCK; if (!g_engine) return RIPP_OK;
     Engine* e = g_engine;
     if (hipSetDevice(e->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { set_err("ripp_release_scratch: device synchronisation failed"); return RIPP_ERR_DEVICE; }
-    for (DevBuf* b : {&e->lines, &e->partA, &e->partB, &e->jacG1, &e->jacG2, &e->tmpA, &e->tmpB, &e->tmpR, &e->affG1, &e->affG2, &e->qtab, &e->scale_tab, &e->fold_tab1, &e->fold_mult, &e->fold_tab, &e->fold_jac1, &e->fold_jac2}) b->release();
+    for (DevBuf* b : {&e->lines, &e->partA, &e->partB, &e->jacG1, &e->jacG2, &e->tmpA, &e->tmpB, &e->tmpR, &e->affG1, &e->affG2, &e->qtab, &e->scale_tab, &e->fold_tab1, &e->fold_mult, &e->fold_tab, &e->fold_jac1, &e->fold_jac2, &e->fix_flags, &e->scale_flags}) b->release();
     e->msm_scratch[0].release(); e->msm_scratch[1].release(); e->kzg_q[0].release(); e->kzg_q[1].release(); e->kzg_bases[0].release(); e->kzg_bases[1].release();
     for (PinBuf& pb : e->stage) pb.release();             // pinned host staging (up to 2 x 32 MB after a verifier call at n = 2^20)
     e->tab_owner = nullptr;

@@ -146,10 +146,11 @@ __device__ __forceinline__ bool jmadd2_q(JacQ2& p, LOADX loadx, LOADY loady, uin
 }
 #endif
 
-// NS digit strings; string t works on table rows t M .. t M + M - 1 (kernels.hpp k_fold_g2_tab).  Exceptional lanes are recomputed with the
-// complete formulas (fold_g2_tab_complete).
+// NS digit strings; string t works on table rows t M .. t M + M - 1 (kernels.hpp k_fold_g2_tab).  Exceptional lanes are FLAGGED (flag[i] = 1) and redone
+// with the complete formulas by k_fold_g2_tab_fix, launched behind this kernel: the out-of-line fallback and its stack frame stay out of the
+// throughput kernel (as a callee its frame was the kernel's whole private segment: 870 B per lane with no register spilled).
 template <class D, int NS>
-__global__ void __launch_bounds__(64, 2) k_fold_g2_tab_q(const uint4* __restrict__ qtab, size_t stride, int M, const G2A* __restrict__ lo, uint32_t half, D dg, G2J* __restrict__ out) {
+__global__ void __launch_bounds__(64, 2) k_fold_g2_tab_q(const uint4* __restrict__ qtab, size_t stride, int M, const G2A* __restrict__ lo, uint32_t half, D dg, G2J* __restrict__ out, uint8_t* __restrict__ flag) {
     __shared__ uint4 park_[7 * 64];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= half) return;
@@ -164,10 +165,11 @@ __global__ void __launch_bounds__(64, 2) k_fold_g2_tab_q(const uint4* __restrict
         for (int t = 0; t < NS; ++t) {
             const int d = dg.d[t][pos];
             if (d == 0) continue;
-            const uint4* base = qtab + ((size_t)t * M + ((d < 0 ? -d : d) >> 1)) * G2A_CHUNKS * stride + i;
-            auto ldfp2 = [&](int q0) { Fp2 v; uint4* dd = reinterpret_cast<uint4*>(&v);
+            uint32_t il = i; asm volatile("" : "+v"(il));                     // (the loop-invariant qtab + i is re-formed per addition instead of living in a spilled register pair)
+            const uint4* base = qtab + ((size_t)t * M + ((d < 0 ? -d : d) >> 1)) * G2A_CHUNKS * stride + il;
+            auto ldfp2 = [&](int q0) { Fp2 v; uint4* dd = reinterpret_cast<uint4*>(&v); const uint4* b2 = opaque(base);      // re-loaded where it is used (merged with the identity check below, x and y stayed alive from the top of the addition)
 #pragma unroll
-                for (int q = 0; q < 6; ++q) dd[q] = base[(size_t)(q0 + q) * stride]; return v; };
+                for (int q = 0; q < 6; ++q) dd[q] = b2[(size_t)(q0 + q) * stride]; return v; };
             auto loadx = [&]() { return f2_from(ldfp2(0)); };
             auto loady = [&]() { const Fp2 y = ldfp2(6); return f2_from(d < 0 ? neg(y) : y); };
             if (inf) {                                                    // first addition: acc <- +-Q
@@ -180,12 +182,19 @@ __global__ void __launch_bounds__(64, 2) k_fold_g2_tab_q(const uint4* __restrict
             }
         }
     }
-    const G2A l = lo[i];
-    if (inf) { out[i] = to_jac(l); return; }
-    if (!is_inf(l)) bad |= jmadd2_q(acc, [&]() { return f2_from(l.x); }, [&]() { return f2_from(l.y); }, park);
-    if (bad) fold_g2_tab_complete<D, NS>(qtab, stride, M, lo, i, dg, out);
-    else out[i] = G2J{f2_to(acc.x), f2_to(acc.y), f2_to(acc.z)};
+    const G2A* lp = lo + i;                                             // (re-read where it is used: held in registers, the 48 words of lo[i] were the kernel's only spills)
+    if (inf) { out[i] = to_jac(*lp); flag[i] = 0; return; }
+    bool linf; { const G2A l = *lp; linf = is_inf(l); }
+    if (!linf) bad |= jmadd2_q(acc, [&]() { return f2_from(opaque(lp)->x); }, [&]() { return f2_from(opaque(lp)->y); }, park);
+    flag[i] = bad;
+    if (!bad) out[i] = G2J{f2_to(acc.x), f2_to(acc.y), f2_to(acc.z)};
 #endif
+}
+template <class D, int NS>
+__global__ void __launch_bounds__(64) k_fold_g2_tab_fix(const uint4* __restrict__ qtab, size_t stride, int M, const G2A* __restrict__ lo, uint32_t half, D dg, G2J* __restrict__ out, const uint8_t* __restrict__ flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= half || !flag[i]) return;
+    fold_g2_tab_complete<D, NS>(qtab, stride, M, lo, i, dg, out);
 }
 
 // Odd multiples 3 Q, 5 Q, .., (2 M - 1) Q of the fold tables (kernels.hpp k_odd_multiples: out[m][i] = (2m + 3) base[i], Jacobian, batch-normalised
@@ -193,7 +202,8 @@ __global__ void __launch_bounds__(64, 2) k_fold_g2_tab_q(const uint4* __restrict
 // 12-word products: 1 448 B of scratch per lane, 63 % of its own issue roof).  Here the chain runs on the isomorphic curve on which 2Q = (X2, Y2, Z2)
 // is AFFINE -- (x, y) -> (x Z2^2, y Z2^3) -- so every step is a mixed addition with the same affine addend (X2, Y2) (11 products), and a result
 // (X', Y', Z') is the point (X', Y', Z' Z2) of the original curve (one more product).  (X2, Y2) rest in the element's LAST output slot until the
-// last addition has read them, Z2 and the idle Y1 in LDS.  Exceptional elements (infinity, small order) are redone with the complete formulas.
+// last addition has read them, Z2 and the idle Y1 in LDS.  Exceptional elements (infinity, small order) are flagged and redone with the complete
+// formulas by k_odd_multiples_fix.
 template <class F>
 __device__ __noinline__ void odd_multiples_complete(const Affine<F>* __restrict__ base, uint32_t n, int M, uint32_t i, Jac<F>* __restrict__ out) {
     const Affine<F> b = base[i];
@@ -203,7 +213,7 @@ __device__ __noinline__ void odd_multiples_complete(const Affine<F>* __restrict_
 #pragma unroll 1
     for (int m = 1; m < M - 1; ++m) { t = add(t, b2); out[(size_t)m * n + i] = t; }
 }
-__global__ void __launch_bounds__(64, 2) k_odd_multiples_q(const G2A* __restrict__ base, uint32_t n, int M, G2J* __restrict__ out) {
+__global__ void __launch_bounds__(64, 2) k_odd_multiples_q(const G2A* __restrict__ base, uint32_t n, int M, G2J* __restrict__ out, uint8_t* __restrict__ flag) {
     __shared__ uint4 park_[14 * 64];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || M < 2) return;
@@ -249,14 +259,19 @@ __global__ void __launch_bounds__(64, 2) k_odd_multiples_q(const G2A* __restrict
         Fq2n zo = f2_muld(t.z, ld7(zpark, 64)); f2_pin(zo);
         out[(size_t)m * n + i] = G2J{f2_to(t.x), f2_to(t.y), f2_to(f2_to_coord(zo))};
     }
-    if (bad) odd_multiples_complete<Fp2>(base, n, M, i, out);
+    flag[i] = bad;
 #endif
+}
+__global__ void __launch_bounds__(64) k_odd_multiples_fix(const G2A* __restrict__ base, uint32_t n, int M, G2J* __restrict__ out, const uint8_t* __restrict__ flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || M < 2 || !flag[i]) return;
+    odd_multiples_complete<Fp2>(base, n, M, i, out);
 }
 
 // The 4-lane GLS fold of the latency-bound rounds (kernels.hpp k_fold_g2_gls_split: lane (i, j) multiplies psi^j(hi[i]) by digit string j; the
 // combine kernel sums the four parts) on the carry-free form: the chain of 33 doublings + ~11 additions is ~1 150 Fp products per lane at one wave
 // per SIMD, i.e. pure latency -- ~420 instead of ~600 instructions per product and no scratch traffic (the 12-word form spills 262 dwords).
-// The first non-zero digit LOADS the point; an exceptional addition (acc = +-Q) or an identity input redoes the lane with the complete formulas.
+// The first non-zero digit LOADS the point; an exceptional addition (acc = +-Q) or an identity input flags the lane for k_fold_g2_gls_split_fix.
 __device__ __noinline__ inline G2J fold_g2_gls_split_complete(const G2A& q, const GlsDigits& dg, int j) {
     G2J acc = jac_inf<Fp2>();
 #pragma unroll 1
@@ -267,7 +282,7 @@ __device__ __noinline__ inline G2J fold_g2_gls_split_complete(const G2A& q, cons
     }
     return acc;
 }
-__global__ void __launch_bounds__(64, 2) k_fold_g2_gls_split_q(const G2A* __restrict__ hi, uint32_t half, GlsDigits dg, G2J* __restrict__ parts /* [4][half] */) {
+__global__ void __launch_bounds__(64, 2) k_fold_g2_gls_split_q(const G2A* __restrict__ hi, uint32_t half, GlsDigits dg, G2J* __restrict__ parts /* [4][half] */, uint8_t* __restrict__ flag /* [4][half] */) {
     __shared__ uint4 park_[21 * 64];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= half) return;
@@ -307,10 +322,17 @@ __global__ void __launch_bounds__(64, 2) k_fold_g2_gls_split_q(const G2A* __rest
         if (inf) { acc.x = f2_to_coord(loadx()); acc.y = f2_to_coord(loady()); acc.z = f2_to_coord(Fq2n{fq_one(), fq_zero()}); f2_pin(acc.z); inf = false; }
         else bad |= jmadd2_q(acc, loadx, loady, park);
     }
-    if (bad) parts[(size_t)j * half + i] = fold_g2_gls_split_complete(gls_image(hi[i], j), dg, j);
-    else if (inf) parts[(size_t)j * half + i] = jac_inf<Fp2>();
+    flag[(size_t)j * half + i] = bad;
+    if (bad) return;
+    if (inf) parts[(size_t)j * half + i] = jac_inf<Fp2>();
     else parts[(size_t)j * half + i] = G2J{f2_to(acc.x), f2_to(acc.y), f2_to(acc.z)};
 #endif
+}
+__global__ void __launch_bounds__(64) k_fold_g2_gls_split_fix(const G2A* __restrict__ hi, uint32_t half, GlsDigits dg, G2J* __restrict__ parts, const uint8_t* __restrict__ flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (i >= half || !flag[(size_t)j * half + i]) return;
+    parts[(size_t)j * half + i] = fold_g2_gls_split_complete(gls_image(hi[i], j), dg, j);
 }
 
 }  // namespace ripp

@@ -6,7 +6,7 @@
 //   * k_msm_slot_sum_q: the slot loop with madd-2007-bl on 14 x 28-bit limbs (G1: fq_curve.hpp's jmadd_q; G2: the same formulas over Fp2
 //     products written as two lazily reduced sums of two products, fq_miller.hpp) -- fewer instructions on an issue-bound kernel, no scratch
 //     for G1.  Exceptional additions (T = +-Q) are DETECTED and that slot is redone with the complete formulas (msm_slot_sum_complete), like
-//     everywhere the low-liveness additions are used.  BLS12-381 only.
+//     everywhere the low-liveness additions are used (here by a second, tiny launch: k_msm_slot_sum_fix).  BLS12-381 only.
 #pragma once
 #include "fq_miller.hpp"
 #include "msm.hpp"
@@ -47,15 +47,8 @@ __global__ void __launch_bounds__(256) k_msm_extend_q(const Affine<F>* __restric
 #endif
 }
 
-// k_msm_slot_sum with the gathered additions on the carry-free form; `ext` from k_msm_extend_q (term t <-> ext[t]); same grid, outputs and slot layout
-template <class F>
-__global__ void __launch_bounds__(64, 2) k_msm_slot_sum_q(const Affine<F>* __restrict__ bases, const QAff<F>* __restrict__ ext, MsmPlan p, const uint32_t* __restrict__ hist,
-                                                        const uint32_t* __restrict__ offs, const uint32_t* __restrict__ slot_offs, const uint32_t* __restrict__ slots_per_window,
-                                                        const uint32_t* __restrict__ sorted, Jac<F>* __restrict__ slot_sums, uint32_t max_slots, bool hom) {
-    __shared__ uint4 park_[7 * 64];
-    const int w = blockIdx.y;
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= slots_per_window[w]) return;
+// the terms [begin, end) of window w's sorted index array that slot s sums (the slot layout of msm.hpp k_msm_slot_sum)
+__device__ __forceinline__ void msm_slot_range(const MsmPlan& p, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offs, const uint32_t* __restrict__ slot_offs, int w, uint32_t s, uint32_t& begin, uint32_t& end) {
     const uint32_t* so = slot_offs + (size_t)w * p.nb;
     uint32_t lo = 0, hi = p.nb - 1;
     while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (so[mid] <= s) lo = mid; else hi = mid - 1; }
@@ -63,8 +56,21 @@ __global__ void __launch_bounds__(64, 2) k_msm_slot_sum_q(const Affine<F>* __res
     while (d > 0 && (hist[(size_t)w * p.nb + d] + p.ch - 1) / p.ch + so[d] <= s) --d;
     const uint32_t part = s - so[d];
     const uint32_t cnt = hist[(size_t)w * p.nb + d];
-    const uint32_t begin = offs[(size_t)w * p.nb + d] + part * p.ch;
-    const uint32_t end = min(offs[(size_t)w * p.nb + d] + cnt, begin + p.ch);
+    begin = offs[(size_t)w * p.nb + d] + part * p.ch;
+    end = min(offs[(size_t)w * p.nb + d] + cnt, begin + p.ch);
+}
+// k_msm_slot_sum with the gathered additions on the carry-free form; `ext` from k_msm_extend_q (term t <-> ext[t]); same grid, outputs and slot layout.
+// A slot with an exceptional addition is flagged and summed again by k_msm_slot_sum_fix (complete formulas), launched behind this kernel.
+template <class F>
+__global__ void __launch_bounds__(64, 2) k_msm_slot_sum_q(const QAff<F>* __restrict__ ext, MsmPlan p, const uint32_t* __restrict__ hist,
+                                                        const uint32_t* __restrict__ offs, const uint32_t* __restrict__ slot_offs, const uint32_t* __restrict__ slots_per_window,
+                                                        const uint32_t* __restrict__ sorted, Jac<F>* __restrict__ slot_sums, uint32_t max_slots, bool hom, uint8_t* __restrict__ flag) {
+    __shared__ uint4 park_[7 * 64];
+    const int w = blockIdx.y;
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= slots_per_window[w]) return;
+    uint32_t begin, end;
+    msm_slot_range(p, hist, offs, slot_offs, w, s, begin, end);
     Jac<F> acc = jac_inf<F>();
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(RIPP_BLS12_377)
     bool inf = true, bad = false;
@@ -93,8 +99,22 @@ __global__ void __launch_bounds__(64, 2) k_msm_slot_sum_q(const Affine<F>* __res
         }
         if (!inf && !bad) acc = G2J{f2_to(a.x), f2_to(a.y), f2_to(a.z)};
     }
-    if (bad) msm_slot_sum_complete<F>(bases, sorted + (size_t)w * p.n, begin, end, p.nreal, &acc);
+    flag[(size_t)w * max_slots + s] = bad;
+    if (bad) return;
 #endif
+    slot_sums[(size_t)w * max_slots + s] = hom ? msm_jac_to_h(acc) : acc;
+}
+template <class F>
+__global__ void __launch_bounds__(64) k_msm_slot_sum_fix(const Affine<F>* __restrict__ bases, MsmPlan p, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offs,
+                                                       const uint32_t* __restrict__ slot_offs, const uint32_t* __restrict__ slots_per_window, const uint32_t* __restrict__ sorted,
+                                                       Jac<F>* __restrict__ slot_sums, uint32_t max_slots, bool hom, const uint8_t* __restrict__ flag) {
+    const int w = blockIdx.y;
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= slots_per_window[w] || !flag[(size_t)w * max_slots + s]) return;
+    uint32_t begin, end;
+    msm_slot_range(p, hist, offs, slot_offs, w, s, begin, end);
+    Jac<F> acc;
+    msm_slot_sum_complete<F>(bases, sorted + (size_t)w * p.n, begin, end, p.nreal, &acc);
     slot_sums[(size_t)w * max_slots + s] = hom ? msm_jac_to_h(acc) : acc;
 }
 

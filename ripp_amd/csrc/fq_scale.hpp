@@ -8,7 +8,7 @@
 // its own digit row, so in the lane-interleaved layout of scale.hpp a 128-byte line served one or two lanes (49.5 GB of HBM traffic per 2^20-element
 // launch, 174 x the algorithmic bytes); here a lookup reads one 144-byte run.
 // Exceptional additions (acc = +-T: H = 0) cannot occur for the digit patterns of a proper GLV split, but they are DETECTED and such a lane
-// is recomputed by plain double-and-add with the complete formulas of curve.hpp.  BLS12-381 only (the 377 build keeps the 12 x 32-bit kernel).
+// is flagged and recomputed (k_scale_g1_fix) by plain double-and-add with the complete formulas of curve.hpp.  BLS12-381 only (the 377 build keeps the 12 x 32-bit kernel).
 #pragma once
 #include "fq_curve.hpp"
 #include "scale.hpp"
@@ -71,12 +71,12 @@ __device__ __noinline__ inline G1J scale_g1_plain(const G1A& p, const Fr& k) {
 
 // same arguments, table size and output as k_scale_g1_glv
 __global__ void __launch_bounds__(256, 2) k_scale_g1_glv_q(const G1A* __restrict__ base, uint32_t base_stride, const Fr* __restrict__ k_mont, uint32_t n,
-                                                           uint4* __restrict__ tab, G1J* __restrict__ out) {
+                                                           uint4* __restrict__ tab, G1J* __restrict__ out, uint8_t* __restrict__ flag) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(RIPP_BLS12_377)
     const G1A p = base[(size_t)i * base_stride];
-    if (is_inf(p)) { out[i] = jac_inf<Fp>(); return; }
+    if (is_inf(p)) { out[i] = jac_inf<Fp>(); flag[i] = 0; return; }
     uint32_t d1[5], d2[5];
     Fr kc = from_mont(k_mont[i]);
     {
@@ -113,9 +113,18 @@ __global__ void __launch_bounds__(256, 2) k_scale_g1_glv_q(const G1A* __restrict
             if (inf) { acc = t; inf = false; } else bad |= jadd_q(acc, t);
         }
     }
-    if (bad) out[i] = scale_g1_plain(p, kc);
-    else if (inf) out[i] = jac_inf<Fp>();
+    flag[i] = bad;
+    if (bad) return;
+    if (inf) out[i] = jac_inf<Fp>();
     else out[i] = jacq_to_g1j(acc);
+#endif
+}
+// the flagged lanes of k_scale_g1_glv_q, by plain double-and-add with the complete formulas
+__global__ void __launch_bounds__(256) k_scale_g1_fix(const G1A* __restrict__ base, uint32_t base_stride, const Fr* __restrict__ k_mont, uint32_t n, G1J* __restrict__ out, const uint8_t* __restrict__ flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RIPP_BLS12_377)
+    out[i] = scale_g1_plain(base[(size_t)i * base_stride], from_mont(k_mont[i]));
 #endif
 }
 
