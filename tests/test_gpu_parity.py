@@ -177,6 +177,24 @@ def test_msm_endomorphism_edge_scalars(engine, orc):
     assert np.array_equal(engine.normalize_batch_g2(engine.MultiexponentiationInnerProductG2.inner_product(j2, s)), orc.g2_to_affine(orc.msm_g2_a(b2, s)).reshape(1, 24))
 
 
+def test_msm_repeated_bases_vs_oracle(engine, orc):
+    """Equal bases with equal scalars land in the same bucket slot, so the gathered mixed additions of k_msm_slot_sum_q meet T = Q (doubling) and
+    T = -Q (the identity) -- the exceptional cases its low-liveness formulas only DETECT: those slots are flagged and summed again by
+    k_msm_slot_sum_fix with the complete formulas.  Identities among the bases and zero scalars ride along."""
+    n = 1 << 12
+    b1, b2 = orc.gen_g1(25, n), orc.gen_g2(26, n)
+    vals = [(i % 5) * 0x1F2E3D4C5B6A79881726354453627180 + 7 for i in range(n)]
+    for k in range(0, n, 16):                                               # runs of identical terms, one negated term per run
+        for t in range(1, 6): b1[k + t] = b1[k]; b2[k + t] = b2[k]; vals[k + t] = vals[k]
+        b1[k + 6, :6] = b1[k, :6]; b1[k + 6, 6:] = orc.fp_to_limbs((orc.P - orc.limbs_to_fp(b1[k, 6:])) % orc.P); vals[k + 6] = vals[k]
+    b1[9] = 0; b2[10] = 0; vals[11] = 0
+    s = orc.fr_array([v % orc.R for v in vals])
+    assert np.array_equal(engine.normalize_batch_g1(engine.MultiexponentiationInnerProductG1.inner_product(orc.blind_g1(b1, 3), s)),
+                          orc.g1_to_affine(orc.msm_g1_a(b1, s)).reshape(1, 12))
+    assert np.array_equal(engine.normalize_batch_g2(engine.MultiexponentiationInnerProductG2.inner_product(orc.blind_g2(b2, 4), s)),
+                          orc.g2_to_affine(orc.msm_g2_a(b2, s)).reshape(1, 24))
+
+
 @pytest.mark.parametrize("lg", [15, 17, 18])
 def test_msm_mid_sizes_vs_oracle(engine, orc, lg):
     """Sizes where the window width leaves a SHORT top window (c = lg - 6: 255 mod 9/11/12 = 3/2/3 bits, i.e. 7/3/7 buckets holding
@@ -226,9 +244,10 @@ def test_sipp_prove_vs_oracle(engine, orc, n):
         assert not engine.SIPP.verify(a, b, r, value, bad)
 
 
-@pytest.mark.parametrize("n", [8, 64, 4096])
+@pytest.mark.parametrize("n", [8, 64, 4096, 32768])
 def test_sipp_degenerate_statement_vs_oracle(engine, orc, n):
-    """Zero coefficients (r_i = 0 -> the scaled a_i is the identity), identities on both sides, repeated and negated points (folds
+    """(n = 32768: round 0 folds G2 with the carry-free 4-lane GLS kernel, whose flagged lanes go to k_fold_g2_gls_split_fix.)
+    Zero coefficients (r_i = 0 -> the scaled a_i is the identity), identities on both sides, repeated and negated points (folds
     meet P + P and P - P), on the scalar kernels (n = 4096 in its first rounds) and on the VM kernels: the proof must still equal the
     oracle's byte for byte and verify."""
     a, b, r = orc.gen_g1(70, n), orc.gen_g2(80, n), orc.gen_scalars(9, n)
