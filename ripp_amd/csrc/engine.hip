@@ -1027,10 +1027,16 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true,
             GlsDigits2 d2; d2.a = gls_digits(s_inv); d2.b = gls_digits(sx_inv);
             hipLaunchKernelGGL(k_vm_fold_g2_joint2, dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VM_G2_SLOTS * sizeof(VmSlot), e->stream, b, b + half, (uint32_t)half, d2, j->jac2.as<G2J>());
         } else {
-        if ((rc = e->qtab.reserve(8 * half * sizeof(G2J))) != RIPP_OK) return rc;
-        hipLaunchKernelGGL(k_fold_g2_gls_split, dim3(nblk(half, 64), 4), dim3(64), 0, e->stream, b, (uint32_t)half, gls_digits(s_inv), e->qtab.as<G2J>());
+        if ((rc = e->qtab.reserve(8 * half * sizeof(G2J))) != RIPP_OK || (rc = e->fix_flags.reserve(8 * half)) != RIPP_OK) return rc;
         HIPCHK(hipStreamWaitEvent(e->stream3, e->ev_fork, 0));                        // the two multiplications side by side: they are latency-bound
-        hipLaunchKernelGGL(k_fold_g2_gls_split, dim3(nblk(half, 64), 4), dim3(64), 0, e->stream3, b + half, (uint32_t)half, gls_digits(sx_inv), e->qtab.as<G2J>() + 4 * half);
+        for (int t = 0; t < 2; ++t) {
+            hipStream_t st2 = t ? e->stream3 : e->stream; const G2A* src = t ? b + half : b; const GlsDigits dg2 = gls_digits(t ? sx_inv : s_inv);
+            G2J* parts = e->qtab.as<G2J>() + (size_t)t * 4 * half; uint8_t* flags = e->fix_flags.as<uint8_t>() + (size_t)t * 4 * half;
+            if (!e->sw.no_fq) {
+                hipLaunchKernelGGL(k_fold_g2_gls_split_q, dim3(nblk(half, 64), 4), dim3(64), 0, st2, src, (uint32_t)half, dg2, parts, flags);
+                hipLaunchKernelGGL(k_fold_g2_gls_split_fix, dim3(nblk(half, 64), 4), dim3(64), 0, st2, src, (uint32_t)half, dg2, parts, flags);
+            } else hipLaunchKernelGGL(k_fold_g2_gls_split, dim3(nblk(half, 64), 4), dim3(64), 0, st2, src, (uint32_t)half, dg2, parts);
+        }
         HIPCHK(hipEventRecord(e->ev_join3, e->stream3)); HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join3, 0));
         hipLaunchKernelGGL(k_fold_g2_combine8, dim3(nblk(half, 64)), dim3(64), 0, e->stream, e->qtab.as<G2J>(), (uint32_t)half, j->jac2.as<G2J>());
         }

@@ -105,6 +105,54 @@ __global__ void __launch_bounds__(256, 2) k_fold_g1_naf_q(const G1A* __restrict_
 #endif
 }
 
+// out[i] = s * hi[i] + lo[i] with the FULL-WIDTH challenge of a GIPA round split through the GLV endomorphism (kernels.hpp k_fold_g1_glv: two NAF strings
+// of ~128 digits on P and phi(P) = (beta x, y), shared by the launch): the carry-free twin, one 128-step chain per lane at ~420 instead of ~600
+// instructions per Fp product.  The first non-zero digit LOADS its point; an exceptional addition redoes the lane with the complete formulas.
+__global__ void __launch_bounds__(256, 2) k_fold_g1_glv_q(const G1A* __restrict__ hi, const G1A* __restrict__ lo, uint32_t half, GlvDigits dg, G1J* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= half) return;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RIPP_BLS12_377)
+    const G1A* hp = hi + i; const G1A* lp = lo + i;                         // hi[i] / lo[i] are re-read where they are needed, not held for 128 steps
+    AffQ q; Fqn bx, ny;
+    {
+        const G1A p = *hp;
+        if (is_inf(p)) { out[i] = to_jac(*lp); return; }
+        q = affq_from(p);
+        bx = fq_mul(q.x, fq_from_fp(fp_const(RIPP_GLV_BETA)));             // phi(P) = (beta x, y)
+        ny = fq_reduce(fq_neg(q.y));
+    }
+    JacQ acc; acc.x = acc.y = fq_coord(fq_one()); acc.z = fq_coord(fq_zero());
+    bool inf = true, bad = false;                                         // inf is wave-uniform (shared digit strings)
+#pragma unroll 1
+    for (int pos = dg.len - 1; pos >= 0; --pos) {
+        if (!inf) jdbl_q(acc);
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+            const int d = h ? dg.d2[pos] : dg.d1[pos];
+            if (d == 0) continue;
+            const Fqn& x = h ? bx : q.x;
+            if (inf) { acc.x = fq_coord(x); acc.y = fq_coord(d < 0 ? ny : q.y); acc.z = fq_coord(fq_one()); inf = false; }
+            else bad |= jmadd_q(acc, x, d < 0 ? ny : q.y);
+        }
+    }
+    if (inf) { out[i] = to_jac(*lp); return; }
+    { const G1A l = *opaque(lp); if (!is_inf(l)) { const AffQ lq = affq_from(l); bad |= jmadd_q(acc, lq.x, lq.y); } }
+    if (bad) {
+        const G1A p = *opaque(hp);
+        G1A q2 = p; q2.x = fmul(p.x, fp_const(RIPP_GLV_BETA));
+        G1J a2 = jac_inf<Fp>();
+#pragma unroll 1
+        for (int pos = dg.len - 1; pos >= 0; --pos) {
+            a2 = dbl(a2);
+            const int d1 = dg.d1[pos], d2 = dg.d2[pos];
+            if (d1 != 0) { G1A t = p; if (d1 < 0) t.y = neg(t.y); a2 = add_mixed(a2, t); }
+            if (d2 != 0) { G1A t = q2; if (d2 < 0) t.y = neg(t.y); a2 = add_mixed(a2, t); }
+        }
+        out[i] = add_mixed(a2, *opaque(lp));
+    } else out[i] = jacq_to_g1j(acc);
+#endif
+}
+
 // the table fold of round 0 (kernels.hpp k_fold_g1_tab): tab[e][i], e = M b + m: (2m + 1) * (base b of element i); four wNAF strings
 __global__ void __launch_bounds__(256, 2) k_fold_g1_tab_q(const G1A* __restrict__ tab, int M, const G1A* __restrict__ lo, uint32_t half, Wnaf4 dg, G1J* __restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
