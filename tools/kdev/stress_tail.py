@@ -6,7 +6,7 @@ import numpy as np, orclib as o, ripp_amd as R
 R.init(0)
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 bad = 0; t0 = time.time(); cnt = 0
-while time.time() - t0 < float(sys.argv[2]) if len(sys.argv) > 2 else 60:
+while time.time() - t0 < (float(sys.argv[2]) if len(sys.argv) > 2 else 60):
     lg = int(rng.integers(int(sys.argv[3]) if len(sys.argv) > 3 else 1, int(sys.argv[4]) if len(sys.argv) > 4 else 11)); n = 1 << lg
     sa, sb, sr = (int(x) for x in rng.integers(1, 1 << 30, 3))
     a, b, r = o.gen_g1(sa, n), o.gen_g2(sb, n), o.gen_scalars(sr, n)
