@@ -351,9 +351,9 @@ struct Engine {
         int32_t rc = scale_tab.reserve((size_t)SCALE_TAB * G1J_CHUNKS * n * sizeof(uint4)); if (rc) return rc;
         if (!sw.no_fq && !std::getenv("RIPP_SCALE_NO_FQ"))      // the carry-free twin (fq_scale.hpp)
         {
-            if ((rc = scale_flags.reserve(n))) return rc;
+            if ((rc = scale_flags.reserve(n + 16))) return rc;
             hipLaunchKernelGGL(k_scale_g1_glv_q, dim3(nblk(n, 256)), dim3(256), 0, st, base, base_stride, k, (uint32_t)n, scale_tab.as<uint4>(), out, scale_flags.as<uint8_t>());
-            hipLaunchKernelGGL(k_scale_g1_fix, dim3(nblk(n, 256)), dim3(256), 0, st, base, base_stride, k, (uint32_t)n, out, scale_flags.as<uint8_t>());
+            hipLaunchKernelGGL(k_scale_g1_fix, dim3(FIX_GRID), dim3(64), 0, st, base, base_stride, k, (uint32_t)n, out, scale_flags.as<uint8_t>());
         }
         else
         hipLaunchKernelGGL(k_scale_g1_glv, dim3(nblk(n, 256)), dim3(256), 0, st, base, base_stride, k, (uint32_t)n, scale_tab.as<uint4>(), out);
@@ -408,11 +408,11 @@ struct Engine {
 #if !defined(RIPP_BLS12_377)
         if (!sw.no_fq) {        // gathered additions on the carry-free form over the extended base array (fq_msm.hpp)
             const int split = (int)(n / nreal);
-            if ((rc = ms.ext.reserve(n * sizeof(Affine<F>))) || (rc = ms.flags.reserve((size_t)p.nwin * max_slots))) return rc;
+            if ((rc = ms.ext.reserve(n * sizeof(Affine<F>))) || (rc = ms.flags.reserve((size_t)p.nwin * max_slots + 16))) return rc;
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_extend_q<F>), dim3(nblk(nreal, 256), split), dim3(256), 0, st, bases, (uint32_t)nreal, split, ms.ext.as<QAff<F>>());
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_slot_sum_q<F>), dim3(nblk(max_slots, 64), p.nwin), dim3(64), 0, st, ms.ext.as<QAff<F>>(), p, ms.hist.as<uint32_t>(), ms.offs.as<uint32_t>(),
                                ms.slotoffs.as<uint32_t>(), ms.spw.as<uint32_t>(), ms.sorted.as<uint32_t>(), ms.slots.as<Jac<F>>(), max_slots, hom, ms.flags.as<uint8_t>());
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_slot_sum_fix<F>), dim3(nblk(max_slots, 64), p.nwin), dim3(64), 0, st, bases, p, ms.hist.as<uint32_t>(), ms.offs.as<uint32_t>(),
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_slot_sum_fix<F>), dim3(FIX_GRID), dim3(64), 0, st, bases, p, ms.hist.as<uint32_t>(), ms.offs.as<uint32_t>(),
                                ms.slotoffs.as<uint32_t>(), ms.spw.as<uint32_t>(), ms.sorted.as<uint32_t>(), ms.slots.as<Jac<F>>(), max_slots, hom, ms.flags.as<uint8_t>());
         } else
 #endif
@@ -910,7 +910,7 @@ int32_t job_precompute_round0(Engine* e, ripp_sipp_job* j) {
     constexpr size_t M = FOLD_TAB_M;
     const size_t njt = (M - 1) * half;
     if ((rc = e->fold_tab1.reserve(4 * M * half * sizeof(G1A))) || (rc = e->fold_mult.reserve(4 * M * half * sizeof(G2A))) || (rc = e->fold_tab.reserve(16 * M * G2A_CHUNKS * qstride * sizeof(uint4))) ||
-        (rc = e->fold_jac1.reserve(njt * sizeof(G1J))) || (rc = e->fold_jac2.reserve(njt * sizeof(G2J))) || (rc = e->fix_flags.reserve(4 * half))) return rc;      // all sized BEFORE the first launch: reserve() may reallocate
+        (rc = e->fold_jac1.reserve(njt * sizeof(G1J))) || (rc = e->fold_jac2.reserve(njt * sizeof(G2J))) || (rc = e->fix_flags.reserve(4 * half + 16))) return rc;      // all sized BEFORE the first launch: reserve() may reallocate
     e->tab_owner = j;
     G1A* t1 = e->fold_tab1.as<G1A>(); G2A* t2 = e->fold_mult.as<G2A>();
     G1J* sj1 = e->fold_jac1.as<G1J>(); G2J* sj2 = e->fold_jac2.as<G2J>();
@@ -932,7 +932,9 @@ int32_t job_precompute_round0(Engine* e, ripp_sipp_job* j) {
         if ((rc = e->normalize_dev<Fp>(sj1, njt, base1 + half))) return rc;
         if (!e->sw.no_fq) {
             hipLaunchKernelGGL(k_odd_multiples_q, dim3(nblk(half, 64)), dim3(64), 0, e->stream, base2, (uint32_t)half, (int)M, sj2, e->fix_flags.as<uint8_t>());
-            hipLaunchKernelGGL(k_odd_multiples_fix, dim3(nblk(half, 64)), dim3(64), 0, e->stream, base2, (uint32_t)half, (int)M, sj2, e->fix_flags.as<uint8_t>());
+#if !defined(RIPP_INLINE_FALLBACK)
+            hipLaunchKernelGGL(k_odd_multiples_fix, dim3(FIX_GRID), dim3(64), 0, e->stream, base2, (uint32_t)half, (int)M, sj2, e->fix_flags.as<uint8_t>());
+#endif
         }
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_odd_multiples<Fp2>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, base2, (uint32_t)half, (int)M, sj2);
         HIPCHK(hipGetLastError());
@@ -952,13 +954,15 @@ int32_t fold_g2_table(Engine* e, hipStream_t st, const G2A* hi, const G2A* lo, s
     const size_t qstride = (half + 63) & ~(size_t)63;
     int32_t rc;
     if ((rc = e->fold_mult.reserve((size_t)M * half * sizeof(G2A))) || (rc = e->fold_tab.reserve((size_t)4 * M * G2A_CHUNKS * qstride * sizeof(uint4))) ||
-        (rc = e->fold_jac2.reserve((size_t)(M - 1) * half * sizeof(G2J))) || (rc = jac.reserve(half * sizeof(G2J))) || (rc = e->fix_flags.reserve(4 * half))) return rc;
+        (rc = e->fold_jac2.reserve((size_t)(M - 1) * half * sizeof(G2J))) || (rc = jac.reserve(half * sizeof(G2J))) || (rc = e->fix_flags.reserve(4 * half + 16))) return rc;
     e->tab_owner = nullptr;                                     // whatever round-0 tables were there are overwritten
     G2A* mult = e->fold_mult.as<G2A>();
     HIPCHK(hipMemcpyAsync(mult, hi, half * sizeof(G2A), hipMemcpyDeviceToDevice, st));
     if (!e->sw.no_fq) {
         hipLaunchKernelGGL(k_odd_multiples_q, dim3(nblk(half, 64)), dim3(64), 0, st, hi, (uint32_t)half, M, e->fold_jac2.as<G2J>(), e->fix_flags.as<uint8_t>());
-        hipLaunchKernelGGL(k_odd_multiples_fix, dim3(nblk(half, 64)), dim3(64), 0, st, hi, (uint32_t)half, M, e->fold_jac2.as<G2J>(), e->fix_flags.as<uint8_t>());
+#if !defined(RIPP_INLINE_FALLBACK)
+        hipLaunchKernelGGL(k_odd_multiples_fix, dim3(FIX_GRID), dim3(64), 0, st, hi, (uint32_t)half, M, e->fold_jac2.as<G2J>(), e->fix_flags.as<uint8_t>());
+#endif
     }
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_odd_multiples<Fp2>), dim3(nblk(half, 64)), dim3(64), 0, st, hi, (uint32_t)half, M, e->fold_jac2.as<G2J>());
     HIPCHK(hipGetLastError());
@@ -967,7 +971,9 @@ int32_t fold_g2_table(Engine* e, hipStream_t st, const G2A* hi, const G2A* lo, s
     if (!e->sw.no_fq && half >= e->fq_min)
     {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab_q<GlsDigits, 4>), dim3(nblk(half, 64)), dim3(64), 0, st, e->fold_tab.as<uint4>(), qstride, M, lo, (uint32_t)half, gls_wnaf(s, 4), jac.as<G2J>(), e->fix_flags.as<uint8_t>());
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab_fix<GlsDigits, 4>), dim3(nblk(half, 64)), dim3(64), 0, st, e->fold_tab.as<uint4>(), qstride, M, lo, (uint32_t)half, gls_wnaf(s, 4), jac.as<G2J>(), e->fix_flags.as<uint8_t>());
+#if !defined(RIPP_INLINE_FALLBACK)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab_fix<GlsDigits, 4>), dim3(FIX_GRID), dim3(64), 0, st, e->fold_tab.as<uint4>(), qstride, M, lo, (uint32_t)half, gls_wnaf(s, 4), jac.as<G2J>(), e->fix_flags.as<uint8_t>());
+#endif
     }
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab<GlsDigits, 4>), dim3(nblk(half, 64)), dim3(64), 0, st, e->fold_tab.as<uint4>(), qstride, M, lo, (uint32_t)half, gls_wnaf(s, 4), jac.as<G2J>());
@@ -1027,14 +1033,16 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true,
             GlsDigits2 d2; d2.a = gls_digits(s_inv); d2.b = gls_digits(sx_inv);
             hipLaunchKernelGGL(k_vm_fold_g2_joint2, dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VM_G2_SLOTS * sizeof(VmSlot), e->stream, b, b + half, (uint32_t)half, d2, j->jac2.as<G2J>());
         } else {
-        if ((rc = e->qtab.reserve(8 * half * sizeof(G2J))) != RIPP_OK || (rc = e->fix_flags.reserve(8 * half)) != RIPP_OK) return rc;
+        if ((rc = e->qtab.reserve(8 * half * sizeof(G2J))) != RIPP_OK || (rc = e->fix_flags.reserve(8 * half + 32)) != RIPP_OK) return rc;
         HIPCHK(hipStreamWaitEvent(e->stream3, e->ev_fork, 0));                        // the two multiplications side by side: they are latency-bound
         for (int t = 0; t < 2; ++t) {
             hipStream_t st2 = t ? e->stream3 : e->stream; const G2A* src = t ? b + half : b; const GlsDigits dg2 = gls_digits(t ? sx_inv : s_inv);
-            G2J* parts = e->qtab.as<G2J>() + (size_t)t * 4 * half; uint8_t* flags = e->fix_flags.as<uint8_t>() + (size_t)t * 4 * half;
+            G2J* parts = e->qtab.as<G2J>() + (size_t)t * 4 * half; uint8_t* flags = e->fix_flags.as<uint8_t>() + (size_t)t * ((4 * half + 15) & ~(size_t)15);
             if (!e->sw.no_fq) {
                 hipLaunchKernelGGL(k_fold_g2_gls_split_q, dim3(nblk(half, 64), 4), dim3(64), 0, st2, src, (uint32_t)half, dg2, parts, flags);
-                hipLaunchKernelGGL(k_fold_g2_gls_split_fix, dim3(nblk(half, 64), 4), dim3(64), 0, st2, src, (uint32_t)half, dg2, parts, flags);
+#if !defined(RIPP_INLINE_FALLBACK)
+                hipLaunchKernelGGL(k_fold_g2_gls_split_fix, dim3(FIX_GRID), dim3(64), 0, st2, src, (uint32_t)half, dg2, parts, flags);
+#endif
             } else hipLaunchKernelGGL(k_fold_g2_gls_split, dim3(nblk(half, 64), 4), dim3(64), 0, st2, src, (uint32_t)half, dg2, parts);
         }
         HIPCHK(hipEventRecord(e->ev_join3, e->stream3)); HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join3, 0));
@@ -1048,9 +1056,11 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true,
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_combine<Fp2>), dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VmCurve<Fp2>::SLOTS * sizeof(VmSlot), e->stream, j->parts2.as<G2J>(), 8, b, (uint32_t)half, j->jac2.as<G2J>());
     } else
     if (tab && !e->sw.no_fq && half >= e->fq_min) {
-        if ((rc = e->fix_flags.reserve(4 * half))) return rc;
+        if ((rc = e->fix_flags.reserve(4 * half + 16))) return rc;
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab_q<Wnaf16, 16>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, e->fold_tab.as<uint4>(), j->tab2_stride, (int)FOLD_TAB_M, g2_lo, (uint32_t)half, gls16_wnaf(g2_s), j->jac2.as<G2J>(), e->fix_flags.as<uint8_t>());
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab_fix<Wnaf16, 16>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, e->fold_tab.as<uint4>(), j->tab2_stride, (int)FOLD_TAB_M, g2_lo, (uint32_t)half, gls16_wnaf(g2_s), j->jac2.as<G2J>(), e->fix_flags.as<uint8_t>());
+#if !defined(RIPP_INLINE_FALLBACK)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab_fix<Wnaf16, 16>), dim3(FIX_GRID), dim3(64), 0, e->stream, e->fold_tab.as<uint4>(), j->tab2_stride, (int)FOLD_TAB_M, g2_lo, (uint32_t)half, gls16_wnaf(g2_s), j->jac2.as<G2J>(), e->fix_flags.as<uint8_t>());
+#endif
     } else
     if (tab) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab<Wnaf16, 16>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, e->fold_tab.as<uint4>(), j->tab2_stride, (int)FOLD_TAB_M, g2_lo, (uint32_t)half, gls16_wnaf(g2_s), j->jac2.as<G2J>());
@@ -1073,9 +1083,11 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true,
     if (half <= e->gls_split_max) {     // latency-bound round: 4 lanes per element
         if ((rc = e->qtab.reserve(std::max<size_t>(4 * G2A_CHUNKS * qstride * sizeof(uint4), 4 * half * sizeof(G2J)))) != RIPP_OK) return rc;
         if (!e->sw.no_fq) {
-            if ((rc = e->fix_flags.reserve(4 * half))) return rc;
+            if ((rc = e->fix_flags.reserve(4 * half + 16))) return rc;
             hipLaunchKernelGGL(k_fold_g2_gls_split_q, dim3(nblk(half, 64), 4), dim3(64), 0, e->stream, g2_hi, (uint32_t)half, gls_digits(g2_s), e->qtab.as<G2J>(), e->fix_flags.as<uint8_t>());
-            hipLaunchKernelGGL(k_fold_g2_gls_split_fix, dim3(nblk(half, 64), 4), dim3(64), 0, e->stream, g2_hi, (uint32_t)half, gls_digits(g2_s), e->qtab.as<G2J>(), e->fix_flags.as<uint8_t>());
+#if !defined(RIPP_INLINE_FALLBACK)
+            hipLaunchKernelGGL(k_fold_g2_gls_split_fix, dim3(FIX_GRID), dim3(64), 0, e->stream, g2_hi, (uint32_t)half, gls_digits(g2_s), e->qtab.as<G2J>(), e->fix_flags.as<uint8_t>());
+#endif
         }
         else hipLaunchKernelGGL(k_fold_g2_gls_split, dim3(nblk(half, 64), 4), dim3(64), 0, e->stream, g2_hi, (uint32_t)half, gls_digits(g2_s), e->qtab.as<G2J>());
         hipLaunchKernelGGL(k_fold_g2_combine, dim3(nblk(half, 64)), dim3(64), 0, e->stream, e->qtab.as<G2J>(), g2_lo, (uint32_t)half, j->jac2.as<G2J>());

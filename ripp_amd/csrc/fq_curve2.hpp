@@ -148,7 +148,9 @@ __device__ __forceinline__ bool jmadd2_q(JacQ2& p, LOADX loadx, LOADY loady, uin
 
 // NS digit strings; string t works on table rows t M .. t M + M - 1 (kernels.hpp k_fold_g2_tab).  Exceptional lanes are FLAGGED (flag[i] = 1) and redone
 // with the complete formulas by k_fold_g2_tab_fix, launched behind this kernel: the out-of-line fallback and its stack frame stay out of the
-// throughput kernel (as a callee its frame was the kernel's whole private segment: 870 B per lane with no register spilled).
+// throughput kernel (as a callee its frame was the kernel's whole private segment: 870 B per lane with no register spilled).  -DRIPP_INLINE_FALLBACK
+// keeps the callee (A/B: the same round times -- a *_fix launch waits for a free SIMD while the G1 fold of the other stream fills the chip, but so does
+// whatever kernel comes next on this stream).
 template <class D, int NS>
 __global__ void __launch_bounds__(64, 2) k_fold_g2_tab_q(const uint4* __restrict__ qtab, size_t stride, int M, const G2A* __restrict__ lo, uint32_t half, D dg, G2J* __restrict__ out, uint8_t* __restrict__ flag) {
     __shared__ uint4 park_[7 * 64];
@@ -183,18 +185,25 @@ __global__ void __launch_bounds__(64, 2) k_fold_g2_tab_q(const uint4* __restrict
         }
     }
     const G2A* lp = lo + i;                                             // (re-read where it is used: held in registers, the 48 words of lo[i] were the kernel's only spills)
-    if (inf) { out[i] = to_jac(*lp); flag[i] = 0; return; }
+    if (inf) { out[i] = to_jac(*lp);
+#if !defined(RIPP_INLINE_FALLBACK)
+        flag[i] = 0;
+#endif
+        return; }
     bool linf; { const G2A l = *lp; linf = is_inf(l); }
     if (!linf) bad |= jmadd2_q(acc, [&]() { return f2_from(opaque(lp)->x); }, [&]() { return f2_from(opaque(lp)->y); }, park);
+#if !defined(RIPP_INLINE_FALLBACK)
     flag[i] = bad;
     if (!bad) out[i] = G2J{f2_to(acc.x), f2_to(acc.y), f2_to(acc.z)};
+#else
+    if (bad) fold_g2_tab_complete<D, NS>(qtab, stride, M, lo, i, dg, out);
+    else out[i] = G2J{f2_to(acc.x), f2_to(acc.y), f2_to(acc.z)};
+#endif
 #endif
 }
 template <class D, int NS>
 __global__ void __launch_bounds__(64) k_fold_g2_tab_fix(const uint4* __restrict__ qtab, size_t stride, int M, const G2A* __restrict__ lo, uint32_t half, D dg, G2J* __restrict__ out, const uint8_t* __restrict__ flag) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= half || !flag[i]) return;
-    fold_g2_tab_complete<D, NS>(qtab, stride, M, lo, i, dg, out);
+    for_flagged(flag, half, [&](uint32_t i) { fold_g2_tab_complete<D, NS>(qtab, stride, M, lo, i, dg, out); });
 }
 
 // Odd multiples 3 Q, 5 Q, .., (2 M - 1) Q of the fold tables (kernels.hpp k_odd_multiples: out[m][i] = (2m + 3) base[i], Jacobian, batch-normalised
@@ -259,13 +268,16 @@ __global__ void __launch_bounds__(64, 2) k_odd_multiples_q(const G2A* __restrict
         Fq2n zo = f2_muld(t.z, ld7(zpark, 64)); f2_pin(zo);
         out[(size_t)m * n + i] = G2J{f2_to(t.x), f2_to(t.y), f2_to(f2_to_coord(zo))};
     }
+#if !defined(RIPP_INLINE_FALLBACK)
     flag[i] = bad;
+#else
+    if (bad) odd_multiples_complete<Fp2>(base, n, M, i, out);
+#endif
 #endif
 }
 __global__ void __launch_bounds__(64) k_odd_multiples_fix(const G2A* __restrict__ base, uint32_t n, int M, G2J* __restrict__ out, const uint8_t* __restrict__ flag) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || M < 2 || !flag[i]) return;
-    odd_multiples_complete<Fp2>(base, n, M, i, out);
+    if (M < 2) return;
+    for_flagged(flag, n, [&](uint32_t i) { odd_multiples_complete<Fp2>(base, n, M, i, out); });
 }
 
 // The 4-lane GLS fold of the latency-bound rounds (kernels.hpp k_fold_g2_gls_split: lane (i, j) multiplies psi^j(hi[i]) by digit string j; the
@@ -322,17 +334,18 @@ __global__ void __launch_bounds__(64, 2) k_fold_g2_gls_split_q(const G2A* __rest
         if (inf) { acc.x = f2_to_coord(loadx()); acc.y = f2_to_coord(loady()); acc.z = f2_to_coord(Fq2n{fq_one(), fq_zero()}); f2_pin(acc.z); inf = false; }
         else bad |= jmadd2_q(acc, loadx, loady, park);
     }
+#if !defined(RIPP_INLINE_FALLBACK)
     flag[(size_t)j * half + i] = bad;
     if (bad) return;
+#else
+    if (bad) { parts[(size_t)j * half + i] = fold_g2_gls_split_complete(gls_image(hi[i], j), dg, j); return; }
+#endif
     if (inf) parts[(size_t)j * half + i] = jac_inf<Fp2>();
     else parts[(size_t)j * half + i] = G2J{f2_to(acc.x), f2_to(acc.y), f2_to(acc.z)};
 #endif
 }
 __global__ void __launch_bounds__(64) k_fold_g2_gls_split_fix(const G2A* __restrict__ hi, uint32_t half, GlsDigits dg, G2J* __restrict__ parts, const uint8_t* __restrict__ flag) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = blockIdx.y;
-    if (i >= half || !flag[(size_t)j * half + i]) return;
-    parts[(size_t)j * half + i] = fold_g2_gls_split_complete(gls_image(hi[i], j), dg, j);
+    for_flagged(flag, 4 * half, [&](uint32_t f) { const int j = (int)(f / half); const uint32_t i = f - (uint32_t)j * half; parts[f] = fold_g2_gls_split_complete(gls_image(hi[i], j), dg, j); });
 }
 
 }  // namespace ripp

@@ -108,14 +108,14 @@ template <class F>
 __global__ void __launch_bounds__(64) k_msm_slot_sum_fix(const Affine<F>* __restrict__ bases, MsmPlan p, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offs,
                                                        const uint32_t* __restrict__ slot_offs, const uint32_t* __restrict__ slots_per_window, const uint32_t* __restrict__ sorted,
                                                        Jac<F>* __restrict__ slot_sums, uint32_t max_slots, bool hom, const uint8_t* __restrict__ flag) {
-    const int w = blockIdx.y;
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= slots_per_window[w] || !flag[(size_t)w * max_slots + s]) return;
-    uint32_t begin, end;
-    msm_slot_range(p, hist, offs, slot_offs, w, s, begin, end);
-    Jac<F> acc;
-    msm_slot_sum_complete<F>(bases, sorted + (size_t)w * p.n, begin, end, p.nreal, &acc);
-    slot_sums[(size_t)w * max_slots + s] = hom ? msm_jac_to_h(acc) : acc;
+    for_flagged(flag, (uint32_t)p.nwin * max_slots, [&](uint32_t f) {
+        const int w = (int)(f / max_slots); const uint32_t s = f - (uint32_t)w * max_slots;
+        if (s >= slots_per_window[w]) return;                                   // (a byte the throughput kernel never wrote)
+        uint32_t begin, end;
+        msm_slot_range(p, hist, offs, slot_offs, w, s, begin, end);
+        Jac<F> acc;
+        msm_slot_sum_complete<F>(bases, sorted + (size_t)w * p.n, begin, end, p.nreal, &acc);
+        slot_sums[f] = hom ? msm_jac_to_h(acc) : acc; });
 }
 
 }  // namespace ripp

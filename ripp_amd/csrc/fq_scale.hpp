@@ -120,11 +120,9 @@ __global__ void __launch_bounds__(256, 2) k_scale_g1_glv_q(const G1A* __restrict
 #endif
 }
 // the flagged lanes of k_scale_g1_glv_q, by plain double-and-add with the complete formulas
-__global__ void __launch_bounds__(256) k_scale_g1_fix(const G1A* __restrict__ base, uint32_t base_stride, const Fr* __restrict__ k_mont, uint32_t n, G1J* __restrict__ out, const uint8_t* __restrict__ flag) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || !flag[i]) return;
+__global__ void __launch_bounds__(64) k_scale_g1_fix(const G1A* __restrict__ base, uint32_t base_stride, const Fr* __restrict__ k_mont, uint32_t n, G1J* __restrict__ out, const uint8_t* __restrict__ flag) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(RIPP_BLS12_377)
-    out[i] = scale_g1_plain(base[(size_t)i * base_stride], from_mont(k_mont[i]));
+    for_flagged(flag, n, [&](uint32_t i) { out[i] = scale_g1_plain(base[(size_t)i * base_stride], from_mont(k_mont[i])); });
 #endif
 }
 

@@ -72,6 +72,21 @@ struct PairSets { const G1A* a[MAX_PRODUCTS]; const G2A* b[MAX_PRODUCTS]; };
 #endif
 #define SB() __builtin_amdgcn_sched_barrier(0)
 template <class T> __device__ __forceinline__ const T* opaque(const T* p) { asm volatile("" : "+v"(p)); return p; }   // defeats hoisting: operands are RE-LOADED where used
+// The *_fix kernels behind the carry-free throughput kernels: a SMALL fixed grid (FIX_GRID x 64 lanes) walks the flag bytes 16 at a time and redoes the
+// flagged lanes with the complete formulas.  (One lane per element, as first written, cost 2.4 ms per 2^19-lane launch with NOTHING flagged: these
+// kernels hold 256 + 110 registers and a 400-1 300 B frame per lane, and dispatching 8 192 such waves is not free.)  flag: 16-byte aligned, readable
+// up to the next multiple of 16; bytes at or beyond n, and bytes the throughput kernel did not write, are ignored by the caller's own range checks.
+constexpr int FIX_GRID = 128;
+template <class FN> __device__ __forceinline__ void for_flagged(const uint8_t* __restrict__ flag, uint32_t n, FN fn) {
+    const uint32_t nth = gridDim.x * blockDim.x;
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; (uint64_t)c * 16 < n; c += nth) {
+        const uint4 f = reinterpret_cast<const uint4*>(flag)[c];
+        if ((f.x | f.y | f.z | f.w) == 0) continue;
+        const uint32_t w[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll 1
+        for (int k = 0; k < 16; ++k) { const uint32_t i = c * 16 + (uint32_t)k; if (i < n && ((w[k >> 2] >> (8 * (k & 3))) & 0xFFu)) fn(i); }
+    }
+}
 // low-liveness order; lines are stored as soon as they are complete
 __device__ __forceinline__ void line_double_store(Fp2& X, Fp2& Y, Fp2& Z, const G1A* p, uint4* lines, size_t s, size_t stride, size_t i, bool skip) {
     const Fp2 t1 = sqr(add(Y, Z)); SB();
