@@ -238,6 +238,10 @@ def main():
                                                   "frac": (dom[2] * fpm / (dom[0] * 1e-3) / 1e9 / MAD_ISSUE_PEAK_G) if dom[0] > 0 else 0.0,
                                                   "multiplier_peak": FP_MUL_PEAK_G,
                                                   "frac_of_multiplier": (dom[2] * fpm / (dom[0] * 1e-3) / 1e9 / FP_MUL_PEAK_G) if dom[0] > 0 else 0.0,
+                                                  # (multiplier_peak is the standalone 12 x 32-bit multiplier of profiles/r02_fpbench_production.txt: the carry-free kernels need fewer
+                                                  #  instructions per product and may exceed it.)  The ceiling of a kernel that runs at 2 waves per SIMD: a lone wave issues one
+                                                  #  v_mad_u64_u32 per 3.99 ns, two waves one per 2.11 ns, eight one per 1.89 ns (profiles/r01_ubench_valu_rates.txt).
+                                                  "occupancy_ceiling": {"waves_per_simd": 2, "frac_of_issue_roof": round(1.89 / 2.11, 3)},
                                                   "fp_products_per_pair": fpm})(68 * 39 if dom[3].startswith("k_line_products") else 63 * 25 + 5 * 41),
                          "note": "integer-ALU bound (381-bit Montgomery arithmetic, ~5e3 Fp products per 288 input bytes); see DESIGN.md"},
             "phase_ms": {k: round(v, 3) for k, v in stats.items() if k.endswith("_ms")},
