@@ -204,6 +204,10 @@ int32_t ripp_sipp_prove_sharded(const ripp_g1a* a, const ripp_g2a* b, const ripp
 /* the same on a resident shard: job from ripp_sipp_job_create(shard, n_local, ripp_comm_rank(), ripp_comm_world()) */
 int32_t ripp_sipp_job_prove_sharded(ripp_sipp_job* job, const ripp_gt* value, const ripp_g1a* full_a, const ripp_g2a* full_b, const ripp_fr* full_r,
                                     const uint8_t* seed_digest, ripp_gt* proof, ripp_fr* challenges, ripp_stats* stats);
+/* TEST HOOK (no counterpart in the reference): the fold of round `round` on rank `rank` of this process's NEXT SIPP proof reports
+ * RIPP_ERR_DEVICE instead of running -- a local failure in the middle of a sharded proof.  One shot; (-1, -1) disarms.  Every rank
+ * of the proof must then return non-zero from the same exchange (tests/test_sharded_gloo.py::test_collective_error_exit_*). */
+void    ripp_test_inject_failure(int32_t rank, int32_t round);
 
 /* ---- GIPA prover, TIPP instantiation  -- GIPA::prove_with_aux / _prove, ip_proofs/src/gipa.rs:162-312 ------------
  * GIPA<PairingInnerProduct, AFGHOCommitmentG1, AFGHOCommitmentG2, IdentityCommitment<GT, Fr>, Blake2b> (the instantiation

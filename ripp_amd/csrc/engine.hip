@@ -1687,6 +1687,7 @@ static int32_t job_lookahead(Engine* e, ripp_sipp_job* j, int eighths, bool forc
             room = std::min(room, (double)j->hash_total / 0.9e6 - elapsed);
             const double cost = (double)qblk * (double)((size_t)1 << (2 * R)) * std::max(ms_per_pair, 5.0e-5);
             if (trace_on()) fprintf(stderr, "[ripp] look-ahead item (%d,%c): hash %.0f %% after %.1f ms, room %.1f ms, item %.1f ms\n", R, side ? 'r' : 'l', 100.0 * (double)done / (double)j->hash_total, elapsed, room, cost);
+            if (room <= 0) break;                                        // the window is over (or the clamp above says it must be): nothing more fits
             frac = room >= cost ? 8 : -(int)(32.0 * room / cost);        // adaptive: 32nds (negative = in 32nds)
             if (frac < 0 && frac > -6) break;
         }
@@ -1777,6 +1778,15 @@ static bool look_full(ripp_sipp_job* j, size_t round) { const auto* l = look_fin
 // One protocol for every world size: the ranks walk the same sequence of exchanges (plan, one per round while the vectors are sharded, the
 // tail gather), every message carries the sender's status, and a rank that failed locally keeps walking until the next exchange has told the
 // others -- no rank is left blocked in a collective (all ranks return an error together).
+// Test hook (ripp_test_inject_failure): the fold of round `round` on rank `rank` of the NEXT sharded / single proof reports a device error instead of
+// running -- what an allocation or launch failure in the middle of a proof looks like to the protocol.  One shot: consumed when it fires.
+static std::atomic<int> g_fail_rank{-1}, g_fail_round{-1};
+static bool test_fail_hit(int rank, size_t round) {
+    if (g_fail_rank.load(std::memory_order_relaxed) != rank || g_fail_round.load(std::memory_order_relaxed) != (int)round) return false;
+    g_fail_rank = -1; g_fail_round = -1;
+    set_err("injected failure (ripp_test_inject_failure) in the fold of round " + std::to_string(round) + " on rank " + std::to_string(rank));
+    return true;
+}
 struct SippPlanMsg { uint64_t n_local; int32_t world, rank, look_items, window, rc, pad; };
 struct SippRoundMsg { Fp12 z[2]; uint8_t digest[32]; int32_t rc, pad[3]; };
 struct SippTailMsg { G1A a; G2A b; int32_t rc, pad[3]; };
@@ -1784,6 +1794,14 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
     const int world0 = j->world0, rank = j->rank;
     const double t_start = now_ms();
     double exchange_ms = 0;
+    // whatever the exit path -- the plan exchange below included: nothing enqueued by this proof may still be running when the caller gets control
+    // back (engine scratch, tp_rows and the job's vectors are reused by the next call), no prepared state may leak into the next proof, and the hash
+    // thread, which reads the CALLER's buffers (borrowed statement), is never left running behind a return.  Constructed BEFORE the thread starts.
+    struct Quiesce { Engine* e; ripp_sipp_job* j; ~Quiesce() {
+        (void)hipStreamSynchronize(e->stream); (void)hipStreamSynchronize(e->stream2); (void)hipStreamSynchronize(e->stream3);
+        j->tp_round[0] = j->tp_round[1] = ~(size_t)0; j->pre_vm_ready = false; j->pre_vm_side = false; j->pre_ready = false; j->tab_ready = false; j->look.clear();
+        if (j->hash_thread.joinable()) j->hash_thread.join();
+        j->ha_ext = nullptr; j->hb_ext = nullptr; j->hr_ext = nullptr; j->hash_prestarted = false; } } quiesce{e, j};
     // rank 0 (the only rank of a single-GPU proof) hashes the statement on a host thread: THE serial floor, started before anything else
     const bool window = rank == 0 && !seed_digest;
     if (rank == 0) {
@@ -1811,13 +1829,6 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
     e->quiet_waits = window && std::getenv("RIPP_QUIET_WAITS");
     j->look_rows[0].blocking = j->look_rows[1].blocking = e->quiet_waits;
     struct XsOff { ripp_sipp_job* j; ~XsOff() { j->xs_enabled = false; } } xs_off{j};
-    // whatever the exit path: nothing enqueued by this proof may still be running when the caller gets control back (engine scratch, tp_rows and
-    // the job's vectors are reused by the next call), and no prepared state may leak into the next proof
-    struct Quiesce { Engine* e; ripp_sipp_job* j; ~Quiesce() {
-        (void)hipStreamSynchronize(e->stream); (void)hipStreamSynchronize(e->stream2); (void)hipStreamSynchronize(e->stream3);
-        j->tp_round[0] = j->tp_round[1] = ~(size_t)0; j->pre_vm_ready = false; j->pre_vm_side = false; j->pre_ready = false; j->tab_ready = false; j->look.clear();
-        if (j->hash_thread.joinable()) j->hash_thread.join();      // it reads the caller's buffers (borrowed statement): never left running behind a return
-        j->ha_ext = nullptr; j->hb_ext = nullptr; j->hr_ext = nullptr; } } quiesce{e, j};
     j->xs_enabled = true; j->seeded = false;
     int32_t lrc = job_begin(e, j);                                        // local status: carried to the next exchange while the proof is sharded
     if (lrc && world0 == 1) return lrc;
@@ -1948,6 +1959,7 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
         const bool known = look_full(j, round + 1);
         if (!sharded && len == 2) { j->len = 0; j->pre_vm_ready = false; }      // the one-element vectors of the LAST fold are discarded by the prover (sipp/src/lib.rs:87-104 ends the loop): not computed
         else {
+            if (!lrc && test_fail_hit(rank, round)) lrc = RIPP_ERR_DEVICE;
             if (!lrc) lrc = job_fold(e, j, x, true, pipelined || known);
             if (!lrc && pipelined) {              // behind the fold, on the new vectors: the second fold bases of the next round, the values of the round after it
                 if (!j->pre_vm_ready) lrc = job_precompute_vm(e, j, true);
@@ -1970,6 +1982,8 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
     if (st) *st = e->stats;
     return RIPP_OK;
 }
+
+API void ripp_test_inject_failure(int32_t rank, int32_t round) { g_fail_rank = rank; g_fail_round = round; }
 
 API int32_t ripp_sipp_job_prove(ripp_sipp_job* j, const ripp_gt* value, ripp_gt* proof, ripp_fr* challenges, ripp_stats* st) {
     LOCK; ENGINE; if (!j || !value || !proof || j->world0 != 1) return RIPP_ERR_ARG;

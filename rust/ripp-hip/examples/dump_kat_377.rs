@@ -2,8 +2,10 @@
 //! (sipp/src/lib.rs:229, sipp/examples/scaling-ipp.rs:2).  Prints, from REAL arkworks 0.4 + the reference's `ark-sipp`:
 //!   * every known answer tests/golden/bls12_377_vectors.json holds (generic SW point encoding with SWFlags in the last byte, e(G1, G2),
 //!     bilinearity, an 8-pair product with infinities, MSMs, a SIPP proof of n = 4 with its seed digest and challenges);
-//!   * `base_case`: the reference's `prove_and_verify_base_case` (sipp/src/lib.rs:232-254) VERBATIM -- seed b"falafel", 32 points and scalars
-//!     drawn from FiatShamirRng<Blake2s> -- with its inputs, the value z and the whole proof.  tools/compare_kat.py feeds those inputs to this
+//!   * `base_case`: the reference's `prove_and_verify_base_case` (sipp/src/lib.rs:232-254) -- seed b"falafel", 32 points and scalars drawn from
+//!     FiatShamirRng<Blake2s>, `SIPP::prove` + `SIPP::verify` as the test runs them -- with its inputs, the value z and the proof elements.
+//!     (`Proof::gt_elems` is private, sipp/src/lib.rs:32-34: the elements come from `sipp_replay`, the body of `SIPP::prove` on the crate's
+//!     public pieces, and are checked against the verifier's equation.)  tools/compare_kat.py feeds those inputs to this
 //!     repository's BLS12-377 oracle and compares z and the proof: the reference's only SIPP test becomes a byte-level known answer.
 //!
 //!   cargo run --release --no-default-features --example dump_kat_377 -- ../../tests/golden/bls12_377_vectors.json > kat_arkworks_377.json
@@ -12,10 +14,9 @@
 //! Needs no GPU and does not link libripp_hip.
 use ark_bls12_377::{Bls12_377, Fq, Fq2, Fr, G1Affine, G1Projective, G2Affine, G2Projective};
 use ark_ec::{pairing::{Pairing, PairingOutput}, AffineRepr, CurveGroup, VariableBaseMSM};
-use ark_ff::{PrimeField, UniformRand};
+use ark_ff::{BigInteger, Field, One, PrimeField, UniformRand};
 use ark_serialize::CanonicalSerialize;
 use ark_sipp::{product_of_pairings, product_of_pairings_with_coeffs, rng::FiatShamirRng, SIPP};
-use ark_std::rand::Rng;
 use blake2::Blake2s;
 use digest::Digest;
 use serde_json::{json, Value};
@@ -34,26 +35,87 @@ fn g2(v: &Value) -> G2Affine {
 }
 fn ser<T: CanonicalSerialize>(x: &T) -> String { let mut b = Vec::new(); x.serialize_uncompressed(&mut b).unwrap(); hex::encode(b) }
 fn ser_c<T: CanonicalSerialize>(x: &T) -> String { let mut b = Vec::new(); x.serialize_compressed(&mut b).unwrap(); hex::encode(b) }
-fn hexint<F: PrimeField>(x: &F) -> String { let mut b = x.into_bigint().to_bytes_be(); while b.len() > 1 && b[0] == 0 { b.remove(0); } format!("0x{}", hex::encode(b).trim_start_matches('0')) }
+fn hexint<F: PrimeField>(x: &F) -> String { let h = hex::encode(x.into_bigint().to_bytes_be()); let t = h.trim_start_matches('0'); format!("0x{}", if t.is_empty() { "0" } else { t }) }
 fn pg1(p: &G1Affine) -> Value { if p.infinity { Value::Null } else { json!([hexint(&p.x), hexint(&p.y)]) } }
 fn pg2(p: &G2Affine) -> Value { if p.infinity { Value::Null } else { json!([[hexint(&p.x.c0), hexint(&p.x.c1)], [hexint(&p.y.c0), hexint(&p.y.c1)]]) } }
 
 type GT = PairingOutput<Bls12_377>;
 
-/// value, seed digest, proof and replayed challenges of one SIPP statement (sipp/src/lib.rs:42-106, 134-149)
+/// value, seed digest, proof and challenges of one SIPP statement (sipp/src/lib.rs:42-106)
 fn sipp_section(a: &[G1Affine], b: &[G2Affine], r: &[Fr]) -> Value {
     let value: GT = product_of_pairings_with_coeffs::<Bls12_377>(a, b, r);
-    let mut seed = Vec::new(); (&a.to_vec(), &b.to_vec(), &r.to_vec(), &value).serialize_uncompressed(&mut seed).unwrap();      // what SIPP::prove hashes (:56-59): Vec prefixes included
-    let proof = SIPP::<Bls12_377, Blake2s>::prove(a, b, r, value).unwrap();
-    assert!(SIPP::<Bls12_377, Blake2s>::verify(a, b, r, value, &proof).unwrap());
-    let mut rng = FiatShamirRng::<Blake2s>::from_seed(&seed);
-    let mut chs = Vec::new();
-    for (zl, zr) in proof.gt_elems.iter() {
-        let mut buf = Vec::new(); (zl, zr).serialize_uncompressed(&mut buf).unwrap(); rng.absorb(&buf);
-        let x: Fr = rng.gen::<u128>().into(); chs.push(hexint(&x));
-    }
+    // the reference's prover and verifier on this statement: it accepts its own proof (whose elements are private, see sipp_replay)
+    let ref_proof = SIPP::<Bls12_377, Blake2s>::prove(a, b, r, value).unwrap();
+    assert!(SIPP::<Bls12_377, Blake2s>::verify(a, b, r, value, &ref_proof).unwrap());
+    let (seed, proof, chs) = sipp_replay::<Bls12_377>(a, b, r, value);
+    assert!(sipp_equation_holds::<Bls12_377>(a, b, r, value, &proof, &chs));
     json!({"value": ser(&value), "seed_digest": hex::encode(Blake2s::digest(&seed)),
-           "proof": proof.gt_elems.iter().map(|(l, r)| json!([ser(l), ser(r)])).collect::<Vec<_>>(), "challenges": chs})
+           "proof": proof.iter().map(|(l, r)| json!([ser(l), ser(r)])).collect::<Vec<_>>(), "challenges": chs.iter().map(hexint).collect::<Vec<_>>()})
+}
+/// `SIPP::prove`'s body (sipp/src/lib.rs:56-101) replayed statement by statement on the crate's PUBLIC pieces (`product_of_pairings`,
+/// `rng::FiatShamirRng`, arkworks group operations).  `Proof::gt_elems` is a PRIVATE field (sipp/src/lib.rs:32-34) and `Proof` derives no
+/// serialisation, so the elements of `SIPP::prove`'s result cannot be read from outside the crate; `main` still runs `SIPP::prove` +
+/// `SIPP::verify` (the reference accepts its own proof of the statement) and checks the replayed elements against the verifier's equation.
+/// Returns (the bytes the prover hashes, (z_l, z_r) per round, the challenges).
+fn sipp_replay<E: Pairing>(a: &[E::G1Affine], b: &[E::G2Affine], r: &[E::ScalarField], value: PairingOutput<E>)
+    -> (Vec<u8>, Vec<(PairingOutput<E>, PairingOutput<E>)>, Vec<E::ScalarField>) {
+    let mut seed = Vec::new();
+    (a, b, r, value).serialize_uncompressed(&mut seed).unwrap();                                     // :56-59, the reference's own expression
+    let mut rng = FiatShamirRng::<Blake2s>::from_seed(&seed);
+    let a = a.iter().zip(r).map(|(&a, r)| a * r).collect::<Vec<_>>();                                 // :61-65
+    let mut a = E::G1::normalize_batch(&a);                                                           // :66
+    let mut b = b.to_vec();
+    let mut length = a.len();
+    let (mut proof_vec, mut challenges) = (Vec::new(), Vec::new());
+    while length != 1 {                                                                               // :69-104
+        length /= 2;
+        let (a_l, a_r) = (&a[..length], &a[length..]);
+        let (b_l, b_r) = (&b[..length], &b[length..]);
+        let z_l = product_of_pairings::<E>(a_r, b_l);
+        let z_r = product_of_pairings::<E>(a_l, b_r);
+        proof_vec.push((z_l, z_r));
+        {
+            let mut buf = Vec::new();
+            (z_l, z_r).serialize_uncompressed(&mut buf).unwrap();
+            rng.absorb(&buf);
+        }
+        let x: E::ScalarField = u128::rand(&mut rng).into();
+        challenges.push(x);
+        let a_proj = a_l.iter().zip(a_r).map(|(a_l, &a_r)| a_r * x + a_l).collect::<Vec<_>>();
+        let a_next = E::G1::normalize_batch(&a_proj);
+        let x_inv = x.inverse().unwrap();
+        let b_proj = b_l.iter().zip(b_r).map(|(b_l, &b_r)| b_r * x_inv + b_l).collect::<Vec<_>>();
+        let b_next = E::G2::normalize_batch(&b_proj);
+        a = a_next;
+        b = b_next;
+    }
+    (seed, proof_vec, challenges)
+}
+
+/// The equation `SIPP::verify` checks (sipp/src/lib.rs:151-177) on the replayed elements and challenges, with arkworks arithmetic.
+fn sipp_equation_holds<E: Pairing>(a: &[E::G1Affine], b: &[E::G2Affine], r: &[E::ScalarField], claimed_value: PairingOutput<E>,
+                                   proof: &[(PairingOutput<E>, PairingOutput<E>)], x_s: &[E::ScalarField]) -> bool {
+    let length = a.len();
+    let proof_len = proof.len();
+    let mut z_prime = claimed_value;
+    for ((z_l, z_r), x) in proof.iter().zip(x_s) {
+        z_prime = z_prime + (*z_l * *x) + (*z_r * x.inverse().unwrap());
+    }
+    let mut s = vec![E::ScalarField::one(); length];
+    let mut s_invs = vec![E::ScalarField::one(); length];
+    for (j, x) in x_s.iter().enumerate() {
+        let x_inv = x.inverse().unwrap();
+        for i in 0..length {
+            if i & (1 << (proof_len - j - 1)) != 0 {
+                s[i] *= x;
+                s_invs[i] *= &x_inv;
+            }
+        }
+    }
+    let s = s.into_iter().zip(r).map(|(x, r)| x * r).collect::<Vec<_>>();
+    let a_prime = E::G1::msm(a, &s).unwrap();
+    let b_prime = E::G2::msm(b, &s_invs).unwrap();
+    E::pairing(a_prime, b_prime) == z_prime
 }
 
 fn main() {

@@ -72,12 +72,11 @@ def test_sipp_prove_2p20_vs_oracle(engine, orc, sipp_2p20):
     assert np.array_equal(engine.SIPP.prove(a, b, r, value), eproof)
 
 
-def _sharded_2p20_worker(rank, world, port, path, look_items, ret):
+def _sharded_2p20_worker(rank, world, port, path, env, ret):
     import os
     import sys
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    if look_items is not None:
-        os.environ["RIPP_LOOK_ITEMS"] = str(look_items)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), RIPP_RANKS_PER_DEVICE=str(world))
+    os.environ.update(env)
     here = os.path.dirname(os.path.abspath(__file__))
     for p in (os.path.dirname(here), here):
         if p not in sys.path:
@@ -87,7 +86,7 @@ def _sharded_2p20_worker(rank, world, port, path, look_items, ret):
     from ripp_amd.sharded import NativeComm, native_sipp_job_prove
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        R.init(0)                                      # both ranks share cuda:0; gloo carries the library's all-gather (callback transport)
+        R.init(0)                                      # the ranks share cuda:0; gloo carries the library's all-gather (callback transport)
         comm = NativeComm("callback")
         n = N; nl = n // world
         exp = np.load(path)
@@ -97,24 +96,34 @@ def _sharded_2p20_worker(rank, world, port, path, look_items, ret):
         proof, ch, st = native_sipp_job_prove(job, exp["value"], full=full)
         ok = np.array_equal(proof, exp["proof"]) and np.array_equal(ch, exp["ch"])
         job.close(); comm.close()
-        ret[rank] = (bool(ok), int(st["look_items"]))
+        ret[rank] = (bool(ok), int(st["look_items"]), int(st["look_pairs"]))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("look_items", [None, 3])
-def test_sipp_prove_2p20_sharded_world2_vs_oracle(engine, sipp_2p20, look_items):
-    """Config 4's sharded code path at its own size: ripp_sipp_job_prove_sharded with two ranks (index residues mod 2, both on cuda:0, the
-    library's all-gather carried by gloo) -- the single-GPU schedule on every shard (x-scaled folds, fold tables, look-ahead in the hash
-    window, pipelined tail).  All 40 GT elements and 20 challenges equal the ORACLE's proof of the unsharded statement.  look_items = 3:
-    the two-GPU plan (both values of round 1 and z_l of round 2 pre-evaluated), which a shared GPU would not choose by itself."""
+@pytest.mark.parametrize("world,env,items", [(2, {}, None), (2, {"RIPP_LOOK_ITEMS": "3"}, 3), (4, {"RIPP_LOOK_EIGHTHS": "45"}, 6), (8, {}, None), (8, {"RIPP_LOOK_EIGHTHS": "48"}, 6)])
+def test_sipp_prove_2p20_sharded_vs_oracle(engine, sipp_2p20, world, env, items):
+    """Config 4's sharded code path at its own size: ripp_sipp_job_prove_sharded with 2, 4 and 8 ranks (index residues mod world, all on cuda:0,
+    the library's all-gather carried by gloo) -- the single-GPU schedule on every shard (x-scaled folds, fold tables, look-ahead in the hash
+    window, pipelined tail; with 8 ranks the three replicated tail rounds after the gather).  All 40 GT elements and 20 challenges of EVERY
+    rank equal the ORACLE's proof of the unsharded statement.  Forced plans: the ones `look_plan` picks on real 2 / 4 / 8-GPU nodes (3 items;
+    45 eighths = rounds 1-2 + (3,l) + 5/8 of (3,r); 48 = rounds 1-3 in full), which ranks sharing one GPU would not choose by themselves."""
     import socket
+    import time
     import torch.multiprocessing as mp
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
     mgr = mp.Manager(); ret = mgr.dict()
-    mp.spawn(_sharded_2p20_worker, args=(2, port, sipp_2p20["path"], look_items, ret), nprocs=2, join=True)
+    ctx = mp.spawn(_sharded_2p20_worker, args=(world, port, sipp_2p20["path"], env, ret), nprocs=world, join=False)
+    deadline = time.time() + 1500
+    try:
+        while not ctx.join(timeout=5):
+            assert time.time() < deadline, "a rank hangs"
+    finally:
+        for pr in ctx.processes:
+            if pr.is_alive():
+                pr.kill()
     got = dict(ret)
-    assert got[0][0] and got[1][0], got
-    if look_items is not None:
-        assert got[0][1] == look_items and got[1][1] == look_items, got
+    assert sorted(got) == list(range(world)) and all(got[k][0] for k in got), got
+    if items is not None:
+        assert all(got[k][1] == items for k in got), got

@@ -93,10 +93,12 @@ def _run(world, n, use_gpu):
     assert dict(ret) == {r: True for r in range(world)}
 
 
-@pytest.mark.parametrize("n", [2, 8, 32])
-def test_sharded_prover_world2_gloo_matches_single_process(n):
-    os.environ.setdefault("OMP_NUM_THREADS", "4")
-    _run(2, n, use_gpu=False)
+@pytest.mark.parametrize("world,n", [(2, 2), (2, 8), (2, 32), (4, 4), (4, 8), (4, 32), (8, 8), (8, 16), (8, 64)])
+def test_sharded_prover_gloo_matches_single_process(world, n):
+    """World sizes 2, 4 and 8 (config 4 names 8 GPUs), incl. n == world -- every rank starts with ONE element, the proof is the tail gather
+    plus log2(world) replicated rounds -- and n == 2 * world (one sharded round)."""
+    os.environ["OMP_NUM_THREADS"] = str(max(1, 8 // world))
+    _run(world, n, use_gpu=False)
 
 
 @pytest.mark.gpu
@@ -163,12 +165,12 @@ def _run_ip(world, n, use_gpu):
     assert dict(ret) == {r: True for r in range(world)}
 
 
-@pytest.mark.parametrize("n", [2, 10])
-def test_sharded_inner_products_world2_gloo(n):
+@pytest.mark.parametrize("world,n", [(2, 2), (2, 10), (4, 4), (4, 12), (8, 8), (8, 24)])
+def test_sharded_inner_products_gloo(world, n):
     """PairingInnerProduct and both MSMs over residue-sharded vectors: all-gather of one Miller value / one point per rank, one final
-    exponentiation -- equal to the unsharded result (host logic on CPU, oracle-backed primitives)."""
-    os.environ.setdefault("OMP_NUM_THREADS", "4")
-    _run_ip(2, n, use_gpu=False)
+    exponentiation -- equal to the unsharded result (host logic on CPU, oracle-backed primitives); 2, 4 and 8 ranks."""
+    os.environ["OMP_NUM_THREADS"] = str(max(1, 8 // world))
+    _run_ip(world, n, use_gpu=False)
 
 
 @pytest.mark.gpu
@@ -178,81 +180,187 @@ def test_sharded_inner_products_world2_real_engine(engine, n):
 
 
 # ---------------------------------------------------------------- native driver: round loop + collective inside libripp_hip.so
-def _native_worker(rank, world, port, n, ret):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+def _native_worker(rank, world, port, n, env, ret):
+    """One rank of `world`, all on cuda:0: the library's round loop with the all-gather supplied by the host (gloo).  Hands what it computed
+    back to the parent, which compares every rank's outputs with the oracle's on the unsharded vectors (ONE oracle run, not one per rank)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), RIPP_RANKS_PER_DEVICE=str(world))
+    os.environ.update(env)
     for p in (os.path.dirname(HERE), HERE, os.path.join(HERE, "model")):
         if p not in sys.path:
             sys.path.insert(0, p)
     import torch.distributed as dist
-    import orclib as o
     import ripp_amd as R
     from ripp_amd.sharded import NativeComm, shard, native_sipp_job_prove, native_pairing_inner_product, native_msm
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         R.init(0)
-        # both ranks share cuda:0: RCCL needs one device per rank, gloo carries the all-gather.  With RIPP_COMM_NO_RCCL the RCCL transport is
+        # the ranks share cuda:0: RCCL needs one device per rank, gloo carries the all-gather.  With RIPP_COMM_NO_RCCL the RCCL transport is
         # REQUESTED and its bring-up made to fail, so the ranks must agree on the fallback to the host's process group (what bench.py relies on)
         comm = NativeComm("rccl" if os.environ.get("RIPP_COMM_NO_RCCL") else "callback")
         assert comm.transport == "callback"
-        a, b, r = o.gen_g1(123, n), o.gen_g2(456, n), o.gen_scalars(7, n)
-        value = o.product_of_pairings_with_coeffs(a, b, r)
+        a, b, r = R.synth_g1(123, n), R.synth_g2(456, n), R.synth_fr(7, n)
+        value = R.product_of_pairings_with_coeffs(a, b, r)
         job = R.SippJob(shard(a, rank, world), shard(b, rank, world), shard(r, rank, world), rank=rank, world=world)
-        proof, ch, _ = native_sipp_job_prove(job, value, full=(a, b, r) if rank == 0 else None)
-        rc, eproof, ech = o.sipp_prove(a, b, r, value)
-        ok = rc == 0 and np.array_equal(proof, eproof) and np.array_equal(ch, ech)
+        proof, ch, st = native_sipp_job_prove(job, value, full=(a, b, r) if rank == 0 else None)
         # second proof on the same resident shard, digest precomputed by the host
         proof2, _, _ = native_sipp_job_prove(job, value, seed_digest=R.sipp_seed_digest(a, b, r, value) if rank == 0 else None)
-        ok = ok and np.array_equal(proof2, eproof)
         job.close()
-        aj, bj, s = o.blind_g1(a, 1), o.blind_g2(b, 2), o.gen_scalars(9, n)
-        ok = ok and np.array_equal(native_pairing_inner_product(shard(aj, rank, world), shard(bj, rank, world)), o.pairing_product_j(aj, bj)[1])
-        ok = ok and np.array_equal(o.g1_to_affine(native_msm(shard(aj, rank, world), shard(s, rank, world), "g1")), o.g1_to_affine(o.msm_g1_j(aj, s)[1]))
-        ok = ok and np.array_equal(o.g2_to_affine(native_msm(shard(bj, rank, world), shard(s, rank, world), "g2")), o.g2_to_affine(o.msm_g2_j(bj, s)[1]))
+        out = {"value": value, "proof": proof, "ch": ch, "proof2": proof2, "look_items": int(st["look_items"])}
+        if not env.get("RIPP_TEST_SIPP_ONLY"):
+            import orclib as o
+            aj, bj, s = o.blind_g1(a, 1), o.blind_g2(b, 2), R.synth_fr(9, n)
+            out["ip"] = native_pairing_inner_product(shard(aj, rank, world), shard(bj, rank, world))
+            out["m1"] = native_msm(shard(aj, rank, world), shard(s, rank, world), "g1")
+            out["m2"] = native_msm(shard(bj, rank, world), shard(s, rank, world), "g2")
         comm.close()
-        ret[rank] = bool(ok)
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn(fn, world, args, timeout=900):
+    """mp.spawn with a deadline: a hung collective fails the test instead of the session (the children are ended by PID, never by pattern)."""
+    import time
+    import torch.multiprocessing as mp
+    mgr = mp.Manager(); ret = mgr.dict()
+    ctx = mp.spawn(fn, args=(world, _free_port()) + tuple(args) + (ret,), nprocs=world, join=False)
+    deadline = time.time() + timeout
+    try:
+        while not ctx.join(timeout=5):
+            if time.time() > deadline:
+                raise TimeoutError(f"{world} ranks did not finish within {timeout} s: a rank hangs in a collective")
+    finally:
+        for pr in ctx.processes:
+            if pr.is_alive():
+                pr.kill()
+    return dict(ret)
+
+
+def _run_native(orc, world, n, env=None, sipp_only=False):
+    env = dict(env or {})
+    if sipp_only:
+        env["RIPP_TEST_SIPP_ONLY"] = "1"
+    got = _spawn(_native_worker, world, (n, env))
+    assert sorted(got) == list(range(world)), sorted(got)
+    o = orc
+    a, b, r = o.gen_g1(123, n), o.gen_g2(456, n), o.gen_scalars(7, n)
+    value = o.product_of_pairings_with_coeffs(a, b, r)
+    rc, eproof, ech = o.sipp_prove(a, b, r, value)
+    assert rc == 0
+    if not sipp_only:
+        aj, bj, s = o.blind_g1(a, 1), o.blind_g2(b, 2), o.gen_scalars(9, n)
+        eip = o.pairing_product_j(aj, bj)[1]; em1 = o.g1_to_affine(o.msm_g1_j(aj, s)[1]); em2 = o.g2_to_affine(o.msm_g2_j(bj, s)[1])
+    for rank in range(world):
+        g = got[rank]
+        assert np.array_equal(g["value"], value), rank
+        assert np.array_equal(g["proof"], eproof) and np.array_equal(g["ch"], ech), f"rank {rank}: proof differs from the oracle's"
+        assert np.array_equal(g["proof2"], eproof), f"rank {rank}: second proof on the resident shard differs"
+        if not sipp_only:
+            assert np.array_equal(g["ip"], eip), rank
+            assert np.array_equal(o.g1_to_affine(g["m1"]), em1) and np.array_equal(o.g2_to_affine(g["m2"]), em2), rank
+    return got
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n", [(2, 2), (2, 4), (2, 64), (2, 1 << 12),
+                                     (4, 4), (4, 8), (4, 64), (4, 1 << 12), (4, 1 << 14),
+                                     (8, 8), (8, 16), (8, 64), (8, 1 << 12), (8, 1 << 14)])
+def test_native_sharded_driver_callback_transport(engine, orc, world, n):
+    """ripp_sipp_job_prove_sharded / ripp_*_sharded_j: the library's own round loop and collectives with 2, 4 and 8 ranks on cuda:0, the
+    all-gather supplied by the host (gloo): proofs, pairing product and MSMs of EVERY rank equal the oracle's on the unsharded vectors.
+    n == world: every rank starts with one element (tail gather first, log2(world) replicated rounds -- three for 8 ranks);
+    n == 2 * world: one sharded round.  Reference loop: sipp/src/lib.rs:69-104."""
+    _run_native(orc, world, n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n,env", [(2, 16, {"RIPP_LOOK_ITEMS": "6"}), (2, 64, {"RIPP_LOOK_ITEMS": "4"}), (2, 1 << 12, {"RIPP_LOOK_ITEMS": "6"}),
+                                         (2, 1 << 14, {"RIPP_LOOK_ITEMS": "3"}),
+                                         (4, 64, {"RIPP_LOOK_EIGHTHS": "48"}), (4, 1 << 12, {"RIPP_LOOK_EIGHTHS": "45"}), (4, 1 << 14, {"RIPP_LOOK_EIGHTHS": "45"}),
+                                         (8, 128, {"RIPP_LOOK_EIGHTHS": "48"}), (8, 1 << 14, {"RIPP_LOOK_EIGHTHS": "48"}), (8, 1 << 14, {"RIPP_LOOK_EIGHTHS": "45"}),
+                                         (8, 1 << 15, {"RIPP_LOOK_EIGHTHS": "29"})])
+def test_native_sharded_driver_with_lookahead(engine, orc, world, n, env):
+    """The sharded prover with the multi-GPU look-ahead plans forced onto small statements: every rank pre-evaluates the values of rounds
+    1..3 from ITS shard's round-0 blocks, reduces them with the challenges and contributes the partial GT values; folds of those rounds are
+    not waited for.  RIPP_LOOK_EIGHTHS = 45 / 48: the plans `look_plan` picks for 4 / 8 ranks at n = 2^20 (rounds 1-2 + (3,l) + 5/8 of (3,r);
+    rounds 1-3 in full).  Proofs of every rank equal the oracle's on the unsharded vectors."""
+    got = _run_native(orc, world, n, env, sipp_only=True)
+    eighths = 8 * min(6, int(env["RIPP_LOOK_ITEMS"])) if "RIPP_LOOK_ITEMS" in env else min(48, int(env["RIPP_LOOK_EIGHTHS"]))
+    nl, want = n // world, 0
+    for it in range((eighths + 7) // 8):                            # job_lookahead's static plan: items (1,l) (1,r) (2,l) .. on blocks of nl >> (R + 1) pairs
+        qblk, frac = nl >> (it // 2 + 2), min(8, eighths - 8 * it)
+        q = qblk if frac >= 8 else (qblk * frac // 8) & ~63         # a partial item is cut to a multiple of 64 pairs
+        if q == 0:
+            break
+        want += 1
+    for rank in range(world):
+        assert got[rank]["look_items"] == want, (rank, got[rank]["look_items"], want)
+
+
+@pytest.mark.gpu
+def test_native_comm_falls_back_to_the_process_group(engine, orc):
+    """bench.py asks for the library's own RCCL communicator; when that cannot be brought up on every rank the ranks agree (one all-reduce)
+    to run the library's collectives through torch.distributed instead.  Forced here with RIPP_COMM_NO_RCCL on two ranks sharing cuda:0."""
+    _run_native(orc, 2, 64, {"RIPP_COMM_NO_RCCL": "1"})
+
+
+# ---------------------------------------------------------------- collective error exit
+def _fail_worker(rank, world, port, n, fail_rank, fail_round, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), RIPP_RANKS_PER_DEVICE=str(world))
+    for p in (os.path.dirname(HERE), HERE, os.path.join(HERE, "model")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import ctypes
+    import torch.distributed as dist
+    import ripp_amd as R
+    from ripp_amd._lib import lib
+    from ripp_amd.sharded import NativeComm, shard, native_sipp_job_prove
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        R.init(0)
+        comm = NativeComm("callback")
+        a, b, r = R.synth_g1(123, n), R.synth_g2(456, n), R.synth_fr(7, n)
+        value = R.product_of_pairings_with_coeffs(a, b, r)
+        job = R.SippJob(shard(a, rank, world), shard(b, rank, world), shard(r, rank, world), rank=rank, world=world)
+        lib().ripp_test_inject_failure.restype = None
+        if rank == fail_rank:
+            lib().ripp_test_inject_failure(ctypes.c_int32(fail_rank), ctypes.c_int32(fail_round))
+        err = None
+        try:
+            native_sipp_job_prove(job, value, full=(a, b, r) if rank == 0 else None)
+        except Exception as exc:
+            err = str(exc)
+        # the protocol is in step again (every rank left at the same exchange): the NEXT proof on the same communicator and the same
+        # resident shard succeeds -- no fresh processes needed, nothing re-executed
+        proof, ch, _ = native_sipp_job_prove(job, value, full=(a, b, r) if rank == 0 else None)
+        job.close(); comm.close()
+        ret[rank] = {"err": err, "proof": proof, "ch": ch}
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [2, 4, 64, 1 << 12])
-def test_native_sharded_driver_world2_callback_transport(engine, n):
-    """ripp_sipp_job_prove_sharded / ripp_*_sharded_j: the library's own round loop and collectives, two ranks on cuda:0 with the
-    all-gather supplied by the host (gloo): proofs, pairing product and MSMs equal the oracle's on the unsharded vectors."""
-    import torch.multiprocessing as mp
-    mgr = mp.Manager(); ret = mgr.dict()
-    mp.spawn(_native_worker, args=(2, _free_port(), n, ret), nprocs=2, join=True)
-    assert dict(ret) == {0: True, 1: True}
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("n,items", [(16, 6), (64, 4), (1 << 12, 6), (1 << 14, 3)])
-def test_native_sharded_driver_world2_with_lookahead(engine, n, items):
-    """The sharded prover with the multi-GPU look-ahead plan forced onto small statements (RIPP_LOOK_ITEMS): every rank pre-evaluates the
-    values of rounds 1..3 from ITS shard's round-0 blocks, reduces them with the challenges and contributes the partial GT values; folds of
-    those rounds are not waited for.  Proofs equal the oracle's on the unsharded vectors."""
-    import torch.multiprocessing as mp
-    os.environ["RIPP_LOOK_ITEMS"] = str(items)
-    try:
-        mgr = mp.Manager(); ret = mgr.dict()
-        mp.spawn(_native_worker, args=(2, _free_port(), n, ret), nprocs=2, join=True)
-    finally:
-        del os.environ["RIPP_LOOK_ITEMS"]
-    assert dict(ret) == {0: True, 1: True}
-
-
-@pytest.mark.gpu
-def test_native_comm_falls_back_to_the_process_group(engine):
-    """bench.py asks for the library's own RCCL communicator; when that cannot be brought up on every rank the ranks agree (one all-reduce)
-    to run the library's collectives through torch.distributed instead.  Forced here with RIPP_COMM_NO_RCCL on two ranks sharing cuda:0."""
-    import torch.multiprocessing as mp
-    os.environ["RIPP_COMM_NO_RCCL"] = "1"
-    try:
-        mgr = mp.Manager(); ret = mgr.dict()
-        mp.spawn(_native_worker, args=(2, _free_port(), 64, ret), nprocs=2, join=True)
-    finally:
-        del os.environ["RIPP_COMM_NO_RCCL"]
-    assert dict(ret) == {0: True, 1: True}
+@pytest.mark.parametrize("world,n,fail_rank,fail_round", [(2, 64, 1, 0), (4, 1 << 12, 2, 3), (8, 1 << 12, 5, 0), (8, 1 << 12, 0, 4), (8, 64, 7, 2), (4, 1 << 14, 3, 12)])
+def test_collective_error_exit_no_rank_hangs(engine, orc, world, n, fail_rank, fail_round):
+    """ONE rank fails locally in the fold of round r (ripp_test_inject_failure).  Every message of the protocol carries the sender's status, so
+    the failing rank keeps walking the skeleton until the next exchange has told the others: EVERY rank returns an error (nothing hangs: the
+    spawn has a deadline), and the next proof on the same communicator equals the oracle's.  Last case: the failing round lies in the
+    replicated tail (after the gather) -- a local matter of that rank, the others finish their proof."""
+    got = _spawn(_fail_worker, world, (n, fail_rank, fail_round), timeout=600)
+    assert sorted(got) == list(range(world))
+    sharded_rounds = (n // world).bit_length() - 1                  # rounds whose exchange is collective
+    a, b, r = orc.gen_g1(123, n), orc.gen_g2(456, n), orc.gen_scalars(7, n)
+    value = orc.product_of_pairings_with_coeffs(a, b, r)
+    rc, eproof, ech = orc.sipp_prove(a, b, r, value)
+    for rank in range(world):
+        if fail_round < sharded_rounds:
+            assert got[rank]["err"], f"rank {rank} returned success although rank {fail_rank} failed in round {fail_round}"
+            assert ("injected failure" in got[rank]["err"]) == (rank == fail_rank), got[rank]["err"]
+            if rank != fail_rank:
+                assert f"rank {fail_rank} failed" in got[rank]["err"], got[rank]["err"]
+        else:
+            assert bool(got[rank]["err"]) == (rank == fail_rank), (rank, got[rank]["err"])
+        assert np.array_equal(got[rank]["proof"], eproof) and np.array_equal(got[rank]["ch"], ech), f"rank {rank}: the proof after the failure differs"
 
 
 _RCCL_SCRIPT = r"""
@@ -300,76 +408,96 @@ def test_native_rccl_transport_single_rank(engine):
 
 
 # ---------------------------------------------------------------- sharded GIPA / aggregate_proofs (config 5 across ranks)
-def _agg_worker(rank, world, port, n, ret):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+def _agg_worker(rank, world, port, path, ret):
+    """One rank of the sharded GIPA / TIPP prover and of ripp_aggregate_proofs_sharded on the instance the parent prepared (`path`);
+    hands every output back to the parent."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), RIPP_RANKS_PER_DEVICE=str(world))
     for p in (os.path.dirname(HERE), HERE, os.path.join(HERE, "model")):
         if p not in sys.path:
             sys.path.insert(0, p)
     import torch.distributed as dist
-    import orclib as o
-    import helpers as h
     import ripp_amd as R
+    from ripp_amd._lib import AggregateProof
     from ripp_amd.sharded import NativeComm, shard
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         R.init(0)
         comm = NativeComm("callback")
-        ok = True
-        # GIPA / TIPP on sharded vectors vs the oracle's prover on the whole vectors
-        m_a, m_b = o.blind_g1(o.gen_g1(11, n), 1), o.blind_g2(o.gen_g2(22, n), 2)
-        ck_a, ck_b = o.blind_g2(o.gen_g2(33, n), 3), o.blind_g1(o.gen_g1(44, n), 4)
-        steps, tr, (ba, bb), (ka, kb) = R.gipa_tipp_prove_sharded(shard(m_a, rank, world), shard(m_b, rank, world), shard(ck_a, rank, world), shard(ck_b, rank, world))
-        rc, esteps, etr, eba, ebb, eka, ekb = o.gipa_tipp_prove(m_a, m_b, ck_a, ck_b)
-        ok = ok and rc == 0 and np.array_equal(steps, esteps) and np.array_equal(tr, etr)
-        ok = ok and np.array_equal(o.g1_to_affine(ba), o.g1_to_affine(eba)) and np.array_equal(o.g2_to_affine(bb), o.g2_to_affine(ebb))
-        ok = ok and np.array_equal(o.g2_to_affine(ka), o.g2_to_affine(eka)) and np.array_equal(o.g1_to_affine(kb), o.g1_to_affine(ekb))
-        # aggregate_proofs: every member equal to the oracle's, and the oracle's verifier accepts
-        osrs = h.make_srs(n, 0xa1fa + n, 0xbe7a + n); srs = R.SRS(osrs[0], osrs[1], osrs[2], osrs[3])
-        vk, pub, a, b, c = h.fake_groth16(n, 2, seed=n)
-        got, _ = R.aggregate_proofs_sharded(srs, shard(a, rank, world), shard(b, rank, world), shard(c, rank, world))
-        rc, exp = o.aggregate_proofs(osrs[0], osrs[1], a, b, c)
-        ok = ok and rc == 0
-        rounds = n.bit_length() - 1
-        for k in ("com_a", "com_b", "com_c", "ip_ab", "r", "ab_kzg_c", "c_base_b", "c_kzg_c"):
-            ok = ok and np.array_equal(got.field(k), exp.field(k))
-        for k in ("ab_com_steps", "ab_transcript", "c_com_gt", "c_transcript"):
-            ok = ok and np.array_equal(getattr(got, k), getattr(exp, k))
-        for k in ("agg_c", "ab_base_a", "ab_final_ck_b", "ab_opening_b", "c_base_a"):
-            ok = ok and np.array_equal(o.g1_to_affine(got.field(k)), o.g1_to_affine(exp.field(k)))
-        for k in ("ab_base_b", "ab_final_ck_a", "ab_opening_a", "c_final_ck_a", "c_opening_a"):
-            ok = ok and np.array_equal(o.g2_to_affine(got.field(k)), o.g2_to_affine(exp.field(k)))
-        ok = ok and np.array_equal(o.normalize_g1(got.c_com_g1[: 2 * rounds]), o.normalize_g1(exp.c_com_g1[: 2 * rounds]))
-        ok = ok and o.verify_aggregate_proof(h.verifier_srs(osrs), vk, pub, got) == 1
+        d = np.load(path)
+        sh = lambda k: shard(d[k], rank, world)
+        steps, tr, (ba, bb), (ka, kb) = R.gipa_tipp_prove_sharded(sh("m_a"), sh("m_b"), sh("ck_a"), sh("ck_b"))
+        out = {"steps": steps, "tr": tr, "ba": ba, "bb": bb, "ka": ka, "kb": kb}
+        srs = R.SRS(d["gap"], d["hbp"], d["g_beta"], d["h_alpha"])
+        got, _ = R.aggregate_proofs_sharded(srs, sh("a"), sh("b"), sh("c"))
+        for k in AggregateProof.FIXED:
+            out["agg_" + k] = np.array(got.field(k))
+        for k in AggregateProof.STEPS:
+            out["agg_" + k] = np.array(getattr(got, k))
         srs.close(); comm.close()
-        ret[rank] = bool(ok)
+        ret[rank] = out
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [2, 8, 256, 1 << 14])
-def test_sharded_gipa_and_aggregate_world2(engine, n):
-    """ripp_gipa_tipp_prove_sharded / ripp_aggregate_proofs_sharded with two ranks (callback transport on cuda:0): commitments of every
-    round, transcripts, base cases, KZG openings and the aggregate's members equal the oracle's on the unsharded vectors."""
-    import torch.multiprocessing as mp
-    mgr = mp.Manager(); ret = mgr.dict()
-    mp.spawn(_agg_worker, args=(2, _free_port(), n, ret), nprocs=2, join=True)
-    assert dict(ret) == {0: True, 1: True}
+@pytest.mark.parametrize("world,n", [(2, 2), (2, 8), (2, 256), (2, 1 << 14), (4, 4), (4, 8), (4, 256), (4, 1 << 14), (8, 8), (8, 16), (8, 256), (8, 1 << 14)])
+def test_sharded_gipa_and_aggregate(engine, orc, tmp_path, world, n):
+    """ripp_gipa_tipp_prove_sharded / ripp_aggregate_proofs_sharded with 2, 4 and 8 ranks (callback transport on cuda:0; n == world: every rank
+    holds ONE proof): commitments of every round, transcripts, base cases, KZG openings and every member of the aggregate -- on EVERY rank --
+    equal the oracle's on the unsharded vectors, and the oracle's verifier accepts.  2^14 is config 5's size (groth16_aggregation.rs:77-160)."""
+    import helpers as h
+    from ripp_amd._lib import AggregateProof
+    o = orc
+    m_a, m_b = o.blind_g1(engine.synth_g1(11, n), 1), o.blind_g2(engine.synth_g2(22, n), 2)
+    ck_a, ck_b = o.blind_g2(engine.synth_g2(33, n), 3), o.blind_g1(engine.synth_g1(44, n), 4)
+    osrs = h.make_srs(n, 0xa1fa + n, 0xbe7a + n)
+    vk, pub, a, b, c = h.fake_groth16(n, 2, seed=n)
+    path = str(tmp_path / "instance.npz")
+    np.savez(path, m_a=m_a, m_b=m_b, ck_a=ck_a, ck_b=ck_b, gap=osrs[0], hbp=osrs[1], g_beta=osrs[2], h_alpha=osrs[3], a=a, b=b, c=c)
+    got = _spawn(_agg_worker, world, (path,), timeout=1200)
+    assert sorted(got) == list(range(world))
+    rc, esteps, etr, eba, ebb, eka, ekb = o.gipa_tipp_prove(m_a, m_b, ck_a, ck_b)
+    assert rc == 0
+    rc, exp = o.aggregate_proofs(osrs[0], osrs[1], a, b, c)
+    assert rc == 0
+    rounds = n.bit_length() - 1
+    for rank in range(world):
+        g = got[rank]
+        assert np.array_equal(g["steps"], esteps) and np.array_equal(g["tr"], etr), rank
+        assert np.array_equal(o.g1_to_affine(g["ba"]), o.g1_to_affine(eba)) and np.array_equal(o.g2_to_affine(g["bb"]), o.g2_to_affine(ebb)), rank
+        assert np.array_equal(o.g2_to_affine(g["ka"]), o.g2_to_affine(eka)) and np.array_equal(o.g1_to_affine(g["kb"]), o.g1_to_affine(ekb)), rank
+        for k in ("com_a", "com_b", "com_c", "ip_ab", "r", "ab_kzg_c", "c_base_b", "c_kzg_c"):
+            assert np.array_equal(g["agg_" + k], exp.field(k)), (rank, k)
+        for k in ("ab_com_steps", "ab_transcript", "c_com_gt", "c_transcript"):
+            assert np.array_equal(g["agg_" + k], getattr(exp, k)), (rank, k)
+        for k in ("agg_c", "ab_base_a", "ab_final_ck_b", "ab_opening_b", "c_base_a"):
+            assert np.array_equal(o.g1_to_affine(g["agg_" + k]), o.g1_to_affine(exp.field(k))), (rank, k)
+        for k in ("ab_base_b", "ab_final_ck_a", "ab_opening_a", "c_final_ck_a", "c_opening_a"):
+            assert np.array_equal(o.g2_to_affine(g["agg_" + k]), o.g2_to_affine(exp.field(k))), (rank, k)
+        assert np.array_equal(o.normalize_g1(g["agg_c_com_g1"][: 2 * rounds]), o.normalize_g1(exp.c_com_g1[: 2 * rounds])), rank
+    # the oracle's verifier accepts what the ranks produced (rank world - 1's copy, rebuilt into the struct)
+    pf = AggregateProof(n); g = got[world - 1]
+    for k in AggregateProof.FIXED:
+        pf.field(k)[...] = g["agg_" + k]
+    for k in AggregateProof.STEPS:
+        getattr(pf, k)[...] = g["agg_" + k]
+    assert o.verify_aggregate_proof(h.verifier_srs(osrs), vk, pub, pf) == 1
 
 
 @pytest.mark.gpu
-def test_bench_two_ranks_on_one_device_reports_the_hash_excluded_figures(engine):
-    """`bench.py --gpus 2` end to end (self-launch through torch.distributed.run, two rank processes on cuda:0, the library's collectives over
+@pytest.mark.parametrize("gpus", [2, 8])
+def test_bench_ranks_on_one_device_reports_the_hash_excluded_figures(engine, gpus):
+    """`bench.py --gpus 2 / 8` end to end (self-launch through torch.distributed.run, the rank processes on cuda:0, the library's collectives over
     gloo): the JSON line keeps `value` end to end and adds what makes an N > 1 curve readable -- the time rank 0 was blocked on the statement
     hash, the rest of the step, the hash-excluded rate, the look-ahead the ranks ran in the window, the time in the per-round exchanges."""
     import json
     import subprocess
     env = dict(os.environ, RIPP_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--log-n", "17"], env=env, capture_output=True, text=True, timeout=900)
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", str(gpus), "--steps", "1", "--warmup", "1", "--log-n", "17"], env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
-    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["n"] == 1 << 17
+    assert out["n_gpus"] == gpus and out["scaling"] == "strong" and out["config"]["n"] == 1 << 17 and out["config"]["sharding"] == "index residue mod %d" % gpus
     for k in ("hash_wait_ms", "statement_hash_ms", "exchange_ms", "look_ms"):
         assert k in out["phase_ms"], k
     assert out["gpu_phase_ms"] > 0 and abs(out["gpu_phase_ms"] - (out["ms_per_step"] - out["phase_ms"]["hash_wait_ms"])) < 1e-3
