@@ -2,16 +2,21 @@
 """bench.py -- SIPP prover pairing-products/sec at n = 2^20 on BLS12-381 (BASELINE.json's metric).
 
 One "step" = one complete SIPP::prove (sipp/src/lib.rs:42-106: statement hash, a_i <- r_i a_i, log2 n rounds of
-two pairing products + Fiat-Shamir + two folds) over a synthetic statement of n random-looking G1 x G2 pairs that
-is already resident in HBM when the timed region starts.  `value` = n / t_step  (pairs per second, whole job).
+two pairing products + Fiat-Shamir + two folds) over a synthetic statement of n random-looking G1 x G2 pairs,
+called the way SURVEY.md section 8(d) defines the metric: `ripp_sipp_prove` on HOST slices (the statement in pinned
+host memory; the upload happens inside the call, the statement hash starts on the caller's buffers before it).
+`value` = n / t_step (pairs per second, whole job).  `value_resident` is the same proof from a statement already
+resident in HBM (ripp_sipp_job_prove), timed over the same number of steps right after.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--log-n 20]
   N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
-          (one rank per GPU, RCCL; STRONG scaling: n is fixed, shards are index residues mod N)
+          (one rank per GPU, RCCL; STRONG scaling: n is fixed, shards are index residues mod N; the step is
+           ripp_sipp_prove_sharded on every rank's host shard)
 
 Extra objects on the JSON line: "roofline" (dominant kernel, algorithmic HBM bytes / measured launch time vs the
-8 TB/s peak -- this path is integer-ALU bound) and "cpu_baseline" (the CPU oracle = a C/OpenMP
-restatement of the reference algorithm, timed on this box's host cores on a bounded sample; rank 0, N = 1 only).
+8 TB/s peak -- this path is integer-ALU bound, see DESIGN.md -- with the multiply-adds the kernel executes against the
+hardware's issue rate under "int_alu") and "cpu_baseline" (the CPU oracle = a C/OpenMP restatement of the reference
+algorithm, timed on this box's host cores AT THE HEADLINE SIZE; rank 0, N = 1 only).
 """
 import argparse
 import json
@@ -24,13 +29,16 @@ sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_PAIR = 288          # one affine G1 (96 B) + one affine G2 (192 B) read once
 HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-# Integer-ALU roofs for the 381-bit Montgomery product of the dominant kernel (12 x 32-bit limbs: 288 v_mad_u64_u32 per product):
-#   "mad_issue": the hardware's measured v_mad_u64_u32 issue rate, 34.7 T lane-MAD/s (profiles/r01_ubench_valu_rates.txt) / 288
-#   "multiplier": the multiplier's own measured chip rate (every MAD is followed by the v_addc_co_u32 that captures its carry),
-#                 profiles/r02_fpbench_production.txt.  (The carry-free 14 x 28-bit form of the fold kernels and the field VM, fq28.hpp,
-#                 reaches 78.5 G products/s: profiles/r02_fqbench.txt.)
-MAD_ISSUE_PEAK_G = 34.72e3 / 288
-FP_MUL_PEAK_G = 59.96
+# Integer roof of the dominant kernels: 32 x 32 + 64 -> 64 multiply-adds (v_mad_u64_u32), counted from the code, per pair:
+#   k_line_products_q  68 lines x 3 lanes x 5 488 (12 lazily reduced six-product sums of 196 each + their 196-MAD reductions, fq_line_products.hpp)
+#   k_miller_lines_q   63 doubling steps x 9 800 (6 Fp2 squares of 784, 3 Fp2 products of 1 176, 2 Fp2 x Fp of 784) + 5 addition steps x 16 072 (fq_miller.hpp)
+#   k_line_products    68 x 3 x 8 064, k_miller_lines (63 x 25 + 5 x 41) Fp products x 288: the 12 x 32-bit forms (BLS12-377, RIPP_NO_FQ), every MAD followed by a carry capture
+MADS_PER_PAIR = {"k_line_products_q": 68 * 3 * 5488, "k_miller_lines_q": 63 * 9800 + 5 * 16072,
+                 "k_line_products": 68 * 3 * 8064, "k_miller_lines": (63 * 25 + 5 * 41) * 288}
+MAD_ISSUE_PEAK_T = 34.72          # T lane-MAD/s, the hardware's measured v_mad_u64_u32 issue rate (profiles/r01_ubench_valu_rates.txt)
+# what an isolated multiplier chain reaches, in the same unit: carry-free 14 x 28-bit product 78.5 G/s x 392 MADs (profiles/r03_fqbench.txt);
+# 12 x 32-bit product 59.96 G/s x 288 MADs (profiles/r03_fpbench_production.txt)
+MULTIPLIER_PEAK_T = {"q": 78.5e-3 * 392, "32": 59.96e-3 * 288}
 
 
 def csrc_sha256():
@@ -68,22 +76,28 @@ def self_launch(args):
     sys.exit(p.returncode if p.returncode or line else 1)
 
 
-def cpu_baseline(log_n_sample):
-    """Time the CPU oracle's SIPP prover on all host cores for a bounded sample (same generator, smaller n)."""
+def cpu_baseline(log_n_sample, statement=None):
+    """Time the CPU oracle's SIPP prover on all host cores -- by default at the headline size itself (n = 2^20: ~85 s on the pool's 16-CPU
+    quota), as the reference's harness times every size itself (sipp/examples/scaling-ipp.rs:57-82) -- and on ONE thread at n = 2^14."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
     import orclib as o
     o.lib().orc_set_num_threads(o.effective_cpus())          # = the cgroup CPU quota of this box (16 on the GPU pool)
     n = 1 << log_n_sample
-    a, b, r = o.gen_g1(1000, n), o.gen_g2(2000, n), o.gen_scalars(0, n)
-    value = o.product_of_pairings_with_coeffs(a, b, r)
+    if statement is not None and len(statement[0]) >= n:     # the engine's synthetic statement (the same generator: __graft_entry__.smoke() asserts it) and its value
+        a, b, r = (np.ascontiguousarray(v[:n]) for v in statement[:3])
+        value = statement[3] if len(statement[0]) == n else o.product_of_pairings_with_coeffs(a, b, r)
+    else:
+        a, b, r = o.gen_g1(1000, n), o.gen_g2(2000, n), o.gen_scalars(0, n)
+        value = o.product_of_pairings_with_coeffs(a, b, r)
     t0 = time.perf_counter()
     rc, _, _ = o.sipp_prove(a, b, r, value)
     dt = time.perf_counter() - t0
     assert rc == 0
     out = {"value": n / dt, "unit": "pairs/s", "cores": int(o.lib().orc_num_threads()), "kind": "port",
-           "sample": f"oracle sipp_prove, n=2^{log_n_sample}, same synthetic generator (seeds 1000/2000/0), one run of {dt:.2f} s"}
+           "sample": f"oracle sipp_prove, n=2^{log_n_sample} (the headline statement itself when 20), same synthetic generator (seeds 1000/2000/0), one run of {dt:.2f} s"}
     # the per-core figure BASELINE.md section 2 asks for: the same prover on ONE thread, on a smaller sample of the same statement
-    n1 = 1 << min(log_n_sample, 13)
+    n1 = 1 << min(log_n_sample, 14)
     o.lib().orc_set_num_threads(1)
     v1 = o.product_of_pairings_with_coeffs(a[:n1], b[:n1], r[:n1])
     t0 = time.perf_counter()
@@ -98,10 +112,10 @@ def cpu_baseline(log_n_sample):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log-n", type=int, default=20)
-    ap.add_argument("--cpu-log-n", type=int, default=18, help="log2 size of the CPU-baseline sample (0 disables)")
+    ap.add_argument("--cpu-log-n", type=int, default=20, help="log2 size of the CPU-baseline run (default: the headline size, ~85 s on 16 CPUs; 0 disables)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -115,7 +129,7 @@ def main():
     import numpy as np
     import torch
     import ripp_amd as R
-    from ripp_amd.sharded import NativeComm, native_sipp_job_prove
+    from ripp_amd.sharded import NativeComm, native_sipp_job_prove, native_sipp_prove
 
     # test hooks (used on 1-GPU boxes to exercise the N > 1 control flow): all ranks on device 0, gloo transport
     single_dev = bool(os.environ.get("RIPP_BENCH_SINGLE_DEVICE"))
@@ -141,61 +155,78 @@ def main():
     # ---- synthetic statement: a_i = (1000+i) G1, b_i = (2000+i) G2, r_i from SplitMix64(0) ----
     # every rank generates its shard on its own GPU; rank 0 additionally holds the full statement on the host because
     # the prover hashes ALL of it (sipp/src/lib.rs:56-59).  `value` (the claimed product) is part of the statement.
+    # The host copies live in PINNED memory (section 8d: "from host inputs resident in pinned memory"), unless RIPP_BENCH_PAGEABLE is set.
+    def pinned(arr):
+        if os.environ.get("RIPP_BENCH_PAGEABLE"):
+            return arr
+        t = torch.empty(arr.shape, dtype=torch.int64, pin_memory=True)
+        v = t.numpy().view(np.uint64); v[...] = arr
+        keep.append(t)
+        return v
+    keep = []
     if world == 1:
-        a, b, r = R.synth_g1(1000, n), R.synth_g2(2000, n), R.synth_fr(0, n)
+        a, b, r = (pinned(v) for v in (R.synth_g1(1000, n), R.synth_g2(2000, n), R.synth_fr(0, n)))
         full = (a, b, r)
         value = R.product_of_pairings_with_coeffs(a, b, r)
     else:
         nl = n // world
-        a, b, r = R.synth_g1(1000, nl, first=rank, stride=world), R.synth_g2(2000, nl, first=rank, stride=world), R.synth_fr(0, nl, first=rank, stride=world)
+        a, b, r = (pinned(v) for v in (R.synth_g1(1000, nl, first=rank, stride=world), R.synth_g2(2000, nl, first=rank, stride=world), R.synth_fr(0, nl, first=rank, stride=world)))
         value = np.zeros(72, dtype=np.uint64); full = None
         if rank == 0:
-            full = (R.synth_g1(1000, n), R.synth_g2(2000, n), R.synth_fr(0, n))
+            full = tuple(pinned(v) for v in (R.synth_g1(1000, n), R.synth_g2(2000, n), R.synth_fr(0, n)))
             value = R.product_of_pairings_with_coeffs(*full)
         t = torch.from_numpy(value.view(np.int64).copy()); t = t.cuda() if backend == "nccl" else t
         dist.broadcast(t, src=0); value = t.cpu().numpy().view(np.uint64)
-
-    job = R.SippJob(a, b, r, rank=rank, world=world)      # statement (shard) now resident in HBM
-
-    def one_step():
-        if world == 1:
-            proof, ch, st = job.prove(value)              # hashing overlaps the first kernels inside the engine
-            return proof, st
-        # ripp_sipp_job_prove_sharded: rank 0 hashes the full statement on a host thread of the library while all ranks run round 0
-        proof, ch, st = native_sipp_job_prove(job, value, full=full if rank == 0 else None)
-        return proof, st
 
     def fence():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        proof, st = one_step()
-    times, stats, ref_proof = [], None, None
-    for _ in range(args.steps):
-        fence(); t0 = time.perf_counter()
-        proof, st = one_step()
-        fence(); times.append(time.perf_counter() - t0)
-        stats = st
-        if ref_proof is None:
-            ref_proof = proof
-        assert np.array_equal(proof, ref_proof), "non-deterministic proof"
-    total = sum(times)
-    if dist is not None:
-        tt = torch.tensor([total], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu"); dist.all_reduce(tt, op=dist.ReduceOp.MAX); total = float(tt.item())
-    ms_per_step = total / args.steps * 1e3
+    def timed(step, warmup, steps, ref_proof):
+        """W untimed + exactly K timed steps, each bracketed by barrier + synchronize; (sum of the K times, MAX over ranks; per-step times; last stats; proof)"""
+        for _ in range(warmup):
+            proof, st = step()
+        times, stats_all = [], []
+        for _ in range(steps):
+            fence(); t0 = time.perf_counter()
+            proof, st = step()
+            fence(); times.append(time.perf_counter() - t0)
+            stats_all.append(st)
+            if ref_proof is None:
+                ref_proof = proof
+            assert np.array_equal(proof, ref_proof), "non-deterministic proof"
+        total = sum(times)
+        if dist is not None:
+            tt = torch.tensor([total] + times, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu"); dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            total = float(tt[0].item()); times = [float(x) for x in tt[1:].tolist()]
+        return total, times, stats_all, ref_proof
 
-    # the call SURVEY.md section 8(d) defines the metric on: ripp_sipp_prove from HOST slices (upload of the 336 MB statement inside the call,
-    # the statement hash started on the caller's buffers before it).  Reported beside `value` (resident statement), never as `value`.
-    host_slices_ms = None
-    if world == 1:
-        job.close(); job = None
-        ts = []
-        for _ in range(2):
-            t0 = time.perf_counter(); p2 = R.SIPP.prove(a, b, r, value); ts.append(time.perf_counter() - t0)
-            assert np.array_equal(p2, ref_proof), "one-shot proof differs from the resident-statement proof"
-        host_slices_ms = min(ts) * 1e3
+    # ---- the timed region: the section 8(d) call.  HOST slices in, proof bytes out; upload of the statement (shard) inside the call
+    def host_step():
+        if world == 1:
+            proof, ch, st = R.SIPP.prove_one_shot(a, b, r, value)       # ripp_sipp_prove: hashing starts on the caller's buffers, overlaps the upload and the first kernels
+        else:
+            proof, ch, st = native_sipp_prove(a, b, r, value, full=full if rank == 0 else None)      # ripp_sipp_prove_sharded
+        return proof, st
+    total, times, stats_all, ref_proof = timed(host_step, args.warmup, args.steps, None)
+    ms_per_step = total / args.steps * 1e3
+    ms_median = sorted(times)[len(times) // 2] * 1e3 if len(times) % 2 else 0.5 * (sorted(times)[len(times) // 2 - 1] + sorted(times)[len(times) // 2]) * 1e3
+    stats = stats_all[-1]
+    hash_ms_steps = [st["statement_hash_ms"] + st["statement_hash_wait_ms"] for st in stats_all]        # THIS call's hash, per step (rank 0)
+
+    # ---- the same proof from a statement (shard) already resident in HBM: ripp_sipp_job_prove[_sharded]; same number of steps
+    job = R.SippJob(a, b, r, rank=rank, world=world)
+
+    def resident_step():
+        if world == 1:
+            proof, ch, st = job.prove(value)
+        else:
+            proof, ch, st = native_sipp_job_prove(job, value, full=full if rank == 0 else None)
+        return proof, st
+    total_res, times_res, stats_res, _ = timed(resident_step, 1, args.steps, ref_proof)
+    resident_ms = total_res / args.steps * 1e3
+    job.close(); job = None
 
     if rank == 0:
         # dominant kernel of the path on this rank, from HIP events recorded on the engine's own stream
@@ -219,54 +250,55 @@ def main():
                     traffic = tr["bytes_per_launch"] if tr else None
         except Exception:
             traffic = None
+        mads = MADS_PER_PAIR[dom[3]]
+        mad_rate_t = dom[2] * mads / (dom[0] * 1e-3) / 1e12 if dom[0] > 0 else 0.0            # T multiply-adds per second inside the kernel
+        mult_peak_t = MULTIPLIER_PEAK_T["q" if dom[3].endswith("_q") else "32"]
+        hash_ms = sum(hash_ms_steps) / len(hash_ms_steps)
         out = {
             "metric": "SIPP prover pairing-products/sec at n=2^%d BLS12-381" % args.log_n,
             "value": n / (ms_per_step * 1e-3), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": "sipp_prove (all log2 n rounds, Blake2s Fiat-Shamir)", "curve": "BLS12-381", "n": n,
-                       "sharding": "index residue mod %d" % world, "inputs": "a_i=(1000+i)G1, b_i=(2000+i)G2, r_i=SplitMix64(0) 254-bit"},
+                       "sharding": "index residue mod %d" % world, "inputs": "a_i=(1000+i)G1, b_i=(2000+i)G2, r_i=SplitMix64(0) 254-bit",
+                       "call": ("ripp_sipp_prove" if world == 1 else "ripp_sipp_prove_sharded") + " on host slices (%s), upload inside the timed call" % ("pageable" if os.environ.get("RIPP_BENCH_PAGEABLE") else "pinned")},
+            # the step is bound by the HOST's sequential Blake2s of the 336 B x n statement, whose speed differs by a few per cent from box to box: read `value` next to it
+            "statement_hash_ms": round(hash_ms, 3), "ms_per_step_median": ms_median, "value_median": n / (ms_median * 1e-3),
+            "ms_per_step_all": [round(t * 1e3, 3) for t in times],
+            "value_resident": n / (resident_ms * 1e-3), "ms_per_step_resident": resident_ms,
             "roofline": {"bound": "hbm", "kernel": dom[3], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": dom[2] * ALG_BYTES_PER_PAIR / max(dom[1], 1),
                          "avg_launch_ms": dom[0] / max(dom[1], 1), "launches_per_step": dom[1], "pairs_per_step": dom[2],
-                         # the roof that actually binds: 381-bit Montgomery products on the VALU.  Algorithmic Fp products per pair of the
-                         # kernel (k_line_products: 68 sparse mul_by_014 of 13 Fp2 = 39 Fp products; k_miller_lines: 63 doubling steps of 25
-                         # + 5 addition steps of 41) against the multiplier's measured chip rate (profiles/r02_fpbench_production.txt).
-                         "int_alu": (lambda fpm: {"unit": "G Fp-mul/s", "achieved": dom[2] * fpm / (dom[0] * 1e-3) / 1e9 if dom[0] > 0 else 0.0,
-                                                  "peak": MAD_ISSUE_PEAK_G, "peak_kind": "hardware v_mad_u64_u32 issue rate / 288 MADs per product",
-                                                  "frac": (dom[2] * fpm / (dom[0] * 1e-3) / 1e9 / MAD_ISSUE_PEAK_G) if dom[0] > 0 else 0.0,
-                                                  "multiplier_peak": FP_MUL_PEAK_G,
-                                                  "frac_of_multiplier": (dom[2] * fpm / (dom[0] * 1e-3) / 1e9 / FP_MUL_PEAK_G) if dom[0] > 0 else 0.0,
-                                                  # (multiplier_peak is the standalone 12 x 32-bit multiplier of profiles/r02_fpbench_production.txt: the carry-free kernels need fewer
-                                                  #  instructions per product and may exceed it.)  The ceiling of a kernel that runs at 2 waves per SIMD: a lone wave issues one
-                                                  #  v_mad_u64_u32 per 3.99 ns, two waves one per 2.11 ns, eight one per 1.89 ns (profiles/r01_ubench_valu_rates.txt).
-                                                  "occupancy_ceiling": {"waves_per_simd": 2, "frac_of_issue_roof": round(1.89 / 2.11, 3)},
-                                                  "fp_products_per_pair": fpm})(68 * 39 if dom[3].startswith("k_line_products") else 63 * 25 + 5 * 41),
-                         "note": "integer-ALU bound (381-bit Montgomery arithmetic, ~5e3 Fp products per 288 input bytes); see DESIGN.md"},
+                         # the roof that actually binds: multiply-adds on the VALU.  `achieved` = the MADs the kernel EXECUTES (counted from its code,
+                         # MADS_PER_PAIR above) per second of its launches; `peak` = the hardware's measured MAD issue rate; `multiplier_peak` = what an
+                         # isolated product chain of the same limb form reaches (it pays for its non-MAD instructions too).  The ceiling of a kernel that
+                         # runs at 2 waves per SIMD: a lone wave issues one v_mad_u64_u32 per 3.99 ns, two waves one per 2.11 ns, eight one per 1.89 ns.
+                         "int_alu": {"unit": "T MAD/s", "achieved": mad_rate_t, "peak": MAD_ISSUE_PEAK_T, "peak_kind": "measured v_mad_u64_u32 issue rate of the chip",
+                                     "frac": mad_rate_t / MAD_ISSUE_PEAK_T, "mads_per_pair": mads,
+                                     "multiplier_peak": mult_peak_t, "multiplier_kind": "isolated %s Montgomery product chain, MADs/s" % ("14 x 28-bit carry-free" if dom[3].endswith("_q") else "12 x 32-bit"),
+                                     "frac_of_multiplier": mad_rate_t / mult_peak_t,
+                                     "occupancy_ceiling": {"waves_per_simd": 2, "frac_of_issue_roof": round(1.89 / 2.11, 3)}},
+                         "note": "integer-ALU bound (381-bit Montgomery arithmetic, ~1.8 M multiply-adds per 288 input bytes); see DESIGN.md"},
             "phase_ms": {k: round(v, 3) for k, v in stats.items() if k.endswith("_ms")},
         }
         # What the statement hash hides: the prover cannot draw its first challenge before rank 0 has hashed the whole
         # statement with a sequential Blake2s.  hash_wait_ms = time rank 0 was BLOCKED on that hash (everything the GPUs could do without a
         # challenge -- scaling, round 0, fold tables, the look-ahead of rounds 1..k -- was done by then); gpu_phase_ms = the rest of the step;
         # value_excl_hash = n / gpu_phase_ms -- the figure that scales with the number of GPUs.  `value` stays end to end.
-        hd = R.statement_hash_times()
-        out["phase_ms"]["hash_wait_ms"] = round(stats["hash_ms"], 3)
-        out["phase_ms"]["statement_hash_ms"] = round(hd[0] + hd[1], 3)
-        out["gpu_phase_ms"] = ms_per_step - stats["hash_ms"]
-        out["value_excl_hash"] = n / ((ms_per_step - stats["hash_ms"]) * 1e-3)
+        hash_wait = sum(st["hash_ms"] for st in stats_all) / len(stats_all)
+        out["phase_ms"]["hash_wait_ms"] = round(hash_wait, 3)
+        out["gpu_phase_ms"] = ms_per_step - hash_wait
+        out["value_excl_hash"] = n / ((ms_per_step - hash_wait) * 1e-3)
         # The look-ahead FILLS the window (hash_wait_ms -> 0 by design), so the figure that shows what more GPUs buy is the time the proof needs
-        # AFTER the digest exists: post_hash_ms = step - duration of the statement hash (last step's hash; DESIGN.md section 6 has the model).
-        out["post_hash_ms"] = ms_per_step - (hd[0] + hd[1])
+        # AFTER the digest exists: post_hash_ms = step - duration of the statement hash OF THE SAME CALLS (ripp_stats.statement_hash_ms, averaged
+        # over the timed steps; DESIGN.md section 6 has the model).
+        out["post_hash_ms"] = ms_per_step - hash_ms
+        out["post_hash_ms_resident"] = resident_ms - sum(st["statement_hash_ms"] + st["statement_hash_wait_ms"] for st in stats_res) / len(stats_res)
         out["look_ahead"] = {"items": int(stats["look_items"]), "pairs": int(stats["look_pairs"]), "order": "(1,l) (1,r) (2,l) (2,r) (3,l) (3,r)"}
-        if host_slices_ms is not None:
-            out["host_slices_ms"] = host_slices_ms
-            out["value_host_slices"] = n / (host_slices_ms * 1e-3)
         if world == 1 and args.cpu_log_n > 0:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_log_n)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_log_n, (a, b, r, value))
         print(json.dumps(out), flush=True)
-    if job is not None:
-        job.close()
     if dist is not None:
         dist.barrier(); comm.close(); dist.destroy_process_group()
 

@@ -47,11 +47,19 @@ typedef struct {
     double kernel_miller_lines_ms_sum, kernel_line_products_ms_sum;   /* summed launch durations of the two dominant kernels */
     uint64_t kernel_miller_lines_launches, kernel_line_products_launches;
     uint64_t pairs_lines, pairs_products;                             /* units processed by those launches */
-    /* sharded proofs and the hash-window look-ahead (appended in build round 3; older callers read a prefix) */
+    /* sharded proofs and the hash-window look-ahead (appended in build round 3) */
     double exchange_ms;                                               /* time spent in the per-round all-gathers (incl. waiting for the slowest rank) */
     double look_ms;                                                   /* device + host time of the look-ahead evaluation of rounds 1..k in the hash window */
     uint64_t look_items, look_pairs;                                  /* (round, side) values pre-evaluated; pairs that took */
+    /* the statement hash of THIS call (appended in build round 4; 0 on ranks that did not hash): Blake2s itself / waiting for the serialisation workers */
+    double statement_hash_ms, statement_hash_wait_ms;
 } ripp_stats;
+/* ABI guard.  The library WRITES sizeof(ripp_stats) bytes through every `ripp_stats*` it is given, and the struct has grown twice: a caller
+ * compiled against an older header would be overrun.  Bindings must check at load time that RIPP_ABI_VERSION == ripp_abi_version() and
+ * sizeof(their ripp_stats) == ripp_stats_size() (ripp_amd/_lib.py and rust/ripp-hip do). */
+#define RIPP_ABI_VERSION 4
+int32_t ripp_abi_version(void);
+size_t  ripp_stats_size(void);
 
 /* ---- lifecycle.  The traits are static (inner_products/src/lib.rs:40-49: no &self), so the engine is a
  * process-global, lazily created context bound to ONE device (one process per GPU). */

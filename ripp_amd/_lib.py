@@ -10,6 +10,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RIPP_HIP_LIB") or os.path.join(PKG_DIR, "lib", "libripp_hip.so")      # RIPP_HIP_LIB: another build of the same library (A/B runs)
 
 RIPP_OK, RIPP_ERR_LENGTH, RIPP_ERR_POW2, RIPP_ERR_DEVICE, RIPP_ERR_ARG = 0, 1, 2, 3, 4
+RIPP_ABI_VERSION = 4              # include/ripp_hip.h; checked against the library at load time together with sizeof(ripp_stats)
 
 
 class RippStats(ctypes.Structure):
@@ -17,7 +18,8 @@ class RippStats(ctypes.Structure):
         "total_ms", "upload_ms", "scale_ms", "miller_lines_ms", "miller_products_ms", "fold_ms", "normalize_ms",
         "host_ms", "hash_ms", "kernel_miller_lines_ms_sum", "kernel_line_products_ms_sum")] + [
         (n, ctypes.c_uint64) for n in ("kernel_miller_lines_launches", "kernel_line_products_launches", "pairs_lines", "pairs_products")] + [
-        ("exchange_ms", ctypes.c_double), ("look_ms", ctypes.c_double), ("look_items", ctypes.c_uint64), ("look_pairs", ctypes.c_uint64)]
+        ("exchange_ms", ctypes.c_double), ("look_ms", ctypes.c_double), ("look_items", ctypes.c_uint64), ("look_pairs", ctypes.c_uint64),
+        ("statement_hash_ms", ctypes.c_double), ("statement_hash_wait_ms", ctypes.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -92,7 +94,15 @@ def lib():
 
 def load_library(path):
     L = ctypes.CDLL(path)
+    # the library writes sizeof(ripp_stats) bytes through every stats pointer: a binding built for another layout would be overrun
+    ok = hasattr(L, "ripp_abi_version") and hasattr(L, "ripp_stats_size")
+    if ok:
+        L.ripp_stats_size.restype = ctypes.c_size_t
+        ok = L.ripp_abi_version() == RIPP_ABI_VERSION and L.ripp_stats_size() == ctypes.sizeof(RippStats)
+    if not ok:
+        raise RuntimeError(f"{path}: ABI mismatch (this binding: version {RIPP_ABI_VERSION}, ripp_stats of {ctypes.sizeof(RippStats)} bytes); rebuild the library")
     L.ripp_last_error.restype = ctypes.c_char_p
+    L.ripp_test_inject_failure.restype = None
     for name in ("ripp_ser_gt", "ripp_ser_g1", "ripp_ser_g2", "ripp_ser_fr", "ripp_sipp_job_rounds_left", "ripp_sipp_job_local_len", "ripp_vec_len"):
         getattr(L, name).restype = ctypes.c_size_t
     L.ripp_vec_free.restype = None; L.ripp_vec_free.argtypes = [ctypes.c_void_p]

@@ -1130,6 +1130,9 @@ extern "C" {
 #define ENGINE Engine* e; { int32_t rc_ = get_engine(&e); if (rc_ != RIPP_OK) return rc_; }
 
 API const char* ripp_last_error(void) { return g_err.c_str(); }
+static_assert(sizeof(ripp_stats) == 21 * 8, "ripp_stats changed: bump RIPP_ABI_VERSION (include/ripp_hip.h) and the bindings (ripp_amd/_lib.py, rust/ripp-hip/src/ffi.rs)");
+API int32_t ripp_abi_version(void) { return RIPP_ABI_VERSION; }
+API size_t ripp_stats_size(void) { return sizeof(ripp_stats); }
 API void ripp_statement_hash_times(double* hash_ms, double* wait_ms) { if (hash_ms) *hash_ms = g_digest_hash_ms; if (wait_ms) *wait_ms = g_digest_wait_ms; }
 API int32_t ripp_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 API int32_t ripp_init(int32_t dev) {
@@ -1454,15 +1457,18 @@ API int32_t ripp_sipp_verify(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr
 // ---- SIPP ----------------------------------------------------------------------------------------------------------
 // borrow_value != nullptr: one-shot proof -- the caller's (16-byte aligned) buffers outlive the job, so the statement hash runs on them
 // in place and starts BEFORE the upload (it is the critical path: ~0.3 s at n = 2^20) instead of after a 336 MB host copy
-static int32_t sipp_job_create_impl(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr* r, size_t n_local, int32_t rank, int32_t world, const ripp_gt* borrow_value, ripp_sipp_job** job) {
+// (full_a / full_b / full_r, n_full): the statement the hash runs over -- the shard itself for world == 1, the FULL statement on rank 0 of a sharded one-shot proof
+static int32_t sipp_job_create_impl(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr* r, size_t n_local, int32_t rank, int32_t world, const ripp_gt* borrow_value, ripp_sipp_job** job,
+                                    const ripp_g1a* full_a = nullptr, const ripp_g2a* full_b = nullptr, const ripp_fr* full_r = nullptr, size_t n_full = 0) {
     LOCK; ENGINE; if (!a || !b || !r || !job || n_local == 0 || world < 1 || rank < 0 || rank >= world) return RIPP_ERR_ARG;
     if (n_local & (n_local - 1)) return RIPP_ERR_POW2;
     ripp_sipp_job* j = new ripp_sipp_job();
     struct Live { bool keep = false; Live() { ++g_live_handles; } ~Live() { if (!keep) --g_live_handles; } } live;
     j->n_local = n_local; j->rank = rank; j->world = world; j->world0 = world;
-    const bool borrow = borrow_value && world == 1 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)r) & 15u) == 0;
+    if (world == 1 && !full_a) { full_a = a; full_b = b; full_r = r; n_full = n_local; }
+    const bool borrow = borrow_value && full_a && full_b && full_r && n_full == n_local * (size_t)world && rank == 0 && (((uintptr_t)full_a | (uintptr_t)full_b | (uintptr_t)full_r) & 15u) == 0;
     if (borrow) {
-        j->ha_ext = reinterpret_cast<const G1A*>(a); j->hb_ext = reinterpret_cast<const G2A*>(b); j->hr_ext = reinterpret_cast<const Fr*>(r); j->hash_n = n_local;
+        j->ha_ext = reinterpret_cast<const G1A*>(full_a); j->hb_ext = reinterpret_cast<const G2A*>(full_b); j->hr_ext = reinterpret_cast<const Fr*>(full_r); j->hash_n = n_full;
         Fp12 v; std::memcpy(&v, borrow_value, sizeof v);
         job_start_hash(j, v); j->hash_prestarted = true;
     }
@@ -1817,8 +1823,10 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
         const double tx = now_ms();
         int32_t rc = comm_allgather(e, &mine, all.data(), sizeof mine); if (rc) return rc;
         exchange_ms += now_ms() - tx;
-        for (int w = 0; w < world0; ++w)
+        for (int w = 0; w < world0; ++w) {
+            if (all[w].rc) { set_err("sharded SIPP proof: rank " + std::to_string(w) + " failed before the proof started (status " + std::to_string(all[w].rc) + ")"); return RIPP_ERR_DEVICE; }
             if (all[w].n_local != (uint64_t)j->n_local || all[w].world != world0 || all[w].rank != w) { set_err("sharded SIPP proof: the ranks disagree on the shard size / world size / rank order"); return RIPP_ERR_ARG; }
+        }
         look_items = all[0].look_items; j->no_window = !all[0].window;
     }
     struct HotOff { ~HotOff() { host_pool().set_hot(false); } } hot_off;       // whatever the exit path, the workers go back to sleeping waits
@@ -1978,6 +1986,7 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
     if ((rc = e->sync())) return rc; HIPCHK(hipStreamSynchronize(e->stream2)); HIPCHK(hipStreamSynchronize(e->stream3));      // the pipelined tail does not wait for its folds
     e->collect_kernel_stats();
     e->stats.exchange_ms = exchange_ms;
+    e->stats.statement_hash_ms = window ? g_digest_hash_ms : 0; e->stats.statement_hash_wait_ms = window ? g_digest_wait_ms : 0;      // this call's hash (the thread has been joined)
     e->stats.total_ms = now_ms() - t_start;
     if (st) *st = e->stats;
     return RIPP_OK;

@@ -241,6 +241,29 @@ def native_sipp_job_prove(job, value, full=None, seed_digest=None):
     return proof[: 2 * lg], ch[:lg], st.as_dict()
 
 
+def native_sipp_prove(a_shard, b_shard, r_shard, value, full=None, seed_digest=None):
+    """ripp_sipp_prove_sharded: the one-shot form on HOST slices -- this rank's shard is uploaded inside the call, rank 0's statement hash
+    starts on `full` = (a, b, r) of the whole statement before that upload.  Returns (proof, challenges, stats)."""
+    import ctypes
+    from ._lib import lib, RippStats
+    from . import api
+    a, b, r = api._c(a_shard, 12), api._c(b_shard, 24), api._c(r_shard, 4)
+    assert len(a) == len(b) == len(r)
+    world = int(lib().ripp_comm_world())
+    n = len(a) * world; lg = n.bit_length() - 1
+    value = np.ascontiguousarray(value, dtype=np.uint64).reshape(72)
+    proof = np.zeros((2 * max(lg, 1), 72), dtype=np.uint64); ch = np.zeros((max(lg, 1), 4), dtype=np.uint64); st = RippStats()
+    z = ctypes.c_void_p(None)
+    fa = fb = fr = z
+    if full is not None:
+        fa_, fb_, fr_ = api._c(full[0], 12), api._c(full[1], 24), api._c(full[2], 4)
+        assert len(fa_) == len(fb_) == len(fr_) == n
+        fa, fb, fr = api._p(fa_), api._p(fb_), api._p(fr_)
+    dg = (ctypes.c_uint8 * 32).from_buffer_copy(seed_digest) if seed_digest is not None else z
+    api._check(lib().ripp_sipp_prove_sharded(api._p(a), api._p(b), api._p(r), ctypes.c_size_t(len(a)), api._p(value), fa, fb, fr, dg, api._p(proof), api._p(ch), ctypes.byref(st)))
+    return proof[: 2 * lg], ch[:lg], st.as_dict()
+
+
 def native_pairing_inner_product(left_shard, right_shard):
     """PairingInnerProduct::inner_product over vectors sharded by index residue, collective inside the library."""
     import ctypes

@@ -27,7 +27,13 @@ pub struct RippStats {
     pub kernel_miller_lines_launches: u64, pub kernel_line_products_launches: u64,
     pub pairs_lines: u64, pub pairs_products: u64,
     pub exchange_ms: f64, pub look_ms: f64, pub look_items: u64, pub look_pairs: u64,
+    pub statement_hash_ms: f64, pub statement_hash_wait_ms: f64,
 }
+/// `RIPP_ABI_VERSION` of include/ripp_hip.h this binding was written against; `abi_check()` compares it (and the size of `RippStats`, which
+/// the library writes in full through every stats pointer) with the loaded library.
+pub const RIPP_ABI_VERSION: i32 = 4;
+#[cfg(feature = "ffi")]
+pub fn abi_check() -> bool { unsafe { ripp_abi_version() == RIPP_ABI_VERSION && ripp_stats_size() == core::mem::size_of::<RippStats>() } }
 
 #[cfg(feature = "ffi")]
 extern "C" {
@@ -35,6 +41,8 @@ extern "C" {
     pub fn ripp_shutdown();
     pub fn ripp_device_count() -> i32;
     pub fn ripp_last_error() -> *const core::ffi::c_char;
+    pub fn ripp_abi_version() -> i32;
+    pub fn ripp_stats_size() -> usize;
     // InnerProduct implementations on host slices
     pub fn ripp_pairing_product_j(l: *const RippG1J, nl: usize, r: *const RippG2J, nr: usize, out: *mut RippGt) -> i32;
     pub fn ripp_pairing_product_a(a: *const RippG1A, b: *const RippG2A, n: usize, out: *mut RippGt) -> i32;

@@ -193,13 +193,24 @@ def test_aggregate_proofs_degenerate_inputs_vs_oracle(engine, orc):
 
 def test_aggregate_proofs_config5_size(engine, orc):
     """n = 2^14 synthetic (A, B, C) triples (random group elements, the prover never checks Groth16
-    validity).  The oracle needs minutes at this size, so check the proof through the oracle's TIPA / SSM verifiers (O(log n) work
-    each) plus the algebraic relations the aggregate must satisfy."""
+    validity).  EVERY member of the aggregate equals the oracle's `aggregate_proofs` on the same SRS and triples (a few seconds of
+    oracle time on the GPU box's host cores), and the proof passes the oracle's and the engine's TIPA / SSM verifiers."""
     n = 1 << 14
     alpha, beta = orc.fr_array([0xa1fa0001]), orc.fr_array([0xbe7a0001])
     srs = engine.SRS.from_trapdoors(alpha[0], beta[0], n)
     a, b, c = engine.synth_g1(101, n), engine.synth_g2(202, n), engine.synth_g1(303, n)
     got, stats = engine.aggregate_proofs(srs, a, b, c)
+    rc, exp = orc.aggregate_proofs(srs.g_alpha_powers, srs.h_beta_powers, a, b, c)
+    assert rc == 0
+    for k in ("com_a", "com_b", "com_c", "ip_ab", "r", "ab_kzg_c", "c_base_b", "c_kzg_c"):
+        assert np.array_equal(got.field(k), exp.field(k)), k
+    for k in ("ab_com_steps", "ab_transcript", "c_com_gt", "c_transcript"):
+        assert np.array_equal(getattr(got, k), getattr(exp, k)), k
+    for k in ("agg_c", "ab_base_a", "ab_final_ck_b", "ab_opening_b", "c_base_a"):
+        assert same_g1(engine, orc, got.field(k), exp.field(k)), k
+    for k in ("ab_base_b", "ab_final_ck_a", "ab_opening_a", "c_final_ck_a", "c_opening_a"):
+        assert same_g2(engine, orc, got.field(k), exp.field(k)), k
+    assert same_g1(engine, orc, got.c_com_g1, exp.c_com_g1)
     vs = srs.get_verifier_key(); g, hh, g_beta, h_alpha = vs["g"], vs["h"], vs["g_beta"], vs["h_alpha"]
     r = got.field("r")
     tipp = dict(steps=got.ab_com_steps, base_a=got.field("ab_base_a"), base_b=got.field("ab_base_b"), final_ck_a=got.field("ab_final_ck_a"),

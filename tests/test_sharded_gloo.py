@@ -503,6 +503,10 @@ def test_bench_ranks_on_one_device_reports_the_hash_excluded_figures(engine, gpu
     assert out["gpu_phase_ms"] > 0 and abs(out["gpu_phase_ms"] - (out["ms_per_step"] - out["phase_ms"]["hash_wait_ms"])) < 1e-3
     assert abs(out["value_excl_hash"] - out["config"]["n"] / (out["gpu_phase_ms"] * 1e-3)) < 1e-6 * out["value_excl_hash"]
     assert out["value"] <= out["value_excl_hash"] * (1 + 1e-9)
-    assert abs(out["post_hash_ms"] - (out["ms_per_step"] - out["phase_ms"]["statement_hash_ms"])) < 2e-3
+    assert abs(out["post_hash_ms"] - (out["ms_per_step"] - out["statement_hash_ms"])) < 2e-3 and out["statement_hash_ms"] > 0
+    assert out["config"]["call"].startswith("ripp_sipp_prove_sharded on host slices") and out["value_resident"] > 0
+    for k, v in out["roofline"]["int_alu"].items():                   # no fraction of a roof may exceed 1
+        assert not k.startswith("frac") or 0 < v <= 1, (k, v)
+    assert 0 < out["roofline"]["frac"] <= 1
     assert set(out["look_ahead"]) >= {"items", "pairs"}
     assert "cpu_baseline" not in out                                  # rank 0 at N = 1 only
