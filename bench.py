@@ -3,8 +3,8 @@
 
 One "step" = one complete SIPP::prove (sipp/src/lib.rs:42-106: statement hash, a_i <- r_i a_i, log2 n rounds of
 two pairing products + Fiat-Shamir + two folds) over a synthetic statement of n random-looking G1 x G2 pairs,
-called the way SURVEY.md section 8(d) defines the metric: `ripp_sipp_prove` on HOST slices (the statement in pinned
-host memory; the upload happens inside the call, the statement hash starts on the caller's buffers before it).
+called the way SURVEY.md section 8(d) defines the metric: `ripp_sipp_prove` on HOST slices (the statement in host
+memory; the upload happens inside the call, the statement hash starts on the caller's buffers before it).
 `value` = n / t_step (pairs per second, whole job).  `value_resident` is the same proof from a statement already
 resident in HBM (ripp_sipp_job_prove), timed over the same number of steps right after.
 
@@ -155,9 +155,13 @@ def main():
     # ---- synthetic statement: a_i = (1000+i) G1, b_i = (2000+i) G2, r_i from SplitMix64(0) ----
     # every rank generates its shard on its own GPU; rank 0 additionally holds the full statement on the host because
     # the prover hashes ALL of it (sipp/src/lib.rs:56-59).  `value` (the claimed product) is part of the statement.
-    # The host copies live in PINNED memory (section 8d: "from host inputs resident in pinned memory"), unless RIPP_BENCH_PAGEABLE is set.
+    # The host copies are ordinary (pageable) numpy arrays -- what a caller of the trait surface hands over; the HIP runtime pins them for the upload
+    # and caches the registration.  RIPP_BENCH_PINNED=1 places them in hipHostMalloc'ed memory instead (section 8d's wording): measured SLOWER on the
+    # pool's boxes, 457.4 against 443.8 ms per proof on the same box (profiles/r04_bench_pinned_vs_pageable.txt) -- the CPU side of the proof, the
+    # sequential hash and the serialisation workers, reads the statement more slowly from that mapping (hash 319.6 against 316.6 ms) and so does
+    # everything behind it.
     def pinned(arr):
-        if os.environ.get("RIPP_BENCH_PAGEABLE"):
+        if not os.environ.get("RIPP_BENCH_PINNED"):
             return arr
         t = torch.empty(arr.shape, dtype=torch.int64, pin_memory=True)
         v = t.numpy().view(np.uint64); v[...] = arr
@@ -261,7 +265,7 @@ def main():
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": "sipp_prove (all log2 n rounds, Blake2s Fiat-Shamir)", "curve": "BLS12-381", "n": n,
                        "sharding": "index residue mod %d" % world, "inputs": "a_i=(1000+i)G1, b_i=(2000+i)G2, r_i=SplitMix64(0) 254-bit",
-                       "call": ("ripp_sipp_prove" if world == 1 else "ripp_sipp_prove_sharded") + " on host slices (%s), upload inside the timed call" % ("pageable" if os.environ.get("RIPP_BENCH_PAGEABLE") else "pinned")},
+                       "call": ("ripp_sipp_prove" if world == 1 else "ripp_sipp_prove_sharded") + " on host slices (%s), upload inside the timed call" % ("pinned" if os.environ.get("RIPP_BENCH_PINNED") else "pageable")},
             # the step is bound by the HOST's sequential Blake2s of the 336 B x n statement, whose speed differs by a few per cent from box to box: read `value` next to it
             "statement_hash_ms": round(hash_ms, 3), "ms_per_step_median": ms_median, "value_median": n / (ms_median * 1e-3),
             "ms_per_step_all": [round(t * 1e3, 3) for t in times],

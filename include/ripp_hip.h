@@ -72,6 +72,26 @@ int32_t ripp_device_count(void);
 int32_t ripp_release_scratch(void);
 const char* ripp_last_error(void);   /* message of the calling thread's last failed call (thread-local, errno-style) */
 
+/* ---- configuration (no counterpart in the reference: its tuning knobs are cargo features and rayon's thread count) --------------------------
+ * Every choice among implementations of the same function -- which kernels, from which launch size, the hash-window look-ahead plan -- is a
+ * member of ripp_config.  Usage: ripp_config c; ripp_config_default(&c); c.tail_pipe_max = 0; ripp_configure(&c);   (process-wide, takes
+ * effect from the next call; ripp_configure(NULL) returns to the defaults).  Every setting selects among forms that produce the same bytes.
+ * The RIPP_* environment variables of DESIGN.md section 7b remain as a DEBUG override on top (read in one place, once per call). */
+typedef struct {
+    uint32_t struct_size;            /* sizeof(ripp_config), set by ripp_config_default; ripp_configure rejects any other value */
+    /* implementation selectors: non-zero switches the named form OFF (DESIGN.md section 7b has the effect of each) */
+    uint32_t no_vm, no_precompute, no_fold_tables, no_msm_glv, lp_one_lane, no_endo, no_fq, no_xscale, scale_no_fq, agg_sequential, look_static, quiet_waits;
+    int32_t  look_eighths;           /* hash-window look-ahead plan: -1 automatic (cost model / adaptive), 8 k + f = k (round, side) items and f/8 of the next, FORCED */
+    int32_t  ranks_per_device;       /* ranks sharing one GPU (test rigs): the look-ahead plan prices the window per device */
+    int32_t  msm_c; uint32_t msm_ch, msm_gmin;       /* MSM window width, slot length, grouping threshold; 0 = the plan's own choice */
+    /* crossover launch sizes between the latency and the throughput forms */
+    uint64_t vm_lines_max, vm_fold_max, vm_tree_max, gls_split_max, msm_vm_merge_max, fold_tab_min, fq_min, lp_fq_min, vm_joint_max, vm_scale_max,
+             tail_pipe_max, ml_fq_min, fq_min_g1;
+} ripp_config;
+int32_t ripp_config_default(ripp_config* cfg);      /* the built-in defaults of this build; needs no device */
+int32_t ripp_configure(const ripp_config* cfg);     /* NULL: back to the defaults */
+int32_t ripp_config_get(ripp_config* cfg);          /* what the next call will run with: defaults < ripp_configure < environment */
+
 /* ---- L1 trait surface on host slices ------------------------------------------------------------------ */
 /* PairingInnerProduct::inner_product(left: &[G1], right: &[G2])  -- inner_products/src/lib.rs:61-73 (cfg_multi_pairing :77-116) */
 int32_t ripp_pairing_product_j(const ripp_g1j* left, size_t n_left, const ripp_g2j* right, size_t n_right, ripp_gt* out);

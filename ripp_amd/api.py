@@ -18,7 +18,7 @@ __all__ = ["InnerProductError", "DeviceError", "Vec", "PairingInnerProduct", "Mu
            "PedersenCommitmentG2", "SIPP", "SippJob", "GIPA_TIPP", "SRS", "TIPA_TIPP", "TIPAWithSSM", "aggregate_proofs", "aggregate_proofs_sharded", "gipa_tipp_prove_sharded", "verify_aggregate_proof", "AggregateProof", "ser_tipa_tipp_proof", "de_tipa_tipp_proof", "ser_tipa_ssm_proof", "de_tipa_ssm_proof", "ser_g1_compressed", "ser_g2_compressed", "product_of_pairings", "product_of_pairings_with_coeffs",
            "normalize_batch_g1", "normalize_batch_g2", "fold_g1_affine", "fold_g2_affine", "fold_g1", "fold_g2",
            "scale_g1_affine", "synth_g1", "synth_g2", "synth_fr", "init", "device_count", "final_exponentiation",
-           "ser_gt", "ser_g1", "ser_g2", "ser_fr", "sipp_seed_digest", "gt_mul", "statement_hash_times"]
+           "ser_gt", "ser_g1", "ser_g2", "ser_fr", "sipp_seed_digest", "gt_mul", "statement_hash_times", "configure", "config_default", "config_get"]
 
 
 class InnerProductError(Exception):
@@ -58,6 +58,31 @@ def _check(rc, left=None, right=None):
     if rc == RIPP_ERR_DEVICE:
         raise DeviceError("HIP engine unavailable: " + last_error())
     raise ValueError(f"libripp_hip status {rc}: {last_error()}")
+
+
+def config_default():
+    """ripp_config_default: the built-in defaults (a RippConfig to modify and hand to `configure`)."""
+    from ._lib import RippConfig
+    c = RippConfig(); _check(lib().ripp_config_default(ctypes.byref(c))); return c
+
+
+def configure(cfg=None, **changes):
+    """ripp_configure: process-wide settings from the next call on.  configure() / configure(None) returns to the defaults;
+    configure(tail_pipe_max=0, look_eighths=24) changes the named members of the defaults; configure(cfg) installs a RippConfig."""
+    if cfg is None and not changes:
+        _check(lib().ripp_configure(None)); return None
+    c = cfg if cfg is not None else config_default()
+    for k, v in changes.items():
+        if not hasattr(c, k):
+            raise AttributeError(f"ripp_config has no member {k!r}")
+        setattr(c, k, v)
+    _check(lib().ripp_configure(ctypes.byref(c))); return c
+
+
+def config_get():
+    """ripp_config_get: what the next call runs with (defaults < configure() < RIPP_* environment overrides)."""
+    from ._lib import RippConfig
+    c = RippConfig(); _check(lib().ripp_config_get(ctypes.byref(c))); return c
 
 
 def init(device=0):

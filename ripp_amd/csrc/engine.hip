@@ -45,6 +45,7 @@ static_assert(sizeof(ripp_g1j) == sizeof(G1J) && sizeof(ripp_g2j) == sizeof(G2J)
 namespace {
 
 std::mutex g_mu;
+ripp_config g_cfg{}; bool g_cfg_set = false;      // ripp_configure(): process-wide, applied by Engine::refresh_switches at the start of every C-ABI call
 thread_local std::string g_err;          // last error message of the CALLING thread (errno-style; ripp_last_error)
 
 // Persistent host workers for the per-round serial glue (final exponentiations, GT powers, KZG quotients).  std::async spawns a
@@ -175,9 +176,10 @@ struct PinBuf {
 struct MsmScratch {
     DevBuf digits, hist, offs, cursor, slotoffs, spw, sorted, slots, buckets, seg, seg2, win, out;
     DevBuf ext;                          // bases and their endomorphism images in the carry-free form (fq_msm.hpp)
-    DevBuf flags;                        // one byte per slot: exceptional additions, redone by k_msm_slot_sum_fix
+    DevBuf flags;                        // one byte per slot: exceptional additions, redone by k_msm_slot_sum_fix[_vm]
+    DevBuf nflag;                        // RIPP_TRACE: number of flagged slots of the last MSM
     void* host_out = nullptr;            // pinned landing zone for the result
-    void release() { for (DevBuf* b : {&digits, &hist, &offs, &cursor, &slotoffs, &spw, &sorted, &slots, &buckets, &seg, &seg2, &win, &out, &ext, &flags}) b->release(); if (host_out) (void)hipHostFree(host_out); host_out = nullptr; }
+    void release() { for (DevBuf* b : {&digits, &hist, &offs, &cursor, &slotoffs, &spw, &sorted, &slots, &buckets, &seg, &seg2, &win, &out, &ext, &flags, &nflag}) b->release(); if (host_out) (void)hipHostFree(host_out); host_out = nullptr; }
 };
 
 struct Timer {   // HIP-event stopwatch on the engine stream
@@ -245,23 +247,44 @@ struct Engine {
     // an A/B run flips them on a live engine)
     struct Sizes { size_t vm_lines_max, vm_fold_max, vm_tree_max, gls_split_max, msm_vm_merge_max, fold_tab_min, fq_min, lp_fq_min, vm_joint_max, vm_scale_max, tail_pipe_max, ml_fq_min, fq_min_g1; } defaults{};
     MsmTune msm_tune;
+    // the hash-window look-ahead plan and a few whole-call choices (ripp_config: look_eighths, ranks_per_device, look_static, quiet_waits, agg_sequential, scale_no_fq)
+    int look_eighths = -1; double ranks_per_device = 1.0; bool look_static = false, quiet_waits_cfg = false, agg_sequential = false, scale_no_fq = false;
+    // Precedence: built-in defaults < ripp_configure() < environment variables (a debug / A-B override).  This function is the ONLY place of the
+    // library that reads RIPP_* configuration from the environment (RIPP_TRACE aside), once per C-ABI call (get_engine) -- never inside a proof.
     void refresh_switches() {
-        { const char* s; msm_tune = MsmTune(); if ((s = std::getenv("RIPP_MSM_C"))) msm_tune.c = std::atoi(s); if ((s = std::getenv("RIPP_MSM_CH"))) msm_tune.ch = (uint32_t)std::strtoul(s, nullptr, 10); if ((s = std::getenv("RIPP_MSM_GMIN"))) msm_tune.gmin = (uint32_t)std::strtoul(s, nullptr, 10); }
-        auto env_sz = [](const char* k, size_t dflt, size_t& v) { const char* s = std::getenv(k); v = s ? (size_t)std::strtoull(s, nullptr, 10) : dflt; };
-        env_sz("RIPP_VM_LINES_MAX", defaults.vm_lines_max, vm_lines_max); env_sz("RIPP_VM_FOLD_MAX", defaults.vm_fold_max, vm_fold_max); env_sz("RIPP_VM_TREE_MAX", defaults.vm_tree_max, vm_tree_max);
-        env_sz("RIPP_GLS_SPLIT_MAX", defaults.gls_split_max, gls_split_max); env_sz("RIPP_MSM_VM_MERGE_MAX", defaults.msm_vm_merge_max, msm_vm_merge_max); env_sz("RIPP_FOLD_TAB_MIN", defaults.fold_tab_min, fold_tab_min);
-        env_sz("RIPP_FQ_MIN", defaults.fq_min, fq_min); env_sz("RIPP_LP_FQ_MIN", defaults.lp_fq_min, lp_fq_min); env_sz("RIPP_VM_JOINT_MAX", defaults.vm_joint_max, vm_joint_max);
-        env_sz("RIPP_VM_SCALE_MAX", defaults.vm_scale_max, vm_scale_max); env_sz("RIPP_TAIL_PIPE_MAX", defaults.tail_pipe_max, tail_pipe_max); env_sz("RIPP_ML_FQ_MIN", defaults.ml_fq_min, ml_fq_min); env_sz("RIPP_FQ_MIN_G1", defaults.fq_min_g1, fq_min_g1);
-        sw.no_vm = std::getenv("RIPP_NO_VM") != nullptr; sw.no_precompute = std::getenv("RIPP_NO_PRECOMPUTE") != nullptr;
-        sw.no_fold_tables = std::getenv("RIPP_NO_FOLD_TABLES") != nullptr; sw.no_msm_glv = std::getenv("RIPP_NO_MSM_GLV") != nullptr;
-        sw.lp_one_lane = std::getenv("RIPP_LP_ONE_LANE") != nullptr;
-        sw.no_endo = std::getenv("RIPP_NO_ENDO") != nullptr;            // plain scalar multiplications in the folds / scaling (no GLV, no psi)
-        sw.no_xscale = std::getenv("RIPP_NO_XSCALE") != nullptr;        // G2 folds always on the plain vector with the full-width x^-1
-        sw.no_fq = std::getenv("RIPP_NO_FQ") != nullptr;                // the 12 x 32-bit forms of the kernels that have a carry-free twin (fq_curve.hpp)
-#if defined(RIPP_BLS12_377)
-        // this build has the GLV / GLS constants (bls12_377/params.hpp) and the VM programs (bls12_377/vm_programs.inc) of its curve; the carry-free
-        // THROUGHPUT kernels (fq_curve*.hpp, fq_line_products.hpp, fq_miller.hpp) are written for u^2 = -1 and the M-type twist: 12 x 32-bit forms here
-        sw.no_fq = true; sw.lp_one_lane = false;
+        msm_tune = MsmTune();
+        vm_lines_max = defaults.vm_lines_max; vm_fold_max = defaults.vm_fold_max; vm_tree_max = defaults.vm_tree_max; gls_split_max = defaults.gls_split_max;
+        msm_vm_merge_max = defaults.msm_vm_merge_max; fold_tab_min = defaults.fold_tab_min; fq_min = defaults.fq_min; lp_fq_min = defaults.lp_fq_min; vm_joint_max = defaults.vm_joint_max;
+        vm_scale_max = defaults.vm_scale_max; tail_pipe_max = defaults.tail_pipe_max; ml_fq_min = defaults.ml_fq_min; fq_min_g1 = defaults.fq_min_g1;
+        sw = Switches(); look_eighths = -1; ranks_per_device = 1.0; look_static = quiet_waits_cfg = agg_sequential = scale_no_fq = false;
+        if (g_cfg_set) {
+            const ripp_config& c = g_cfg;
+            sw.no_vm = c.no_vm; sw.no_precompute = c.no_precompute; sw.no_fold_tables = c.no_fold_tables; sw.no_msm_glv = c.no_msm_glv; sw.lp_one_lane = c.lp_one_lane;
+            sw.no_endo = c.no_endo; sw.no_fq = c.no_fq; sw.no_xscale = c.no_xscale; scale_no_fq = c.scale_no_fq; agg_sequential = c.agg_sequential; look_static = c.look_static; quiet_waits_cfg = c.quiet_waits;
+            look_eighths = c.look_eighths; ranks_per_device = c.ranks_per_device > 1 ? (double)c.ranks_per_device : 1.0;
+            msm_tune.c = c.msm_c; msm_tune.ch = c.msm_ch; msm_tune.gmin = c.msm_gmin;
+            vm_lines_max = c.vm_lines_max; vm_fold_max = c.vm_fold_max; vm_tree_max = c.vm_tree_max; gls_split_max = c.gls_split_max; msm_vm_merge_max = c.msm_vm_merge_max; fold_tab_min = c.fold_tab_min;
+            fq_min = c.fq_min; lp_fq_min = c.lp_fq_min; vm_joint_max = c.vm_joint_max; vm_scale_max = c.vm_scale_max; tail_pipe_max = c.tail_pipe_max; ml_fq_min = c.ml_fq_min; fq_min_g1 = c.fq_min_g1;
+        }
+        { const char* s; if ((s = std::getenv("RIPP_MSM_C"))) msm_tune.c = std::atoi(s); if ((s = std::getenv("RIPP_MSM_CH"))) msm_tune.ch = (uint32_t)std::strtoul(s, nullptr, 10); if ((s = std::getenv("RIPP_MSM_GMIN"))) msm_tune.gmin = (uint32_t)std::strtoul(s, nullptr, 10); }
+        auto env_sz = [](const char* k, size_t& v) { if (const char* s = std::getenv(k)) v = (size_t)std::strtoull(s, nullptr, 10); };
+        env_sz("RIPP_VM_LINES_MAX", vm_lines_max); env_sz("RIPP_VM_FOLD_MAX", vm_fold_max); env_sz("RIPP_VM_TREE_MAX", vm_tree_max);
+        env_sz("RIPP_GLS_SPLIT_MAX", gls_split_max); env_sz("RIPP_MSM_VM_MERGE_MAX", msm_vm_merge_max); env_sz("RIPP_FOLD_TAB_MIN", fold_tab_min);
+        env_sz("RIPP_FQ_MIN", fq_min); env_sz("RIPP_LP_FQ_MIN", lp_fq_min); env_sz("RIPP_VM_JOINT_MAX", vm_joint_max);
+        env_sz("RIPP_VM_SCALE_MAX", vm_scale_max); env_sz("RIPP_TAIL_PIPE_MAX", tail_pipe_max); env_sz("RIPP_ML_FQ_MIN", ml_fq_min); env_sz("RIPP_FQ_MIN_G1", fq_min_g1);
+        auto env_on = [](const char* k, bool& v) { if (std::getenv(k)) v = true; };
+        env_on("RIPP_NO_VM", sw.no_vm); env_on("RIPP_NO_PRECOMPUTE", sw.no_precompute); env_on("RIPP_NO_FOLD_TABLES", sw.no_fold_tables); env_on("RIPP_NO_MSM_GLV", sw.no_msm_glv);
+        env_on("RIPP_LP_ONE_LANE", sw.lp_one_lane);
+        env_on("RIPP_NO_ENDO", sw.no_endo);            // plain scalar multiplications in the folds / scaling (no GLV, no psi)
+        env_on("RIPP_NO_XSCALE", sw.no_xscale);        // G2 folds always on the plain vector with the full-width x^-1
+        env_on("RIPP_NO_FQ", sw.no_fq);                // the 12 x 32-bit forms of the kernels that have a carry-free twin (fq_curve.hpp)
+        env_on("RIPP_SCALE_NO_FQ", scale_no_fq); env_on("RIPP_AGG_SEQUENTIAL", agg_sequential); env_on("RIPP_LOOK_STATIC", look_static); env_on("RIPP_QUIET_WAITS", quiet_waits_cfg);
+        if (const char* s = std::getenv("RIPP_LOOK_ITEMS")) look_eighths = 8 * std::max(0, std::atoi(s));            // whole (round, side) items
+        if (const char* s = std::getenv("RIPP_LOOK_EIGHTHS")) look_eighths = std::max(0, std::atoi(s));               // 8 k + f: k items and f/8 of the next
+        if (const char* s = std::getenv("RIPP_RANKS_PER_DEVICE")) ranks_per_device = std::max(1.0, std::atof(s));
+        // (both builds run the carry-free throughput kernels: fq_curve2.hpp FQ2_BETA, fq_miller.hpp / fq_line_products.hpp per twist type)
+#if !defined(RIPP_AB_KERNELS) || defined(RIPP_BLS12_377)
+        sw.lp_one_lane = false;                        // k_line_products1 is compiled into A/B builds of the BLS12-381 library only (-DRIPP_AB_KERNELS)
 #endif
     }
 
@@ -349,7 +372,7 @@ struct Engine {
             return RIPP_OK;
         }
         int32_t rc = scale_tab.reserve((size_t)SCALE_TAB * G1J_CHUNKS * n * sizeof(uint4)); if (rc) return rc;
-        if (!sw.no_fq && !std::getenv("RIPP_SCALE_NO_FQ"))      // the carry-free twin (fq_scale.hpp)
+        if (!sw.no_fq && !scale_no_fq)      // the carry-free twin (fq_scale.hpp)
         {
             if ((rc = scale_flags.reserve(n + 16))) return rc;
             hipLaunchKernelGGL(k_scale_g1_glv_q, dim3(nblk(n, 256)), dim3(256), 0, st, base, base_stride, k, (uint32_t)n, scale_tab.as<uint4>(), out, scale_flags.as<uint8_t>());
@@ -405,17 +428,25 @@ struct Engine {
         // the gather work on homogeneous coordinates and the ones with few points run on the field VM (msm.hpp)
         const bool hom = !sw.no_vm;
         const size_t vm_lds = 4 * VM_EPW * VmCurve<F>::SLOTS * sizeof(VmSlot);
-#if !defined(RIPP_BLS12_377)
-        if (!sw.no_fq) {        // gathered additions on the carry-free form over the extended base array (fq_msm.hpp)
+        if (!sw.no_fq) {        // gathered additions on the carry-free form over the extended base array (fq_msm.hpp), both curves
             const int split = (int)(n / nreal);
             if ((rc = ms.ext.reserve(n * sizeof(Affine<F>))) || (rc = ms.flags.reserve((size_t)p.nwin * max_slots + 16))) return rc;
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_extend_q<F>), dim3(nblk(nreal, 256), split), dim3(256), 0, st, bases, (uint32_t)nreal, split, ms.ext.as<QAff<F>>());
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_slot_sum_q<F>), dim3(nblk(max_slots, 64), p.nwin), dim3(64), 0, st, ms.ext.as<QAff<F>>(), p, ms.hist.as<uint32_t>(), ms.offs.as<uint32_t>(),
                                ms.slotoffs.as<uint32_t>(), ms.spw.as<uint32_t>(), ms.sorted.as<uint32_t>(), ms.slots.as<Jac<F>>(), max_slots, hom, ms.flags.as<uint8_t>());
+            if (hom) {      // flagged slots on the field VM, one wave each (fq_msm.hpp)
+                if ((rc = ms.nflag.reserve(16))) return rc;
+                if (trace_on()) HIPCHK(hipMemsetAsync(ms.nflag.p, 0, 4, st));
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_slot_sum_fix_vm<F>), dim3(FIX_GRID), dim3(64), VM_EPW * VmCurve<F>::SLOTS * sizeof(VmSlot), st, bases, p, ms.hist.as<uint32_t>(), ms.offs.as<uint32_t>(),
+                                   ms.slotoffs.as<uint32_t>(), ms.spw.as<uint32_t>(), ms.sorted.as<uint32_t>(), ms.slots.as<Jac<F>>(), max_slots, ms.flags.as<uint8_t>(), trace_on() ? ms.nflag.as<uint32_t>() : nullptr);
+                if (trace_on()) {
+                    uint32_t nf = 0; HIPCHK(hipMemcpyAsync(&nf, ms.nflag.p, 4, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
+                    fprintf(stderr, "[ripp] msm %s n=%zu: %u of %u slots had an exceptional addition (redone on the field VM)\n", std::is_same<F, Fp>::value ? "G1" : "G2", nreal, nf, (uint32_t)p.nwin * max_slots);
+                }
+            } else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_slot_sum_fix<F>), dim3(FIX_GRID), dim3(64), 0, st, bases, p, ms.hist.as<uint32_t>(), ms.offs.as<uint32_t>(),
                                ms.slotoffs.as<uint32_t>(), ms.spw.as<uint32_t>(), ms.sorted.as<uint32_t>(), ms.slots.as<Jac<F>>(), max_slots, hom, ms.flags.as<uint8_t>());
         } else
-#endif
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_slot_sum<F>), dim3(nblk(max_slots, 64), p.nwin), dim3(64), 0, st, bases, p, ms.hist.as<uint32_t>(), ms.offs.as<uint32_t>(),
                            ms.slotoffs.as<uint32_t>(), ms.spw.as<uint32_t>(), ms.sorted.as<uint32_t>(), ms.slots.as<Jac<F>>(), max_slots, hom);
         uint32_t passes = 0;                                                       // a bucket holds at most n / ch + 1 slots
@@ -490,13 +521,14 @@ struct Engine {
         if ((rc = partA.reserve(nrows * FP12_CHUNKS * (size_t)T * sizeof(uint4))) != RIPP_OK) return rc;
         if ((rc = partB.reserve(nrows * FP12_CHUNKS * (size_t)((T + 1) / 2) * sizeof(uint4))) != RIPP_OK) return rc;
         if ((rc = mark(ev_prod, true)) != RIPP_OK) return rc;
-#if !defined(RIPP_BLS12_377)
-        if (sw.lp_one_lane)
+#if defined(RIPP_AB_KERNELS) && !defined(RIPP_BLS12_377)
+        if (sw.lp_one_lane)           // build round 1's one-lane-per-accumulator form: A/B builds only (-DRIPP_AB_KERNELS; it spills 1 248 B per lane)
             hipLaunchKernelGGL(k_line_products1, dim3(nblk(T, 64), (unsigned)nrows), dim3(64), 0, stream, lines.as<uint4>(), stride, (uint32_t)m, partA.as<uint4>(), T);
-        else if (!sw.no_fq && m * nprod >= lp_fq_min)          // throughput-sized launches: the carry-free twin (fq_line_products.hpp)
-            hipLaunchKernelGGL(k_line_products_q, dim3(nblk(T, LP_GROUPS_PER_WAVE), (unsigned)nrows), dim3(64), 0, stream, lines.as<uint4>(), stride, (uint32_t)m, partA.as<uint4>(), T);
         else
 #endif
+        if (!sw.no_fq && m * nprod >= lp_fq_min)          // throughput-sized launches: the carry-free twin (fq_line_products.hpp), both curves
+            hipLaunchKernelGGL(k_line_products_q, dim3(nblk(T, LP_GROUPS_PER_WAVE), (unsigned)nrows), dim3(64), 0, stream, lines.as<uint4>(), stride, (uint32_t)m, partA.as<uint4>(), T);
+        else
             hipLaunchKernelGGL(k_line_products, dim3(nblk(T, LP_GROUPS_PER_WAVE), (unsigned)nrows), dim3(64), 0, stream, lines.as<uint4>(), stride, (uint32_t)m, partA.as<uint4>(), T);
         HIPCHK(hipGetLastError());
         if ((rc = mark(ev_prod, false)) != RIPP_OK) return rc;
@@ -1641,10 +1673,8 @@ static HostPool& look_pool() { static HostPool pool(3); return pool; }      // o
 // whole item of round R costs 2^(R-1) n pairs, so the last one is cut to what is left).
 static int look_plan(const Engine* e, size_t n_local, int world, bool window) {
     if (!window || e->sw.no_precompute || e->sw.no_endo) return 0;
-    if (const char* s = std::getenv("RIPP_LOOK_EIGHTHS")) return std::max(0, std::min(16 * LOOK_MAX_R, std::atoi(s)));
-    if (const char* s = std::getenv("RIPP_LOOK_ITEMS")) return 8 * std::max(0, std::min(2 * LOOK_MAX_R, std::atoi(s)));
-    double share = 1.0;                                             // ranks sharing this rank's GPU (test rigs: several ranks on one device): their work adds up in the same window
-    if (const char* s = std::getenv("RIPP_RANKS_PER_DEVICE")) share = std::max(1.0, std::atof(s));
+    if (e->look_eighths >= 0) return std::min(16 * LOOK_MAX_R, e->look_eighths);      // forced plan (ripp_config.look_eighths / RIPP_LOOK_EIGHTHS / RIPP_LOOK_ITEMS)
+    const double share = e->ranks_per_device;                       // ranks sharing this rank's GPU (test rigs: several ranks on one device): their work adds up in the same window
     const double nl = (double)n_local * share, n = (double)n_local * world;
     if (n < (double)((size_t)1 << 17)) return 0;                    // small statements: the hash is done long before the GPU is
     const double ms_per_pair = 7.7e-5;                              // 2^20 pairs through lines + products: ~80 ms with the carry-free kernels (profiles/r03_*)
@@ -1669,7 +1699,7 @@ static int look_plan(const Engine* e, size_t n_local, int world, bool window) {
 // by +-3 % in hash speed and +-5 % in GPU speed, more than the static plan's margin.  Other ranks follow the plan rank 0 sent.
 static int32_t job_lookahead(Engine* e, ripp_sipp_job* j, int eighths, bool forced, double ms_per_pair) {
     j->look.clear();
-    const bool adaptive = !forced && j->hash_total > 0 && !j->no_window && eighths > 0 && !std::getenv("RIPP_LOOK_STATIC");
+    const bool adaptive = !forced && j->hash_total > 0 && !j->no_window && eighths > 0 && !e->look_static;
     const int items = adaptive ? std::min(2 * LOOK_MAX_R, eighths / 8 + 2) : (eighths + 7) / 8;      // adaptive: at most one whole item beyond what the static model expects
     if (items <= 0 || (j->digest_ready.load() && !forced)) return RIPP_OK;      // the hash is already done: nothing to hide the work behind (forced: RIPP_LOOK_ITEMS, tests)
     const double t0 = now_ms();
@@ -1814,7 +1844,7 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
         if (seed_digest) { if (j->hash_thread.joinable()) j->hash_thread.join(); std::memcpy(j->digest, seed_digest, 32); j->digest_ready = true; j->hash_prestarted = false; }
         else job_start_hash(j, val);
     }
-    const bool look_forced = std::getenv("RIPP_LOOK_ITEMS") != nullptr || std::getenv("RIPP_LOOK_EIGHTHS") != nullptr;
+    const bool look_forced = e->look_eighths >= 0;
     int look_items = (rank == 0 || look_forced) ? look_plan(e, j->n_local, world0, window || look_forced) : 0;
     j->no_window = !window;
     if (world0 > 1) {
@@ -1834,7 +1864,7 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
     // RIPP_QUIET_WAITS=1: sleeping instead of spinning waits while this rank hashes.  Measured A/B on four boxes (profiles/r03_quiet_vs_spin_waits.txt):
     // the hash is not faster for it (313-322 vs 312-330 ms) and the wake-up latencies make the adaptive look-ahead overrun the window: 460-470 ms
     // against 458-465 ms with spinning waits.  Off by default.
-    e->quiet_waits = window && std::getenv("RIPP_QUIET_WAITS");
+    e->quiet_waits = window && e->quiet_waits_cfg;
     j->look_rows[0].blocking = j->look_rows[1].blocking = e->quiet_waits;
     struct XsOff { ripp_sipp_job* j; ~XsOff() { j->xs_enabled = false; } } xs_off{j};
     j->xs_enabled = true; j->seeded = false;
@@ -1989,6 +2019,35 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
     e->stats.statement_hash_ms = window ? g_digest_hash_ms : 0; e->stats.statement_hash_wait_ms = window ? g_digest_wait_ms : 0;      // this call's hash (the thread has been joined)
     e->stats.total_ms = now_ms() - t_start;
     if (st) *st = e->stats;
+    return RIPP_OK;
+}
+
+// ---- configuration (include/ripp_hip.h: ripp_config) ------------------------------------------------------------------------------------------
+static void config_from_engine(const Engine* e, ripp_config* c) {
+    std::memset(c, 0, sizeof *c); c->struct_size = (uint32_t)sizeof *c;
+    c->no_vm = e->sw.no_vm; c->no_precompute = e->sw.no_precompute; c->no_fold_tables = e->sw.no_fold_tables; c->no_msm_glv = e->sw.no_msm_glv; c->lp_one_lane = e->sw.lp_one_lane;
+    c->no_endo = e->sw.no_endo; c->no_fq = e->sw.no_fq; c->no_xscale = e->sw.no_xscale; c->scale_no_fq = e->scale_no_fq; c->agg_sequential = e->agg_sequential; c->look_static = e->look_static; c->quiet_waits = e->quiet_waits_cfg;
+    c->look_eighths = e->look_eighths; c->ranks_per_device = (int32_t)e->ranks_per_device; c->msm_c = e->msm_tune.c; c->msm_ch = e->msm_tune.ch; c->msm_gmin = e->msm_tune.gmin;
+    c->vm_lines_max = e->vm_lines_max; c->vm_fold_max = e->vm_fold_max; c->vm_tree_max = e->vm_tree_max; c->gls_split_max = e->gls_split_max; c->msm_vm_merge_max = e->msm_vm_merge_max; c->fold_tab_min = e->fold_tab_min;
+    c->fq_min = e->fq_min; c->lp_fq_min = e->lp_fq_min; c->vm_joint_max = e->vm_joint_max; c->vm_scale_max = e->vm_scale_max; c->tail_pipe_max = e->tail_pipe_max; c->ml_fq_min = e->ml_fq_min; c->fq_min_g1 = e->fq_min_g1;
+}
+API int32_t ripp_config_default(ripp_config* cfg) {            // the built-in defaults of this build (needs no device: a throw-away Engine object is never initialised)
+    if (!cfg) return RIPP_ERR_ARG;
+    Engine tmp; tmp.defaults = Engine::Sizes{tmp.vm_lines_max, tmp.vm_fold_max, tmp.vm_tree_max, tmp.gls_split_max, tmp.msm_vm_merge_max, tmp.fold_tab_min, tmp.fq_min, tmp.lp_fq_min, tmp.vm_joint_max, tmp.vm_scale_max, tmp.tail_pipe_max, tmp.ml_fq_min, tmp.fq_min_g1};
+    config_from_engine(&tmp, cfg); cfg->look_eighths = -1; cfg->ranks_per_device = 1;
+    return RIPP_OK;
+}
+API int32_t ripp_configure(const ripp_config* cfg) {
+    LOCK;
+    if (!cfg) { g_cfg_set = false; return RIPP_OK; }
+    if (cfg->struct_size != sizeof(ripp_config)) { set_err("ripp_configure: struct_size does not match this library's ripp_config (fill the struct with ripp_config_default first)"); return RIPP_ERR_ARG; }
+    g_cfg = *cfg; g_cfg_set = true;
+    return RIPP_OK;
+}
+API int32_t ripp_config_get(ripp_config* cfg) {                // what the NEXT call runs with: defaults < ripp_configure < environment
+    if (!cfg) return RIPP_ERR_ARG;
+    LOCK; ENGINE;
+    config_from_engine(e, cfg);
     return RIPP_OK;
 }
 

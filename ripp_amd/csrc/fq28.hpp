@@ -59,6 +59,8 @@ constexpr Limbs times_p(uint32_t c) {
 constexpr Limbs ONE_M392 = slice28(big_pow2_mod(392));      // Montgomery one
 constexpr Limbs C_IN = slice28(big_pow2_mod(400));          // mont(x, 2^400) = x * 2^8      : Mont-384 -> Mont-392
 constexpr Limbs C_OUT = slice28(big_r1());                  // mont(x~, 2^384) = x~ * 2^-8   : Mont-392 -> Mont-384
+// a Montgomery-384 constant of the engine (12 words, canonical) -> its Montgomery-392 limbs, at compile time: times 2^8 mod p
+constexpr Limbs from_mont384(const uint32_t (&v)[12]) { Big12 r{}; for (int i = 0; i < 12; ++i) r.l[i] = v[i]; for (int i = 0; i < 8; ++i) r = big_dbl_mod(r); return slice28(r); }
 constexpr uint32_t P_TOP = P28.l[NL - 1];                   // p >> 364
 constexpr int VMAX = 2500;                                  // R' / p = 2519.6: products with V1 * V2 <= VMAX reduce to < 2p
 }  // namespace fq28
@@ -69,6 +71,8 @@ template <uint64_t LM = FQ_LN, int VB = 2>
 struct Fq {
     static_assert(LM >= 1 && LM <= ((uint64_t)1 << 32), "limb bound");
     static_assert(VB >= 1 && VB <= fq28::VMAX, "value bound");
+    static constexpr uint64_t LMAX = LM;
+    static constexpr int VMAXB = VB;
     uint32_t l[fq28::NL];
 };
 using Fqn = Fq<FQ_LN, 2>;         // what every multiplication returns

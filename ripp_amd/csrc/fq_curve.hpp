@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256, 2) k_fold_g1_naf_q(const G1A* __restrict_
 __global__ void __launch_bounds__(256, 2) k_fold_g1_glv_q(const G1A* __restrict__ hi, const G1A* __restrict__ lo, uint32_t half, GlvDigits dg, G1J* __restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= half) return;
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(RIPP_BLS12_377)
+#if defined(__HIP_DEVICE_COMPILE__)
     const G1A* hp = hi + i; const G1A* lp = lo + i;                         // hi[i] / lo[i] are re-read where they are needed, not held for 128 steps
     AffQ q; Fqn bx, ny;
     {

@@ -2,12 +2,25 @@
 // the same low-liveness order, Y1 parked in LDS while it is idle).  An Fp2 product is two lazily reduced sums of two products
 // (a0 b0 + (K - a1) b1 and a0 b1 + a1 b0: 4 x 196 limb products + 2 reductions, no Karatsuba additions), a square is (a0 + a1)(a0 - a1) and
 // (2 a0) a1 on lazy operands.  Every bound is checked by the compiler (fq28.hpp).
+// Both towers: Fp2 = Fp[u] / (u^2 + FQ2_BETA) with FQ2_BETA = 1 (BLS12-381) or 5 (BLS12-377) -- the factor is a limb-wise lazy multiple of the
+// operand that is negated anyway (K - 5 a1), so a BLS12-377 product costs the same multiply-adds; its square is a0 a0 + (K - 5 a1) a1 and (2 a0) a1
+// (588 + 392 multiply-adds against 392 + 392: the (a0 + a1)(a0 - a1) trick needs u^2 = -1).
 #pragma once
 #include "fq_curve.hpp"
 
 namespace ripp {
 
 #if defined(__HIP_DEVICE_COMPILE__)
+#if defined(RIPP_BLS12_377)
+constexpr int FQ2_BETA = 5;               // u^2 = -5
+#else
+constexpr int FQ2_BETA = 1;               // u^2 = -1
+#endif
+// FQ2_BETA * a, limb-wise (lazy)
+template <uint64_t L1, int V1> __device__ __forceinline__ auto fq_mul_beta(const Fq<L1, V1>& a) {
+    if constexpr (FQ2_BETA == 1) return a;
+    else { static_assert(FQ2_BETA == 5, "FQ2_BETA"); return fq_add(fq_dbl(fq_dbl(a)), a); }
+}
 template <uint64_t LM = FQ_LN, int VB = 2> struct Fq2T { Fq<LM, VB> c0, c1; };
 using Fq2n = Fq2T<FQ_LN, 2>;          // a product
 using Fq2C = Fq2T<FQ_LN, 4>;          // a coordinate between two group operations
@@ -20,68 +33,32 @@ template <uint64_t L1, int V1> __device__ __forceinline__ Fq2n f2_reduce(const F
 template <uint64_t L1, int V1> __device__ __forceinline__ Fq2C f2_coord(const Fq2T<L1, V1>& a) { return {fq_coord(a.c0), fq_coord(a.c1)}; }
 template <uint64_t L1, int V1> __device__ __forceinline__ void f2_pin(Fq2T<L1, V1>& a) { fq_pin(a.c0); fq_pin(a.c1); }
 __device__ __forceinline__ bool f2_is_zero(const Fq2n& a) { return fq_is_zero(a.c0) && fq_is_zero(a.c1); }
-// THE call boundary of the G2 kernels: one out-of-line Fq product with vector-typed register arguments (28 VGPRs in, 14 out -- within the
-// 32 argument registers of the AMDGPU convention, nothing on the stack).  Inlining the ~550-instruction product 20 times per group
-// operation lets the scheduler interleave them and spills ~340 dwords; behind a call every product is a liveness barrier.
-typedef uint32_t fq_v4u __attribute__((ext_vector_type(4)));
-typedef uint32_t fq_v2u __attribute__((ext_vector_type(2)));
-struct FqRegs { fq_v4u v0, v1, v2; fq_v2u v3; };
-using FqW = Fq<((uint64_t)1 << 30), 50>;              // what the out-of-line product is compiled for: limbs < 2^30, V1 * V2 <= 2500 (checked by the wrapper)
-__device__ __noinline__ inline FqRegs fq_mul_call(fq_v4u a0, fq_v4u a1, fq_v4u a2, fq_v2u a3, fq_v4u b0, fq_v4u b1, fq_v4u b2, fq_v2u b3) {
-    FqW a, b;
-    a.l[0] = a0.x; a.l[1] = a0.y; a.l[2] = a0.z; a.l[3] = a0.w; a.l[4] = a1.x; a.l[5] = a1.y; a.l[6] = a1.z; a.l[7] = a1.w; a.l[8] = a2.x; a.l[9] = a2.y; a.l[10] = a2.z; a.l[11] = a2.w; a.l[12] = a3.x; a.l[13] = a3.y;
-    b.l[0] = b0.x; b.l[1] = b0.y; b.l[2] = b0.z; b.l[3] = b0.w; b.l[4] = b1.x; b.l[5] = b1.y; b.l[6] = b1.z; b.l[7] = b1.w; b.l[8] = b2.x; b.l[9] = b2.y; b.l[10] = b2.z; b.l[11] = b2.w; b.l[12] = b3.x; b.l[13] = b3.y;
-    const Fqn r = fq_mul(a, b);
-    FqRegs o;
-    o.v0 = fq_v4u{r.l[0], r.l[1], r.l[2], r.l[3]}; o.v1 = fq_v4u{r.l[4], r.l[5], r.l[6], r.l[7]}; o.v2 = fq_v4u{r.l[8], r.l[9], r.l[10], r.l[11]}; o.v3 = fq_v2u{r.l[12], r.l[13]};
-    return o;
-}
-template <uint64_t L1, int V1, uint64_t L2, int V2>
-__device__ __forceinline__ Fqn fq_mulc(const Fq<L1, V1>& a, const Fq<L2, V2>& b) {
-    static_assert(L1 <= ((uint64_t)1 << 30) && L2 <= ((uint64_t)1 << 30), "normalise the operand first");
-    static_assert((long)V1 * V2 <= fq28::VMAX, "value bound");
-    const FqRegs r = fq_mul_call(fq_v4u{a.l[0], a.l[1], a.l[2], a.l[3]}, fq_v4u{a.l[4], a.l[5], a.l[6], a.l[7]}, fq_v4u{a.l[8], a.l[9], a.l[10], a.l[11]}, fq_v2u{a.l[12], a.l[13]},
-                                 fq_v4u{b.l[0], b.l[1], b.l[2], b.l[3]}, fq_v4u{b.l[4], b.l[5], b.l[6], b.l[7]}, fq_v4u{b.l[8], b.l[9], b.l[10], b.l[11]}, fq_v2u{b.l[12], b.l[13]});
-    Fqn o;
-    o.l[0] = r.v0.x; o.l[1] = r.v0.y; o.l[2] = r.v0.z; o.l[3] = r.v0.w; o.l[4] = r.v1.x; o.l[5] = r.v1.y; o.l[6] = r.v1.z; o.l[7] = r.v1.w; o.l[8] = r.v2.x; o.l[9] = r.v2.y; o.l[10] = r.v2.z; o.l[11] = r.v2.w; o.l[12] = r.v3.x; o.l[13] = r.v3.y;
-    return o;
-}
-// operands of a product are normalised (one carry pass per coefficient) when their limbs could exceed LIM
-template <uint64_t LIM, uint64_t L1, int V1> __device__ __forceinline__ auto f2_n(const Fq2T<L1, V1>& a) { if constexpr (L1 <= LIM) return a; else return f2_norm(a); }
-// (a0 + a1 u)(b0 + b1 u), u^2 = -1: Karatsuba on three out-of-line products; the three additions and five subtractions are limb-wise.
-// The result is LAZY (c0 < 5p, c1 < 8p, limbs < 5 * 2^28).
-template <uint64_t L1, int V1, uint64_t L2, int V2>
-__device__ __forceinline__ auto f2_mul(const Fq2T<L1, V1>& a_, const Fq2T<L2, V2>& b_) {
-    const auto a = f2_n<((uint64_t)1 << 29)>(a_); const auto b = f2_n<((uint64_t)1 << 29)>(b_);
-    const Fqn t0 = fq_mulc(a.c0, b.c0), t1 = fq_mulc(a.c1, b.c1);
-    const Fqn m = fq_mulc(fq_add(a.c0, a.c1), fq_add(b.c0, b.c1));
-    const auto c0 = fq_sub(t0, t1); const auto c1 = fq_sub(fq_sub(m, t0), t1);
-    constexpr uint64_t LO = fq28::sub_lm(fq28::sub_lm(FQ_LN, FQ_LN), FQ_LN);
-    return Fq2T<LO, 8>{fq_widen<LO, 8>(c0), fq_widen<LO, 8>(c1)};
-}
-// (a0 + a1)(a0 - a1), (2 a0) a1: two products; the result is reduced
-template <uint64_t L1, int V1>
-__device__ __forceinline__ Fq2n f2_sqr(const Fq2T<L1, V1>& a_) {
-    const auto a = f2_n<FQ_LN>(a_);
-    return {fq_mulc(fq_add(a.c0, a.c1), fq_sub(a.c0, a.c1)), fq_mulc(fq_dbl(a.c0), a.c1)};
-}
-
 // ---- the inlined forms (no call, no Karatsuba temporaries): what the throughput kernels use.  The first half of a product is PINNED (fq28.hpp
 // fq_pin) so that the two column sets are never alive together.
-// (a0 + a1 u)(b0 + b1 u), u^2 = -1: two lazily reduced sums of two products, inlined; the result is reduced (< 2p, normalised limbs)
+// (a0 + a1 u)(b0 + b1 u), u^2 = -FQ2_BETA: two lazily reduced sums of two products, inlined; the result is reduced (< 2p, normalised limbs).
+// BLS12-377: the operand that carries the factor 5 is normalised first when its limbs are lazy (the column sums would leave 64 bits otherwise).
 template <uint64_t L1, int V1, uint64_t L2, int V2>
-__device__ __forceinline__ Fq2n f2_muld(const Fq2T<L1, V1>& a, const Fq2T<L2, V2>& b) {
-    const auto na1 = fq_neg(a.c1);                                     // K - a1, K = (V1 + 1) p with dominating limbs
+__device__ __forceinline__ Fq2n f2_muld(const Fq2T<L1, V1>& a_, const Fq2T<L2, V2>& b_) {
+    constexpr bool fits = fq28::dot_fits(2, fq28::sub_lm(1, (uint64_t)FQ2_BETA * (L1 - 1) + 1), L2);
+    const auto a = [&]() { if constexpr (fits) return a_; else return Fq2T<FQ_LN, V1>{fq_norm(a_.c0), fq_norm(a_.c1)}; }();
+    const auto b = [&]() { if constexpr (fits || L2 <= FQ_LN) return b_; else return Fq2T<FQ_LN, V2>{fq_norm(b_.c0), fq_norm(b_.c1)}; }();
+    using TA0 = decltype(a.c0); using TB0 = decltype(b.c0);
+    const auto na1 = fq_neg(fq_mul_beta(a.c1));                        // K - beta a1, K a multiple of p with dominating limbs
     using TA = decltype(na1);
     Fq2n r;
-    { const TA aa[2] = {fq_widen<fq28::sub_lm(1, L1), V1 + 2>(a.c0), na1}; const Fq<L2, V2> bb[2] = {b.c0, b.c1}; r.c0 = fq_dot<2>(aa, bb); } fq_pin(r.c0);
-    { const Fq<L1, V1> aa[2] = {a.c0, a.c1}; const Fq<L2, V2> bb[2] = {b.c1, b.c0}; r.c1 = fq_dot<2>(aa, bb); }
+    { const TA aa[2] = {fq_widen<TA::LMAX, TA::VMAXB>(a.c0), na1}; const TB0 bb[2] = {b.c0, b.c1}; r.c0 = fq_dot<2>(aa, bb); } fq_pin(r.c0);
+    { const TA0 aa[2] = {a.c0, a.c1}; const TB0 bb[2] = {b.c1, b.c0}; r.c1 = fq_dot<2>(aa, bb); }
     return r;
 }
 template <uint64_t L1, int V1>
 __device__ __forceinline__ Fq2n f2_sqrd(const Fq2T<L1, V1>& a) {
     Fq2n r;
-    r.c0 = fq_mul(fq_add(a.c0, a.c1), fq_sub(a.c0, a.c1)); fq_pin(r.c0);
+    if constexpr (FQ2_BETA == 1) { r.c0 = fq_mul(fq_add(a.c0, a.c1), fq_sub(a.c0, a.c1)); fq_pin(r.c0); }
+    else {                                                              // a0 a0 + (K - beta a1) a1
+        const auto na1 = fq_neg(fq_mul_beta(a.c1)); using TA = decltype(na1);
+        const TA aa[2] = {fq_widen<TA::LMAX, TA::VMAXB>(a.c0), na1}; const Fq<L1, V1> bb[2] = {a.c0, a.c1};
+        r.c0 = fq_dot<2>(aa, bb); fq_pin(r.c0);
+    }
     r.c1 = fq_mul(fq_dbl(a.c0), a.c1);
     return r;
 }

@@ -8,9 +8,11 @@
 // The line buffer is read as it is: the 12 x u32 words of a Montgomery-384 value, re-sliced into 28-bit limbs, ARE the Montgomery-392 form
 // of that value times 2^-8 -- every line, hence every per-step product, is merely scaled by an element of Fp, which the final exponentiation
 // removes (the same argument that lets stage 1 scale its lines, bls12_381/pairing.hpp).
+// Both curves: BLS12-381 (M-type twist: line = l0 + l1 w^2 + l2 w^3, xi = 1 + u, u^2 = -1) and BLS12-377 (D-type: l0 + l1 w + l2 w^3, xi = u,
+// u^2 = -5 -- the factor 5 of a real part is a transient, normalised multiple of the LINE operand; line_products.hpp has the operand tables).
 #pragma once
 #include <hip/hip_runtime.h>
-#include "fq28.hpp"
+#include "fq_curve2.hpp"
 #include "line_products.hpp"
 
 namespace ripp {
@@ -68,14 +70,23 @@ __global__ void __launch_bounds__(64, 2) k_line_products_q(const uint4* __restri
         st_fq(j, 0, j == 0 ? fq_one() : fq_zero()); st_fq(j, 1, fq_zero()); st_fq(j + 3, 0, fq_zero()); st_fq(j + 3, 1, fq_zero());
     }
     __syncthreads();
+#if defined(RIPP_BLS12_377)
+    // D-type twist, out_k = f_k l0 + [xi] f_(k-1) l1 + [xi] f_(k-3) l2.  k = j + 3: (f_(j+3), f_(j+2), f_j) against (l0, l1, l2);
+    // k = j: (f_j, f_(j+5 mod 6), f_(j+3)) against (l0, xi^[j=0] l1, xi l2)
+    const int a1 = (int)((j + 5) % 6), s1b = (int)j + 2;
+    const bool xi1 = j < 1;
+    constexpr int FYV = 7;                                                       // a line coefficient times xi = u: (K - 5 c1, c0), value < 7p
+#else
     // operand slots of this lane's outputs.  k = j + 3: (f_(j+3), f_(j+1), f_j) against (l0, l1, l2);
     // k = j: (f_j, f_(j+4 mod 6), f_(j+3)) against (l0, xi^[j<2] l1, xi l2)
-    const int a1 = (int)((j + 4) % 6);
+    const int a1 = (int)((j + 4) % 6), s1b = (int)j + 1;
     const bool xi1 = j < 2;
+    constexpr int FYV = 3;                                                       // times xi = 1 + u: (c0 - c1, c0 + c1), value < 3p
+#endif
     const uint32_t st = (uint32_t)stride;
     const uint4* __restrict__ lrow = lines + row * 18 * stride;
     const uint32_t iters = (M + T - 1) / T;
-    using FY = Fq<FQ_LN, 3>;                                                     // a line coefficient (canonical in HBM), possibly times xi (normalised)
+    using FY = Fq<FQ_LN, FYV>;                                                   // a line coefficient (canonical in HBM), possibly times xi (normalised)
 #pragma unroll 1
     for (uint32_t it = 0; it < iters; ++it) {
         const uint32_t i = group_index() + it * T;
@@ -90,7 +101,7 @@ __global__ void __launch_bounds__(64, 2) k_line_products_q(const uint4* __restri
             uint32_t w[12];
 #pragma unroll
             for (int c = 0; c < 3; ++c) { w[4 * c] = q[c].x; w[4 * c + 1] = q[c].y; w[4 * c + 2] = q[c].z; w[4 * c + 3] = q[c].w; }
-            { const Fqn u = fq_unpack(w); Fq<FQ_LN, 1> c; for (int q = 0; q < NL; ++q) c.l[q] = u.l[q]; y[f] = fq_widen<FQ_LN, 3>(c); }      // stage 1 stores canonical values (< p)
+            { const Fqn u = fq_unpack(w); Fq<FQ_LN, 1> c; for (int q = 0; q < NL; ++q) c.l[q] = u.l[q]; y[f] = fq_widen<FQ_LN, FYV>(c); }      // stage 1 stores canonical values (< p)
         }
         Fqn o1r, o1i, o0r, o0i;
         // One output coefficient part = sum of six products with ONE reduction, evaluated ROW-WISE: the limbs of the accumulator operands are
@@ -98,7 +109,7 @@ __global__ void __launch_bounds__(64, 2) k_line_products_q(const uint4* __restri
         // accumulator side in registers (84 fewer live registers than the column-wise fq_dot: the kernel no longer spills) and 14
         // independent dependency chains for the multiplier.  xsel[t]: slot / part of the t-th accumulator operand, neg: take K - x
         // (K = 3p with limbs that dominate a reduced value's: fq28::sub_bias), ysel[t]: index of the line-side operand.
-        static_assert(dot_fits(6, (uint64_t)1 << 29, FQ_LN) && 6 * 4 * 3 <= VMAX, "six products of (x or K - x) by a line coefficient fit the 64-bit columns");
+        static_assert(dot_fits(6, (uint64_t)1 << 29, FQ_LN) && 6 * 4 * FYV * FQ2_BETA <= VMAX, "six products of (x or K - x) by a line coefficient fit the 64-bit columns");
         constexpr Limbs KN = sub_bias<FQ_LN, 2>();
         // One accumulator coefficient (slot, part) = four 16-byte LDS reads, issued by hand one operand pass AHEAD of their use (asm: the
         // compiler merged the repeated reads of a coefficient -- each is an operand of two sums, slots j and j + 3 of four -- into one and kept all
@@ -112,7 +123,7 @@ __global__ void __launch_bounds__(64, 2) k_line_products_q(const uint4* __restri
         };
         auto arrived = [&](LqBuf& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b.q[0]), "+v"(b.q[1]), "+v"(b.q[2]), "+v"(b.q[3])); };
         // col += (x or K - x) * yt, x = the fetched coefficient
-        auto mads = [&](uint64_t (&col)[2 * NL - 1], const LqBuf& b, bool neg, const FY& yt) {
+        auto mads = [&](uint64_t (&col)[2 * NL - 1], const LqBuf& b, bool neg, const auto& yt) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const uint32_t xl[4] = {b.q[q].x, b.q[q].y, b.q[q].z, b.q[q].w};
@@ -166,17 +177,28 @@ __global__ void __launch_bounds__(64, 2) k_line_products_q(const uint4* __restri
                 for (int t = 0; t < 3; ++t) {                                    // x.c0 y.c0 + (K - x.c1) y.c1
                     fetch(b1, sl[t], 1, col[NL - 1]); mads(col, b0, false, y[2 * t]); TIE(col); arrived(b1);
                     if (t < 2) fetch(b0, sl[t + 1], 0, col[NL - 1]);
-                    mads(col, b1, true, y[2 * t + 1]); TIE(col);
+                    // u^2 = -FQ2_BETA: the factor goes to the line operand, as a transient normalised multiple (one live value, not three)
+                    if constexpr (FQ2_BETA == 1) mads(col, b1, true, y[2 * t + 1]);
+                    else { const auto yb = fq_norm(fq_mul_beta(y[2 * t + 1])); mads(col, b1, true, yb); }
+                    TIE(col);
                     if (t < 2) arrived(b0);
                 }
                 re = reduce_cols(col); TIE14(re.l);
             }
         };
-        two_dots((int)j + 3, (int)j + 1, (int)j, o1r, o1i);                      // k = j + 3: plain line
-        {   // xi l2 always, xi l1 on lanes 0 and 1: (c0 - c1, c0 + c1), normalised
+        two_dots((int)j + 3, s1b, (int)j, o1r, o1i);                              // k = j + 3: plain line
+        {   // xi l2 always, xi l1 on the lanes whose operand wraps around w^6 = xi; normalised
             auto raw = [&](int f) { Fq<FQ_LN, 1> c; for (int q = 0; q < NL; ++q) c.l[q] = y[f].l[q]; return c; };       // still the canonical values loaded above
+#if defined(RIPP_BLS12_377)
+            // xi = u: (c0 + c1 u) u = -5 c1 + c0 u
+            const auto d2 = fq_norm(fq_neg(fq_mul_beta(raw(5)))); const auto s2 = raw(4);
+            const auto d1 = fq_norm(fq_neg(fq_mul_beta(raw(3)))); const auto s1 = raw(2);
+            static_assert(decltype(d2)::VMAXB <= FYV, "");
+#else
+            // xi = 1 + u: (c0 - c1, c0 + c1)
             const auto d2 = fq_norm(fq_sub(raw(4), raw(5))); const auto s2 = fq_norm(fq_add(raw(4), raw(5)));
             const auto d1 = fq_norm(fq_sub(raw(2), raw(3))); const auto s1 = fq_norm(fq_add(raw(2), raw(3)));
+#endif
             static_assert(sizeof(d2) == sizeof(FY) && sizeof(s2) == sizeof(FY), "");
 #pragma unroll
             for (int q = 0; q < NL; ++q) { y[4].l[q] = d2.l[q]; y[5].l[q] = s2.l[q]; y[2].l[q] = xi1 ? d1.l[q] : y[2].l[q]; y[3].l[q] = xi1 ? s1.l[q] : y[3].l[q]; }

@@ -13,13 +13,14 @@
 // All values are true Montgomery-392 values (P and Q are converted with the exact x 2^8 re-slicing + one quotient estimate).  A line coefficient is
 // stored as the 12 words of its canonical Montgomery-392 integer: read as a Montgomery-384 value (k_line_products) that is the coefficient times
 // 2^8 -- every line is scaled by the same element of Fp, which the final exponentiation removes; k_line_products_q reads the words as they are.
-// BLS12-381 (M-type twist) only: the BLS12-377 build keeps the 12 x 32-bit kernel.
+// Both twists: BLS12-381 (M-type, b' = 4 (1 + u), line slots (free, xP, yP)) and BLS12-377 (D-type, b' = 1 / u = (0, -1/5), line slots
+// (yP, xP, free): kernels.hpp LINE_SLOT_*); the tower's non-residue is in the Fp2 products (fq_curve2.hpp FQ2_BETA).
 #pragma once
 #include "fq_curve2.hpp"
 
 namespace ripp {
 
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(RIPP_BLS12_377)
+#if defined(__HIP_DEVICE_COMPILE__)
 // a line coefficient (value < 2p) -> the canonical integer, 12 words, chunked SoA (kernels.hpp store_chunks layout)
 __device__ __forceinline__ void store_line_q(uint4* lines, size_t row, size_t stride, size_t i, const Fq2n& v) {
     uint32_t w[24];
@@ -66,15 +67,23 @@ __device__ __forceinline__ void line_double_store_q(Fq2C& X, Fq2C& Y, Fq2C& Z, c
     auto nh = f2_norm(f2_sub(f2_add(b, c), t1)); f2_pin(nh);                      // -h, value < 7p
     {
         Fq2n l2 = f2_mul_fq(nh, ld_park_fq(park, 1)); f2_pin(l2);
-        if (skip) store_line_raw(lines, s * 3 + 2, stride, i, Fp2::zero()); else store_line_q(lines, s * 3 + 2, stride, i, l2);
+        if (skip) store_line_raw(lines, s * 3 + LINE_SLOT_YP, stride, i, LINE_UNIT_YP); else store_line_q(lines, s * 3 + LINE_SLOT_YP, stride, i, l2);
     }
-    Fq2n e;                                                                       // b' * 3c, b' = 4 (1 + u): 4 (c0 - c1) + 4 (c0 + c1) u
+    Fq2n e;                                                                       // b' * 3c
     {
         const auto c3 = f2_add(f2_add(c, c), c);
+#if defined(RIPP_BLS12_377)
+        // b' = 1 / u = (0, B1), B1 = -1/5:  (c0 + c1 u) B1 u = -5 B1 c1 + B1 c0 u = (c1, B1 c0): one product by a constant
+        e.c0 = fq_reduce(c3.c1);
+        { constexpr uint32_t b1w[12] = RIPP_FP_TWIST_B1; constexpr fq28::Limbs B1 = fq28::from_mont384(b1w);
+          e.c1 = fq_mul(fq_norm(c3.c0), fq_const<FQ_LN, 1>(B1)); }
+#else
+        // b' = 4 (1 + u): 4 (c0 - c1) + 4 (c0 + c1) u
         e.c0 = fq_reduce(fq_dbl(fq_dbl(fq_norm(fq_sub(c3.c0, c3.c1)))));
         e.c1 = fq_reduce(fq_dbl(fq_dbl(fq_norm(fq_add(c3.c0, c3.c1)))));
+#endif
     } f2_pin(e);
-    if (skip) store_line_raw(lines, s * 3 + 0, stride, i, Fp2::one()); else store_line_q(lines, s * 3 + 0, stride, i, f2_reduce(f2_sub(e, b)));
+    if (skip) store_line_raw(lines, s * 3 + LINE_SLOT_FREE, stride, i, LINE_UNIT_FREE); else store_line_q(lines, s * 3 + LINE_SLOT_FREE, stride, i, f2_reduce(f2_sub(e, b)));
     Fq2n a2 = f2_muld(X, Y); f2_pin(a2);                                          // a' = X Y
     {
         Fq2n j = f2_sqrd(X); f2_pin(j);
@@ -100,13 +109,13 @@ __device__ __forceinline__ void line_add_store_q(Fq2C& X, Fq2C& Y, Fq2C& Z, cons
         Fq2n t; { const Fq2n qy = f2_load_conv(&opaque(q)->y); t = f2_muld(lambda, qy); } f2_pin(t);
         const Fq2n qx = f2_load_conv(&opaque(q)->x);
         Fq2n nj = f2_reduce(f2_sub(t, f2_muld(theta, qx))); f2_pin(nj);             // lambda qy - theta qx = -j
-        if (skip) store_line_raw(lines, s * 3 + 0, stride, i, Fp2::one()); else store_line_q(lines, s * 3 + 0, stride, i, nj);
+        if (skip) store_line_raw(lines, s * 3 + LINE_SLOT_FREE, stride, i, LINE_UNIT_FREE); else store_line_q(lines, s * 3 + LINE_SLOT_FREE, stride, i, nj);
     }
     { Fq2n l1 = f2_mul_fq(theta, ld_park_fq(park, 0)); f2_pin(l1);
       if (skip) store_line_raw(lines, s * 3 + 1, stride, i, Fp2::zero()); else store_line_q(lines, s * 3 + 1, stride, i, l1); }
     { const auto nl = Fq2T<fq28::sub_lm(1, FQ_LN), 4>{fq_neg(lambda.c0), fq_neg(lambda.c1)};
       Fq2n l2 = f2_mul_fq(nl, ld_park_fq(park, 1)); f2_pin(l2);
-      if (skip) store_line_raw(lines, s * 3 + 2, stride, i, Fp2::zero()); else store_line_q(lines, s * 3 + 2, stride, i, l2); }
+      if (skip) store_line_raw(lines, s * 3 + LINE_SLOT_YP, stride, i, LINE_UNIT_YP); else store_line_q(lines, s * 3 + LINE_SLOT_YP, stride, i, l2); }
     Fq2n f;
     { Fq2n c = f2_sqrd(theta); f2_pin(c); f = f2_muld(c, Z); } f2_pin(f);
     Fq2n d = f2_sqrd(lambda); f2_pin(d);
@@ -126,7 +135,7 @@ __global__ void __launch_bounds__(256, RIPP_OCC) k_miller_lines_q(PairSets ps, u
     __shared__ uint4 park_[16 * 256];                            // per lane: xP, yP and (addition steps) the two halves of Y
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(RIPP_BLS12_377)
+#if defined(__HIP_DEVICE_COMPILE__)
     const G1A* __restrict__ a = ps.a[blockIdx.y];
     const G2A* __restrict__ b = ps.b[blockIdx.y];
     uint4* park = park_ + threadIdx.x;

@@ -8,14 +8,14 @@
 // its own digit row, so in the lane-interleaved layout of scale.hpp a 128-byte line served one or two lanes (49.5 GB of HBM traffic per 2^20-element
 // launch, 174 x the algorithmic bytes); here a lookup reads one 144-byte run.
 // Exceptional additions (acc = +-T: H = 0) cannot occur for the digit patterns of a proper GLV split, but they are DETECTED and such a lane
-// is flagged and recomputed (k_scale_g1_fix) by plain double-and-add with the complete formulas of curve.hpp.  BLS12-381 only (the 377 build keeps the 12 x 32-bit kernel).
+// is flagged and recomputed (k_scale_g1_fix) by plain double-and-add with the complete formulas of curve.hpp.  Both curves (the group law of G1 does not involve the tower).
 #pragma once
 #include "fq_curve.hpp"
 #include "scale.hpp"
 
 namespace ripp {
 
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(RIPP_BLS12_377)
+#if defined(__HIP_DEVICE_COMPILE__)
 #define SBS() __builtin_amdgcn_sched_barrier(0)
 // add-2007-bl (both operands Jacobian, neither the identity) in a low-liveness order.  Returns true when H = 0 (p = +-q): result not valid.
 __device__ __forceinline__ bool jadd_q(JacQ& p, const JacQ& q) {
@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(256, 2) k_scale_g1_glv_q(const G1A* __restrict
                                                            uint4* __restrict__ tab, G1J* __restrict__ out, uint8_t* __restrict__ flag) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(RIPP_BLS12_377)
+#if defined(__HIP_DEVICE_COMPILE__)
     const G1A p = base[(size_t)i * base_stride];
     if (is_inf(p)) { out[i] = jac_inf<Fp>(); flag[i] = 0; return; }
     uint32_t d1[5], d2[5];
@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(256, 2) k_scale_g1_glv_q(const G1A* __restrict
 }
 // the flagged lanes of k_scale_g1_glv_q, by plain double-and-add with the complete formulas
 __global__ void __launch_bounds__(64) k_scale_g1_fix(const G1A* __restrict__ base, uint32_t base_stride, const Fr* __restrict__ k_mont, uint32_t n, G1J* __restrict__ out, const uint8_t* __restrict__ flag) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(RIPP_BLS12_377)
+#if defined(__HIP_DEVICE_COMPILE__)
     for_flagged(flag, n, [&](uint32_t i) { out[i] = scale_g1_plain(base[(size_t)i * base_stride], from_mont(k_mont[i])); });
 #endif
 }

@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(256, RIPP_OCC) k_miller_lines(PairSets ps, uin
 
 // ---- stage 2a: sparse accumulation -------------------------------------------------------------------------
 // grid = (T / block, rows).  Lane t of row r multiplies lines r[t], r[t+T], ... (< M) and writes one dense partial.
-#if !defined(RIPP_BLS12_377)       // A/B reference form (mul_by_014): BLS12-381 build only
+#if defined(RIPP_AB_KERNELS) && !defined(RIPP_BLS12_377)       // A/B reference form (mul_by_014): BLS12-381 builds with -DRIPP_AB_KERNELS only
 __global__ void __launch_bounds__(64, RIPP_OCC_PROD) k_line_products1(const uint4* __restrict__ lines, size_t stride, uint32_t M,
                                                         uint4* __restrict__ partials, uint32_t T) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;

@@ -50,6 +50,23 @@ def test_bls12_377_library_exports_the_same_abi_and_its_own_point_encodings():
     assert R7.ser_g1_compressed(np.zeros(12, dtype=np.uint64)).hex() == g["ser_g1_inf_compressed"] and R7.ser_g2_compressed(np.zeros(24, dtype=np.uint64)).hex() == g["ser_g2_inf_compressed"]
 
 
+def test_abi_guard_and_config_defaults_need_no_device(hiplib):
+    """The ABI guard (version + sizeof(ripp_stats), checked by the loader) and ripp_config: the defaults are readable without a device, a
+    struct of another size is rejected, ripp_configure(NULL) returns to the defaults."""
+    import ripp_amd as R
+    from ripp_amd._lib import RippConfig, RippStats, RIPP_ABI_VERSION
+    assert hiplib.ripp_abi_version() == RIPP_ABI_VERSION and hiplib.ripp_stats_size() == ctypes.sizeof(RippStats)
+    c = R.config_default()
+    assert c.struct_size == ctypes.sizeof(RippConfig) and c.look_eighths == -1 and c.ranks_per_device == 1
+    assert c.tail_pipe_max == 1 << 11 and c.fold_tab_min == 32768 and c.no_vm == 0 and c.no_precompute == 0 and c.lp_fq_min == 0
+    bad = RippConfig(); bad.struct_size = 8
+    assert hiplib.ripp_configure(ctypes.byref(bad)) == 4             # RIPP_ERR_ARG
+    assert hiplib.ripp_configure(ctypes.byref(c)) == 0 and hiplib.ripp_configure(None) == 0
+    with pytest.raises(AttributeError):
+        R.configure(no_such_member=1)
+    R.configure()
+
+
 def test_no_cpu_fallback_without_device(hiplib):
     if hiplib.ripp_device_count() > 0:
         pytest.skip("a HIP device is present; the refusal path is exercised on the CPU-only builder")

@@ -58,8 +58,9 @@ def test_synthetic_inputs_match_oracle(E, o):
     assert np.array_equal(E.synth_fr(3, n), o.gen_scalars(3, n))
 
 
-@pytest.mark.parametrize("n", [0, 1, 2, 3, 33, 64, 1000, 1 << 13])
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 33, 64, 1000, 1 << 13, (1 << 16) + 3])
 def test_pairing_inner_product_vs_oracle(E, o, n):
+    """(2^16 + 3: above the VM crossover -- the carry-free throughput kernels k_miller_lines_q / k_line_products_q with the D-type twist's lines.)"""
     a, b = o.gen_g1(50, n), o.gen_g2(60, n)
     if n > 5:
         a[2] = 0; b[4] = 0
@@ -153,7 +154,10 @@ def test_sipp_2p17_endomorphism_paths_vs_oracle(E, o):
     proof, ch, st = E.SIPP.prove_with_stats(a, b, r, value)
     assert np.array_equal(proof, eproof) and np.array_equal(ch, ech)
     assert E.SIPP.verify(a, b, r, value, proof) and o.sipp_verify(a, b, r, value, proof) == 1
-    for env in ({"RIPP_NO_ENDO": "1"}, {"RIPP_NO_FOLD_TABLES": "1"}, {"RIPP_NO_XSCALE": "1"}, {"RIPP_NO_PRECOMPUTE": "1"}, {"RIPP_LOOK_EIGHTHS": "12"}, {"RIPP_NO_MSM_GLV": "1"}):
+    # RIPP_NO_FQ: the 12 x 32-bit throughput kernels this build ran until build round 4 (the default is now the carry-free forms with u^2 = -5 and the
+    # D-type twist's line placement: fq_curve2.hpp FQ2_BETA, fq_miller.hpp, fq_line_products.hpp); RIPP_*_FQ_MIN switch single kernels back
+    for env in ({"RIPP_NO_ENDO": "1"}, {"RIPP_NO_FOLD_TABLES": "1"}, {"RIPP_NO_XSCALE": "1"}, {"RIPP_NO_PRECOMPUTE": "1"}, {"RIPP_LOOK_EIGHTHS": "12"}, {"RIPP_NO_MSM_GLV": "1"},
+                {"RIPP_NO_FQ": "1"}, {"RIPP_LP_FQ_MIN": "4294967295"}, {"RIPP_ML_FQ_MIN": "4294967295"}, {"RIPP_FQ_MIN": "4096", "RIPP_FQ_MIN_G1": "64"}):
         os.environ.update(env)
         try:
             assert np.array_equal(E.SIPP.prove(a, b, r, value), eproof), env

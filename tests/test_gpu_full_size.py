@@ -127,3 +127,22 @@ def test_sipp_prove_2p20_sharded_vs_oracle(engine, sipp_2p20, world, env, items)
     assert sorted(got) == list(range(world)) and all(got[k][0] for k in got), got
     if items is not None:
         assert all(got[k][1] == items for k in got), got
+
+
+def test_sipp_prove_2p20_bls12_377_host_slices_vs_oracle():
+    """The reference's own SIPP curve at the largest size its `scaling-ipp` harness reaches (sipp/examples/scaling-ipp.rs:2,10,57-82: BLS12-377,
+    n up to 2^20): ripp_sipp_prove of libripp_hip_377.so on HOST slices -- all 40 GT elements equal the BLS12-377 oracle's proof of the same
+    statement, and both verifiers accept."""
+    import orclib377 as o7
+    import ripp_amd.bls12_377 as R7
+    if R7.device_count() <= 0:
+        pytest.skip("no HIP device in this environment")
+    R7.init(0)
+    a, b, r = R7.synth_g1(1000, N), R7.synth_g2(2000, N), R7.synth_fr(0, N)
+    value = R7.product_of_pairings_with_coeffs(a, b, r)
+    assert np.array_equal(value, o7.product_of_pairings_with_coeffs(a, b, r))
+    rc, eproof, ech = o7.sipp_prove(a, b, r, value)
+    assert rc == 0
+    proof, ch, st = R7.SIPP.prove_one_shot(a, b, r, value)
+    assert proof.shape == (40, 72) and np.array_equal(proof, eproof) and np.array_equal(ch, ech)
+    assert R7.SIPP.verify(a, b, r, value, proof) and o7.sipp_verify(a, b, r, value, proof) == 1

@@ -177,11 +177,13 @@ def test_msm_endomorphism_edge_scalars(engine, orc):
     assert np.array_equal(engine.normalize_batch_g2(engine.MultiexponentiationInnerProductG2.inner_product(j2, s)), orc.g2_to_affine(orc.msm_g2_a(b2, s)).reshape(1, 24))
 
 
-def test_msm_repeated_bases_vs_oracle(engine, orc):
+@pytest.mark.parametrize("n", [1 << 12, 1 << 17])
+def test_msm_repeated_bases_vs_oracle(engine, orc, n):
     """Equal bases with equal scalars land in the same bucket slot, so the gathered mixed additions of k_msm_slot_sum_q meet T = Q (doubling) and
-    T = -Q (the identity) -- the exceptional cases its low-liveness formulas only DETECT: those slots are flagged and summed again by
-    k_msm_slot_sum_fix with the complete formulas.  Identities among the bases and zero scalars ride along."""
-    n = 1 << 12
+    T = -Q (the identity) -- the exceptional cases its low-liveness formulas only DETECT: those slots are flagged and summed again with the
+    complete addition law by k_msm_slot_sum_fix_vm (one wave per flagged slot on the field VM; four 16-lane groups sum every fourth term, then
+    group 0 adds the other partial sums; k_msm_slot_sum_fix under RIPP_NO_VM).  Identities among the bases and zero scalars ride along.
+    n = 2^17: slots of 32 terms (eight per group), hundreds of flagged slots per window."""
     b1, b2 = orc.gen_g1(25, n), orc.gen_g2(26, n)
     vals = [(i % 5) * 0x1F2E3D4C5B6A79881726354453627180 + 7 for i in range(n)]
     for k in range(0, n, 16):                                               # runs of identical terms, one negated term per run
@@ -521,3 +523,40 @@ def test_lookahead_rounds_vs_oracle(engine, orc, n, items):
             assert st["look_items"] == min(k, 2 * max(min(lg - 1, 3), 0)), (n, k, st["look_items"])
     finally:
         job.close()
+
+
+def test_configure_api_selects_the_same_forms_as_the_environment(engine, orc):
+    """ripp_configure (include/ripp_hip.h: ripp_config) is the API for what the RIPP_* variables select: a forced look-ahead plan, the
+    round-by-round tail, the single-lane kernels -- each gives the oracle's proof; ripp_config_get shows what the next call runs with
+    (defaults < ripp_configure < environment), and configure() returns to the defaults."""
+    import os
+    n = 1 << 12
+    a, b, r = orc.gen_g1(61, n), orc.gen_g2(62, n), orc.gen_scalars(63, n)
+    v = orc.product_of_pairings_with_coeffs(a, b, r)
+    rc, eproof, ech = orc.sipp_prove(a, b, r, v)
+    assert rc == 0
+    job = engine.SippJob(a, b, r)
+    try:
+        d = engine.config_get()
+        assert d.look_eighths == -1 and d.tail_pipe_max == 1 << 11 and d.no_vm == 0
+        engine.configure(look_eighths=29, tail_pipe_max=0)
+        g = engine.config_get()
+        assert g.look_eighths == 29 and g.tail_pipe_max == 0
+        proof, ch, st = job.prove(v)
+        assert np.array_equal(proof, eproof) and np.array_equal(ch, ech) and st["look_items"] == 4
+        os.environ["RIPP_LOOK_EIGHTHS"] = "8"                     # the environment overrides the configured value
+        try:
+            assert engine.config_get().look_eighths == 8
+            proof, ch, st = job.prove(v)
+        finally:
+            del os.environ["RIPP_LOOK_EIGHTHS"]
+        assert np.array_equal(proof, eproof) and st["look_items"] == 1
+        engine.configure(no_vm=1, no_precompute=1)
+        assert engine.config_get().no_vm == 1 and engine.config_get().look_eighths == -1
+        proof, ch, st = job.prove(v)
+        assert np.array_equal(proof, eproof) and np.array_equal(ch, ech) and st["look_items"] == 0
+    finally:
+        engine.configure()
+        job.close()
+    d = engine.config_get()
+    assert d.look_eighths == -1 and d.tail_pipe_max == 1 << 11 and d.no_vm == 0 and d.no_precompute == 0
