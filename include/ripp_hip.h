@@ -53,6 +53,7 @@ typedef struct {
     uint64_t look_items, look_pairs;                                  /* (round, side) values pre-evaluated; pairs that took */
     /* the statement hash of THIS call (appended in build round 4; 0 on ranks that did not hash): Blake2s itself / waiting for the serialisation workers */
     double statement_hash_ms, statement_hash_wait_ms;
+    uint64_t chains_lines;                                            /* G2 chains the carry-free stage-1 kernel walked (<= pairs_lines: products over one Q vector share a chain) */
 } ripp_stats;
 /* ABI guard.  The library WRITES sizeof(ripp_stats) bytes through every `ripp_stats*` it is given, and the struct has grown twice: a caller
  * compiled against an older header would be overrun.  Bindings must check at load time that RIPP_ABI_VERSION == ripp_abi_version() and
@@ -80,7 +81,7 @@ const char* ripp_last_error(void);   /* message of the calling thread's last fai
 typedef struct {
     uint32_t struct_size;            /* sizeof(ripp_config), set by ripp_config_default; ripp_configure rejects any other value */
     /* implementation selectors: non-zero switches the named form OFF (DESIGN.md section 7b has the effect of each) */
-    uint32_t no_vm, no_precompute, no_fold_tables, no_msm_glv, lp_one_lane, no_endo, no_fq, no_xscale, scale_no_fq, agg_sequential, look_static, quiet_waits;
+    uint32_t no_vm, no_precompute, no_fold_tables, no_msm_glv, lp_one_lane, no_endo, no_fq, no_xscale, scale_no_fq, agg_sequential, look_static, quiet_waits, no_share;
     int32_t  look_eighths;           /* hash-window look-ahead plan: -1 automatic (cost model / adaptive), 8 k + f = k (round, side) items and f/8 of the next, FORCED */
     int32_t  ranks_per_device;       /* ranks sharing one GPU (test rigs): the look-ahead plan prices the window per device */
     int32_t  msm_c; uint32_t msm_ch, msm_gmin;       /* MSM window width, slot length, grouping threshold; 0 = the plan's own choice */

@@ -242,12 +242,13 @@ struct Engine {
         return aux;
     }
     // run-time switches: read from the environment ONCE per C-ABI call (get_engine), never inside round loops
-    struct Switches { bool no_vm = false, no_precompute = false, no_fold_tables = false, no_msm_glv = false, lp_one_lane = false, no_endo = false, no_fq = false, no_xscale = false; } sw;
+    struct Switches { bool no_vm = false, no_precompute = false, no_fold_tables = false, no_msm_glv = false, lp_one_lane = false, no_endo = false, no_fq = false, no_xscale = false, no_share = false; } sw;
     // crossover sizes: the member initialisers above are the defaults, the environment overrides them PER CALL (a test or
     // an A/B run flips them on a live engine)
     struct Sizes { size_t vm_lines_max, vm_fold_max, vm_tree_max, gls_split_max, msm_vm_merge_max, fold_tab_min, fq_min, lp_fq_min, vm_joint_max, vm_scale_max, tail_pipe_max, ml_fq_min, fq_min_g1; } defaults{};
     MsmTune msm_tune;
     // the hash-window look-ahead plan and a few whole-call choices (ripp_config: look_eighths, ranks_per_device, look_static, quiet_waits, agg_sequential, scale_no_fq)
+    double cal_ms_per_pair = 0, cal_hash_bytes_per_ms = 0;        // look_plan's rates as measured by the last large proof of this process (0: not yet)
     int look_eighths = -1; double ranks_per_device = 1.0; bool look_static = false, quiet_waits_cfg = false, agg_sequential = false, scale_no_fq = false;
     // Precedence: built-in defaults < ripp_configure() < environment variables (a debug / A-B override).  This function is the ONLY place of the
     // library that reads RIPP_* configuration from the environment (RIPP_TRACE aside), once per C-ABI call (get_engine) -- never inside a proof.
@@ -260,7 +261,7 @@ struct Engine {
         if (g_cfg_set) {
             const ripp_config& c = g_cfg;
             sw.no_vm = c.no_vm; sw.no_precompute = c.no_precompute; sw.no_fold_tables = c.no_fold_tables; sw.no_msm_glv = c.no_msm_glv; sw.lp_one_lane = c.lp_one_lane;
-            sw.no_endo = c.no_endo; sw.no_fq = c.no_fq; sw.no_xscale = c.no_xscale; scale_no_fq = c.scale_no_fq; agg_sequential = c.agg_sequential; look_static = c.look_static; quiet_waits_cfg = c.quiet_waits;
+            sw.no_endo = c.no_endo; sw.no_fq = c.no_fq; sw.no_xscale = c.no_xscale; sw.no_share = c.no_share; scale_no_fq = c.scale_no_fq; agg_sequential = c.agg_sequential; look_static = c.look_static; quiet_waits_cfg = c.quiet_waits;
             look_eighths = c.look_eighths; ranks_per_device = c.ranks_per_device > 1 ? (double)c.ranks_per_device : 1.0;
             msm_tune.c = c.msm_c; msm_tune.ch = c.msm_ch; msm_tune.gmin = c.msm_gmin;
             vm_lines_max = c.vm_lines_max; vm_fold_max = c.vm_fold_max; vm_tree_max = c.vm_tree_max; gls_split_max = c.gls_split_max; msm_vm_merge_max = c.msm_vm_merge_max; fold_tab_min = c.fold_tab_min;
@@ -278,6 +279,7 @@ struct Engine {
         env_on("RIPP_NO_ENDO", sw.no_endo);            // plain scalar multiplications in the folds / scaling (no GLV, no psi)
         env_on("RIPP_NO_XSCALE", sw.no_xscale);        // G2 folds always on the plain vector with the full-width x^-1
         env_on("RIPP_NO_FQ", sw.no_fq);                // the 12 x 32-bit forms of the kernels that have a carry-free twin (fq_curve.hpp)
+        env_on("RIPP_NO_SHARE", sw.no_share);          // every pairing product walks its own G2 chain (no ChainSets grouping, no merged round 0 + look-ahead)
         env_on("RIPP_SCALE_NO_FQ", scale_no_fq); env_on("RIPP_AGG_SEQUENTIAL", agg_sequential); env_on("RIPP_LOOK_STATIC", look_static); env_on("RIPP_QUIET_WAITS", quiet_waits_cfg);
         if (const char* s = std::getenv("RIPP_LOOK_ITEMS")) look_eighths = 8 * std::max(0, std::atoi(s));            // whole (round, side) items
         if (const char* s = std::getenv("RIPP_LOOK_EIGHTHS")) look_eighths = std::max(0, std::atoi(s));               // 8 k + f: k items and f/8 of the next
@@ -503,18 +505,45 @@ struct Engine {
             if ((rc = mark(ev_lines, true)) != RIPP_OK) return rc;
             if (m * nprod <= vm_lines_max && !sw.no_vm)
                 hipLaunchKernelGGL(k_vm_miller_lines, dim3(nblk(m, 4 * VM_EPW), nprod), dim3(256), 4 * VM_EPW * VM_LINES_SLOTS * sizeof(VmSlot), stream, ps, (uint32_t)m, lines.as<uint4>(), stride);
-            else if (!sw.no_fq && m * nprod >= ml_fq_min)         // the carry-free twin (fq_miller.hpp): ~25 % fewer instructions on an issue-bound kernel
-                hipLaunchKernelGGL(k_miller_lines_q, dim3(nblk(m, 256), nprod), dim3(256), 0, stream, ps, (uint32_t)m, lines.as<uint4>(), stride);
-            else
+            else if (!sw.no_fq && m * nprod >= ml_fq_min) {       // the carry-free twin (fq_miller.hpp): ~25 % fewer instructions on an issue-bound kernel
+                // consecutive products over the SAME Q vector share one chain (up to MAX_SHARE P's per lane): the callers order their product lists accordingly
+                ChainSets cs{}; int ng = 0;
+                for (int p = 0; p < nprod; ++p) {
+                    cs.a[p] = ps.a[p];
+                    if (!sw.no_share && ng > 0 && ps.b[p] == cs.b[ng - 1] && cs.np[ng - 1] < MAX_SHARE) ++cs.np[ng - 1];
+                    else { cs.b[ng] = ps.b[p]; cs.first[ng] = (uint8_t)p; cs.np[ng] = 1; ++ng; }
+                }
+                hipLaunchKernelGGL(k_miller_lines_q, dim3(nblk(m, 256), ng), dim3(256), 0, stream, cs, (uint32_t)m, lines.as<uint4>(), stride);
+                stats.chains_lines += m * (size_t)ng;
+            } else
                 hipLaunchKernelGGL(k_miller_lines, dim3(nblk(m, 256), nprod), dim3(256), 0, stream, ps, (uint32_t)m, lines.as<uint4>(), stride);
             HIPCHK(hipGetLastError());
             if ((rc = mark(ev_lines, false)) != RIPP_OK) return rc;
             stats.pairs_lines += m * nprod;
         }
+        // stage 2 per PIECE of the product list.  A row (product, step) gets T accumulators and the launch has ceil(T / 21) * rows waves, which should
+        // fill the chip's 2 waves per SIMD exactly once: rows = 68 * {1, 2, 3, 5, 6} products leave <= 0.4 % of the slots empty, 4 or 7 products 7 %,
+        // EIGHT products 20 % (3 * 544 = 1 632 of 2 048 slots: k_line_products_q then takes 25 % longer per pair -- measured on the first shared
+        // round-0 launches of build round 4, where it ate the whole gain of the shared G2 chains).  Throughput-sized launches of 8 / 7 / 4 products
+        // are therefore split 6 + 2 / 5 + 2 / 2 + 2; the lines of all products still come from ONE stage-1 launch.
+        int pieces[3] = {nprod, 0, 0};
+        if (m * (size_t)nprod >= ((size_t)1 << 17) && !sw.lp_one_lane) {
+            if (nprod == 8) { pieces[0] = 6; pieces[1] = 2; } else if (nprod == 7) { pieces[0] = 5; pieces[1] = 2; } else if (nprod == 4) { pieces[0] = 2; pieces[1] = 2; }
+        }
+        int p_lo = 0;
+        for (int pc = 0; pc < 3 && pieces[pc] > 0; p_lo += pieces[pc], ++pc)
+            if ((rc = enqueue_stage2(p_lo, pieces[pc], m, stride, dst_pinned)) != RIPP_OK) return rc;
+        return RIPP_OK;
+    }
+    // stage 2 (per-step products + tree + copy) of the products [p_lo, p_lo + np2) of the line buffer stage 1 has just filled
+    int32_t enqueue_stage2(int p_lo, int np2, size_t m, size_t stride, Fp12* dst_pinned) {
+        int32_t rc;
+        const size_t nrows = (size_t)np2 * N_LINES;
+        const uint4* lrows = lines.as<uint4>() + (size_t)p_lo * N_LINES * LINE_CHUNKS * stride;
         // stage 2a: T lanes per row
         // one resident batch: rows * T / 64 waves <= SIMDs * RIPP_OCC, so no partially filled second batch
         // T accumulators per row.  Spill-free form (line_products.hpp): 3 lanes per accumulator, 21 accumulators per wave;
-        // RIPP_LP_ONE_LANE=1 selects the one-lane-per-accumulator kernel (A/B reference).
+        // RIPP_LP_ONE_LANE=1 selects the one-lane-per-accumulator kernel (A/B builds only).
         const uint32_t per_wave = sw.lp_one_lane ? 64 : LP_GROUPS_PER_WAVE;
         uint32_t T = (uint32_t)std::max<size_t>(per_wave, ((size_t)n_simd * RIPP_OCC_PROD / nrows) * per_wave);
         if (T > m) T = (uint32_t)m;
@@ -523,16 +552,16 @@ struct Engine {
         if ((rc = mark(ev_prod, true)) != RIPP_OK) return rc;
 #if defined(RIPP_AB_KERNELS) && !defined(RIPP_BLS12_377)
         if (sw.lp_one_lane)           // build round 1's one-lane-per-accumulator form: A/B builds only (-DRIPP_AB_KERNELS; it spills 1 248 B per lane)
-            hipLaunchKernelGGL(k_line_products1, dim3(nblk(T, 64), (unsigned)nrows), dim3(64), 0, stream, lines.as<uint4>(), stride, (uint32_t)m, partA.as<uint4>(), T);
+            hipLaunchKernelGGL(k_line_products1, dim3(nblk(T, 64), (unsigned)nrows), dim3(64), 0, stream, lrows, stride, (uint32_t)m, partA.as<uint4>(), T);
         else
 #endif
-        if (!sw.no_fq && m * nprod >= lp_fq_min)          // throughput-sized launches: the carry-free twin (fq_line_products.hpp), both curves
-            hipLaunchKernelGGL(k_line_products_q, dim3(nblk(T, LP_GROUPS_PER_WAVE), (unsigned)nrows), dim3(64), 0, stream, lines.as<uint4>(), stride, (uint32_t)m, partA.as<uint4>(), T);
+        if (!sw.no_fq && m * (size_t)np2 >= lp_fq_min)          // throughput-sized launches: the carry-free twin (fq_line_products.hpp), both curves
+            hipLaunchKernelGGL(k_line_products_q, dim3(nblk(T, LP_GROUPS_PER_WAVE), (unsigned)nrows), dim3(64), 0, stream, lrows, stride, (uint32_t)m, partA.as<uint4>(), T);
         else
-            hipLaunchKernelGGL(k_line_products, dim3(nblk(T, LP_GROUPS_PER_WAVE), (unsigned)nrows), dim3(64), 0, stream, lines.as<uint4>(), stride, (uint32_t)m, partA.as<uint4>(), T);
+            hipLaunchKernelGGL(k_line_products, dim3(nblk(T, LP_GROUPS_PER_WAVE), (unsigned)nrows), dim3(64), 0, stream, lrows, stride, (uint32_t)m, partA.as<uint4>(), T);
         HIPCHK(hipGetLastError());
         if ((rc = mark(ev_prod, false)) != RIPP_OK) return rc;
-        stats.pairs_products += m * nprod;
+        stats.pairs_products += m * (size_t)np2;
         // stage 2b: dense tree, radix 4
         uint4* cur = partA.as<uint4>(); uint4* nxt = partB.as<uint4>();
         while (T > 1) {
@@ -547,7 +576,7 @@ struct Engine {
             std::swap(cur, nxt); T = Tout;
         }
         // rows are now [nrows][36][1] == nrows contiguous Fp12
-        HIPCHK(hipMemcpyAsync(dst_pinned, cur, nrows * sizeof(Fp12), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(dst_pinned + (size_t)p_lo * N_LINES, cur, nrows * sizeof(Fp12), hipMemcpyDeviceToHost, stream));
         return RIPP_OK;
     }
     int32_t step_products(const G1A* const* a, const G2A* const* b, int nprod, size_t M, Fp12* rows_out) {
@@ -1162,7 +1191,7 @@ extern "C" {
 #define ENGINE Engine* e; { int32_t rc_ = get_engine(&e); if (rc_ != RIPP_OK) return rc_; }
 
 API const char* ripp_last_error(void) { return g_err.c_str(); }
-static_assert(sizeof(ripp_stats) == 21 * 8, "ripp_stats changed: bump RIPP_ABI_VERSION (include/ripp_hip.h) and the bindings (ripp_amd/_lib.py, rust/ripp-hip/src/ffi.rs)");
+static_assert(sizeof(ripp_stats) == 22 * 8, "ripp_stats changed: bump RIPP_ABI_VERSION (include/ripp_hip.h) and the bindings (ripp_amd/_lib.py, rust/ripp-hip/src/ffi.rs)");
 API int32_t ripp_abi_version(void) { return RIPP_ABI_VERSION; }
 API size_t ripp_stats_size(void) { return sizeof(ripp_stats); }
 API void ripp_statement_hash_times(double* hash_ms, double* wait_ms) { if (hash_ms) *hash_ms = g_digest_hash_ms; if (wait_ms) *wait_ms = g_digest_wait_ms; }
@@ -1677,9 +1706,14 @@ static int look_plan(const Engine* e, size_t n_local, int world, bool window) {
     const double share = e->ranks_per_device;                       // ranks sharing this rank's GPU (test rigs: several ranks on one device): their work adds up in the same window
     const double nl = (double)n_local * share, n = (double)n_local * world;
     if (n < (double)((size_t)1 << 17)) return 0;                    // small statements: the hash is done long before the GPU is
-    const double ms_per_pair = 7.7e-5;                              // 2^20 pairs through lines + products: ~80 ms with the carry-free kernels (profiles/r03_*)
-    const double hash_ms = n * 336.0 / 1.12e6;                      // the statement hash: 313-317 ms at n = 2^20 (1.06 GB/s of Blake2s in situ + serialisation hidden)
-    double budget = hash_ms - (nl * (3.2e-5 + ms_per_pair + 5.3e-5) + 1.0);      // scaling, round 0, fold tables (measured at n = 2^20: 33 + 80 + 55 ms)
+    // Rates: compiled-in for the FIRST proof of a process (2^20 pairs through lines + products ~80 ms with the carry-free kernels; the statement hash
+    // 313-317 ms at n = 2^20 = 1.06-1.12 GB/s of Blake2s in situ), MEASURED afterwards: sipp_prove_core records this box's hash rate and this device's
+    // pairing rate at the end of every large proof that hashed (Engine::cal_*), so the static plan the non-hashing ranks follow is priced with what
+    // rank 0's box and GPU really do (boxes differ by +-3 % / +-5 %).  Scaling and the fold tables move with the GPU factor.
+    const double ms_per_pair = e->cal_ms_per_pair > 0 ? e->cal_ms_per_pair : 7.7e-5;
+    const double gpu_f = ms_per_pair / 7.7e-5;
+    const double hash_ms = n * 336.0 / (e->cal_hash_bytes_per_ms > 0 ? e->cal_hash_bytes_per_ms : 1.12e6);
+    double budget = hash_ms - (nl * (3.2e-5 * gpu_f + ms_per_pair + 5.3e-5 * gpu_f) + 1.0);      // scaling, round 0, fold tables (measured at n = 2^20: 33 + 80 + 55 ms)
     int items = 0;
     for (int it = 0; it < 2 * LOOK_MAX_R; ++it) {
         const int R = it / 2 + 1;
@@ -1697,8 +1731,9 @@ static int look_plan(const Engine* e, size_t n_local, int world, bool window) {
 // sizes every item ADAPTIVELY: the hash thread counts the bytes it has consumed, so the time the window still has is known to a few per cent,
 // the device queue is drained before an item is sized, and the item takes the whole / the fraction of its pairs that still fits -- boxes differ
 // by +-3 % in hash speed and +-5 % in GPU speed, more than the static plan's margin.  Other ranks follow the plan rank 0 sent.
-static int32_t job_lookahead(Engine* e, ripp_sipp_job* j, int eighths, bool forced, double ms_per_pair) {
-    j->look.clear();
+// first_item = 1: item (1,l) was already produced together with round 0 (job_round0_shared).
+static int32_t job_lookahead(Engine* e, ripp_sipp_job* j, int eighths, bool forced, double ms_per_pair, int first_item = 0) {
+    if (first_item == 0) j->look.clear();
     const bool adaptive = !forced && j->hash_total > 0 && !j->no_window && eighths > 0 && !e->look_static;
     const int items = adaptive ? std::min(2 * LOOK_MAX_R, eighths / 8 + 2) : (eighths + 7) / 8;      // adaptive: at most one whole item beyond what the static model expects
     if (items <= 0 || (j->digest_ready.load() && !forced)) return RIPP_OK;      // the hash is already done: nothing to hide the work behind (forced: RIPP_LOOK_ITEMS, tests)
@@ -1706,7 +1741,7 @@ static int32_t job_lookahead(Engine* e, ripp_sipp_job* j, int eighths, bool forc
     const size_t len = j->len;
     const G1A* a = j->a.as<G1A>(); const G2A* b = j->b.as<G2A>();
     int32_t rc;
-    for (int it = 0; it < items; ++it) {
+    for (int it = first_item; it < items; ++it) {
         const int R = it / 2 + 1, side = it & 1;
         const size_t qblk = len >> (R + 1);
         if (qblk == 0 || qblk > e->max_pairs_per_batch) break;
@@ -1732,7 +1767,8 @@ static int32_t job_lookahead(Engine* e, ripp_sipp_job* j, int eighths, bool forc
         const int ngroups = pow3(R);
         struct Prod { const G1A* a; const G2A* b; int g; };
         std::vector<Prod> prods;
-        for (int eb = 0; eb < (1 << R); ++eb) for (int fb = 0; fb < (1 << R); ++fb) {
+        // B block outermost: the 2^R products that pair one B block with different A blocks are ADJACENT and share its G2 chain (ChainSets)
+        for (int fb = 0; fb < (1 << R); ++fb) for (int eb = 0; eb < (1 << R); ++eb) {
             int g = 0;
             for (int t = 0; t < R; ++t) g = g * 3 + (((eb >> (R - 1 - t)) & 1) - ((fb >> (R - 1 - t)) & 1) + 1);
             const size_t ia = ((size_t)eb << 1) | (side == 0 ? 1u : 0u), ib = ((size_t)fb << 1) | (side == 0 ? 0u : 1u);
@@ -1809,6 +1845,37 @@ static void look_apply(ripp_sipp_job* j, size_t t, const Fr& x) {
 static ripp_sipp_job::LookItem* look_find(ripp_sipp_job* j, size_t round, int side) { for (auto& it : j->look) if ((size_t)it.R == round && it.side == side) return &it; return nullptr; }
 // both values of `round` are known in full: nothing of that round is left for the device
 static bool look_full(ripp_sipp_job* j, size_t round) { const auto* l = look_find(j, round, 0); const auto* r = look_find(j, round, 1); return l && r && l->npairs == l->q && r->npairs == r->q; }
+
+// Round 0 and the look-ahead item (1,l) in ONE evaluation.  With the quarters A0..A3 / B0..B3 of the round-0 vectors, round 0 needs
+// z_l = E(A2,B0) E(A3,B1), z_r = E(A0,B2) E(A1,B3) and item (1,l) the four products E(A1,B0), E(A1,B2), E(A3,B0), E(A3,B2): B0 and B2 each meet THREE
+// A blocks, so their G2 chains are walked once for three line sets (fq_miller.hpp) -- 4 chains instead of 8 for these eight quarter products, and
+// item (1,r) pairs B1 and B3 with two A blocks each (job_lookahead): 6 chain walks per quarter where the separate evaluations took 12.
+// rows: the per-step products of z_l and z_r like job_round_partials; the item is appended to j->look (exponent groups d = e - f as in job_lookahead).
+static int32_t job_round0_shared(Engine* e, ripp_sipp_job* j, Fp12* rows) {
+    const size_t q = j->len / 4;
+    const G1A* a = j->a.as<G1A>(); const G2A* b = j->b.as<G2A>();
+    const G1A* as[8] = {a + 2 * q, a + q, a + 3 * q,   a, a + q, a + 3 * q,   a + 3 * q,   a + q};
+    const G2A* bs[8] = {b, b, b,   b + 2 * q, b + 2 * q, b + 2 * q,   b + q,   b + 3 * q};
+    std::vector<Fp12> all((size_t)8 * N_LINES);
+    const double t0 = now_ms();
+    int32_t rc = e->step_products(as, bs, 8, q, all.data());
+    e->stats.miller_products_ms += now_ms() - t0;
+    if (rc) return rc;
+    auto row = [&](int p) { return all.data() + (size_t)p * N_LINES; };
+    for (int s2 = 0; s2 < N_LINES; ++s2) { rows[s2] = mul(row(0)[s2], row(6)[s2]); rows[N_LINES + s2] = mul(row(3)[s2], row(7)[s2]); }
+    j->look.clear();
+    j->look.emplace_back();
+    ripp_sipp_job::LookItem& li = j->look.back();
+    li.R = 1; li.side = 0; li.level = 0; li.npairs = q; li.q = q;
+    // exponent groups g = e - f + 1:  0: E(A1,B2)   1: E(A1,B0) E(A3,B2)   2: E(A3,B0)
+    for (int g = 0; g < 3; ++g) {
+        auto grows = std::make_shared<std::vector<Fp12>>((size_t)N_LINES);
+        for (int s2 = 0; s2 < N_LINES; ++s2) (*grows)[s2] = g == 0 ? row(4)[s2] : g == 1 ? mul(row(1)[s2], row(5)[s2]) : row(2)[s2];
+        li.fe.push_back(look_pool().submit([grows]() { return final_exponentiation(miller_combine(grows->data())); }));
+    }
+    ++e->stats.look_items; e->stats.look_pairs += 4 * q;
+    return RIPP_OK;
+}
 
 // ---- SIPP::prove (sipp/src/lib.rs:42-106) on this rank's shard; world0 == 1: the whole proof on one GPU --------------------------------------
 // One protocol for every world size: the ranks walk the same sequence of exchanges (plan, one per round while the vectors are sharded, the
@@ -1915,6 +1982,7 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
         const bool tp_round = !lrc && j->tp_round[round & 1] == round;                       // pipelined tail: this round's products were enqueued a round ago
         double t0 = tr0;
         double round0_ms_per_pair = 7.7e-5;                                                     // measured below in round 0 (lines + products + tree + copy per pair)
+        bool shared_r0 = false;                                                                 // round 0 evaluated together with look-ahead item (1,l)
         Fp12 zl = Fp12::one(), zr = Fp12::one();
         auto local_values = [&]() -> int32_t {
             int32_t rc;
@@ -1924,8 +1992,14 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
             const bool dev[2] = {!tp_round && start[0] < half, !tp_round && start[1] < half};
             if (dev[0] && dev[1] && start[0] == 0 && start[1] == 0) {
                 const double tp = now_ms();
-                if ((rc = job_round_partials(e, j, rows))) return rc;
-                if (round == 0 && j->len >= ((size_t)1 << 16)) round0_ms_per_pair = (now_ms() - tp) / (double)j->len;      // 2 products x len / 2 pairs
+                // round 0 with item (1,l) of the look-ahead planned in full: one evaluation with shared G2 chains (job_round0_shared)
+                shared_r0 = round == 0 && !j->seeded && look_items >= 8 && j->len >= 4 && !e->sw.no_share && !e->sw.no_precompute && (look_forced || !j->digest_ready.load());
+                if (shared_r0) { if ((rc = job_round0_shared(e, j, rows))) return rc; }
+                else if ((rc = job_round_partials(e, j, rows))) return rc;
+                if (round == 0 && j->len >= ((size_t)1 << 16)) {
+                    round0_ms_per_pair = (now_ms() - tp) / (double)(shared_r0 ? 2 * j->len : j->len);      // 2 products x len / 2 pairs (shared: 8 x len / 4)
+                    if (e->ranks_per_device <= 1.0) e->cal_ms_per_pair = round0_ms_per_pair;                 // (a time-sliced device would count its neighbours' work)
+                }
             }
             else for (int sd = 0; sd < 2; ++sd) {
                 if (!dev[sd]) continue;
@@ -1956,7 +2030,7 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
                 if (lk_l) { look_finish_level(*lk_l); zl = dev[0] ? mul(lk_l->Z[0], zd[0]) : lk_l->Z[0]; }
                 if (lk_r) { look_finish_level(*lk_r); zr = dev[1] ? mul(lk_r->Z[0], zd[1]) : lk_r->Z[0]; }
             }
-            if (round == 0 && !j->seeded && (rc = job_lookahead(e, j, look_items, look_forced, round0_ms_per_pair))) return rc;      // blocks on the GPU while the hash thread is still busy
+            if (round == 0 && !j->seeded && (rc = job_lookahead(e, j, look_items, look_forced, round0_ms_per_pair, shared_r0 ? 1 : 0))) return rc;      // blocks on the GPU while the hash thread is still busy
             return RIPP_OK;
         };
         if (!lrc) lrc = local_values();
@@ -2017,6 +2091,7 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
     e->collect_kernel_stats();
     e->stats.exchange_ms = exchange_ms;
     e->stats.statement_hash_ms = window ? g_digest_hash_ms : 0; e->stats.statement_hash_wait_ms = window ? g_digest_wait_ms : 0;      // this call's hash (the thread has been joined)
+    if (window && j->hash_total >= ((uint64_t)336 << 16) && g_digest_hash_ms + g_digest_wait_ms > 1.0) e->cal_hash_bytes_per_ms = (double)j->hash_total / (g_digest_hash_ms + g_digest_wait_ms);
     e->stats.total_ms = now_ms() - t_start;
     if (st) *st = e->stats;
     return RIPP_OK;
@@ -2026,7 +2101,7 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
 static void config_from_engine(const Engine* e, ripp_config* c) {
     std::memset(c, 0, sizeof *c); c->struct_size = (uint32_t)sizeof *c;
     c->no_vm = e->sw.no_vm; c->no_precompute = e->sw.no_precompute; c->no_fold_tables = e->sw.no_fold_tables; c->no_msm_glv = e->sw.no_msm_glv; c->lp_one_lane = e->sw.lp_one_lane;
-    c->no_endo = e->sw.no_endo; c->no_fq = e->sw.no_fq; c->no_xscale = e->sw.no_xscale; c->scale_no_fq = e->scale_no_fq; c->agg_sequential = e->agg_sequential; c->look_static = e->look_static; c->quiet_waits = e->quiet_waits_cfg;
+    c->no_endo = e->sw.no_endo; c->no_fq = e->sw.no_fq; c->no_xscale = e->sw.no_xscale; c->no_share = e->sw.no_share; c->scale_no_fq = e->scale_no_fq; c->agg_sequential = e->agg_sequential; c->look_static = e->look_static; c->quiet_waits = e->quiet_waits_cfg;
     c->look_eighths = e->look_eighths; c->ranks_per_device = (int32_t)e->ranks_per_device; c->msm_c = e->msm_tune.c; c->msm_ch = e->msm_tune.ch; c->msm_gmin = e->msm_tune.gmin;
     c->vm_lines_max = e->vm_lines_max; c->vm_fold_max = e->vm_fold_max; c->vm_tree_max = e->vm_tree_max; c->gls_split_max = e->gls_split_max; c->msm_vm_merge_max = e->msm_vm_merge_max; c->fold_tab_min = e->fold_tab_min;
     c->fq_min = e->fq_min; c->lp_fq_min = e->lp_fq_min; c->vm_joint_max = e->vm_joint_max; c->vm_scale_max = e->vm_scale_max; c->tail_pipe_max = e->tail_pipe_max; c->ml_fq_min = e->ml_fq_min; c->fq_min_g1 = e->fq_min_g1;

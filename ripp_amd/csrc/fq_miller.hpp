@@ -58,9 +58,33 @@ template <class FQ> __device__ __forceinline__ void st_park_fq(uint4* park, int 
     for (int c = 0; c < 4; ++c) park[(slot * 4 + c) * 256] = uint4{w[4 * c], w[4 * c + 1], w[4 * c + 2], w[4 * c + 3]};
 }
 
+// ---- one G2 chain, several P's (ChainSets, kernels.hpp).  The doubling / addition steps on Q do not depend on P: of a line only the two
+// coefficients scaled by xP / yP do.  When several products of one launch pair the SAME Q vector with different P vectors -- round 0 of a SIPP proof
+// and the look-ahead of the following rounds: every B block meets up to 2^R + 1 A blocks (engine.hip job_round0_shared / job_lookahead) -- ONE lane
+// walks Q's chain and emits the lines of all of them: per extra P and step two Fp2 x Fp products (1 568 multiply-adds) + the conversion of its two
+// coordinates (re-loaded from global memory in the engine's form: no LDS for them) against ~9 800 / ~16 000 for the step itself.
+struct ExtraP { const G1A* const* a; int np; };       // a[t], t = 1 .. np - 1: the other P vectors of the group (already offset).  Wave-uniform (SGPRs).
+// skipbits (ONE register per lane: the kernel sits at 256): bit t = "the pair (P_t[i], Q[i]) has a point at infinity", t = 0 the group's first P
+// the lines of the extra P's for one step: (yP-scaled from cy, xP-scaled from cx, free coefficient cf), rows of product t at s + t * N_LINES
+template <class CY, class CX>
+__device__ __forceinline__ void extra_lines_q(const ExtraP& xp, const CY& cy, const CX& cx, const Fq2n& cf, uint32_t skipbits, uint4* lines, size_t s, size_t stride, size_t i) {
+#pragma unroll 1
+    for (int t = 1; t < xp.np; ++t) {
+        const size_t st = s + (size_t)t * N_LINES;
+        const bool sk = (skipbits >> t) & 1u;                      // (its OWN P or the shared Q at infinity; the group's first P being the identity does not concern it)
+        const G1A* pp = opaque(xp.a[t] + i);
+        { Fq2n l2 = f2_mul_fq(cy, fq_from_fp_fast(pp->y)); f2_pin(l2);
+          if (sk) store_line_raw(lines, st * 3 + LINE_SLOT_YP, stride, i, LINE_UNIT_YP); else store_line_q(lines, st * 3 + LINE_SLOT_YP, stride, i, l2); }
+        { Fq2n l1 = f2_mul_fq(cx, fq_from_fp_fast(opaque(pp)->x)); f2_pin(l1);
+          if (sk) store_line_raw(lines, st * 3 + 1, stride, i, Fp2::zero()); else store_line_q(lines, st * 3 + 1, stride, i, l1); }
+        if (sk) store_line_raw(lines, st * 3 + LINE_SLOT_FREE, stride, i, LINE_UNIT_FREE); else store_line_q(lines, st * 3 + LINE_SLOT_FREE, stride, i, cf);
+    }
+}
+
 // doubling step + its line; (X, Y, Z) <- -4 x the doubled point.  park: slots 0 (xP), 1 (yP).  Every product is PINNED where it is written
 // (fq28.hpp fq_pin): the compiler otherwise carries un-reduced column sums of one step across the loop's branch into the next.
-__device__ __forceinline__ void line_double_store_q(Fq2C& X, Fq2C& Y, Fq2C& Z, const uint4* park, uint4* lines, size_t s, size_t stride, size_t i, bool skip) {
+__device__ __forceinline__ void line_double_store_q(Fq2C& X, Fq2C& Y, Fq2C& Z, const uint4* park, uint4* lines, size_t s, size_t stride, size_t i, uint32_t skipbits, const ExtraP& xp) {
+    const bool skip = skipbits & 1u;
     Fq2n t1 = f2_sqrd(f2_norm(f2_add(Y, Z))); f2_pin(t1);
     Fq2n c = f2_sqrd(Z); f2_pin(c);
     Fq2n b = f2_sqrd(Y); f2_pin(b);
@@ -87,8 +111,10 @@ __device__ __forceinline__ void line_double_store_q(Fq2C& X, Fq2C& Y, Fq2C& Z, c
     Fq2n a2 = f2_muld(X, Y); f2_pin(a2);                                          // a' = X Y
     {
         Fq2n j = f2_sqrd(X); f2_pin(j);
-        Fq2n l1 = f2_mul_fq(f2_add(f2_add(j, j), j), ld_park_fq(park, 0)); f2_pin(l1);
+        const auto j3 = f2_add(f2_add(j, j), j);
+        Fq2n l1 = f2_mul_fq(j3, ld_park_fq(park, 0)); f2_pin(l1);
         if (skip) store_line_raw(lines, s * 3 + 1, stride, i, Fp2::zero()); else store_line_q(lines, s * 3 + 1, stride, i, l1);
+        if (xp.np > 1) extra_lines_q(xp, nh, j3, f2_reduce(f2_sub(e, b)), skipbits, lines, s, stride, i);      // (wave-uniform branch)
     }
     Z = f2_to_coord(f2_muld(f2_dbl(b), f2_dbl(nh))); f2_pin(Z);                   // (2b)(2 nh) = -4 b h
     const auto f = f2_add(f2_add(e, e), e);                                       // 3e, lazy
@@ -100,7 +126,8 @@ __device__ __forceinline__ void line_double_store_q(Fq2C& X, Fq2C& Y, Fq2C& Z, c
 }
 __device__ __forceinline__ Fq2n f2_load_conv(const Fp2* p) { const Fp2 v = *p; return f2_from(v); }
 // mixed addition step + its line (-j, theta xP, -lambda yP) = -1 x the textbook line
-__device__ __forceinline__ void line_add_store_q(Fq2C& X, Fq2C& Y, Fq2C& Z, const G2A* q, const uint4* park, uint4* lines, size_t s, size_t stride, size_t i, bool skip) {
+__device__ __forceinline__ void line_add_store_q(Fq2C& X, Fq2C& Y, Fq2C& Z, const G2A* q, const uint4* park, uint4* lines, size_t s, size_t stride, size_t i, uint32_t skipbits, const ExtraP& xp) {
+    const bool skip = skipbits & 1u;
     Fq2n theta, lambda;
     { const Fq2n qy = f2_load_conv(&opaque(q)->y); theta = f2_reduce(f2_sub(Y, f2_muld(qy, Z))); } f2_pin(theta);
     st_park_fq(const_cast<uint4*>(park), 2, Y.c0); st_park_fq(const_cast<uint4*>(park), 3, Y.c1);      // Y rests in LDS until the step's last product
@@ -110,6 +137,10 @@ __device__ __forceinline__ void line_add_store_q(Fq2C& X, Fq2C& Y, Fq2C& Z, cons
         const Fq2n qx = f2_load_conv(&opaque(q)->x);
         Fq2n nj = f2_reduce(f2_sub(t, f2_muld(theta, qx))); f2_pin(nj);             // lambda qy - theta qx = -j
         if (skip) store_line_raw(lines, s * 3 + LINE_SLOT_FREE, stride, i, LINE_UNIT_FREE); else store_line_q(lines, s * 3 + LINE_SLOT_FREE, stride, i, nj);
+        if (xp.np > 1) {                                                            // the other P's of the group: (-lambda yP_t, theta xP_t, -j)
+            const auto nl = Fq2T<fq28::sub_lm(1, FQ_LN), 4>{fq_neg(lambda.c0), fq_neg(lambda.c1)};
+            extra_lines_q(xp, nl, theta, nj, skipbits, lines, s, stride, i);
+        }
     }
     { Fq2n l1 = f2_mul_fq(theta, ld_park_fq(park, 0)); f2_pin(l1);
       if (skip) store_line_raw(lines, s * 3 + 1, stride, i, Fp2::zero()); else store_line_q(lines, s * 3 + 1, stride, i, l1); }
@@ -130,32 +161,37 @@ __device__ __forceinline__ void line_add_store_q(Fq2C& X, Fq2C& Y, Fq2C& Z, cons
 }
 #endif
 
-// same arguments, grid and line-buffer layout as k_miller_lines
-__global__ void __launch_bounds__(256, RIPP_OCC) k_miller_lines_q(PairSets ps, uint32_t M, uint4* __restrict__ lines, size_t stride) {
-    __shared__ uint4 park_[16 * 256];                            // per lane: xP, yP and (addition steps) the two halves of Y
+// same line-buffer layout as k_miller_lines; grid.y = CHAIN (a group of cs.np[g] consecutive products first[g] .. that pair ONE Q vector with different P vectors)
+__global__ void __launch_bounds__(256, RIPP_OCC) k_miller_lines_q(ChainSets cs, uint32_t M, uint4* __restrict__ lines, size_t stride) {
+    __shared__ uint4 park_[16 * 256];                            // per lane: xP, yP (the group's first P) and (addition steps) the two halves of Y
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
 #if defined(__HIP_DEVICE_COMPILE__)
-    const G1A* __restrict__ a = ps.a[blockIdx.y];
-    const G2A* __restrict__ b = ps.b[blockIdx.y];
+    const int p0 = cs.first[blockIdx.y];
+    const G1A* __restrict__ a = cs.a[p0];
+    const G2A* __restrict__ b = cs.b[blockIdx.y];
     uint4* park = park_ + threadIdx.x;
     Fq2C X, Y, Z;
-    bool skip;
+    uint32_t skip;                                               // skipbits of this lane
+    const ExtraP xp{cs.a + p0, cs.np[blockIdx.y]};
     {
         const G2A Q = b[i]; const G1A P = a[i];
-        skip = is_inf(P) || (Q.x.is_zero() && Q.y.is_zero());
+        const bool qinf = Q.x.is_zero() && Q.y.is_zero();
+        skip = (is_inf(P) || qinf) ? 1u : 0u;
+#pragma unroll 1
+        for (int t = 1; t < xp.np; ++t) { const G1A Pt = xp.a[t][i]; if (is_inf(Pt) || qinf) skip |= 1u << t; }
         X = f2_to_coord(f2_from(Q.x)); Y = f2_to_coord(f2_from(Q.y)); Z = f2_to_coord(Fq2n{fq_one(), fq_zero()});
         st_park_fq(park, 0, fq_from_fp_fast(P.x)); st_park_fq(park, 1, fq_from_fp_fast(P.y));
         f2_pin(X); f2_pin(Y); f2_pin(Z);                             // (Z = 1 is not to be folded into a peeled first iteration: that copy of the loop body spilled)
     }
-    size_t s = (size_t)blockIdx.y * N_LINES;
+    size_t s = (size_t)p0 * N_LINES;
 #pragma unroll 1
     for (int bit = 62; bit >= 0; --bit) {
-        line_double_store_q(X, Y, Z, park, lines, s, stride, i, skip);
+        line_double_store_q(X, Y, Z, park, lines, s, stride, i, skip, xp);
         ++s;
         if ((BLS_X_ABS >> bit) & 1ull) {
             uint32_t iq = i; asm volatile("" : "+v"(iq));                  // Q's address is re-formed here (kept alive across the loop it was the kernel's last spilled register pair)
-            line_add_store_q(X, Y, Z, b + iq, park, lines, s, stride, i, skip);
+            line_add_store_q(X, Y, Z, b + iq, park, lines, s, stride, i, skip, xp);
             ++s;
         }
     }

@@ -51,6 +51,10 @@ __device__ __forceinline__ T load_chunks(const uint4* buf, size_t row, size_t st
 // Pairs with a point at infinity emit the unit line.  Both pairing products of a SIPP round go in ONE launch.
 constexpr int MAX_PRODUCTS = 8;     // pairing products sharing one launch (2 per SIPP round, 6 per GIPA/TIPP round, 8 quarter products of a pipelined SIPP tail round)
 struct PairSets { const G1A* a[MAX_PRODUCTS]; const G2A* b[MAX_PRODUCTS]; };
+// The same products grouped into CHAINS (fq_miller.hpp k_miller_lines_q): chain g walks b[g] once and emits the lines of the np[g] consecutive
+// products first[g] .. first[g] + np[g] - 1, whose P vectors are a[first[g]] ..  (a chain of one product is the plain form).
+constexpr int MAX_SHARE = 4;
+struct ChainSets { const G1A* a[MAX_PRODUCTS]; const G2A* b[MAX_PRODUCTS]; uint8_t first[MAX_PRODUCTS], np[MAX_PRODUCTS]; };
 // Register discipline of this kernel (it used to spill 273 dwords, ~35 GB of scratch traffic per launch): the steps below are written in
 // a LOW-LIVENESS order pinned with scheduling barriers -- every line coefficient is stored the moment it is complete, P and Q are
 // re-loaded from L2 where they are used instead of being held for 68 steps, and the addition step (5 of 68) parks Y and theta in LDS

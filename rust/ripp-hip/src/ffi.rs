@@ -28,6 +28,17 @@ pub struct RippStats {
     pub pairs_lines: u64, pub pairs_products: u64,
     pub exchange_ms: f64, pub look_ms: f64, pub look_items: u64, pub look_pairs: u64,
     pub statement_hash_ms: f64, pub statement_hash_wait_ms: f64,
+    pub chains_lines: u64,
+}
+/// `ripp_config` of include/ripp_hip.h: every choice among implementations of the same function (fill with `ripp_config_default` first).
+#[repr(C)] #[derive(Copy, Clone, Default, Debug)]
+pub struct RippConfig {
+    pub struct_size: u32,
+    pub no_vm: u32, pub no_precompute: u32, pub no_fold_tables: u32, pub no_msm_glv: u32, pub lp_one_lane: u32, pub no_endo: u32, pub no_fq: u32,
+    pub no_xscale: u32, pub scale_no_fq: u32, pub agg_sequential: u32, pub look_static: u32, pub quiet_waits: u32, pub no_share: u32,
+    pub look_eighths: i32, pub ranks_per_device: i32, pub msm_c: i32, pub msm_ch: u32, pub msm_gmin: u32,
+    pub vm_lines_max: u64, pub vm_fold_max: u64, pub vm_tree_max: u64, pub gls_split_max: u64, pub msm_vm_merge_max: u64, pub fold_tab_min: u64,
+    pub fq_min: u64, pub lp_fq_min: u64, pub vm_joint_max: u64, pub vm_scale_max: u64, pub tail_pipe_max: u64, pub ml_fq_min: u64, pub fq_min_g1: u64,
 }
 /// `RIPP_ABI_VERSION` of include/ripp_hip.h this binding was written against; `abi_check()` compares it (and the size of `RippStats`, which
 /// the library writes in full through every stats pointer) with the loaded library.
@@ -41,6 +52,10 @@ extern "C" {
     pub fn ripp_shutdown();
     pub fn ripp_device_count() -> i32;
     pub fn ripp_last_error() -> *const core::ffi::c_char;
+    pub fn ripp_config_default(cfg: *mut RippConfig) -> i32;
+    pub fn ripp_configure(cfg: *const RippConfig) -> i32;
+    pub fn ripp_config_get(cfg: *mut RippConfig) -> i32;
+    pub fn ripp_test_inject_failure(rank: i32, round: i32);
     pub fn ripp_abi_version() -> i32;
     pub fn ripp_stats_size() -> usize;
     // InnerProduct implementations on host slices

@@ -157,7 +157,8 @@ def test_sipp_2p17_endomorphism_paths_vs_oracle(E, o):
     # RIPP_NO_FQ: the 12 x 32-bit throughput kernels this build ran until build round 4 (the default is now the carry-free forms with u^2 = -5 and the
     # D-type twist's line placement: fq_curve2.hpp FQ2_BETA, fq_miller.hpp, fq_line_products.hpp); RIPP_*_FQ_MIN switch single kernels back
     for env in ({"RIPP_NO_ENDO": "1"}, {"RIPP_NO_FOLD_TABLES": "1"}, {"RIPP_NO_XSCALE": "1"}, {"RIPP_NO_PRECOMPUTE": "1"}, {"RIPP_LOOK_EIGHTHS": "12"}, {"RIPP_NO_MSM_GLV": "1"},
-                {"RIPP_NO_FQ": "1"}, {"RIPP_LP_FQ_MIN": "4294967295"}, {"RIPP_ML_FQ_MIN": "4294967295"}, {"RIPP_FQ_MIN": "4096", "RIPP_FQ_MIN_G1": "64"}):
+                {"RIPP_NO_FQ": "1"}, {"RIPP_LP_FQ_MIN": "4294967295"}, {"RIPP_ML_FQ_MIN": "4294967295"}, {"RIPP_FQ_MIN": "4096", "RIPP_FQ_MIN_G1": "64"},
+                {"RIPP_LOOK_EIGHTHS": "48"}, {"RIPP_LOOK_EIGHTHS": "48", "RIPP_NO_SHARE": "1"}):
         os.environ.update(env)
         try:
             assert np.array_equal(E.SIPP.prove(a, b, r, value), eproof), env

@@ -296,7 +296,8 @@ def test_sipp_prove_2p17_vs_oracle_with_precomputed_round0(engine, orc):
     big = str((1 << 32) - 1)
     for env in ({"RIPP_NO_FOLD_TABLES": "1"}, {"RIPP_NO_XSCALE": "1"}, {"RIPP_FQ_MIN": "4096", "RIPP_LP_FQ_MIN": "1"},
                 {"RIPP_FQ_MIN": "4096", "RIPP_NO_XSCALE": "1"}, {"RIPP_NO_FQ": "1"}, {"RIPP_LP_FQ_MIN": big}, {"RIPP_ML_FQ_MIN": big},
-                {"RIPP_LOOK_EIGHTHS": "11"}, {"RIPP_LOOK_EIGHTHS": "5"}, {"RIPP_LOOK_EIGHTHS": "20", "RIPP_NO_XSCALE": "1"}):
+                {"RIPP_LOOK_EIGHTHS": "11"}, {"RIPP_LOOK_EIGHTHS": "5"}, {"RIPP_LOOK_EIGHTHS": "20", "RIPP_NO_XSCALE": "1"},
+                {"RIPP_LOOK_EIGHTHS": "48"}, {"RIPP_LOOK_EIGHTHS": "48", "RIPP_NO_SHARE": "1"}, {"RIPP_LOOK_EIGHTHS": "24", "RIPP_ML_FQ_MIN": big}):      # shared G2 chains (fq_miller.hpp) / every product its own chain
         os.environ.update(env)
         try:
             assert np.array_equal(engine.SIPP.prove(a, b, r, value), eproof), env
@@ -560,3 +561,34 @@ def test_configure_api_selects_the_same_forms_as_the_environment(engine, orc):
         job.close()
     d = engine.config_get()
     assert d.look_eighths == -1 and d.tail_pipe_max == 1 << 11 and d.no_vm == 0 and d.no_precompute == 0
+
+
+@pytest.mark.parametrize("n,eighths", [(4, 16), (16, 48), (256, 48), (1 << 12, 29), (1 << 13, 16), (1 << 14, 45)])
+def test_shared_g2_chains_vs_oracle(engine, orc, n, eighths):
+    """Products over the SAME Q vector share one G2 chain in the carry-free stage-1 kernel (fq_miller.hpp: ChainSets, up to four P's per lane):
+    round 0 is evaluated together with look-ahead item (1,l) -- B0 and B2 each meet three A blocks (engine.hip job_round0_shared) -- and the later
+    items pair every B block with 2^R A blocks.  vm_lines_max = 0 sends even these small launches to the throughput kernel.  Identities among the
+    P's and Q's of every quarter (the per-P skip masks).  Same proof bytes as the oracle, with and without sharing; the chain count shows the sharing."""
+    a, b, r = orc.gen_g1(71, n), orc.gen_g2(72, n), orc.gen_scalars(73, n)
+    if n >= 16:
+        q = n // 4
+        a[q + 1] = 0; a[3 * q + 2] = 0; a[2 * q] = 0; a[0] = 0              # identities in A1, A3, A2, A0
+        b[1] = 0; b[2 * q + 3] = 0; b[q + 2] = 0; b[3 * q] = 0                # .. and in B0, B2, B1, B3
+        b[q + 1] = 0                                                          # P and Q both the identity in one pair of (1,r)'s blocks
+    v = orc.product_of_pairings_with_coeffs(a, b, r)
+    rc, eproof, ech = orc.sipp_prove(a, b, r, v)
+    assert rc == 0
+    job = engine.SippJob(a, b, r)
+    try:
+        engine.configure(vm_lines_max=0, look_eighths=eighths)
+        proof, ch, st = job.prove(v)
+        assert np.array_equal(proof, eproof) and np.array_equal(ch, ech)
+        assert 0 < st["chains_lines"] < st["pairs_lines"], (st["chains_lines"], st["pairs_lines"])
+        shared = st["chains_lines"]
+        engine.configure(vm_lines_max=0, look_eighths=eighths, no_share=1)
+        proof, ch, st = job.prove(v)
+        assert np.array_equal(proof, eproof) and np.array_equal(ch, ech)
+        assert st["chains_lines"] == st["pairs_lines"] > shared
+    finally:
+        engine.configure()
+        job.close()

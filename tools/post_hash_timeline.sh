@@ -1,4 +1,4 @@
-# GPU timeline of the mid rounds (after the statement hash) of one n = 2^20 proof: bash tools/kdev/mid_trace.sh [first_ms] [last_ms]
+# GPU timeline of the mid rounds (after the statement hash) of one n = 2^20 proof: bash tools/post_hash_timeline.sh [first_ms] [last_ms]
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 rm -rf gpurun_out/mt; mkdir -p gpurun_out/mt
 rocprofv3 --kernel-trace -d gpurun_out/mt -o t --output-format csv -- python3 bench.py --steps 1 --warmup 0 --cpu-log-n 0 > gpurun_out/mt/run.log 2>&1

@@ -1,14 +1,15 @@
-"""Ad-hoc stress of the sharded prover (one round loop for every world size, look-ahead, pipelined tail): two ranks on ONE GPU (callback transport over
-gloo), many proofs of random statements with random look-ahead plans against the CPU oracle; also the one-rank form with the same plans.
-  python tools/kdev/stress_sharded.py <seed> <seconds> <min log n> <max log n>"""
+"""Randomized stress of the sharded prover (one round loop for every world size, look-ahead with shared G2 chains, pipelined tail): WORLD ranks
+(2, 4 or 8) on ONE GPU (callback transport over gloo), many proofs of random statements with random look-ahead plans against the CPU oracle;
+also the one-rank form with the same plans.
+  python tools/stress_sharded.py <seed> <seconds> <min log n> <max log n> [world = 2]"""
 import os, socket, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 
 
 def worker(rank, world, port, seed, seconds, lo, hi, ret):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), RIPP_RANKS_PER_DEVICE=str(world), OMP_NUM_THREADS=str(max(1, 16 // world)))
     import torch.distributed as dist
     import orclib as o
     import ripp_amd as R
@@ -23,7 +24,7 @@ def worker(rank, world, port, seed, seconds, lo, hi, ret):
         import torch
         t = torch.from_numpy(go); dist.broadcast(t, src=0)
         if int(t.item()) == 0: break
-        lg = int(rng.integers(lo, hi + 1)); n = 1 << lg
+        lg = int(rng.integers(max(lo, world.bit_length() - 1), hi + 1)); n = 1 << lg          # n >= world: every rank holds at least one element
         sa, sb, sr = (int(x) for x in rng.integers(1, 1 << 30, 3))
         plan = int(rng.integers(0, 49))
         a, b, r = o.gen_g1(sa, n), o.gen_g2(sb, n), o.gen_scalars(sr, n)
@@ -37,8 +38,6 @@ def worker(rank, world, port, seed, seconds, lo, hi, ret):
         proof, ch, _ = native_sipp_job_prove(job, v, full=(a, b, r) if rank == 0 else None)
         job.close()
         ok = rc == 0 and np.array_equal(proof, ep) and np.array_equal(ch, ech)
-        if rank == 0:                               # the one-rank form with the same plan, on the same engine
-            comm1 = None
         cnt += 1
         if not ok: bad += 1; print("MISMATCH rank", rank, n, sa, sb, sr, plan, flush=True)
     os.environ.pop("RIPP_LOOK_EIGHTHS", None)
@@ -51,11 +50,12 @@ if __name__ == "__main__":
     import torch.multiprocessing as mp
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1; seconds = float(sys.argv[2]) if len(sys.argv) > 2 else 60
     lo = int(sys.argv[3]) if len(sys.argv) > 3 else 1; hi = int(sys.argv[4]) if len(sys.argv) > 4 else 13
+    world = int(sys.argv[5]) if len(sys.argv) > 5 else 2
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
     mgr = mp.Manager(); ret = mgr.dict()
-    mp.spawn(worker, args=(2, port, seed, seconds, lo, hi, ret), nprocs=2, join=True)
-    print("two ranks:", dict(ret))
+    mp.spawn(worker, args=(world, port, seed, seconds, lo, hi, ret), nprocs=world, join=True)
+    print(world, "ranks (proofs, mismatches) per rank:", dict(ret))
     # one rank, same generator of statements and plans
     import orclib as o, ripp_amd as R
     R.init(0)

@@ -1,6 +1,6 @@
-"""Ad-hoc stress of the pipelined tail: many proofs of random small statements against the CPU oracle, interleaved sizes, one process."""
+"""Randomized stress of the pipelined tail (python tools/stress_tail.py <seed> <seconds> <min log n> <max log n>): many proofs of random small statements against the CPU oracle, interleaved sizes, one process."""
 import sys, os, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, orclib as o, ripp_amd as R
 R.init(0)
