@@ -242,7 +242,7 @@ struct Engine {
         return aux;
     }
     // run-time switches: read from the environment ONCE per C-ABI call (get_engine), never inside round loops
-    struct Switches { bool no_vm = false, no_precompute = false, no_fold_tables = false, no_msm_glv = false, lp_one_lane = false, no_endo = false, no_fq = false, no_xscale = false, no_share = false; } sw;
+    struct Switches { bool no_vm = false, no_precompute = false, no_fold_tables = false, no_msm_glv = false, lp_one_lane = false, no_endo = false, no_fq = false, no_xscale = false, no_share = false, no_fuse = false; } sw;
     // crossover sizes: the member initialisers above are the defaults, the environment overrides them PER CALL (a test or
     // an A/B run flips them on a live engine)
     struct Sizes { size_t vm_lines_max, vm_fold_max, vm_tree_max, gls_split_max, msm_vm_merge_max, fold_tab_min, fq_min, lp_fq_min, vm_joint_max, vm_scale_max, tail_pipe_max, ml_fq_min, fq_min_g1; } defaults{};
@@ -261,7 +261,7 @@ struct Engine {
         if (g_cfg_set) {
             const ripp_config& c = g_cfg;
             sw.no_vm = c.no_vm; sw.no_precompute = c.no_precompute; sw.no_fold_tables = c.no_fold_tables; sw.no_msm_glv = c.no_msm_glv; sw.lp_one_lane = c.lp_one_lane;
-            sw.no_endo = c.no_endo; sw.no_fq = c.no_fq; sw.no_xscale = c.no_xscale; sw.no_share = c.no_share; scale_no_fq = c.scale_no_fq; agg_sequential = c.agg_sequential; look_static = c.look_static; quiet_waits_cfg = c.quiet_waits;
+            sw.no_endo = c.no_endo; sw.no_fq = c.no_fq; sw.no_xscale = c.no_xscale; sw.no_share = c.no_share; sw.no_fuse = c.no_fuse; scale_no_fq = c.scale_no_fq; agg_sequential = c.agg_sequential; look_static = c.look_static; quiet_waits_cfg = c.quiet_waits;
             look_eighths = c.look_eighths; ranks_per_device = c.ranks_per_device > 1 ? (double)c.ranks_per_device : 1.0;
             msm_tune.c = c.msm_c; msm_tune.ch = c.msm_ch; msm_tune.gmin = c.msm_gmin;
             vm_lines_max = c.vm_lines_max; vm_fold_max = c.vm_fold_max; vm_tree_max = c.vm_tree_max; gls_split_max = c.gls_split_max; msm_vm_merge_max = c.msm_vm_merge_max; fold_tab_min = c.fold_tab_min;
@@ -279,6 +279,7 @@ struct Engine {
         env_on("RIPP_NO_ENDO", sw.no_endo);            // plain scalar multiplications in the folds / scaling (no GLV, no psi)
         env_on("RIPP_NO_XSCALE", sw.no_xscale);        // G2 folds always on the plain vector with the full-width x^-1
         env_on("RIPP_NO_FQ", sw.no_fq);                // the 12 x 32-bit forms of the kernels that have a carry-free twin (fq_curve.hpp)
+        env_on("RIPP_NO_FUSE", sw.no_fuse);            // rounds 0 and 1 always fold one after the other (no three-quarter tables, no job_fold_fused)
         env_on("RIPP_NO_SHARE", sw.no_share);          // every pairing product walks its own G2 chain (no ChainSets grouping, no merged round 0 + look-ahead)
         env_on("RIPP_SCALE_NO_FQ", scale_no_fq); env_on("RIPP_AGG_SEQUENTIAL", agg_sequential); env_on("RIPP_LOOK_STATIC", look_static); env_on("RIPP_QUIET_WAITS", quiet_waits_cfg);
         if (const char* s = std::getenv("RIPP_LOOK_ITEMS")) look_eighths = 8 * std::max(0, std::atoi(s));            // whole (round, side) items
@@ -696,10 +697,21 @@ int wnaf4_recode(uint64_t v, int8_t* digits, int maxd, int W = RIPP_FOLD_W) {
     }
     return len;
 }
-Wnaf4 split32_wnaf(const Fr& s_mont) {                          // 128-bit challenge -> width-4 wNAF strings of its four 32-bit words
+Wnaf4 split32_wnaf(const Fr& s_mont, int W = RIPP_FOLD_W) {    // 128-bit challenge -> width-W wNAF strings of its four 32-bit words
     const Fr c = from_mont(s_mont);
     Wnaf4 g; std::memset(&g, 0, sizeof g);
-    for (int t = 0; t < 4; ++t) g.len = std::max(g.len, wnaf4_recode(c.l[t], g.d[t], 35));
+    for (int t = 0; t < 4; ++t) g.len = std::max(g.len, wnaf4_recode(c.l[t], g.d[t], 35, W));
+    return g;
+}
+int tab_width(int M) { int w = 2; while ((1 << (w - 2)) < M) ++w; return w; }      // M = 2^(W - 2) odd multiples per base <-> wNAF width W
+void glv_split(const Fr& s_mont, uint32_t rem[9], uint32_t quo[8]);
+// the sixteen strings of the fused G1 fold (fq_curve.hpp k_fold_g1_fused_q): x0 | k1 | k2 | x1 with x0 x1 = k1 + k2 lambda
+WnafG1x4 fused_digits_g1(const Fr& x0, const Fr& x1, int W) {
+    WnafG1x4 g; std::memset(&g, 0, sizeof g);
+    const Fr c0 = from_mont(x0), c1 = from_mont(x1);
+    uint32_t rem[9], quo[8]; glv_split(mul(x0, x1), rem, quo);
+    const uint32_t* src[4] = {c0.l, rem, quo, c1.l};
+    for (int u = 0; u < 4; ++u) for (int b = 0; b < 4; ++b) g.len = std::max(g.len, wnaf4_recode(src[u][b], g.d[4 * u + b], 35, W));
     return g;
 }
 GlvDigits split64_digits(const Fr& s_mont) {                     // 128-bit challenge -> its two 64-bit halves
@@ -728,7 +740,7 @@ Gls8Digits gls8_digits(const Fr& s_mont) {                        // base-u digi
     return g;
 }
 
-Wnaf16 gls16_wnaf(const Fr& s_mont) {                            // base-u digits, each cut into four 16-bit pieces, width-4 wNAF strings
+Wnaf16 gls16_wnaf(const Fr& s_mont, int W = RIPP_FOLD_W) {     // base-u digits, each cut into four 16-bit pieces, width-W wNAF strings
     const Fr c = from_mont(s_mont);
     uint64_t v[4] = {(uint64_t)c.l[0] | ((uint64_t)c.l[1] << 32), (uint64_t)c.l[2] | ((uint64_t)c.l[3] << 32),
                      (uint64_t)c.l[4] | ((uint64_t)c.l[5] << 32), (uint64_t)c.l[6] | ((uint64_t)c.l[7] << 32)};
@@ -737,8 +749,14 @@ Wnaf16 gls16_wnaf(const Fr& s_mont) {                            // base-u digit
         unsigned __int128 rem = 0;
         for (int i = 3; i >= 0; --i) { const unsigned __int128 cur = (rem << 64) | v[i]; v[i] = (uint64_t)(cur / BLS_X_ABS); rem = cur % BLS_X_ABS; }
         const uint64_t dj = (uint64_t)rem;
-        for (int b = 0; b < 4; ++b) g.len = std::max(g.len, wnaf4_recode((dj >> (16 * b)) & 0xffffu, g.d[4 * b + j], 19));
+        for (int b = 0; b < 4; ++b) g.len = std::max(g.len, wnaf4_recode((dj >> (16 * b)) & 0xffffu, g.d[4 * b + j], 19, W));
     }
+    return g;
+}
+// the three digit sets of the fused G2 fold (fq_curve2.hpp k_fold_g2_fused_q): x0 x1 (full width) | x0 | x1
+Wnaf16x3 fused_digits_g2(const Fr& x0, const Fr& x1, int W) {
+    Wnaf16x3 g; g.s[0] = gls16_wnaf(mul(x0, x1), W); g.s[1] = gls16_wnaf(x0, W); g.s[2] = gls16_wnaf(x1, W);
+    g.len = std::max(g.s[0].len, std::max(g.s[1].len, g.s[2].len));
     return g;
 }
 
@@ -849,6 +867,9 @@ struct ripp_sipp_job {
     DevBuf a0, b0, r0;                    // resident statement shard
     DevBuf a, b, a_next, b_next, jac1, jac2;   // working vectors
     size_t tab2_stride = 0; bool tab_ready = false;   // round-0 tables (odd multiples of four bases) of this job are in the engine's fold_* buffers
+    // tab_fused: the tables cover THREE quarters (A1 | A2 | A3 and B0 | B1 | B2: tab_cnt = 3 len / 4 elements per row, tab_M odd multiples per base) so that
+    // rounds 0 and 1 can be folded in one pass once both challenges are known (job_fold_fused); otherwise a_r / b_l (b_r), tab_cnt = len / 2
+    size_t tab_cnt = 0; int tab_M = FOLD_TAB_M; bool tab_fused = false;
     // x-SCALED G2 vector (single-GPU prover, large rounds): the device holds bt = bs * b instead of b, folded as bt' = x bt_l + bt_r with the
     // 128-bit challenge x (two GLS digit strings instead of four: ~36 % less G2 fold work); the round's two GT values are then z^bs and
     // the host takes them to the power 1/bs.  The first round below the table-fold size returns to the plain vector in its own fold.
@@ -948,14 +969,17 @@ int32_t job_precompute_vm(Engine* e, ripp_sipp_job* j, bool side = false) {
     return RIPP_OK;
 }
 
-int32_t job_precompute_round0(Engine* e, ripp_sipp_job* j) {
-    const size_t half = j->len / 2;
+// fuse: the look-ahead is expected to deliver BOTH values of round 1 in the hash window, so x0 and x1 will be known together -- build the tables over
+// three quarters (a[q .. 4q) = A1 | A2 | A3, b[0 .. 3q) = B0 | B1 | B2) with FOUR odd multiples per base (width-4 strings): about the table work of
+// the half-vector tables with eight, and rounds 0 and 1 then fold in one pass (job_fold_fused).  If x1 is late after all, round 0 folds alone over
+// the same tables (element offset q on G1, none on G2).
+int32_t job_precompute_round0(Engine* e, ripp_sipp_job* j, bool fuse = false) {
+    const size_t half = j->len / 2, q = j->len / 4;
     if (half < ((size_t)1 << 16) || j->digest_ready.load() || j->no_window || e->sw.no_precompute) return RIPP_OK;
     int32_t rc;
     const bool tables = !e->sw.no_fold_tables;
-    const size_t qstride = (half + 63) & ~(size_t)63;
     if ((rc = j->a_pow.reserve(half * sizeof(G1A))) || (rc = j->b_pow.reserve(half * sizeof(G2A))) || (rc = j->jac1.reserve(half * sizeof(G1J))) || (rc = j->jac2.reserve(half * sizeof(G2J)))) return rc;
-    j->tab_ready = false;
+    j->tab_ready = false; j->tab_fused = false;
     if (!tables) {                                              // two-base form: 2^64 a_r, 2^32 b_r
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pow2_mul<Fp>), dim3(nblk(half, 256)), dim3(256), 0, e->stream, j->a.as<G1A>() + half, (uint32_t)half, 64, j->jac1.as<G1J>());
         HIPCHK(hipGetLastError());
@@ -966,44 +990,47 @@ int32_t job_precompute_round0(Engine* e, ripp_sipp_job* j) {
         j->pre_ready = true;
         return RIPP_OK;
     }
-    // table form (kernels.hpp): bases 2^(32 b) a_r and 2^(16 b) b_r, b < 4, and the odd multiples 1, 3, .., 2 M - 1 of each.
-    // tab1 / mult2 hold [M b + m][half]; row M b is base b itself, written by the doubling chain's normalisation.
-    constexpr size_t M = FOLD_TAB_M;
-    const size_t njt = (M - 1) * half;
-    if ((rc = e->fold_tab1.reserve(4 * M * half * sizeof(G1A))) || (rc = e->fold_mult.reserve(4 * M * half * sizeof(G2A))) || (rc = e->fold_tab.reserve(16 * M * G2A_CHUNKS * qstride * sizeof(uint4))) ||
-        (rc = e->fold_jac1.reserve(njt * sizeof(G1J))) || (rc = e->fold_jac2.reserve(njt * sizeof(G2J))) || (rc = e->fix_flags.reserve(4 * half + 16))) return rc;      // all sized BEFORE the first launch: reserve() may reallocate
+    // table form (kernels.hpp): bases 2^(32 b) P and 2^(16 b) Q, b < 4, and the odd multiples 1, 3, .., 2 M - 1 of each.
+    // tab1 / mult2 hold [M b + m][cnt]; row M b is base b itself, written by the doubling chain's normalisation.
+    j->tab_on_lo = xscale_round(e, j, half);                    // scaled fold: x multiplies the LOW half
+    fuse = fuse && j->tab_on_lo && !e->sw.no_fq && !e->sw.no_fuse && q >= e->fq_min;
+    const size_t M = fuse ? 4 : FOLD_TAB_M;
+    const size_t cnt = fuse ? 3 * q : half;
+    const size_t qstride = (cnt + 63) & ~(size_t)63;
+    const size_t njt = (M - 1) * cnt;
+    if ((rc = e->fold_tab1.reserve(4 * M * cnt * sizeof(G1A))) || (rc = e->fold_mult.reserve(4 * M * cnt * sizeof(G2A))) || (rc = e->fold_tab.reserve(16 * M * G2A_CHUNKS * qstride * sizeof(uint4))) ||
+        (rc = e->fold_jac1.reserve(njt * sizeof(G1J))) || (rc = e->fold_jac2.reserve(njt * sizeof(G2J))) || (rc = e->fix_flags.reserve(4 * cnt + 16))) return rc;      // all sized BEFORE the first launch: reserve() may reallocate
     e->tab_owner = j;
     G1A* t1 = e->fold_tab1.as<G1A>(); G2A* t2 = e->fold_mult.as<G2A>();
     G1J* sj1 = e->fold_jac1.as<G1J>(); G2J* sj2 = e->fold_jac2.as<G2J>();
-    HIPCHK(hipMemcpyAsync(t1, j->a.as<G1A>() + half, half * sizeof(G1A), hipMemcpyDeviceToDevice, e->stream));
-    j->tab_on_lo = xscale_round(e, j, half);                    // scaled fold: x multiplies the LOW half
-    HIPCHK(hipMemcpyAsync(t2, j->b.as<G2A>() + (j->tab_on_lo ? 0 : half), half * sizeof(G2A), hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(t1, j->a.as<G1A>() + (fuse ? q : half), cnt * sizeof(G1A), hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(t2, j->b.as<G2A>() + (j->tab_on_lo ? 0 : half), cnt * sizeof(G2A), hipMemcpyDeviceToDevice, e->stream));
     for (int b = 0; b < 4; ++b) {
-        G1A* base1 = t1 + M * b * half; G2A* base2 = t2 + M * b * half;
+        G1A* base1 = t1 + M * b * cnt; G2A* base2 = t2 + M * b * cnt;
         if (b > 0) {
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pow2_mul<Fp>), dim3(nblk(half, 256)), dim3(256), 0, e->stream, base1 - M * half, (uint32_t)half, 32, sj1);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pow2_mul<Fp>), dim3(nblk(cnt, 256)), dim3(256), 0, e->stream, base1 - M * cnt, (uint32_t)cnt, 32, sj1);
             HIPCHK(hipGetLastError());
-            if ((rc = e->normalize_dev<Fp>(sj1, half, base1))) return rc;
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pow2_mul<Fp2>), dim3(nblk(half, 256)), dim3(256), 0, e->stream, base2 - M * half, (uint32_t)half, 16, sj2);
+            if ((rc = e->normalize_dev<Fp>(sj1, cnt, base1))) return rc;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pow2_mul<Fp2>), dim3(nblk(cnt, 256)), dim3(256), 0, e->stream, base2 - M * cnt, (uint32_t)cnt, 16, sj2);
             HIPCHK(hipGetLastError());
-            if ((rc = e->normalize_dev<Fp2>(sj2, half, base2))) return rc;
+            if ((rc = e->normalize_dev<Fp2>(sj2, cnt, base2))) return rc;
         }
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_odd_multiples<Fp>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, base1, (uint32_t)half, (int)M, sj1);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_odd_multiples<Fp>), dim3(nblk(cnt, 64)), dim3(64), 0, e->stream, base1, (uint32_t)cnt, (int)M, sj1);
         HIPCHK(hipGetLastError());
-        if ((rc = e->normalize_dev<Fp>(sj1, njt, base1 + half))) return rc;
+        if ((rc = e->normalize_dev<Fp>(sj1, njt, base1 + cnt))) return rc;
         if (!e->sw.no_fq) {
-            hipLaunchKernelGGL(k_odd_multiples_q, dim3(nblk(half, 64)), dim3(64), 0, e->stream, base2, (uint32_t)half, (int)M, sj2, e->fix_flags.as<uint8_t>());
+            hipLaunchKernelGGL(k_odd_multiples_q, dim3(nblk(cnt, 64)), dim3(64), 0, e->stream, base2, (uint32_t)cnt, (int)M, sj2, e->fix_flags.as<uint8_t>());
 #if !defined(RIPP_INLINE_FALLBACK)
-            hipLaunchKernelGGL(k_odd_multiples_fix, dim3(FIX_GRID), dim3(64), 0, e->stream, base2, (uint32_t)half, (int)M, sj2, e->fix_flags.as<uint8_t>());
+            hipLaunchKernelGGL(k_odd_multiples_fix, dim3(FIX_GRID), dim3(64), 0, e->stream, base2, (uint32_t)cnt, (int)M, sj2, e->fix_flags.as<uint8_t>());
 #endif
         }
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_odd_multiples<Fp2>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, base2, (uint32_t)half, (int)M, sj2);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_odd_multiples<Fp2>), dim3(nblk(cnt, 64)), dim3(64), 0, e->stream, base2, (uint32_t)cnt, (int)M, sj2);
         HIPCHK(hipGetLastError());
-        if ((rc = e->normalize_dev<Fp2>(sj2, njt, base2 + half))) return rc;
+        if ((rc = e->normalize_dev<Fp2>(sj2, njt, base2 + cnt))) return rc;
     }
-    hipLaunchKernelGGL(k_g2_tab_images, dim3(nblk(half, 64), 4 * M), dim3(64), 0, e->stream, e->fold_mult.as<G2A>(), (uint32_t)half, (int)M, e->fold_tab.as<uint4>(), qstride);
+    hipLaunchKernelGGL(k_g2_tab_images, dim3(nblk(cnt, 64), 4 * M), dim3(64), 0, e->stream, e->fold_mult.as<G2A>(), (uint32_t)cnt, (int)M, e->fold_tab.as<uint4>(), qstride);
     HIPCHK(hipGetLastError());
-    j->tab2_stride = qstride; j->tab_ready = true;
+    j->tab2_stride = qstride; j->tab_cnt = cnt; j->tab_M = (int)M; j->tab_fused = fuse; j->tab_ready = true;
     return RIPP_OK;
 }
 
@@ -1061,10 +1088,12 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true,
     HIPCHK(hipEventRecord(e->ev_fork, e->stream));
     HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
     const bool tab = j->tab_ready && e->tab_owner == j && fits_128(x); j->tab_ready = false;        // ... with the odd-multiple tables of four bases
+    const int tabW = tab_width(j->tab_M);
+    const G1A* tab1 = e->fold_tab1.as<G1A>() + (j->tab_fused ? half / 2 : 0);      // three-quarter tables start at A1: a_r is q elements in
     if (tab && !e->sw.no_fq && half >= e->fq_min)
-        hipLaunchKernelGGL(k_fold_g1_tab_q, dim3(nblk(half, 256)), dim3(256), 0, e->stream2, e->fold_tab1.as<G1A>(), (int)FOLD_TAB_M, a, (uint32_t)half, split32_wnaf(x), j->jac1.as<G1J>());
+        hipLaunchKernelGGL(k_fold_g1_tab_q, dim3(nblk(half, 256)), dim3(256), 0, e->stream2, tab1, j->tab_cnt, j->tab_M, a, (uint32_t)half, split32_wnaf(x, tabW), j->jac1.as<G1J>());
     else if (tab)
-        hipLaunchKernelGGL(k_fold_g1_tab, dim3(nblk(half, 256)), dim3(256), 0, e->stream2, e->fold_tab1.as<G1A>(), (int)FOLD_TAB_M, a, (uint32_t)half, split32_wnaf(x), j->jac1.as<G1J>());
+        hipLaunchKernelGGL(k_fold_g1_tab, dim3(nblk(half, 256)), dim3(256), 0, e->stream2, tab1, j->tab_cnt, j->tab_M, a, (uint32_t)half, split32_wnaf(x, tabW), j->jac1.as<G1J>());
     else if (pre)
         hipLaunchKernelGGL(k_fold_g1_two, dim3(nblk(half, 256)), dim3(256), 0, e->stream2, a + half, j->a_pow.as<G1A>(), a, (uint32_t)half, split64_digits(x), j->jac1.as<G1J>());
     else if (pre_vm) {
@@ -1118,13 +1147,13 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true,
     } else
     if (tab && !e->sw.no_fq && half >= e->fq_min) {
         if ((rc = e->fix_flags.reserve(4 * half + 16))) return rc;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab_q<Wnaf16, 16>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, e->fold_tab.as<uint4>(), j->tab2_stride, (int)FOLD_TAB_M, g2_lo, (uint32_t)half, gls16_wnaf(g2_s), j->jac2.as<G2J>(), e->fix_flags.as<uint8_t>());
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab_q<Wnaf16, 16>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, e->fold_tab.as<uint4>(), j->tab2_stride, j->tab_M, g2_lo, (uint32_t)half, gls16_wnaf(g2_s, tabW), j->jac2.as<G2J>(), e->fix_flags.as<uint8_t>());
 #if !defined(RIPP_INLINE_FALLBACK)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab_fix<Wnaf16, 16>), dim3(FIX_GRID), dim3(64), 0, e->stream, e->fold_tab.as<uint4>(), j->tab2_stride, (int)FOLD_TAB_M, g2_lo, (uint32_t)half, gls16_wnaf(g2_s), j->jac2.as<G2J>(), e->fix_flags.as<uint8_t>());
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab_fix<Wnaf16, 16>), dim3(FIX_GRID), dim3(64), 0, e->stream, e->fold_tab.as<uint4>(), j->tab2_stride, j->tab_M, g2_lo, (uint32_t)half, gls16_wnaf(g2_s, tabW), j->jac2.as<G2J>(), e->fix_flags.as<uint8_t>());
 #endif
     } else
     if (tab) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab<Wnaf16, 16>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, e->fold_tab.as<uint4>(), j->tab2_stride, (int)FOLD_TAB_M, g2_lo, (uint32_t)half, gls16_wnaf(g2_s), j->jac2.as<G2J>());
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab<Wnaf16, 16>), dim3(nblk(half, 64)), dim3(64), 0, e->stream, e->fold_tab.as<uint4>(), j->tab2_stride, j->tab_M, g2_lo, (uint32_t)half, gls16_wnaf(g2_s, tabW), j->jac2.as<G2J>());
     } else
     if (pre) {
         if ((rc = e->qtab.reserve(8 * G2A_CHUNKS * qstride * sizeof(uint4))) != RIPP_OK) return rc;
@@ -1168,6 +1197,49 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true,
     } else HIPCHK(hipEventRecord(e->ev_fold_async.back().second, e->stream));
     std::swap(j->a, j->a_next); std::swap(j->b, j->b_next);
     j->len = half;
+    return RIPP_OK;
+}
+
+// Rounds 0 and 1 folded in ONE pass over the three-quarter tables of job_precompute_round0 (fq_curve.hpp / fq_curve2.hpp have the algebra):
+//     a''_i  = A0_i + x0 A2_i + x1 A1_i + (x0 x1) A3_i,        bt''_i = (x0 x1) B0_i + x0 B1_i + x1 B2_i + B3_i        (i < q = len / 4)
+// -- the vectors the two folds of job_fold produce one after the other (bt'' = x0 x1 b'': the G2 vector stays x-scaled, bs = x0 x1).  Called with the
+// job's vectors still UNFOLDED (j->len = the round-0 length) once both challenges are known; leaves j->len = len / 4.
+int32_t job_fold_fused(Engine* e, ripp_sipp_job* j, const Fr& x0, const Fr& x1, bool async) {
+    const size_t q = j->len / 4;
+    int32_t rc;
+    if (!(j->tab_ready && j->tab_fused && e->tab_owner == j && j->tab_on_lo && !j->bs_on && fits_128(x0) && fits_128(x1))) { set_err("fused fold: the three-quarter tables of this job are not in place"); return RIPP_ERR_ARG; }
+    j->tab_ready = false; j->pre_ready = false; j->pre_vm_ready = false;
+    hipEvent_t t0 = e->ev_t0, t1 = e->ev_t1;
+    HIPCHK(hipEventRecord(t0, e->stream));
+    if (async) { hipEvent_t fa, fb; HIPCHK(hipEventCreate(&fa)); HIPCHK(hipEventCreate(&fb)); e->ev_fold_async.emplace_back(fa, fb); HIPCHK(hipEventRecord(fa, e->stream)); }
+    if ((rc = j->jac1.reserve(q * sizeof(G1J))) || (rc = j->jac2.reserve(q * sizeof(G2J))) || (rc = e->fix_flags.reserve(2 * ((q + 15) & ~(size_t)15) + 32))) return rc;
+    const int W = tab_width(j->tab_M);
+    G1A* a = j->a.as<G1A>(); G2A* b = j->b.as<G2A>();
+    uint8_t* flag1 = e->fix_flags.as<uint8_t>(); uint8_t* flag2 = flag1 + ((q + 15) & ~(size_t)15) + 16;
+    HIPCHK(hipEventRecord(e->ev_fork, e->stream));
+    HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
+    // G1 on stream2
+    const WnafG1x4 d1 = fused_digits_g1(x0, x1, W);
+    hipLaunchKernelGGL(k_fold_g1_fused_q, dim3(nblk(q, 256)), dim3(256), 0, e->stream2, e->fold_tab1.as<G1A>(), j->tab_cnt, j->tab_M, a, (uint32_t)q, d1, j->jac1.as<G1J>(), flag1);
+    hipLaunchKernelGGL(k_fold_g1_fused_fix, dim3(FIX_GRID), dim3(64), 0, e->stream2, e->fold_tab1.as<G1A>(), j->tab_cnt, j->tab_M, a, (uint32_t)q, d1, j->jac1.as<G1J>(), flag1);
+    HIPCHK(hipGetLastError());
+    if ((rc = e->normalize_dev<Fp>(j->jac1.as<G1J>(), q, j->a_next.as<G1A>(), e->stream2)) != RIPP_OK) return rc;
+    HIPCHK(hipEventRecord(e->ev_join, e->stream2));
+    // G2 on the main stream
+    const Wnaf16x3 d2 = fused_digits_g2(x0, x1, W);
+    hipLaunchKernelGGL(k_fold_g2_fused_q, dim3(nblk(q, 64)), dim3(64), 0, e->stream, e->fold_tab.as<uint4>(), j->tab2_stride, j->tab_M, b + 3 * q, (uint32_t)q, d2, j->jac2.as<G2J>(), flag2);
+    hipLaunchKernelGGL(k_fold_g2_fused_fix, dim3(FIX_GRID), dim3(64), 0, e->stream, e->fold_tab.as<uint4>(), j->tab2_stride, j->tab_M, b + 3 * q, (uint32_t)q, d2, j->jac2.as<G2J>(), flag2);
+    HIPCHK(hipGetLastError());
+    j->bs = mul(x0, x1); j->bs_on = true;                                        // the new vector is (x0 x1) b''
+    if ((rc = e->normalize_dev<Fp2>(j->jac2.as<G2J>(), q, j->b_next.as<G2A>())) != RIPP_OK) return rc;
+    HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
+    HIPCHK(hipEventRecord(t1, e->stream));
+    if (!async) {
+        if ((rc = e->sync()) != RIPP_OK) return rc;
+        float ms = 0; (void)hipEventElapsedTime(&ms, t0, t1); e->stats.fold_ms += ms;
+    } else HIPCHK(hipEventRecord(e->ev_fold_async.back().second, e->stream));
+    std::swap(j->a, j->a_next); std::swap(j->b, j->b_next);
+    j->len = q;
     return RIPP_OK;
 }
 
@@ -1710,8 +1782,8 @@ static int look_plan(const Engine* e, size_t n_local, int world, bool window) {
     // 313-317 ms at n = 2^20 = 1.06-1.12 GB/s of Blake2s in situ), MEASURED afterwards: sipp_prove_core records this box's hash rate and this device's
     // pairing rate at the end of every large proof that hashed (Engine::cal_*), so the static plan the non-hashing ranks follow is priced with what
     // rank 0's box and GPU really do (boxes differ by +-3 % / +-5 %).  Scaling and the fold tables move with the GPU factor.
-    const double ms_per_pair = e->cal_ms_per_pair > 0 ? e->cal_ms_per_pair : 7.7e-5;
-    const double gpu_f = ms_per_pair / 7.7e-5;
+    const double ms_per_pair = e->cal_ms_per_pair > 0 ? e->cal_ms_per_pair : 6.7e-5;      // (shared G2 chains: 138 ms for the 2^21 pair evaluations of round 0 + (1,l) at n = 2^20)
+    const double gpu_f = ms_per_pair / 6.7e-5;
     const double hash_ms = n * 336.0 / (e->cal_hash_bytes_per_ms > 0 ? e->cal_hash_bytes_per_ms : 1.12e6);
     double budget = hash_ms - (nl * (3.2e-5 * gpu_f + ms_per_pair + 5.3e-5 * gpu_f) + 1.0);      // scaling, round 0, fold tables (measured at n = 2^20: 33 + 80 + 55 ms)
     int items = 0;
@@ -1943,6 +2015,9 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
     bool sharded = world0 > 1, digest_sent = world0 == 1;
     size_t round = 0;
     Fr x_prev = Fr::zero();
+    // fused fold of rounds 0 and 1 (job_fold_fused): with both values of round 1 known from the look-ahead, round 0's fold is DEFERRED until x1 exists
+    // (the GT powers of the look-ahead values and one hash later, ~1 ms) and the vectors go from n to n / 4 in one pass over the three-quarter tables
+    bool fuse_pending = false; Fr x0_saved = Fr::zero();
     j->tp_round[0] = j->tp_round[1] = ~(size_t)0;
     while ((sharded ? len * (size_t)world0 : len) > 1) {
         if (sharded && len == 1) {
@@ -1987,7 +2062,7 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
         auto local_values = [&]() -> int32_t {
             int32_t rc;
             // what the look-ahead has not covered goes to the device: pairs [start_s, half) of z_l = prod e(a_r, b_l) (s = 0) and z_r = prod e(a_l, b_r) (s = 1)
-            const size_t half = j->len / 2;
+            const size_t half = fuse_pending ? j->len / 4 : j->len / 2;       // (fuse_pending: the job's vectors are still round 0's; both values of this round come from the look-ahead)
             const size_t start[2] = {lk_l ? std::min(lk_l->npairs, half) : 0, lk_r ? std::min(lk_r->npairs, half) : 0};
             const bool dev[2] = {!tp_round && start[0] < half, !tp_round && start[1] < half};
             if (dev[0] && dev[1] && start[0] == 0 && start[1] == 0) {
@@ -2008,7 +2083,8 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
                 if ((rc = e->step_products(as, bs, 1, half - start[sd], rows + sd * N_LINES))) return rc;
                 e->stats.miller_products_ms += now_ms() - tp;
             }
-            if (round == 0 && !j->seeded && (rc = job_precompute_round0(e, j))) return rc;      // asynchronous: overlaps the host work below and the hash
+            // asynchronous: overlaps the host work below and the hash.  Both items of round 1 planned in full: tables over three quarters for the fused fold
+            if (round == 0 && !j->seeded && (rc = job_precompute_round0(e, j, look_items >= 16 && j->len >= 4))) return rc;
             if (!j->pre_vm_ready && (rc = job_precompute_vm(e, j))) return rc;                   // small rounds: the same on the VM, during the host phase
             // entry into the pipelined tail -- unless the look-ahead has (round 0: is about to get) both values of the next round
             const bool next_known = round == 0 ? (look_items >= 16 && j->len >= 4 && (look_forced || !j->digest_ready.load())) : look_full(j, round + 1);
@@ -2072,6 +2148,9 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
         if (!sharded && len == 2) { j->len = 0; j->pre_vm_ready = false; }      // the one-element vectors of the LAST fold are discarded by the prover (sipp/src/lib.rs:87-104 ends the loop): not computed
         else {
             if (!lrc && test_fail_hit(rank, round)) lrc = RIPP_ERR_DEVICE;
+            if (!lrc && fuse_pending) { lrc = job_fold_fused(e, j, x0_saved, x, pipelined || known); fuse_pending = false; }
+            else if (!lrc && round == 0 && known && j->tab_ready && j->tab_fused && e->tab_owner == j && !j->bs_on) { fuse_pending = true; x0_saved = x; }      // fold with round 1's
+            else
             if (!lrc) lrc = job_fold(e, j, x, true, pipelined || known);
             if (!lrc && pipelined) {              // behind the fold, on the new vectors: the second fold bases of the next round, the values of the round after it
                 if (!j->pre_vm_ready) lrc = job_precompute_vm(e, j, true);
@@ -2101,7 +2180,7 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
 static void config_from_engine(const Engine* e, ripp_config* c) {
     std::memset(c, 0, sizeof *c); c->struct_size = (uint32_t)sizeof *c;
     c->no_vm = e->sw.no_vm; c->no_precompute = e->sw.no_precompute; c->no_fold_tables = e->sw.no_fold_tables; c->no_msm_glv = e->sw.no_msm_glv; c->lp_one_lane = e->sw.lp_one_lane;
-    c->no_endo = e->sw.no_endo; c->no_fq = e->sw.no_fq; c->no_xscale = e->sw.no_xscale; c->no_share = e->sw.no_share; c->scale_no_fq = e->scale_no_fq; c->agg_sequential = e->agg_sequential; c->look_static = e->look_static; c->quiet_waits = e->quiet_waits_cfg;
+    c->no_endo = e->sw.no_endo; c->no_fq = e->sw.no_fq; c->no_xscale = e->sw.no_xscale; c->no_share = e->sw.no_share; c->no_fuse = e->sw.no_fuse; c->scale_no_fq = e->scale_no_fq; c->agg_sequential = e->agg_sequential; c->look_static = e->look_static; c->quiet_waits = e->quiet_waits_cfg;
     c->look_eighths = e->look_eighths; c->ranks_per_device = (int32_t)e->ranks_per_device; c->msm_c = e->msm_tune.c; c->msm_ch = e->msm_tune.ch; c->msm_gmin = e->msm_tune.gmin;
     c->vm_lines_max = e->vm_lines_max; c->vm_fold_max = e->vm_fold_max; c->vm_tree_max = e->vm_tree_max; c->gls_split_max = e->gls_split_max; c->msm_vm_merge_max = e->msm_vm_merge_max; c->fold_tab_min = e->fold_tab_min;
     c->fq_min = e->fq_min; c->lp_fq_min = e->lp_fq_min; c->vm_joint_max = e->vm_joint_max; c->vm_scale_max = e->vm_scale_max; c->tail_pipe_max = e->tail_pipe_max; c->ml_fq_min = e->ml_fq_min; c->fq_min_g1 = e->fq_min_g1;

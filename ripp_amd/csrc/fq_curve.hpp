@@ -154,7 +154,8 @@ __global__ void __launch_bounds__(256, 2) k_fold_g1_glv_q(const G1A* __restrict_
 }
 
 // the table fold of round 0 (kernels.hpp k_fold_g1_tab): tab[e][i], e = M b + m: (2m + 1) * (base b of element i); four wNAF strings
-__global__ void __launch_bounds__(256, 2) k_fold_g1_tab_q(const G1A* __restrict__ tab, int M, const G1A* __restrict__ lo, uint32_t half, Wnaf4 dg, G1J* __restrict__ out) {
+// (tstride: elements per table row -- `half` for a table of a_r alone, 3 q for the table over A1 | A2 | A3 of the fused fold, passed with tab + q)
+__global__ void __launch_bounds__(256, 2) k_fold_g1_tab_q(const G1A* __restrict__ tab, size_t tstride, int M, const G1A* __restrict__ lo, uint32_t half, Wnaf4 dg, G1J* __restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= half) return;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -167,7 +168,7 @@ __global__ void __launch_bounds__(256, 2) k_fold_g1_tab_q(const G1A* __restrict_
         for (int t = 0; t < 4; ++t) {
             const int d = dg.d[t][pos];
             if (d == 0) continue;
-            const G1A qa = tab[(size_t)(M * t + ((d < 0 ? -d : d) >> 1)) * half + i];
+            const G1A qa = tab[(size_t)(M * t + ((d < 0 ? -d : d) >> 1)) * tstride + i];
             bad |= is_inf(qa);
             AffQ q = affq_from(qa);
             if (d < 0) q.y = fq_reduce(fq_neg(q.y));
@@ -184,11 +185,72 @@ __global__ void __launch_bounds__(256, 2) k_fold_g1_tab_q(const G1A* __restrict_
         for (int pos = dg.len - 1; pos >= 0; --pos) {
             a2 = dbl(a2);
 #pragma unroll 1
-            for (int t = 0; t < 4; ++t) { const int d = dg.d[t][pos]; if (d != 0) { G1A q = tab[(size_t)(M * t + ((d < 0 ? -d : d) >> 1)) * half + i]; if (d < 0) q.y = neg(q.y); a2 = add_mixed(a2, q); } }
+            for (int t = 0; t < 4; ++t) { const int d = dg.d[t][pos]; if (d != 0) { G1A q = tab[(size_t)(M * t + ((d < 0 ? -d : d) >> 1)) * tstride + i]; if (d < 0) q.y = neg(q.y); a2 = add_mixed(a2, q); } }
         }
         out[i] = add_mixed(a2, l);
     } else out[i] = jacq_to_g1j(acc);
 #endif
+}
+
+// ---- the FUSED fold of rounds 0 and 1 (engine.hip job_fold_fused).  With both challenges known at once -- the look-ahead delivers round 1's two
+// values in the hash window -- the quarter-length vector of round 2 is, per element i < q (A0 .. A3 the quarters of the round-0 vector),
+//     a''_i = A0_i + x0 A2_i + x1 A1_i + (x0 x1) A3_i,        x0 x1 = k1 + k2 lambda (GLV: both halves < 2^128, phi(P) = (beta x, y)),
+// i.e. SIXTEEN 32-bit strings over the same kind of table the round-0 fold uses (bases 2^(32 b) P, odd multiples), now built over A1 | A2 | A3:
+// 33 doublings + ~16 x 6.4 additions per output where the two folds take 2 x (33 + ~26) for round 0 and 128 + ~43 for round 1.
+// String 4 u + b = 32-bit word b of scalar u:  u = 0: x0 on A2 (table element q + i)   1: k1 on A3 (2 q + i)   2: k2 on phi(A3)   3: x1 on A1 (i).
+struct WnafG1x4 { int8_t d[16][36]; int len; };
+__device__ __noinline__ inline G1J fold_g1_fused_complete(const G1A* __restrict__ tab, size_t tstride, int M, const G1A& l, uint32_t q, uint32_t i, const WnafG1x4& dg) {
+    G1J a2 = jac_inf<Fp>();
+#pragma unroll 1
+    for (int pos = dg.len - 1; pos >= 0; --pos) {
+        a2 = dbl(a2);
+#pragma unroll 1
+        for (int t = 0; t < 16; ++t) {
+            const int d = dg.d[t][pos]; if (d == 0) continue;
+            const int u = t >> 2; const uint32_t el = (u == 0 ? q : u == 3 ? 0u : 2 * q) + i;
+            G1A p = tab[(size_t)(M * (t & 3) + ((d < 0 ? -d : d) >> 1)) * tstride + el];
+            if (u == 2) p.x = fmul(p.x, fp_const(RIPP_GLV_BETA));
+            if (d < 0) p.y = neg(p.y);
+            a2 = add_mixed(a2, p);
+        }
+    }
+    return add_mixed(a2, l);
+}
+__global__ void __launch_bounds__(256, 2) k_fold_g1_fused_q(const G1A* __restrict__ tab, size_t tstride, int M, const G1A* __restrict__ lo, uint32_t q, WnafG1x4 dg, G1J* __restrict__ out, uint8_t* __restrict__ flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= q) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr uint32_t betaw[12] = RIPP_GLV_BETA; constexpr fq28::Limbs BETA = fq28::from_mont384(betaw);
+    JacQ acc; acc.x = acc.y = fq_coord(fq_one()); acc.z = fq_coord(fq_zero());
+    bool inf = true, bad = false;                               // inf is wave-uniform (shared digit strings); a table point at infinity makes the lane `bad`
+#pragma unroll 1
+    for (int pos = dg.len - 1; pos >= 0; --pos) {
+        if (!inf) jdbl_q(acc);
+#pragma unroll 1
+        for (int t = 0; t < 16; ++t) {
+            const int d = dg.d[t][pos];
+            if (d == 0) continue;
+            const int u = t >> 2;
+            uint32_t el = i; asm volatile("" : "+v"(el));
+            el += u == 0 ? q : u == 3 ? 0u : 2 * q;
+            const G1A qa = tab[(size_t)(M * (t & 3) + ((d < 0 ? -d : d) >> 1)) * tstride + el];
+            bad |= is_inf(qa);
+            AffQ p = affq_from(qa);
+            if (u == 2) p.x = fq_mul(p.x, fq_const<FQ_LN, 1>(BETA));
+            if (d < 0) p.y = fq_reduce(fq_neg(p.y));
+            if (inf) { acc.x = fq_coord(p.x); acc.y = fq_coord(p.y); acc.z = fq_coord(fq_one()); inf = false; }
+            else bad |= jmadd_q(acc, p.x, p.y);
+        }
+    }
+    const G1A l = lo[i];
+    if (inf) { out[i] = to_jac(l); flag[i] = 0; return; }
+    if (!is_inf(l)) { const AffQ lq = affq_from(l); bad |= jmadd_q(acc, lq.x, lq.y); }
+    flag[i] = bad;
+    if (!bad) out[i] = jacq_to_g1j(acc);
+#endif
+}
+__global__ void __launch_bounds__(64) k_fold_g1_fused_fix(const G1A* __restrict__ tab, size_t tstride, int M, const G1A* __restrict__ lo, uint32_t q, WnafG1x4 dg, G1J* __restrict__ out, const uint8_t* __restrict__ flag) {
+    for_flagged(flag, q, [&](uint32_t i) { out[i] = fold_g1_fused_complete(tab, tstride, M, lo[i], q, i, dg); });
 }
 
 }  // namespace ripp

@@ -183,6 +183,77 @@ __global__ void __launch_bounds__(64) k_fold_g2_tab_fix(const uint4* __restrict_
     for_flagged(flag, half, [&](uint32_t i) { fold_g2_tab_complete<D, NS>(qtab, stride, M, lo, i, dg, out); });
 }
 
+// ---- the FUSED fold of rounds 0 and 1 on the x-scaled G2 vector (engine.hip job_fold_fused; fq_curve.hpp has the G1 side).  With the quarters
+// B0 .. B3 of the round-0 vector and both challenges known,   bt''_i = (x0 x1) B0_i + x0 B1_i + x1 B2_i + B3_i   (bt'' = x0 x1 b'': the vector
+// stays x-scaled).  Three digit sets over the round-0 kind of table (rows (4 b + j) M + m = psi^j((2 m + 1) 2^(16 b) Q)), built over B0 | B1 | B2:
+// set 0: x0 x1 (full width: four GLS digits) on B0 (element i), set 1: x0 on B1 (q + i), set 2: x1 on B2 (2 q + i) -- 17 doublings + ~32 x 3.2
+// additions per output where the two folds take 2 x (17 + ~45) for round 0 and 65 + ~52 plus its in-round tables for round 1.
+struct Wnaf16x3 { Wnaf16 s[3]; int len; };
+__device__ __noinline__ inline void fold_g2_fused_complete(const uint4* __restrict__ qtab, size_t stride, int M, const G2A* __restrict__ lo, uint32_t q, uint32_t i, const Wnaf16x3& dg, G2J* __restrict__ out) {
+    G2J acc = jac_inf<Fp2>();
+#pragma unroll 1
+    for (int pos = dg.len - 1; pos >= 0; --pos) {
+        acc = dbl(acc);
+#pragma unroll 1
+        for (int u = 0; u < 3; ++u) {
+#pragma unroll 1
+            for (int t = 0; t < 16; ++t) {
+                const int d = dg.s[u].d[t][pos];
+                if (d != 0) {
+                    G2A p = load_chunks<G2A_CHUNKS, G2A>(qtab, (size_t)t * M + ((d < 0 ? -d : d) >> 1), stride, (size_t)u * q + i);
+                    if (d < 0) p.y = neg(p.y);
+                    acc = add_mixed(acc, p);
+                }
+            }
+        }
+    }
+    out[i] = add_mixed(acc, lo[i]);
+}
+__global__ void __launch_bounds__(64, 2) k_fold_g2_fused_q(const uint4* __restrict__ qtab, size_t stride, int M, const G2A* __restrict__ lo, uint32_t q, Wnaf16x3 dg, G2J* __restrict__ out, uint8_t* __restrict__ flag) {
+    __shared__ uint4 park_[7 * 64];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= q) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint4* park = park_ + threadIdx.x;
+    JacQ2 acc; acc.x = acc.y = f2_coord(Fq2n{fq_one(), fq_zero()}); acc.z = f2_coord(Fq2n{fq_zero(), fq_zero()});
+    bool inf = true, bad = false;                                        // inf is wave-uniform: the digit strings are shared by the launch
+#pragma unroll 1
+    for (int pos = dg.len - 1; pos >= 0; --pos) {
+        if (!inf) jdbl2_q(acc);
+#pragma unroll 1
+        for (int ut = 0; ut < 48; ++ut) {
+            const int u = ut >> 4, t = ut & 15;
+            const int d = dg.s[u].d[t][pos];
+            if (d == 0) continue;
+            uint32_t il = i; asm volatile("" : "+v"(il));                     // (re-formed per addition instead of living in a spilled register pair)
+            const uint4* base = qtab + ((size_t)t * M + ((d < 0 ? -d : d) >> 1)) * G2A_CHUNKS * stride + (size_t)u * q + il;
+            auto ldfp2 = [&](int q0) { Fp2 v; uint4* dd = reinterpret_cast<uint4*>(&v); const uint4* b2 = opaque(base);
+#pragma unroll
+                for (int c = 0; c < 6; ++c) dd[c] = b2[(size_t)(q0 + c) * stride]; return v; };
+            auto loadx = [&]() { return f2_from(ldfp2(0)); };
+            auto loady = [&]() { const Fp2 y = ldfp2(6); return f2_from(d < 0 ? neg(y) : y); };
+            if (inf) {                                                    // first addition: acc <- +-Q
+                const Fp2 x0 = ldfp2(0), y0 = ldfp2(6);
+                bad |= x0.is_zero() && y0.is_zero();
+                acc.x = f2_coord(f2_from(x0)); acc.y = f2_coord(f2_from(d < 0 ? neg(y0) : y0)); acc.z = f2_coord(Fq2n{fq_one(), fq_zero()}); inf = false;
+            } else {
+                { const Fp2 x0 = ldfp2(0); bad |= x0.is_zero() && ldfp2(6).is_zero(); }      // a table point at infinity
+                bad |= jmadd2_q(acc, loadx, loady, park);
+            }
+        }
+    }
+    const G2A* lp = lo + i;
+    if (inf) { out[i] = to_jac(*lp); flag[i] = 0; return; }
+    bool linf; { const G2A l = *lp; linf = is_inf(l); }
+    if (!linf) bad |= jmadd2_q(acc, [&]() { return f2_from(opaque(lp)->x); }, [&]() { return f2_from(opaque(lp)->y); }, park);
+    flag[i] = bad;
+    if (!bad) out[i] = G2J{f2_to(acc.x), f2_to(acc.y), f2_to(acc.z)};
+#endif
+}
+__global__ void __launch_bounds__(64) k_fold_g2_fused_fix(const uint4* __restrict__ qtab, size_t stride, int M, const G2A* __restrict__ lo, uint32_t q, Wnaf16x3 dg, G2J* __restrict__ out, const uint8_t* __restrict__ flag) {
+    for_flagged(flag, q, [&](uint32_t i) { fold_g2_fused_complete(qtab, stride, M, lo, q, i, dg, out); });
+}
+
 // Odd multiples 3 Q, 5 Q, .., (2 M - 1) Q of the fold tables (kernels.hpp k_odd_multiples: out[m][i] = (2m + 3) base[i], Jacobian, batch-normalised
 // by the caller) on the carry-free form.  k_odd_multiples<Fp2> chains M - 2 GENERAL Jacobian additions t += 2Q (16 Fp2 products each, out-of-line
 // 12-word products: 1 448 B of scratch per lane, 63 % of its own issue roof).  Here the chain runs on the isomorphic curve on which 2Q = (X2, Y2, Z2)

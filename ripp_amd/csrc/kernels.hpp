@@ -482,7 +482,7 @@ __global__ void __launch_bounds__(64, 2) k_odd_multiples(const Affine<F>* __rest
 struct Wnaf4 { int8_t d[4][36]; int len; };            // G1: string b = 32-bit word b of the 128-bit challenge
 struct Wnaf16 { int8_t d[16][20]; int len; };          // G2: string 4 b + j = 16-bit piece b of GLS digit j
 // tab[e][i], e = M b + m: (2m + 1) * (base b of element i)
-__global__ void __launch_bounds__(256) k_fold_g1_tab(const G1A* __restrict__ tab, int M, const G1A* __restrict__ lo, uint32_t half, Wnaf4 dg, G1J* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_fold_g1_tab(const G1A* __restrict__ tab, size_t tstride, int M, const G1A* __restrict__ lo, uint32_t half, Wnaf4 dg, G1J* __restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= half) return;
     G1J acc = jac_inf<Fp>();
@@ -492,7 +492,7 @@ __global__ void __launch_bounds__(256) k_fold_g1_tab(const G1A* __restrict__ tab
 #pragma unroll 1
         for (int t = 0; t < 4; ++t) {
             const int d = dg.d[t][pos];
-            if (d != 0) { G1A q = tab[(size_t)(M * t + ((d < 0 ? -d : d) >> 1)) * half + i]; if (d < 0) q.y = neg(q.y); acc = add_mixed(acc, q); }
+            if (d != 0) { G1A q = tab[(size_t)(M * t + ((d < 0 ? -d : d) >> 1)) * tstride + i]; if (d < 0) q.y = neg(q.y); acc = add_mixed(acc, q); }
         }
     }
     out[i] = add_mixed(acc, lo[i]);

@@ -297,7 +297,11 @@ def test_sipp_prove_2p17_vs_oracle_with_precomputed_round0(engine, orc):
     for env in ({"RIPP_NO_FOLD_TABLES": "1"}, {"RIPP_NO_XSCALE": "1"}, {"RIPP_FQ_MIN": "4096", "RIPP_LP_FQ_MIN": "1"},
                 {"RIPP_FQ_MIN": "4096", "RIPP_NO_XSCALE": "1"}, {"RIPP_NO_FQ": "1"}, {"RIPP_LP_FQ_MIN": big}, {"RIPP_ML_FQ_MIN": big},
                 {"RIPP_LOOK_EIGHTHS": "11"}, {"RIPP_LOOK_EIGHTHS": "5"}, {"RIPP_LOOK_EIGHTHS": "20", "RIPP_NO_XSCALE": "1"},
-                {"RIPP_LOOK_EIGHTHS": "48"}, {"RIPP_LOOK_EIGHTHS": "48", "RIPP_NO_SHARE": "1"}, {"RIPP_LOOK_EIGHTHS": "24", "RIPP_ML_FQ_MIN": big}):      # shared G2 chains (fq_miller.hpp) / every product its own chain
+                {"RIPP_LOOK_EIGHTHS": "48"}, {"RIPP_LOOK_EIGHTHS": "48", "RIPP_NO_SHARE": "1"}, {"RIPP_LOOK_EIGHTHS": "24", "RIPP_ML_FQ_MIN": big},      # shared G2 chains (fq_miller.hpp) / every product its own chain
+                # >= 16 eighths: both values of round 1 come from the look-ahead, so rounds 0 and 1 fold in ONE pass over three-quarter tables (job_fold_fused:
+                # the degenerate rows above sit in the quarters A2 / B1 / B2 and reach its fix-up kernels); RIPP_NO_FUSE: the two folds one after the other;
+                # 16 + RIPP_NO_XSCALE: tables on the high half, no fusion
+                {"RIPP_LOOK_EIGHTHS": "16"}, {"RIPP_LOOK_EIGHTHS": "16", "RIPP_NO_FUSE": "1"}, {"RIPP_LOOK_EIGHTHS": "16", "RIPP_NO_XSCALE": "1"}, {"RIPP_LOOK_EIGHTHS": "16", "RIPP_FQ_MIN": "4096"}):
         os.environ.update(env)
         try:
             assert np.array_equal(engine.SIPP.prove(a, b, r, value), eproof), env
