@@ -63,28 +63,36 @@ template <class FQ> __device__ __forceinline__ void st_park_fq(uint4* park, int 
 // and the look-ahead of the following rounds: every B block meets up to 2^R + 1 A blocks (engine.hip job_round0_shared / job_lookahead) -- ONE lane
 // walks Q's chain and emits the lines of all of them: per extra P and step two Fp2 x Fp products (1 568 multiply-adds) + the conversion of its two
 // coordinates (re-loaded from global memory in the engine's form: no LDS for them) against ~9 800 / ~16 000 for the step itself.
-struct ExtraP { const G1A* const* a; int np; };       // a[t], t = 1 .. np - 1: the other P vectors of the group (already offset).  Wave-uniform (SGPRs).
-// skipbits (ONE register per lane: the kernel sits at 256): bit t = "the pair (P_t[i], Q[i]) has a point at infinity", t = 0 the group's first P
+struct ExtraP { const G1A* const* a; int np; bool sk1, sk2, sk3; };       // a[t], t = 1 .. np - 1: the other P vectors of the group (already offset).  Wave-uniform (SGPRs).
+// Skip flags ("the pair (P_t[i], Q[i]) has a point at infinity") are BOOLS, i.e. lane masks in scalar registers: the kernel sits at 256 vector registers
 // the lines of the extra P's for one step: (yP-scaled from cy, xP-scaled from cx, free coefficient cf), rows of product t at s + t * N_LINES
-template <class CY, class CX>
-__device__ __forceinline__ void extra_lines_q(const ExtraP& xp, const CY& cy, const CX& cx, const Fq2n& cf, uint32_t skipbits, uint4* lines, size_t s, size_t stride, size_t i) {
+// the free coefficient (the same value for every P of the group) of one step, rows of product t at s + t * N_LINES: stored where it is formed
+__device__ __forceinline__ void extra_free_q(const ExtraP& xp, const Fq2n& cf, uint4* lines, size_t s, size_t stride, size_t i) {
 #pragma unroll 1
     for (int t = 1; t < xp.np; ++t) {
         const size_t st = s + (size_t)t * N_LINES;
-        const bool sk = (skipbits >> t) & 1u;                      // (its OWN P or the shared Q at infinity; the group's first P being the identity does not concern it)
-        const G1A* pp = opaque(xp.a[t] + i);
-        { Fq2n l2 = f2_mul_fq(cy, fq_from_fp_fast(pp->y)); f2_pin(l2);
-          if (sk) store_line_raw(lines, st * 3 + LINE_SLOT_YP, stride, i, LINE_UNIT_YP); else store_line_q(lines, st * 3 + LINE_SLOT_YP, stride, i, l2); }
-        { Fq2n l1 = f2_mul_fq(cx, fq_from_fp_fast(opaque(pp)->x)); f2_pin(l1);
-          if (sk) store_line_raw(lines, st * 3 + 1, stride, i, Fp2::zero()); else store_line_q(lines, st * 3 + 1, stride, i, l1); }
+        const bool sk = t == 1 ? xp.sk1 : t == 2 ? xp.sk2 : xp.sk3;      // (its OWN P or the shared Q at infinity; the group's first P being the identity does not concern it)
         if (sk) store_line_raw(lines, st * 3 + LINE_SLOT_FREE, stride, i, LINE_UNIT_FREE); else store_line_q(lines, st * 3 + LINE_SLOT_FREE, stride, i, cf);
+    }
+}
+// the two P-scaled coefficients: (yP-scaled from cy, xP-scaled from cx)
+template <class CY, class CX>
+__device__ __forceinline__ void extra_scaled_q(const ExtraP& xp, const CY& cy, const CX& cx, uint4* lines, size_t s, size_t stride, size_t i) {
+#pragma unroll 1
+    for (int t = 1; t < xp.np; ++t) {
+        const size_t st = s + (size_t)t * N_LINES;
+        const bool sk = t == 1 ? xp.sk1 : t == 2 ? xp.sk2 : xp.sk3;
+        auto addr = [&]() { uint32_t il = (uint32_t)i; asm volatile("" : "+v"(il)); return xp.a[t] + il; };      // P_t's address is re-formed per use, not held across a product
+        { Fq2n l2 = f2_mul_fq(cy, fq_from_fp_fast(addr()->y)); f2_pin(l2);
+          if (sk) store_line_raw(lines, st * 3 + LINE_SLOT_YP, stride, i, LINE_UNIT_YP); else store_line_q(lines, st * 3 + LINE_SLOT_YP, stride, i, l2); }
+        { Fq2n l1 = f2_mul_fq(cx, fq_from_fp_fast(addr()->x)); f2_pin(l1);
+          if (sk) store_line_raw(lines, st * 3 + 1, stride, i, Fp2::zero()); else store_line_q(lines, st * 3 + 1, stride, i, l1); }
     }
 }
 
 // doubling step + its line; (X, Y, Z) <- -4 x the doubled point.  park: slots 0 (xP), 1 (yP).  Every product is PINNED where it is written
 // (fq28.hpp fq_pin): the compiler otherwise carries un-reduced column sums of one step across the loop's branch into the next.
-__device__ __forceinline__ void line_double_store_q(Fq2C& X, Fq2C& Y, Fq2C& Z, const uint4* park, uint4* lines, size_t s, size_t stride, size_t i, uint32_t skipbits, const ExtraP& xp) {
-    const bool skip = skipbits & 1u;
+__device__ __forceinline__ void line_double_store_q(Fq2C& X, Fq2C& Y, Fq2C& Z, const uint4* park, uint4* lines, size_t s, size_t stride, size_t i, bool skip, const ExtraP& xp) {
     Fq2n t1 = f2_sqrd(f2_norm(f2_add(Y, Z))); f2_pin(t1);
     Fq2n c = f2_sqrd(Z); f2_pin(c);
     Fq2n b = f2_sqrd(Y); f2_pin(b);
@@ -107,14 +115,15 @@ __device__ __forceinline__ void line_double_store_q(Fq2C& X, Fq2C& Y, Fq2C& Z, c
         e.c1 = fq_reduce(fq_dbl(fq_dbl(fq_norm(fq_add(c3.c0, c3.c1)))));
 #endif
     } f2_pin(e);
-    if (skip) store_line_raw(lines, s * 3 + LINE_SLOT_FREE, stride, i, LINE_UNIT_FREE); else store_line_q(lines, s * 3 + LINE_SLOT_FREE, stride, i, f2_reduce(f2_sub(e, b)));
+    { const Fq2n fr = f2_reduce(f2_sub(e, b));
+      if (skip) store_line_raw(lines, s * 3 + LINE_SLOT_FREE, stride, i, LINE_UNIT_FREE); else store_line_q(lines, s * 3 + LINE_SLOT_FREE, stride, i, fr);
+      if (xp.np > 1) extra_free_q(xp, fr, lines, s, stride, i); }                  // (wave-uniform branch)
     Fq2n a2 = f2_muld(X, Y); f2_pin(a2);                                          // a' = X Y
     {
         Fq2n j = f2_sqrd(X); f2_pin(j);
-        const auto j3 = f2_add(f2_add(j, j), j);
-        Fq2n l1 = f2_mul_fq(j3, ld_park_fq(park, 0)); f2_pin(l1);
-        if (skip) store_line_raw(lines, s * 3 + 1, stride, i, Fp2::zero()); else store_line_q(lines, s * 3 + 1, stride, i, l1);
-        if (xp.np > 1) extra_lines_q(xp, nh, j3, f2_reduce(f2_sub(e, b)), skipbits, lines, s, stride, i);      // (wave-uniform branch)
+        { Fq2n l1 = f2_mul_fq(f2_add(f2_add(j, j), j), ld_park_fq(park, 0)); f2_pin(l1);
+          if (skip) store_line_raw(lines, s * 3 + 1, stride, i, Fp2::zero()); else store_line_q(lines, s * 3 + 1, stride, i, l1); }
+        if (xp.np > 1) extra_scaled_q(xp, nh, f2_add(f2_add(j, j), j), lines, s, stride, i);      // (3 j is re-formed, not held)
     }
     Z = f2_to_coord(f2_muld(f2_dbl(b), f2_dbl(nh))); f2_pin(Z);                   // (2b)(2 nh) = -4 b h
     const auto f = f2_add(f2_add(e, e), e);                                       // 3e, lazy
@@ -126,8 +135,7 @@ __device__ __forceinline__ void line_double_store_q(Fq2C& X, Fq2C& Y, Fq2C& Z, c
 }
 __device__ __forceinline__ Fq2n f2_load_conv(const Fp2* p) { const Fp2 v = *p; return f2_from(v); }
 // mixed addition step + its line (-j, theta xP, -lambda yP) = -1 x the textbook line
-__device__ __forceinline__ void line_add_store_q(Fq2C& X, Fq2C& Y, Fq2C& Z, const G2A* q, const uint4* park, uint4* lines, size_t s, size_t stride, size_t i, uint32_t skipbits, const ExtraP& xp) {
-    const bool skip = skipbits & 1u;
+__device__ __forceinline__ void line_add_store_q(Fq2C& X, Fq2C& Y, Fq2C& Z, const G2A* q, const uint4* park, uint4* lines, size_t s, size_t stride, size_t i, bool skip, const ExtraP& xp) {
     Fq2n theta, lambda;
     { const Fq2n qy = f2_load_conv(&opaque(q)->y); theta = f2_reduce(f2_sub(Y, f2_muld(qy, Z))); } f2_pin(theta);
     st_park_fq(const_cast<uint4*>(park), 2, Y.c0); st_park_fq(const_cast<uint4*>(park), 3, Y.c1);      // Y rests in LDS until the step's last product
@@ -137,16 +145,14 @@ __device__ __forceinline__ void line_add_store_q(Fq2C& X, Fq2C& Y, Fq2C& Z, cons
         const Fq2n qx = f2_load_conv(&opaque(q)->x);
         Fq2n nj = f2_reduce(f2_sub(t, f2_muld(theta, qx))); f2_pin(nj);             // lambda qy - theta qx = -j
         if (skip) store_line_raw(lines, s * 3 + LINE_SLOT_FREE, stride, i, LINE_UNIT_FREE); else store_line_q(lines, s * 3 + LINE_SLOT_FREE, stride, i, nj);
-        if (xp.np > 1) {                                                            // the other P's of the group: (-lambda yP_t, theta xP_t, -j)
-            const auto nl = Fq2T<fq28::sub_lm(1, FQ_LN), 4>{fq_neg(lambda.c0), fq_neg(lambda.c1)};
-            extra_lines_q(xp, nl, theta, nj, skipbits, lines, s, stride, i);
-        }
+        if (xp.np > 1) extra_free_q(xp, nj, lines, s, stride, i);                  // the other P's of the group: (-lambda yP_t, theta xP_t, -j)
     }
     { Fq2n l1 = f2_mul_fq(theta, ld_park_fq(park, 0)); f2_pin(l1);
       if (skip) store_line_raw(lines, s * 3 + 1, stride, i, Fp2::zero()); else store_line_q(lines, s * 3 + 1, stride, i, l1); }
     { const auto nl = Fq2T<fq28::sub_lm(1, FQ_LN), 4>{fq_neg(lambda.c0), fq_neg(lambda.c1)};
       Fq2n l2 = f2_mul_fq(nl, ld_park_fq(park, 1)); f2_pin(l2);
-      if (skip) store_line_raw(lines, s * 3 + LINE_SLOT_YP, stride, i, LINE_UNIT_YP); else store_line_q(lines, s * 3 + LINE_SLOT_YP, stride, i, l2); }
+      if (skip) store_line_raw(lines, s * 3 + LINE_SLOT_YP, stride, i, LINE_UNIT_YP); else store_line_q(lines, s * 3 + LINE_SLOT_YP, stride, i, l2);
+      if (xp.np > 1) extra_scaled_q(xp, nl, theta, lines, s, stride, i); }
     Fq2n f;
     { Fq2n c = f2_sqrd(theta); f2_pin(c); f = f2_muld(c, Z); } f2_pin(f);
     Fq2n d = f2_sqrd(lambda); f2_pin(d);
@@ -172,14 +178,15 @@ __global__ void __launch_bounds__(256, RIPP_OCC) k_miller_lines_q(ChainSets cs, 
     const G2A* __restrict__ b = cs.b[blockIdx.y];
     uint4* park = park_ + threadIdx.x;
     Fq2C X, Y, Z;
-    uint32_t skip;                                               // skipbits of this lane
-    const ExtraP xp{cs.a + p0, cs.np[blockIdx.y]};
+    bool skip;
+    ExtraP xp{cs.a + p0, cs.np[blockIdx.y], false, false, false};
     {
         const G2A Q = b[i]; const G1A P = a[i];
         const bool qinf = Q.x.is_zero() && Q.y.is_zero();
-        skip = (is_inf(P) || qinf) ? 1u : 0u;
-#pragma unroll 1
-        for (int t = 1; t < xp.np; ++t) { const G1A Pt = xp.a[t][i]; if (is_inf(Pt) || qinf) skip |= 1u << t; }
+        skip = is_inf(P) || qinf;
+        if (xp.np > 1) xp.sk1 = is_inf(xp.a[1][i]) || qinf;
+        if (xp.np > 2) xp.sk2 = is_inf(xp.a[2][i]) || qinf;
+        if (xp.np > 3) xp.sk3 = is_inf(xp.a[3][i]) || qinf;
         X = f2_to_coord(f2_from(Q.x)); Y = f2_to_coord(f2_from(Q.y)); Z = f2_to_coord(Fq2n{fq_one(), fq_zero()});
         st_park_fq(park, 0, fq_from_fp_fast(P.x)); st_park_fq(park, 1, fq_from_fp_fast(P.y));
         f2_pin(X); f2_pin(Y); f2_pin(Z);                             // (Z = 1 is not to be folded into a peeled first iteration: that copy of the loop body spilled)

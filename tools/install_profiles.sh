@@ -1,5 +1,5 @@
 # Copy the summaries collected by tools/run_profiles.sh <tag> (gpurun_out/prof_<tag>/) into profiles/ under the round's names.
-TAG=${1:-r03}; R=${2:-r03}
+TAG=${1:-r04}; R=${2:-r04}
 S=gpurun_out/prof_$TAG
 cp $S/kstats/k_kernel_stats.csv profiles/${R}_bench_kernel_stats_rocprofv3.csv
 cp $S/bench_n1.json profiles/${R}_bench_n1.json
@@ -21,6 +21,8 @@ if [ -d $F ]; then
   cp $F/c377/ipp-mi355x-hip-bls12_377.csv profiles/${R}_scaling_ipp_bls12_377_mi355x.csv
   cp $F/c377/ipp-cpu-oracle-bls12_377.csv profiles/${R}_scaling_ipp_bls12_377_cpu_oracle_16thr.csv
   cp $F/aggregate_2p14.json profiles/${R}_aggregate_2p14.json
-  cp $F/bench_n2_single_device_gloo.json profiles/${R}_bench_n2_single_device_gloo.json
+  for G in 2 4 8; do [ -s $F/bench_n${G}_single_device_gloo.json ] && cp $F/bench_n${G}_single_device_gloo.json profiles/${R}_bench_n${G}_single_device_gloo.json; done
+  [ -s $F/post_hash_timeline.txt ] && cp $F/post_hash_timeline.txt profiles/${R}_post_hash_timeline.txt
+  for f in stress_world4 stress_world8 stress_tail; do [ -s $F/$f.txt ] && tail -3 $F/$f.txt > profiles/${R}_$f.txt; done
   [ -s $F/poly_commit_bench.csv ] && cp $F/poly_commit_bench.csv profiles/${R}_poly_commit_bench.csv
 fi

@@ -1,12 +1,17 @@
 # End-of-round measurement set on the CURRENT build (GPU box): bash tools/run_final.sh <tag>
 set -x
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 bash tools/run_profiles.sh $TAG > gpurun_out/prof_$TAG.log 2>&1
 O=gpurun_out/final_$TAG; mkdir -p $O
 timeout 900 python3 tools/scaling_ipp.py 1 20 $O --cpu-max 12 > $O/scaling_ipp.log 2>&1
 timeout 300 python3 tools/aggregate_bench.py 14 > $O/aggregate_2p14.json 2> $O/aggregate_2p14.err
-RIPP_BENCH_SINGLE_DEVICE=1 timeout 300 python3 bench.py --gpus 2 --steps 3 --warmup 1 --cpu-log-n 0 > $O/bench_n2_single_device_gloo.json 2> $O/bench_n2.err
-timeout 600 python3 tools/scaling_ipp.py 4 18 $O/c377 --cpu-max 12 --curve 377 > $O/scaling_ipp_377.log 2>&1
+for G in 2 4 8; do RIPP_BENCH_SINGLE_DEVICE=1 timeout 600 python3 bench.py --gpus $G --steps 3 --warmup 1 --cpu-log-n 0 > $O/bench_n${G}_single_device_gloo.json 2> $O/bench_n$G.err; done
+timeout 900 python3 tools/scaling_ipp.py 4 20 $O/c377 --cpu-max 12 --curve 377 > $O/scaling_ipp_377.log 2>&1
+bash tools/post_hash_timeline.sh 300 440 > $O/post_hash_timeline.txt 2>&1
+# randomized stress against the oracle: 4 and 8 ranks on this GPU, then the pipelined tail
+timeout 400 python3 tools/stress_sharded.py 41 90 2 14 4 > $O/stress_world4.txt 2>&1
+timeout 400 python3 tools/stress_sharded.py 81 90 3 14 8 > $O/stress_world8.txt 2>&1
+timeout 200 python3 tools/stress_tail.py 5 60 1 12 > $O/stress_tail.txt 2>&1
 timeout 300 python3 tools/poly_commit_bench.py 2 8 > $O/poly_commit_bench.csv 2> $O/poly_commit.err
-ls -la $O $O/c377; tail -3 $O/scaling_ipp.log; cat $O/aggregate_2p14.json | head -30; cat $O/bench_n2_single_device_gloo.json | cut -c1-300
+ls -la $O $O/c377; tail -3 $O/scaling_ipp.log; cat $O/aggregate_2p14.json | head -30; cat $O/bench_n2_single_device_gloo.json | cut -c1-300; tail -2 $O/stress_world4.txt $O/stress_world8.txt $O/stress_tail.txt

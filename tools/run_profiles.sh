@@ -1,6 +1,6 @@
 # Collects every profile the bench line and DESIGN.md quote, on the CURRENT build.  Usage (GPU box): bash tools/run_profiles.sh <tag>
 set -x
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 ./tools/ubench/build/fpbench > $OUT/fpbench.txt 2>&1
 ./tools/ubench/build/fqbench > $OUT/fqbench.txt 2>&1
 ./tools/ubench/build/invbench > $OUT/invbench.txt 2>&1
-timeout 300 python3 bench.py --steps 5 --warmup 1 > $OUT/bench_n1.json 2> $OUT/bench_n1.err
+timeout 900 python3 bench.py --steps 5 --warmup 1 > $OUT/bench_n1.json 2> $OUT/bench_n1.err        # incl. the CPU baseline at n = 2^20 (~100 s)
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/kstats -o k --output-format csv -- python3 bench.py --steps 3 --warmup 1 --cpu-log-n 0 > $OUT/kstats.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o f --output-format csv -- python3 bench.py --steps 1 --warmup 0 --cpu-log-n 0 > $OUT/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o w --output-format csv -- python3 bench.py --steps 1 --warmup 0 --cpu-log-n 0 > $OUT/pmc_write.log 2>&1
