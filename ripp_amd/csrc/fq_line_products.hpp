@@ -27,14 +27,26 @@ typedef uint32_t lq_v4u __attribute__((ext_vector_type(4)));
 struct LqBuf { lq_v4u q[4]; };                                    // one accumulator coefficient as fetched: 14 limbs + 2
 constexpr int LQ_SLOT_DW = 16;                                     // an Fq in LDS: 14 limbs + 2 (four 16-byte accesses)
 constexpr int LQ_ACC_DW = 6 * 2 * LQ_SLOT_DW;                      // f_0 .. f_5 in Fp2: 768 B per accumulator
-// The 21 accumulators of a wave are laid out with a stride of 49 chunks (784 B), not 48: 768 B is a multiple of the 128-byte bank row, so every
-// group's slot k sat in the SAME banks and the 16-byte accumulator reads of the 21 groups serialised -- SQ_LDS_BANK_CONFLICT was 20 % of the kernel's
-// wave-cycles (first r03 PMC pass; 4.7 % now: profiles/r03_sq_counters_pmc.csv).  With the odd stride consecutive groups are 16 bytes apart modulo a bank
-// row.  Same-box A/B (-DRIPP_LP_NO_PAD): 452.0 against 454.8 ms per proof -- most of those cycles were hidden behind the SIMD's other wave.
+// LDS bank layout.  An accumulator is six 128-byte slots; the three lanes of a group read three different slots in the SAME instruction, and 21 groups do so
+// side by side.  Two things had to be kept apart modulo the 256-byte bank row (64 banks x 4 B):
+//   * the groups: with a stride of 768 B every group's slot k sat in the same banks (SQ_LDS_BANK_CONFLICT 20 % of the kernel's wave-cycles, first r03
+//     PMC pass); an odd stride of 49 chunks took that to 4.7 %, the hand-streamed ds_read_b128 fetches of the second half of build round 3 back to 9.5 %
+//     (profiles/r03_sq_counters_pmc.csv, profiles/r04_sq_counters_pmc.csv before this layout);
+//   * the LANES OF ONE GROUP: lanes 0 and 2 read slots k and k + 2 -- 256 B apart, i.e. the same banks, a two-way conflict on every fetch.
+// A ds_read_b128 is served 16 lanes (256 B) per cycle; a search over slot pitches and group strides (16 fetch patterns x phases of 16 lanes, every lane a
+// distinct 16-byte bank quad wanted) gives a slot pitch of 144 B (slot k at chunk 9 k: one chunk of skew per slot) and a group stride of 59 chunks
+// (944 B = 3 x 256 + 176): 4 serialised cycles over the 16 patterns where the 784-byte layout has 16 and the 768-byte one 152.  19.8 KB of LDS per wave,
+// 158.6 of the CU's 160 KB at 8 waves.
+// Same-box A/B in build round 3 (-DRIPP_LP_NO_PAD, the 768-byte layout): 452.0 against 454.8 ms per proof -- most conflict cycles hide behind the SIMD's other wave.
 #if defined(RIPP_LP_NO_PAD)
 constexpr int LQ_ACC_STRIDE = LQ_ACC_DW / 4;                       // (A/B builds: the conflicting layout)
+#define LQ_CHUNK(slot, part) (((slot) * 2 + (part)) * 4)
+#elif defined(RIPP_LP_PAD49)
+constexpr int LQ_ACC_STRIDE = LQ_ACC_DW / 4 + 1;                   // (A/B builds: build round 3's layout, 49 chunks)
+#define LQ_CHUNK(slot, part) (((slot) * 2 + (part)) * 4)
 #else
-constexpr int LQ_ACC_STRIDE = LQ_ACC_DW / 4 + 1;                   // in 16-byte chunks
+constexpr int LQ_ACC_STRIDE = 59;                                  // in 16-byte chunks
+#define LQ_CHUNK(slot, part) ((slot) * 9 + (part) * 4)             // first chunk of (slot, part)
 #endif
 
 // grid = (ceil(T / 21), rows), block = 64 (one wave); same arguments and output layout as k_line_products
@@ -55,7 +67,7 @@ __global__ void __launch_bounds__(64, 2) k_line_products_q(const uint4* __restri
     uint4* acc = lds + acc_chunk;
     auto ld_fq = [&](int slot, int part) { Fqn v; uint4 q[4];                    // slot = w-index 0..5, part = 0 (real) / 1 (imaginary)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) q[c] = acc[(slot * 2 + part) * 4 + c];
+        for (int c = 0; c < 4; ++c) q[c] = acc[LQ_CHUNK(slot, part) + c];
         const uint32_t* w = reinterpret_cast<const uint32_t*>(q);
 #pragma unroll
         for (int i = 0; i < NL; ++i) v.l[i] = w[i];
@@ -65,7 +77,7 @@ __global__ void __launch_bounds__(64, 2) k_line_products_q(const uint4* __restri
         for (int i = 0; i < NL; ++i) w[i] = v.l[i];
         w[14] = 0; w[15] = 0;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[(slot * 2 + part) * 4 + c] = q[c]; };
+        for (int c = 0; c < 4; ++c) acc[LQ_CHUNK(slot, part) + c] = q[c]; };
     if (active) {                                                               // accumulator <- 1
         st_fq(j, 0, j == 0 ? fq_one() : fq_zero()); st_fq(j, 1, fq_zero()); st_fq(j + 3, 0, fq_zero()); st_fq(j + 3, 1, fq_zero());
     }
@@ -117,7 +129,7 @@ __global__ void __launch_bounds__(64, 2) k_line_products_q(const uint4* __restri
         // re-reads it placed every one directly before its use).  Streaming costs 64 more ds_read_b128 per line; the kernel has no scratch.
         // `pin`: a column the current pass accumulates into -- orders the reads BEFORE that pass's multiply-adds.
         auto fetch = [&](LqBuf& b, int slot, int part, uint64_t& pin) {
-            const uint32_t addr = lds_base + (acc_chunk + (uint32_t)(slot * 2 + part) * 4) * 16;
+            const uint32_t addr = lds_base + (acc_chunk + (uint32_t)LQ_CHUNK(slot, part)) * 16;
             asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:16\n\tds_read_b128 %2, %5 offset:32\n\tds_read_b128 %3, %5 offset:48"
                          : "=&v"(b.q[0]), "=&v"(b.q[1]), "=&v"(b.q[2]), "=&v"(b.q[3]), "+v"(pin) : "v"(addr));
         };
@@ -229,5 +241,6 @@ __global__ void __launch_bounds__(64, 2) k_line_products_q(const uint4* __restri
 }
 #undef TIE
 #undef TIE14
+#undef LQ_CHUNK
 
 }  // namespace ripp
