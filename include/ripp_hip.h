@@ -81,7 +81,7 @@ const char* ripp_last_error(void);   /* message of the calling thread's last fai
 typedef struct {
     uint32_t struct_size;            /* sizeof(ripp_config), set by ripp_config_default; ripp_configure rejects any other value */
     /* implementation selectors: non-zero switches the named form OFF (DESIGN.md section 7b has the effect of each) */
-    uint32_t no_vm, no_precompute, no_fold_tables, no_msm_glv, lp_one_lane, no_endo, no_fq, no_xscale, scale_no_fq, agg_sequential, look_static, quiet_waits, no_share, no_fuse;
+    uint32_t no_vm, no_precompute, no_fold_tables, no_msm_glv, lp_one_lane, no_endo, no_fq, no_xscale, scale_no_fq, agg_sequential, look_static, quiet_waits, no_share, no_fuse, fuse_tables;
     int32_t  look_eighths;           /* hash-window look-ahead plan: -1 automatic (cost model / adaptive), 8 k + f = k (round, side) items and f/8 of the next, FORCED */
     int32_t  ranks_per_device;       /* ranks sharing one GPU (test rigs): the look-ahead plan prices the window per device */
     int32_t  msm_c; uint32_t msm_ch, msm_gmin;       /* MSM window width, slot length, grouping threshold; 0 = the plan's own choice */

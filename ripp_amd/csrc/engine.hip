@@ -242,7 +242,7 @@ struct Engine {
         return aux;
     }
     // run-time switches: read from the environment ONCE per C-ABI call (get_engine), never inside round loops
-    struct Switches { bool no_vm = false, no_precompute = false, no_fold_tables = false, no_msm_glv = false, lp_one_lane = false, no_endo = false, no_fq = false, no_xscale = false, no_share = false, no_fuse = false; } sw;
+    struct Switches { bool no_vm = false, no_precompute = false, no_fold_tables = false, no_msm_glv = false, lp_one_lane = false, no_endo = false, no_fq = false, no_xscale = false, no_share = false, no_fuse = false, fuse_tables = false; } sw;
     // crossover sizes: the member initialisers above are the defaults, the environment overrides them PER CALL (a test or
     // an A/B run flips them on a live engine)
     struct Sizes { size_t vm_lines_max, vm_fold_max, vm_tree_max, gls_split_max, msm_vm_merge_max, fold_tab_min, fq_min, lp_fq_min, vm_joint_max, vm_scale_max, tail_pipe_max, ml_fq_min, fq_min_g1; } defaults{};
@@ -261,7 +261,7 @@ struct Engine {
         if (g_cfg_set) {
             const ripp_config& c = g_cfg;
             sw.no_vm = c.no_vm; sw.no_precompute = c.no_precompute; sw.no_fold_tables = c.no_fold_tables; sw.no_msm_glv = c.no_msm_glv; sw.lp_one_lane = c.lp_one_lane;
-            sw.no_endo = c.no_endo; sw.no_fq = c.no_fq; sw.no_xscale = c.no_xscale; sw.no_share = c.no_share; sw.no_fuse = c.no_fuse; scale_no_fq = c.scale_no_fq; agg_sequential = c.agg_sequential; look_static = c.look_static; quiet_waits_cfg = c.quiet_waits;
+            sw.no_endo = c.no_endo; sw.no_fq = c.no_fq; sw.no_xscale = c.no_xscale; sw.no_share = c.no_share; sw.no_fuse = c.no_fuse; sw.fuse_tables = c.fuse_tables; scale_no_fq = c.scale_no_fq; agg_sequential = c.agg_sequential; look_static = c.look_static; quiet_waits_cfg = c.quiet_waits;
             look_eighths = c.look_eighths; ranks_per_device = c.ranks_per_device > 1 ? (double)c.ranks_per_device : 1.0;
             msm_tune.c = c.msm_c; msm_tune.ch = c.msm_ch; msm_tune.gmin = c.msm_gmin;
             vm_lines_max = c.vm_lines_max; vm_fold_max = c.vm_fold_max; vm_tree_max = c.vm_tree_max; gls_split_max = c.gls_split_max; msm_vm_merge_max = c.msm_vm_merge_max; fold_tab_min = c.fold_tab_min;
@@ -279,6 +279,7 @@ struct Engine {
         env_on("RIPP_NO_ENDO", sw.no_endo);            // plain scalar multiplications in the folds / scaling (no GLV, no psi)
         env_on("RIPP_NO_XSCALE", sw.no_xscale);        // G2 folds always on the plain vector with the full-width x^-1
         env_on("RIPP_NO_FQ", sw.no_fq);                // the 12 x 32-bit forms of the kernels that have a carry-free twin (fq_curve.hpp)
+        env_on("RIPP_FUSE_TABLES", sw.fuse_tables);    // build the three-quarter tables whatever the look-ahead plan (tests: round 0 then folds ALONE over them when x1 is late)
         env_on("RIPP_NO_FUSE", sw.no_fuse);            // rounds 0 and 1 always fold one after the other (no three-quarter tables, no job_fold_fused)
         env_on("RIPP_NO_SHARE", sw.no_share);          // every pairing product walks its own G2 chain (no ChainSets grouping, no merged round 0 + look-ahead)
         env_on("RIPP_SCALE_NO_FQ", scale_no_fq); env_on("RIPP_AGG_SEQUENTIAL", agg_sequential); env_on("RIPP_LOOK_STATIC", look_static); env_on("RIPP_QUIET_WAITS", quiet_waits_cfg);
@@ -2084,7 +2085,7 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
                 e->stats.miller_products_ms += now_ms() - tp;
             }
             // asynchronous: overlaps the host work below and the hash.  Both items of round 1 planned in full: tables over three quarters for the fused fold
-            if (round == 0 && !j->seeded && (rc = job_precompute_round0(e, j, look_items >= 16 && j->len >= 4))) return rc;
+            if (round == 0 && !j->seeded && (rc = job_precompute_round0(e, j, (look_items >= 16 || e->sw.fuse_tables) && j->len >= 4))) return rc;
             if (!j->pre_vm_ready && (rc = job_precompute_vm(e, j))) return rc;                   // small rounds: the same on the VM, during the host phase
             // entry into the pipelined tail -- unless the look-ahead has (round 0: is about to get) both values of the next round
             const bool next_known = round == 0 ? (look_items >= 16 && j->len >= 4 && (look_forced || !j->digest_ready.load())) : look_full(j, round + 1);
@@ -2180,7 +2181,7 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
 static void config_from_engine(const Engine* e, ripp_config* c) {
     std::memset(c, 0, sizeof *c); c->struct_size = (uint32_t)sizeof *c;
     c->no_vm = e->sw.no_vm; c->no_precompute = e->sw.no_precompute; c->no_fold_tables = e->sw.no_fold_tables; c->no_msm_glv = e->sw.no_msm_glv; c->lp_one_lane = e->sw.lp_one_lane;
-    c->no_endo = e->sw.no_endo; c->no_fq = e->sw.no_fq; c->no_xscale = e->sw.no_xscale; c->no_share = e->sw.no_share; c->no_fuse = e->sw.no_fuse; c->scale_no_fq = e->scale_no_fq; c->agg_sequential = e->agg_sequential; c->look_static = e->look_static; c->quiet_waits = e->quiet_waits_cfg;
+    c->no_endo = e->sw.no_endo; c->no_fq = e->sw.no_fq; c->no_xscale = e->sw.no_xscale; c->no_share = e->sw.no_share; c->no_fuse = e->sw.no_fuse; c->fuse_tables = e->sw.fuse_tables; c->scale_no_fq = e->scale_no_fq; c->agg_sequential = e->agg_sequential; c->look_static = e->look_static; c->quiet_waits = e->quiet_waits_cfg;
     c->look_eighths = e->look_eighths; c->ranks_per_device = (int32_t)e->ranks_per_device; c->msm_c = e->msm_tune.c; c->msm_ch = e->msm_tune.ch; c->msm_gmin = e->msm_tune.gmin;
     c->vm_lines_max = e->vm_lines_max; c->vm_fold_max = e->vm_fold_max; c->vm_tree_max = e->vm_tree_max; c->gls_split_max = e->gls_split_max; c->msm_vm_merge_max = e->msm_vm_merge_max; c->fold_tab_min = e->fold_tab_min;
     c->fq_min = e->fq_min; c->lp_fq_min = e->lp_fq_min; c->vm_joint_max = e->vm_joint_max; c->vm_scale_max = e->vm_scale_max; c->tail_pipe_max = e->tail_pipe_max; c->ml_fq_min = e->ml_fq_min; c->fq_min_g1 = e->fq_min_g1;

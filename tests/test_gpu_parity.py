@@ -301,7 +301,10 @@ def test_sipp_prove_2p17_vs_oracle_with_precomputed_round0(engine, orc):
                 # >= 16 eighths: both values of round 1 come from the look-ahead, so rounds 0 and 1 fold in ONE pass over three-quarter tables (job_fold_fused:
                 # the degenerate rows above sit in the quarters A2 / B1 / B2 and reach its fix-up kernels); RIPP_NO_FUSE: the two folds one after the other;
                 # 16 + RIPP_NO_XSCALE: tables on the high half, no fusion
-                {"RIPP_LOOK_EIGHTHS": "16"}, {"RIPP_LOOK_EIGHTHS": "16", "RIPP_NO_FUSE": "1"}, {"RIPP_LOOK_EIGHTHS": "16", "RIPP_NO_XSCALE": "1"}, {"RIPP_LOOK_EIGHTHS": "16", "RIPP_FQ_MIN": "4096"}):
+                {"RIPP_LOOK_EIGHTHS": "16"}, {"RIPP_LOOK_EIGHTHS": "16", "RIPP_NO_FUSE": "1"}, {"RIPP_LOOK_EIGHTHS": "16", "RIPP_NO_XSCALE": "1"}, {"RIPP_LOOK_EIGHTHS": "16", "RIPP_FQ_MIN": "4096"},
+                # RIPP_FUSE_TABLES: the three-quarter tables although x1 will NOT be known with x0 (no / half a value of round 1 from the look-ahead): round 0
+                # folds alone over them (element offset q on G1), round 1 with its in-round tables -- what a proof does when the hash beats the look-ahead
+                {"RIPP_FUSE_TABLES": "1", "RIPP_LOOK_EIGHTHS": "12"}, {"RIPP_FUSE_TABLES": "1", "RIPP_LOOK_EIGHTHS": "8"}, {"RIPP_FUSE_TABLES": "1", "RIPP_LOOK_EIGHTHS": "8", "RIPP_NO_FQ": "1"}):
         os.environ.update(env)
         try:
             assert np.array_equal(engine.SIPP.prove(a, b, r, value), eproof), env
