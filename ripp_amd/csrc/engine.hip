@@ -7,6 +7,7 @@
 // sipp/src/lib.rs:56-60,80-85,94.
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <sched.h>
 #include <condition_variable>
 #include <deque>
 #include <functional>
@@ -105,6 +106,25 @@ private:
     std::atomic<int> pending_{0}, sleepers_{0}; std::atomic<bool> hot_{false};
 };
 HostPool& host_pool() { static HostPool pool(6); return pool; }
+// CPUs this PROCESS TREE may use: the affinity mask capped by the cgroup's CPU quota (cpu.max: the GPU pool's boxes give 16).  The ranks of a sharded proof
+// are separate processes on ONE node and share that allowance.
+static int effective_cpus() {
+    static const int n = []() {
+        int c = (int)std::thread::hardware_concurrency();
+        cpu_set_t set; CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof set, &set) == 0) { const int a = CPU_COUNT(&set); if (a > 0) c = a; }
+        if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[32] = {0}; long period = 0;
+            if (std::fscanf(f, "%31s %ld", q, &period) == 2 && period > 0 && q[0] != 'm') { const long quota = std::atol(q); if (quota > 0) c = std::min<long>(c, (quota + period - 1) / period); }
+            std::fclose(f);
+        }
+        return std::max(1, c);
+    }();
+    return n;
+}
+// Polling ("hot") workers are worth it only when every rank on the node has cores to spare for them: 6 workers + the prover's thread per rank.  With fewer
+// (8 ranks under a 16-CPU quota: two CPUs per rank) spinning threads would time-slice against the other ranks' critical host phases.
+static bool hot_workers_pay(int ranks_on_node) { return effective_cpus() / std::max(1, ranks_on_node) >= 8; }
 // out[k] = final_exponentiation(miller_combine(rows + k * N_LINES)), k < count, with the 63 bits of every product cut into `parts` ranges that run
 // (recurrence + final exponentiation each) on the host workers; the caller's thread takes one task itself.  The final exponentiation is a
 // homomorphism into the cyclotomic subgroup, so  value = conj?( ((E_1^(2^n_2) E_2)^(2^n_3) E_3) ... )  with Granger-Scott squarings: the same
@@ -2134,7 +2154,7 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
         if (!j->seeded) {
             j->rng.from_digest(j->digest); j->seeded = true;
             e->quiet_waits = false;
-            host_pool().set_hot(true);                       // the remaining rounds hand 0.1-0.6 ms tasks to the workers every ~2 ms
+            host_pool().set_hot(hot_workers_pay(world0));      // the remaining rounds hand 0.1-0.6 ms tasks to the workers every ~2 ms
         }
         const Fr x = fs::sipp_challenge(j->rng, zl, zr);
         x_prev = x;
