@@ -85,6 +85,7 @@ typedef struct {
     int32_t  look_eighths;           /* hash-window look-ahead plan: -1 automatic (cost model / adaptive), 8 k + f = k (round, side) items and f/8 of the next, FORCED */
     int32_t  ranks_per_device;       /* ranks sharing one GPU (test rigs): the look-ahead plan prices the window per device */
     int32_t  msm_c; uint32_t msm_ch, msm_gmin;       /* MSM window width, slot length, grouping threshold; 0 = the plan's own choice */
+    uint32_t no_prebuild;            /* (selector, in what was padding) in-round G2 fold tables only after the challenge, not in the host phase before it */
     /* crossover launch sizes between the latency and the throughput forms */
     uint64_t vm_lines_max, vm_fold_max, vm_tree_max, gls_split_max, msm_vm_merge_max, fold_tab_min, fq_min, lp_fq_min, vm_joint_max, vm_scale_max,
              tail_pipe_max, ml_fq_min, fq_min_g1;

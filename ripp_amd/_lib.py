@@ -29,7 +29,7 @@ class RippConfig(ctypes.Structure):
     """`ripp_config` of include/ripp_hip.h: every choice among implementations of the same function (kernel forms, crossover sizes, look-ahead plan)."""
     _fields_ = [("struct_size", ctypes.c_uint32)] + [(n, ctypes.c_uint32) for n in (
         "no_vm", "no_precompute", "no_fold_tables", "no_msm_glv", "lp_one_lane", "no_endo", "no_fq", "no_xscale", "scale_no_fq", "agg_sequential", "look_static", "quiet_waits", "no_share", "no_fuse", "fuse_tables")] + [
-        ("look_eighths", ctypes.c_int32), ("ranks_per_device", ctypes.c_int32), ("msm_c", ctypes.c_int32), ("msm_ch", ctypes.c_uint32), ("msm_gmin", ctypes.c_uint32)] + [
+        ("look_eighths", ctypes.c_int32), ("ranks_per_device", ctypes.c_int32), ("msm_c", ctypes.c_int32), ("msm_ch", ctypes.c_uint32), ("msm_gmin", ctypes.c_uint32), ("no_prebuild", ctypes.c_uint32)] + [
         (n, ctypes.c_uint64) for n in ("vm_lines_max", "vm_fold_max", "vm_tree_max", "gls_split_max", "msm_vm_merge_max", "fold_tab_min", "fq_min", "lp_fq_min", "vm_joint_max",
                                        "vm_scale_max", "tail_pipe_max", "ml_fq_min", "fq_min_g1")]
 

@@ -230,6 +230,9 @@ struct Engine {
     DevBuf fold_tab1, fold_mult, fold_tab, fold_jac1, fold_jac2;
     DevBuf fix_flags, scale_flags;        // one byte per lane of a carry-free G2 fold / table / scaling kernel: lanes with an exceptional addition, redone by the *_fix kernel behind it
     const void* tab_owner = nullptr;
+    size_t msm_chunk_min = (size_t)1 << 20;                               // host-slice MSMs of >= this many G1 bases (half as many G2 bases: the same bytes) run as two halves on two streams (msm_impl: the second half's upload beside the first half's additions)
+    size_t msm_lds_sort_min = (size_t)1 << 19;                            // MSMs of >= this many terms (after the GLV / GLS split) sort through LDS tiles (msm.hpp k_msm_hist_lds / k_msm_scatter_lds)
+    const void* g2tab_hi = nullptr; size_t g2tab_half = 0;               // in-round G2 fold tables built ahead of the challenge (fold_g2_table_build): the vector half they were built over
     size_t vm_scale_max = (size_t)1 << 14;                                // per-element G1 scalings of <= this many elements run on the VM (measured: direct product 6.1 -> 3.8 ms at 2^13, 7.1 -> 6.2 ms at 2^14, level at 2^15)
     size_t vm_joint_max = (size_t)1 << 13;                                // folds with <= this many outputs (and more than vm_fold_max) use the joint one-group-per-element VM forms
     size_t lp_fq_min = 0;                 // pairs per launch from which k_line_products_q replaces k_line_products: always (11 % faster per launch: 5.8 vs 6.5 ms at the proof's launch
@@ -262,7 +265,7 @@ struct Engine {
         return aux;
     }
     // run-time switches: read from the environment ONCE per C-ABI call (get_engine), never inside round loops
-    struct Switches { bool no_vm = false, no_precompute = false, no_fold_tables = false, no_msm_glv = false, lp_one_lane = false, no_endo = false, no_fq = false, no_xscale = false, no_share = false, no_fuse = false, fuse_tables = false; } sw;
+    struct Switches { bool no_vm = false, no_precompute = false, no_fold_tables = false, no_msm_glv = false, lp_one_lane = false, no_endo = false, no_fq = false, no_xscale = false, no_share = false, no_fuse = false, no_prebuild = false, fuse_tables = false; } sw;
     // crossover sizes: the member initialisers above are the defaults, the environment overrides them PER CALL (a test or
     // an A/B run flips them on a live engine)
     struct Sizes { size_t vm_lines_max, vm_fold_max, vm_tree_max, gls_split_max, msm_vm_merge_max, fold_tab_min, fq_min, lp_fq_min, vm_joint_max, vm_scale_max, tail_pipe_max, ml_fq_min, fq_min_g1; } defaults{};
@@ -283,7 +286,7 @@ struct Engine {
             sw.no_vm = c.no_vm; sw.no_precompute = c.no_precompute; sw.no_fold_tables = c.no_fold_tables; sw.no_msm_glv = c.no_msm_glv; sw.lp_one_lane = c.lp_one_lane;
             sw.no_endo = c.no_endo; sw.no_fq = c.no_fq; sw.no_xscale = c.no_xscale; sw.no_share = c.no_share; sw.no_fuse = c.no_fuse; sw.fuse_tables = c.fuse_tables; scale_no_fq = c.scale_no_fq; agg_sequential = c.agg_sequential; look_static = c.look_static; quiet_waits_cfg = c.quiet_waits;
             look_eighths = c.look_eighths; ranks_per_device = c.ranks_per_device > 1 ? (double)c.ranks_per_device : 1.0;
-            msm_tune.c = c.msm_c; msm_tune.ch = c.msm_ch; msm_tune.gmin = c.msm_gmin;
+            msm_tune.c = c.msm_c; msm_tune.ch = c.msm_ch; msm_tune.gmin = c.msm_gmin; sw.no_prebuild = c.no_prebuild;
             vm_lines_max = c.vm_lines_max; vm_fold_max = c.vm_fold_max; vm_tree_max = c.vm_tree_max; gls_split_max = c.gls_split_max; msm_vm_merge_max = c.msm_vm_merge_max; fold_tab_min = c.fold_tab_min;
             fq_min = c.fq_min; lp_fq_min = c.lp_fq_min; vm_joint_max = c.vm_joint_max; vm_scale_max = c.vm_scale_max; tail_pipe_max = c.tail_pipe_max; ml_fq_min = c.ml_fq_min; fq_min_g1 = c.fq_min_g1;
         }
@@ -292,6 +295,8 @@ struct Engine {
         env_sz("RIPP_VM_LINES_MAX", vm_lines_max); env_sz("RIPP_VM_FOLD_MAX", vm_fold_max); env_sz("RIPP_VM_TREE_MAX", vm_tree_max);
         env_sz("RIPP_GLS_SPLIT_MAX", gls_split_max); env_sz("RIPP_MSM_VM_MERGE_MAX", msm_vm_merge_max); env_sz("RIPP_FOLD_TAB_MIN", fold_tab_min);
         env_sz("RIPP_FQ_MIN", fq_min); env_sz("RIPP_LP_FQ_MIN", lp_fq_min); env_sz("RIPP_VM_JOINT_MAX", vm_joint_max);
+        msm_lds_sort_min = (size_t)1 << 19; env_sz("RIPP_MSM_LDS_SORT_MIN", msm_lds_sort_min);
+        msm_chunk_min = (size_t)1 << 20; env_sz("RIPP_MSM_CHUNK_MIN", msm_chunk_min);
         env_sz("RIPP_VM_SCALE_MAX", vm_scale_max); env_sz("RIPP_TAIL_PIPE_MAX", tail_pipe_max); env_sz("RIPP_ML_FQ_MIN", ml_fq_min); env_sz("RIPP_FQ_MIN_G1", fq_min_g1);
         auto env_on = [](const char* k, bool& v) { if (std::getenv(k)) v = true; };
         env_on("RIPP_NO_VM", sw.no_vm); env_on("RIPP_NO_PRECOMPUTE", sw.no_precompute); env_on("RIPP_NO_FOLD_TABLES", sw.no_fold_tables); env_on("RIPP_NO_MSM_GLV", sw.no_msm_glv);
@@ -300,6 +305,7 @@ struct Engine {
         env_on("RIPP_NO_XSCALE", sw.no_xscale);        // G2 folds always on the plain vector with the full-width x^-1
         env_on("RIPP_NO_FQ", sw.no_fq);                // the 12 x 32-bit forms of the kernels that have a carry-free twin (fq_curve.hpp)
         env_on("RIPP_FUSE_TABLES", sw.fuse_tables);    // build the three-quarter tables whatever the look-ahead plan (tests: round 0 then folds ALONE over them when x1 is late)
+        env_on("RIPP_NO_PREBUILD", sw.no_prebuild);    // in-round G2 fold tables after the challenge (fold_g2_table), not in the host phase before it (job_prebuild_g2_tables)
         env_on("RIPP_NO_FUSE", sw.no_fuse);            // rounds 0 and 1 always fold one after the other (no three-quarter tables, no job_fold_fused)
         env_on("RIPP_NO_SHARE", sw.no_share);          // every pairing product walks its own G2 chain (no ChainSets grouping, no merged round 0 + look-ahead)
         env_on("RIPP_SCALE_NO_FQ", scale_no_fq); env_on("RIPP_AGG_SEQUENTIAL", agg_sequential); env_on("RIPP_LOOK_STATIC", look_static); env_on("RIPP_QUIET_WAITS", quiet_waits_cfg);
@@ -444,9 +450,13 @@ struct Engine {
             (rc = ms.seg2.reserve((size_t)p.nwin * ((nseg + MSM_SEG_FAN - 1) / MSM_SEG_FAN) * sizeof(Jac<F>))) ||
             (rc = ms.win.reserve(64 * sizeof(Jac<F>))) || (rc = ms.out.reserve(sizeof(Jac<F>)))) return rc;
         HIPCHK(hipMemsetAsync(ms.hist.p, 0, nwb * 4, st));
-        hipLaunchKernelGGL(k_msm_digits, dim3(nblk(nreal, 256)), dim3(256), 0, st, scalars, p, ms.digits.as<uint16_t>(), ms.hist.as<uint32_t>());
+        const bool lds_sort = n >= msm_lds_sort_min;                   // large sorts count and rank through LDS (msm.hpp)
+        const uint32_t tile = msm_sort_tile(p);
+        hipLaunchKernelGGL(k_msm_digits, dim3(nblk(nreal, 256)), dim3(256), 0, st, scalars, p, ms.digits.as<uint16_t>(), lds_sort ? nullptr : ms.hist.as<uint32_t>());
+        if (lds_sort) hipLaunchKernelGGL(k_msm_hist_lds, dim3(nblk(n, tile), p.nwin), dim3(MSM_SORT_BLOCK), 0, st, ms.digits.as<uint16_t>(), p, tile, ms.hist.as<uint32_t>());
         hipLaunchKernelGGL(k_msm_scan, dim3(p.nwin), dim3(1024), 0, st, ms.hist.as<uint32_t>(), p, ms.offs.as<uint32_t>(), ms.cursor.as<uint32_t>(), ms.slotoffs.as<uint32_t>(), ms.spw.as<uint32_t>());
-        hipLaunchKernelGGL(k_msm_scatter, dim3(nblk(n, 256)), dim3(256), 0, st, ms.digits.as<uint16_t>(), p, ms.cursor.as<uint32_t>(), ms.sorted.as<uint32_t>());
+        if (lds_sort) hipLaunchKernelGGL(k_msm_scatter_lds, dim3(nblk(n, tile), p.nwin), dim3(MSM_SORT_BLOCK), 0, st, ms.digits.as<uint16_t>(), p, tile, ms.cursor.as<uint32_t>(), ms.sorted.as<uint32_t>());
+        else hipLaunchKernelGGL(k_msm_scatter, dim3(nblk(n, 256)), dim3(256), 0, st, ms.digits.as<uint16_t>(), p, ms.cursor.as<uint32_t>(), ms.sorted.as<uint32_t>());
         if (bases_arrive && (rc = (*bases_arrive)())) return rc;
         // RIPP_NO_VM keeps every stage on single lanes in Jacobian coordinates (the A/B and fallback form); otherwise the stages after
         // the gather work on homogeneous coordinates and the ones with few points run on the field VM (msm.hpp)
@@ -1058,12 +1068,15 @@ int32_t job_precompute_round0(Engine* e, ripp_sipp_job* j, bool fuse = false) {
 // G2 fold of a throughput-bound round over in-round tables: odd multiples {1,3,5,7} of every hi element (batch-normalised: the inversion
 // is shared by 16 points) and their psi images, then width-4 wNAF strings -- 65 doublings + ~52 additions instead of 65 + ~87 for
 // ~350 Fp products of table work per element.  Leaves the Jacobian result in jac (first `half` entries).
-int32_t fold_g2_table(Engine* e, hipStream_t st, const G2A* hi, const G2A* lo, size_t half, const Fr& s, DevBuf& jac) {
+// The table half of it depends on the vector only, not on the challenge: fold_g2_table_build may be enqueued before the challenge exists (job_prebuild_g2_tables:
+// the device is idle while the host computes the round's final exponentiations), fold_g2_table then finds e->g2tab_hi / g2tab_half set and goes straight to the fold.
+int32_t fold_g2_table_build(Engine* e, hipStream_t st, const G2A* hi, size_t half) {
     constexpr int M = 4;
     const size_t qstride = (half + 63) & ~(size_t)63;
     int32_t rc;
+    e->g2tab_hi = nullptr;
     if ((rc = e->fold_mult.reserve((size_t)M * half * sizeof(G2A))) || (rc = e->fold_tab.reserve((size_t)4 * M * G2A_CHUNKS * qstride * sizeof(uint4))) ||
-        (rc = e->fold_jac2.reserve((size_t)(M - 1) * half * sizeof(G2J))) || (rc = jac.reserve(half * sizeof(G2J))) || (rc = e->fix_flags.reserve(4 * half + 16))) return rc;
+        (rc = e->fold_jac2.reserve((size_t)(M - 1) * half * sizeof(G2J))) || (rc = e->fix_flags.reserve(4 * half + 16))) return rc;
     e->tab_owner = nullptr;                                     // whatever round-0 tables were there are overwritten
     G2A* mult = e->fold_mult.as<G2A>();
     HIPCHK(hipMemcpyAsync(mult, hi, half * sizeof(G2A), hipMemcpyDeviceToDevice, st));
@@ -1077,6 +1090,18 @@ int32_t fold_g2_table(Engine* e, hipStream_t st, const G2A* hi, const G2A* lo, s
     HIPCHK(hipGetLastError());
     if ((rc = e->normalize_dev<Fp2>(e->fold_jac2.as<G2J>(), (size_t)(M - 1) * half, mult + half, st)) != RIPP_OK) return rc;
     hipLaunchKernelGGL(k_g2_tab_images, dim3(nblk(half, 64), M), dim3(64), 0, st, mult, (uint32_t)half, M, e->fold_tab.as<uint4>(), qstride);
+    HIPCHK(hipGetLastError());
+    e->g2tab_hi = hi; e->g2tab_half = half;
+    return RIPP_OK;
+}
+int32_t fold_g2_table(Engine* e, hipStream_t st, const G2A* hi, const G2A* lo, size_t half, const Fr& s, DevBuf& jac) {
+    constexpr int M = 4;
+    const size_t qstride = (half + 63) & ~(size_t)63;
+    int32_t rc;
+    const bool built = e->g2tab_hi == hi && e->g2tab_half == half && e->tab_owner == nullptr;      // (built on this stream: ordered before the fold)
+    if (!built && (rc = fold_g2_table_build(e, st, hi, half))) return rc;
+    e->g2tab_hi = nullptr;
+    if ((rc = jac.reserve(half * sizeof(G2J))) || (rc = e->fix_flags.reserve(4 * half + 16))) return rc;
     if (!e->sw.no_fq && half >= e->fq_min)
     {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab_q<GlsDigits, 4>), dim3(nblk(half, 64)), dim3(64), 0, st, e->fold_tab.as<uint4>(), qstride, M, lo, (uint32_t)half, gls_wnaf(s, 4), jac.as<G2J>(), e->fix_flags.as<uint8_t>());
@@ -1088,6 +1113,21 @@ int32_t fold_g2_table(Engine* e, hipStream_t st, const G2A* hi, const G2A* lo, s
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_g2_tab<GlsDigits, 4>), dim3(nblk(half, 64)), dim3(64), 0, st, e->fold_tab.as<uint4>(), qstride, M, lo, (uint32_t)half, gls_wnaf(s, 4), jac.as<G2J>());
     HIPCHK(hipGetLastError());
     return RIPP_OK;
+}
+
+// Rounds whose G2 fold takes the in-round table form (fold_g2_table: 2^15 <= half, no round-0 tables): the tables depend on the vector only, so they are
+// enqueued as soon as the round's pairing products have left the device -- the ~0.9 ms in which the host computes the two final exponentiations and the
+// challenge would otherwise be idle device time on the proof's critical path.  Mirrors job_fold's choice of form; a wrong guess costs the table work only.
+int32_t job_prebuild_g2_tables(Engine* e, ripp_sipp_job* j) {
+    const size_t half = j->len / 2;
+    e->g2tab_hi = nullptr;
+    if (e->sw.no_prebuild || e->sw.no_endo || half < 1) return RIPP_OK;
+    const bool vm_form = (half <= e->vm_fold_max || half <= e->vm_joint_max) && !e->sw.no_vm;
+    if (vm_form || j->pre_ready || j->pre_vm_ready || (j->tab_ready && e->tab_owner == j) || !fold_g2_table_pays(e, half)) return RIPP_OK;
+    const bool xs = xscale_round(e, j, half);               // (challenges of SIPP are 128-bit: fits_128 holds)
+    if (j->bs_on && !xs) return RIPP_OK;                    // the un-scaling fold takes no tables
+    const G2A* b = j->b.as<G2A>();
+    return fold_g2_table_build(e, e->stream, xs ? b : b + half, half);
 }
 
 int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true, bool async = false) {
@@ -1106,30 +1146,31 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true,
     if ((rc = e->vm_flag.reserve(sizeof(uint32_t))) != RIPP_OK) return rc;      // (kernel argument of the VM folds; they use the complete addition law and report nothing)
     const bool pre = j->pre_ready && fits_128(x); j->pre_ready = false;      // second bases prepared in the hash window (job_precompute_round0)
     const bool pre_vm = j->pre_vm_ready && fits_128(x) && allow_vm; j->pre_vm_ready = false;   // ... or on the VM during this round's host phase
+    const hipStream_t g1s = e->stream2;
     HIPCHK(hipEventRecord(e->ev_fork, e->stream));
     HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
     const bool tab = j->tab_ready && e->tab_owner == j && fits_128(x); j->tab_ready = false;        // ... with the odd-multiple tables of four bases
     const int tabW = tab_width(j->tab_M);
     const G1A* tab1 = e->fold_tab1.as<G1A>() + (j->tab_fused ? half / 2 : 0);      // three-quarter tables start at A1: a_r is q elements in
     if (tab && !e->sw.no_fq && half >= e->fq_min)
-        hipLaunchKernelGGL(k_fold_g1_tab_q, dim3(nblk(half, 256)), dim3(256), 0, e->stream2, tab1, j->tab_cnt, j->tab_M, a, (uint32_t)half, split32_wnaf(x, tabW), j->jac1.as<G1J>());
+        hipLaunchKernelGGL(k_fold_g1_tab_q, dim3(nblk(half, 256)), dim3(256), 0, g1s, tab1, j->tab_cnt, j->tab_M, a, (uint32_t)half, split32_wnaf(x, tabW), j->jac1.as<G1J>());
     else if (tab)
-        hipLaunchKernelGGL(k_fold_g1_tab, dim3(nblk(half, 256)), dim3(256), 0, e->stream2, tab1, j->tab_cnt, j->tab_M, a, (uint32_t)half, split32_wnaf(x, tabW), j->jac1.as<G1J>());
+        hipLaunchKernelGGL(k_fold_g1_tab, dim3(nblk(half, 256)), dim3(256), 0, g1s, tab1, j->tab_cnt, j->tab_M, a, (uint32_t)half, split32_wnaf(x, tabW), j->jac1.as<G1J>());
     else if (pre)
-        hipLaunchKernelGGL(k_fold_g1_two, dim3(nblk(half, 256)), dim3(256), 0, e->stream2, a + half, j->a_pow.as<G1A>(), a, (uint32_t)half, split64_digits(x), j->jac1.as<G1J>());
+        hipLaunchKernelGGL(k_fold_g1_two, dim3(nblk(half, 256)), dim3(256), 0, g1s, a + half, j->a_pow.as<G1A>(), a, (uint32_t)half, split64_digits(x), j->jac1.as<G1J>());
     else if (pre_vm) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_fold_split2<Fp>), dim3(nblk(half, 4 * VM_EPW), 2), dim3(256), 4 * VM_EPW * VmCurve<Fp>::SLOTS * sizeof(VmSlot), e->stream2, a + half, j->a_pow_h.as<G1J>(), (uint32_t)half, split_digits_g1(x), 1, j->parts1.as<G1J>());
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_combine<Fp>), dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VmCurve<Fp>::SLOTS * sizeof(VmSlot), e->stream2, j->parts1.as<G1J>(), 2, a, (uint32_t)half, j->jac1.as<G1J>());
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_fold_split2<Fp>), dim3(nblk(half, 4 * VM_EPW), 2), dim3(256), 4 * VM_EPW * VmCurve<Fp>::SLOTS * sizeof(VmSlot), g1s, a + half, j->a_pow_h.as<G1J>(), (uint32_t)half, split_digits_g1(x), 1, j->parts1.as<G1J>());
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vm_combine<Fp>), dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VmCurve<Fp>::SLOTS * sizeof(VmSlot), g1s, j->parts1.as<G1J>(), 2, a, (uint32_t)half, j->jac1.as<G1J>());
     }
     else if (use_vm || mid_vm)
-        hipLaunchKernelGGL(k_vm_fold_g1, dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VM_G1_SLOTS * sizeof(VmSlot), e->stream2, a + half, a, (uint32_t)half, naf_digits(x), j->jac1.as<G1J>(), e->vm_flag.as<uint32_t>());
+        hipLaunchKernelGGL(k_vm_fold_g1, dim3(nblk(half, 4 * VM_EPW)), dim3(256), 4 * VM_EPW * VM_G1_SLOTS * sizeof(VmSlot), g1s, a + half, a, (uint32_t)half, naf_digits(x), j->jac1.as<G1J>(), e->vm_flag.as<uint32_t>());
     else if (!e->sw.no_fq && half >= e->fq_min_g1)
-        hipLaunchKernelGGL(k_fold_g1_naf_q, dim3(nblk(half, 256)), dim3(256), 0, e->stream2, a + half, a, (uint32_t)half, naf_digits(x), j->jac1.as<G1J>());
+        hipLaunchKernelGGL(k_fold_g1_naf_q, dim3(nblk(half, 256)), dim3(256), 0, g1s, a + half, a, (uint32_t)half, naf_digits(x), j->jac1.as<G1J>());
     else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_affine_naf<Fp>), dim3(nblk(half, 256)), dim3(256), 0, e->stream2, a + half, a, (uint32_t)half, naf_digits(x), j->jac1.as<G1J>());
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_affine_naf<Fp>), dim3(nblk(half, 256)), dim3(256), 0, g1s, a + half, a, (uint32_t)half, naf_digits(x), j->jac1.as<G1J>());
     HIPCHK(hipGetLastError());
-    if ((rc = e->normalize_dev<Fp>(j->jac1.as<G1J>(), half, j->a_next.as<G1A>(), e->stream2)) != RIPP_OK) return rc;
-    HIPCHK(hipEventRecord(e->ev_join, e->stream2));
+    if ((rc = e->normalize_dev<Fp>(j->jac1.as<G1J>(), half, j->a_next.as<G1A>(), g1s)) != RIPP_OK) return rc;
+    HIPCHK(hipEventRecord(e->ev_join, g1s));
     // ---- G2 side.  xs: this round folds the x-scaled vector, bt' = x bt_l + bt_r (x multiplies the LOW half, the high half is the addend);
     //      unscale: the vector is scaled by bs but this round is too small for the table fold: b' = (1/bs) bt_l + (1/(bs x)) bt_r in one pass
     const bool xs = xscale_round(e, j, half) && fits_128(x) && (!tab || j->tab_on_lo);
@@ -1240,12 +1281,13 @@ int32_t job_fold_fused(Engine* e, ripp_sipp_job* j, const Fr& x0, const Fr& x1, 
     HIPCHK(hipEventRecord(e->ev_fork, e->stream));
     HIPCHK(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
     // G1 on stream2
+    const hipStream_t g1s = e->stream2;
     const WnafG1x4 d1 = fused_digits_g1(x0, x1, W);
-    hipLaunchKernelGGL(k_fold_g1_fused_q, dim3(nblk(q, 256)), dim3(256), 0, e->stream2, e->fold_tab1.as<G1A>(), j->tab_cnt, j->tab_M, a, (uint32_t)q, d1, j->jac1.as<G1J>(), flag1);
-    hipLaunchKernelGGL(k_fold_g1_fused_fix, dim3(FIX_GRID), dim3(64), 0, e->stream2, e->fold_tab1.as<G1A>(), j->tab_cnt, j->tab_M, a, (uint32_t)q, d1, j->jac1.as<G1J>(), flag1);
+    hipLaunchKernelGGL(k_fold_g1_fused_q, dim3(nblk(q, 256)), dim3(256), 0, g1s, e->fold_tab1.as<G1A>(), j->tab_cnt, j->tab_M, a, (uint32_t)q, d1, j->jac1.as<G1J>(), flag1);
+    hipLaunchKernelGGL(k_fold_g1_fused_fix, dim3(FIX_GRID), dim3(64), 0, g1s, e->fold_tab1.as<G1A>(), j->tab_cnt, j->tab_M, a, (uint32_t)q, d1, j->jac1.as<G1J>(), flag1);
     HIPCHK(hipGetLastError());
-    if ((rc = e->normalize_dev<Fp>(j->jac1.as<G1J>(), q, j->a_next.as<G1A>(), e->stream2)) != RIPP_OK) return rc;
-    HIPCHK(hipEventRecord(e->ev_join, e->stream2));
+    if ((rc = e->normalize_dev<Fp>(j->jac1.as<G1J>(), q, j->a_next.as<G1A>(), g1s)) != RIPP_OK) return rc;
+    HIPCHK(hipEventRecord(e->ev_join, g1s));
     // G2 on the main stream
     const Wnaf16x3 d2 = fused_digits_g2(x0, x1, W);
     hipLaunchKernelGGL(k_fold_g2_fused_q, dim3(nblk(q, 64)), dim3(64), 0, e->stream, e->fold_tab.as<uint4>(), j->tab2_stride, j->tab_M, b + 3 * q, (uint32_t)q, d2, j->jac2.as<G2J>(), flag2);
@@ -1317,7 +1359,7 @@ API int32_t ripp_release_scratch(void) {
     for (DevBuf* b : {&e->lines, &e->partA, &e->partB, &e->jacG1, &e->jacG2, &e->tmpA, &e->tmpB, &e->tmpR, &e->affG1, &e->affG2, &e->qtab, &e->scale_tab, &e->fold_tab1, &e->fold_mult, &e->fold_tab, &e->fold_jac1, &e->fold_jac2, &e->fix_flags, &e->scale_flags}) b->release();
     e->msm_scratch[0].release(); e->msm_scratch[1].release(); e->kzg_q[0].release(); e->kzg_q[1].release(); e->kzg_bases[0].release(); e->kzg_bases[1].release();
     for (PinBuf& pb : e->stage) pb.release();             // pinned host staging (up to 2 x 32 MB after a verifier call at n = 2^20)
-    e->tab_owner = nullptr;
+    e->tab_owner = nullptr; e->g2tab_hi = nullptr;
     if (e->aux) { e->aux->destroy(); delete e->aux; e->aux = nullptr; }
     return RIPP_OK;
 }
@@ -1493,7 +1535,31 @@ template <class F, bool JAC> static int32_t msm_impl(const void* bases, size_t n
             HIPCHK(hipStreamWaitEvent(e->stream, e->ev_join, 0));
             return RIPP_OK;
         };
-        if ((rc = e->msm_dev<F>(db, ds, nl, &res, &bases_arrive))) return rc;
+        if (nl >= 2 && nl * sizeof(Affine<F>) >= e->msm_chunk_min * sizeof(G1A)) {          // (measured: pays from 2^20 G1 / 2^19 G2 bases, i.e. from ~96 MB of them)
+            // Large host-slice MSMs in TWO halves on two streams (scratch sets 0 and 1, as the KZG openings use them): the second half of the bases crosses
+            // PCIe while the first half's gathered additions run (the bases are 96 / 192 MB at n = 2^20: ~2 / ~4 ms of a 9.5 / 22 ms call in which only the
+            // 0.35 ms digit sort was hidden), and the first half's latency-bound bucket stages run beside the second half's additions.  sum = MSM(lo) + MSM(hi).
+            const size_t h = nl / 2;
+            auto arrive = [&](size_t off, size_t cnt, hipStream_t st, hipEvent_t ev) -> int32_t {
+                if (JAC) {
+                    HIPCHK(hipMemcpyAsync(jac.as<Jac<F>>() + off, static_cast<const Jac<F>*>(bases) + off, cnt * sizeof(Jac<F>), hipMemcpyHostToDevice, e->stream2));
+                    int32_t r2 = e->normalize_dev<F>(jac.as<Jac<F>>() + off, cnt, db + off, e->stream2); if (r2) return r2;
+                } else HIPCHK(hipMemcpyAsync(db + off, static_cast<const Affine<F>*>(bases) + off, cnt * sizeof(Affine<F>), hipMemcpyHostToDevice, e->stream2));
+                HIPCHK(hipEventRecord(ev, e->stream2));
+                HIPCHK(hipStreamWaitEvent(st, ev, 0));
+                return RIPP_OK;
+            };
+            const std::function<int32_t()> arrive_lo = [&]() { return arrive(0, h, e->stream, e->ev_join); };
+            const std::function<int32_t()> arrive_hi = [&]() { return arrive(h, nl - h, e->stream3, e->ev_join3); };
+            HIPCHK(hipEventRecord(e->ev_fork, e->stream));                                  // the scalars are on the device
+            HIPCHK(hipStreamWaitEvent(e->stream3, e->ev_fork, 0));
+            if ((rc = e->msm_launch<F>(e->msm_scratch[0], e->stream, db, ds, h, &arrive_lo))) return rc;
+            if ((rc = e->msm_launch<F>(e->msm_scratch[1], e->stream3, db + h, ds + h, nl - h, &arrive_hi))) return rc;
+            if ((rc = e->sync())) return rc;
+            HIPCHK(hipStreamSynchronize(e->stream3)); HIPCHK(hipStreamSynchronize(e->stream2));
+            res = add(*reinterpret_cast<const Jac<F>*>(e->msm_scratch[0].host_out), *reinterpret_cast<const Jac<F>*>(e->msm_scratch[1].host_out));
+        }
+        else if ((rc = e->msm_dev<F>(db, ds, nl, &res, &bases_arrive))) return rc;
     }
     std::memcpy(out, &res, sizeof(Jac<F>));
     return RIPP_OK;
@@ -1996,6 +2062,7 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
     struct Quiesce { Engine* e; ripp_sipp_job* j; ~Quiesce() {
         (void)hipStreamSynchronize(e->stream); (void)hipStreamSynchronize(e->stream2); (void)hipStreamSynchronize(e->stream3);
         j->tp_round[0] = j->tp_round[1] = ~(size_t)0; j->pre_vm_ready = false; j->pre_vm_side = false; j->pre_ready = false; j->tab_ready = false; j->look.clear();
+        e->g2tab_hi = nullptr;
         if (j->hash_thread.joinable()) j->hash_thread.join();
         j->ha_ext = nullptr; j->hb_ext = nullptr; j->hr_ext = nullptr; j->hash_prestarted = false; } } quiesce{e, j};
     // rank 0 (the only rank of a single-GPU proof) hashes the statement on a host thread: THE serial floor, started before anything else
@@ -2104,6 +2171,8 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
                 if ((rc = e->step_products(as, bs, 1, half - start[sd], rows + sd * N_LINES))) return rc;
                 e->stats.miller_products_ms += now_ms() - tp;
             }
+            // asynchronous, during the host work below: the challenge-independent half of this round's G2 table fold (rounds of 2^16 and more elements)
+            if (round >= 1 && !fuse_pending && !tp_round && (rc = job_prebuild_g2_tables(e, j))) return rc;
             // asynchronous: overlaps the host work below and the hash.  Both items of round 1 planned in full: tables over three quarters for the fused fold
             if (round == 0 && !j->seeded && (rc = job_precompute_round0(e, j, (look_items >= 16 || e->sw.fuse_tables) && j->len >= 4))) return rc;
             if (!j->pre_vm_ready && (rc = job_precompute_vm(e, j))) return rc;                   // small rounds: the same on the VM, during the host phase
@@ -2202,7 +2271,7 @@ static void config_from_engine(const Engine* e, ripp_config* c) {
     std::memset(c, 0, sizeof *c); c->struct_size = (uint32_t)sizeof *c;
     c->no_vm = e->sw.no_vm; c->no_precompute = e->sw.no_precompute; c->no_fold_tables = e->sw.no_fold_tables; c->no_msm_glv = e->sw.no_msm_glv; c->lp_one_lane = e->sw.lp_one_lane;
     c->no_endo = e->sw.no_endo; c->no_fq = e->sw.no_fq; c->no_xscale = e->sw.no_xscale; c->no_share = e->sw.no_share; c->no_fuse = e->sw.no_fuse; c->fuse_tables = e->sw.fuse_tables; c->scale_no_fq = e->scale_no_fq; c->agg_sequential = e->agg_sequential; c->look_static = e->look_static; c->quiet_waits = e->quiet_waits_cfg;
-    c->look_eighths = e->look_eighths; c->ranks_per_device = (int32_t)e->ranks_per_device; c->msm_c = e->msm_tune.c; c->msm_ch = e->msm_tune.ch; c->msm_gmin = e->msm_tune.gmin;
+    c->look_eighths = e->look_eighths; c->ranks_per_device = (int32_t)e->ranks_per_device; c->msm_c = e->msm_tune.c; c->msm_ch = e->msm_tune.ch; c->msm_gmin = e->msm_tune.gmin; c->no_prebuild = e->sw.no_prebuild;
     c->vm_lines_max = e->vm_lines_max; c->vm_fold_max = e->vm_fold_max; c->vm_tree_max = e->vm_tree_max; c->gls_split_max = e->gls_split_max; c->msm_vm_merge_max = e->msm_vm_merge_max; c->fold_tab_min = e->fold_tab_min;
     c->fq_min = e->fq_min; c->lp_fq_min = e->lp_fq_min; c->vm_joint_max = e->vm_joint_max; c->vm_scale_max = e->vm_scale_max; c->tail_pipe_max = e->tail_pipe_max; c->ml_fq_min = e->ml_fq_min; c->fq_min_g1 = e->fq_min_g1;
 }

@@ -74,7 +74,7 @@ __device__ __forceinline__ void msm_emit_digits(const uint32_t* k, int nlimb, ui
         if (limb + 1 < nlimb) v |= (uint64_t)k[limb + 1] << 32;
         const uint32_t d = (uint32_t)(v >> sh) & (p.nb - 1);
         digits[(size_t)w * p.n + i] = (uint16_t)d;
-        if (d) atomicAdd(&hist[(size_t)w * p.nb + d], 1u);
+        if (d && hist) atomicAdd(&hist[(size_t)w * p.nb + d], 1u);      // (hist == nullptr: the large-sort form counts through LDS, k_msm_hist_lds)
     }
 }
 
@@ -163,6 +163,42 @@ __global__ void __launch_bounds__(256) k_msm_scatter(const uint16_t* __restrict_
         const uint32_t d = digits[(size_t)w * p.n + i];
         if (d) { const uint32_t pos = atomicAdd(&cursor[(size_t)w * p.nb + d], 1u); sorted[(size_t)w * p.n + pos] = i; }
     }
+}
+
+// Large sorts (n >= 2^19 terms): histogram and scatter through LDS, one block per (tile of terms, window).  The lane-per-term forms above issue one
+// device-scope atomic and one lone 4-byte store per term and window -- 21 M of each at n = 2^20, and the counters show every one of them leaving
+// the chip as its own 32 / 64-byte HBM write (0.71 + 1.25 GB per MSM against 42 + 84 MB of digits and indices: profiles/r04_msm_2p20_hbm_traffic_pmc.csv).
+// Here a block counts its tile's digits in LDS (nb <= 8192 counters), adds each non-empty count to the window's histogram / reserves a run of that
+// length in the bucket with ONE global atomic, and ranks the tile's terms inside their runs with LDS atomics: ~5 consecutive indices per bucket and
+// tile, written by one workgroup within microseconds, leave the L2 as combined lines.  The order inside a bucket is as arbitrary as before (sums).
+constexpr uint32_t MSM_SORT_BLOCK = 1024;
+inline uint32_t msm_sort_tile(const MsmPlan& p) {           // ~480 blocks per launch: two 1024-lane blocks per CU, no second wave of blocks
+    const uint32_t tiles = p.nwin >= 480 ? 1u : 480u / (uint32_t)p.nwin;
+    const uint32_t t = (p.n + tiles - 1) / tiles;
+    return (t + MSM_SORT_BLOCK - 1) / MSM_SORT_BLOCK * MSM_SORT_BLOCK;
+}
+__global__ void __launch_bounds__(1024) k_msm_hist_lds(const uint16_t* __restrict__ digits, MsmPlan p, uint32_t tile, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t cnt[8192];
+    const uint32_t w = blockIdx.y, lo = blockIdx.x * tile, hi = min(lo + tile, p.n);
+    for (uint32_t d = threadIdx.x; d < p.nb; d += blockDim.x) cnt[d] = 0;
+    __syncthreads();
+    const uint16_t* dg = digits + (size_t)w * p.n;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) { const uint32_t d = dg[i]; if (d) atomicAdd(&cnt[d], 1u); }
+    __syncthreads();
+    for (uint32_t d = threadIdx.x; d < p.nb; d += blockDim.x) { const uint32_t c = cnt[d]; if (c) atomicAdd(&hist[(size_t)w * p.nb + d], c); }
+}
+__global__ void __launch_bounds__(1024) k_msm_scatter_lds(const uint16_t* __restrict__ digits, MsmPlan p, uint32_t tile, uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
+    __shared__ uint32_t cnt[8192];                              // the tile's count per bucket, then the next free position of the tile's run in it
+    const uint32_t w = blockIdx.y, lo = blockIdx.x * tile, hi = min(lo + tile, p.n);
+    for (uint32_t d = threadIdx.x; d < p.nb; d += blockDim.x) cnt[d] = 0;
+    __syncthreads();
+    const uint16_t* dg = digits + (size_t)w * p.n;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) { const uint32_t d = dg[i]; if (d) atomicAdd(&cnt[d], 1u); }
+    __syncthreads();
+    for (uint32_t d = threadIdx.x; d < p.nb; d += blockDim.x) { const uint32_t c = cnt[d]; if (c) cnt[d] = atomicAdd(&cursor[(size_t)w * p.nb + d], c); }
+    __syncthreads();
+    uint32_t* out = sorted + (size_t)w * p.n;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) { const uint32_t d = dg[i]; if (d) out[atomicAdd(&cnt[d], 1u)] = i; }
 }
 
 // ---- homogeneous projective coordinates (x = X/Z, y = Y/Z; identity (0 : 1 : 0)) ---------------------------------------------------

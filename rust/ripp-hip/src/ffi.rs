@@ -36,7 +36,7 @@ pub struct RippConfig {
     pub struct_size: u32,
     pub no_vm: u32, pub no_precompute: u32, pub no_fold_tables: u32, pub no_msm_glv: u32, pub lp_one_lane: u32, pub no_endo: u32, pub no_fq: u32,
     pub no_xscale: u32, pub scale_no_fq: u32, pub agg_sequential: u32, pub look_static: u32, pub quiet_waits: u32, pub no_share: u32, pub no_fuse: u32, pub fuse_tables: u32,
-    pub look_eighths: i32, pub ranks_per_device: i32, pub msm_c: i32, pub msm_ch: u32, pub msm_gmin: u32,
+    pub look_eighths: i32, pub ranks_per_device: i32, pub msm_c: i32, pub msm_ch: u32, pub msm_gmin: u32, pub no_prebuild: u32,
     pub vm_lines_max: u64, pub vm_fold_max: u64, pub vm_tree_max: u64, pub gls_split_max: u64, pub msm_vm_merge_max: u64, pub fold_tab_min: u64,
     pub fq_min: u64, pub lp_fq_min: u64, pub vm_joint_max: u64, pub vm_scale_max: u64, pub tail_pipe_max: u64, pub ml_fq_min: u64, pub fq_min_g1: u64,
 }

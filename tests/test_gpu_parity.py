@@ -129,6 +129,30 @@ def test_msm_vs_oracle(engine, orc, n):
         assert np.array_equal(engine.normalize_batch_g2(engine.MultiexponentiationInnerProductG2.inner_product(orc.blind_g2(b2, 9), s)), orc.g2_to_affine(orc.msm_g2_a(b2, s)).reshape(1, 24))
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 33, 1000, (1 << 12) + 5, 1 << 16])
+def test_msm_large_forms_vs_oracle(engine, orc, n):
+    """The forms MSMs of >= 2^19 terms take, forced at sizes the oracle finishes in seconds: the digit sort through LDS tiles (msm.hpp k_msm_hist_lds /
+    k_msm_scatter_lds; RIPP_MSM_LDS_SORT_MIN) and the host-slice call in two halves on two streams, the second half's bases uploading beside the first
+    half's additions (engine.hip msm_impl; RIPP_MSM_CHUNK_MIN) -- affine and projective inputs, skewed scalars (every term in one bucket per window),
+    an identity among the bases and a zero scalar."""
+    import os
+    s = orc.gen_scalars(23, n); b1, b2 = orc.gen_g1(7, n), orc.gen_g2(8, n)
+    if n >= 33:
+        b1[5] = 0; b2[7] = 0; s[9] = 0
+    e1, e2 = orc.g1_to_affine(orc.msm_g1_a(b1, s)).reshape(1, 12), (orc.g2_to_affine(orc.msm_g2_a(b2, s)).reshape(1, 24) if n <= 1 << 12 else None)
+    same = np.repeat(orc.fr_array([0x1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF % orc.R]), n, axis=0)
+    es = orc.g1_to_affine(orc.msm_g1_a(b1, same)).reshape(1, 12)
+    for env in ({"RIPP_MSM_LDS_SORT_MIN": "1"}, {"RIPP_MSM_CHUNK_MIN": "1"}, {"RIPP_MSM_LDS_SORT_MIN": "1", "RIPP_MSM_CHUNK_MIN": "1"}):
+        os.environ.update(env)
+        try:
+            assert np.array_equal(engine.normalize_batch_g1(engine.MultiexponentiationInnerProductG1.inner_product(orc.blind_g1(b1, 9), s)), e1), env
+            assert np.array_equal(engine.normalize_batch_g1(engine.MultiexponentiationInnerProductG1.inner_product(orc.to_jac_g1(b1), same)), es), env
+            if e2 is not None:
+                assert np.array_equal(engine.normalize_batch_g2(engine.MultiexponentiationInnerProductG2.inner_product(orc.blind_g2(b2, 9), s)), e2), env
+        finally:
+            for k in env: del os.environ[k]
+
+
 @pytest.mark.parametrize("n", [0, 1, 255, 256, 257, 100003])
 def test_scalar_inner_product(engine, orc, n):
     """ScalarInnerProduct (inner_products/src/lib.rs:144-166) against Python integers; length mismatch raises as the other products do."""
@@ -304,6 +328,8 @@ def test_sipp_prove_2p17_vs_oracle_with_precomputed_round0(engine, orc):
                 {"RIPP_LOOK_EIGHTHS": "16"}, {"RIPP_LOOK_EIGHTHS": "16", "RIPP_NO_FUSE": "1"}, {"RIPP_LOOK_EIGHTHS": "16", "RIPP_NO_XSCALE": "1"}, {"RIPP_LOOK_EIGHTHS": "16", "RIPP_FQ_MIN": "4096"},
                 # RIPP_FUSE_TABLES: the three-quarter tables although x1 will NOT be known with x0 (no / half a value of round 1 from the look-ahead): round 0
                 # folds alone over them (element offset q on G1), round 1 with its in-round tables -- what a proof does when the hash beats the look-ahead
+                # RIPP_NO_PREBUILD: the in-round G2 tables of rounds >= 1 after the challenge instead of in the host phase before it (job_prebuild_g2_tables)
+                {"RIPP_NO_PREBUILD": "1"}, {"RIPP_NO_PREBUILD": "1", "RIPP_LOOK_EIGHTHS": "16", "RIPP_NO_FUSE": "1"}, {"RIPP_NO_PREBUILD": "1", "RIPP_NO_XSCALE": "1"},
                 {"RIPP_FUSE_TABLES": "1", "RIPP_LOOK_EIGHTHS": "12"}, {"RIPP_FUSE_TABLES": "1", "RIPP_LOOK_EIGHTHS": "8"}, {"RIPP_FUSE_TABLES": "1", "RIPP_LOOK_EIGHTHS": "8", "RIPP_NO_FQ": "1"}):
         os.environ.update(env)
         try:

@@ -1,7 +1,7 @@
 """Randomized stress of the hash-window machinery (python tools/stress_window.py <seed> <seconds> <min log n> <max log n>): proofs of random statements
 large enough for the round-0 tables (n >= 2^17), the shared G2 chains and the fused fold of rounds 0 and 1, with a RANDOM look-ahead plan
 (0 .. 48 eighths: whole and partial items, so x1 is sometimes known with x0 and sometimes late), random switches among the forms that must agree
-(RIPP_FUSE_TABLES, RIPP_NO_FUSE, RIPP_NO_SHARE, RIPP_NO_XSCALE, RIPP_NO_FOLD_TABLES) and identities / repeated points planted in every quarter -- each
+(RIPP_FUSE_TABLES, RIPP_NO_FUSE, RIPP_NO_SHARE, RIPP_NO_XSCALE, RIPP_NO_FOLD_TABLES, RIPP_NO_PREBUILD) and identities / repeated points planted in every quarter -- each
 proof against the CPU oracle's, one process, one resident job per statement proved twice (nothing prepared for one proof may leak into the next)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,7 +14,7 @@ seconds = float(sys.argv[2]) if len(sys.argv) > 2 else 120
 lo = int(sys.argv[3]) if len(sys.argv) > 3 else 17
 hi = int(sys.argv[4]) if len(sys.argv) > 4 else 18
 rng = np.random.default_rng(seed)
-SW = ["RIPP_FUSE_TABLES", "RIPP_NO_FUSE", "RIPP_NO_SHARE", "RIPP_NO_XSCALE", "RIPP_NO_FOLD_TABLES"]
+SW = ["RIPP_FUSE_TABLES", "RIPP_NO_FUSE", "RIPP_NO_SHARE", "RIPP_NO_XSCALE", "RIPP_NO_FOLD_TABLES", "RIPP_NO_PREBUILD"]
 bad = cnt = 0; t0 = time.time()
 while time.time() - t0 < seconds:
     n = 1 << int(rng.integers(lo, hi + 1)); q = n // 4
