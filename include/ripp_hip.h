@@ -58,7 +58,7 @@ typedef struct {
 /* ABI guard.  The library WRITES sizeof(ripp_stats) bytes through every `ripp_stats*` it is given, and the struct has grown twice: a caller
  * compiled against an older header would be overrun.  Bindings must check at load time that RIPP_ABI_VERSION == ripp_abi_version() and
  * sizeof(their ripp_stats) == ripp_stats_size() (ripp_amd/_lib.py and rust/ripp-hip do). */
-#define RIPP_ABI_VERSION 4
+#define RIPP_ABI_VERSION 5
 int32_t ripp_abi_version(void);
 size_t  ripp_stats_size(void);
 
@@ -88,7 +88,9 @@ typedef struct {
     uint32_t no_prebuild;            /* (selector, in what was padding) in-round G2 fold tables only after the challenge, not in the host phase before it */
     /* crossover launch sizes between the latency and the throughput forms */
     uint64_t vm_lines_max, vm_fold_max, vm_tree_max, gls_split_max, msm_vm_merge_max, fold_tab_min, fq_min, lp_fq_min, vm_joint_max, vm_scale_max,
-             tail_pipe_max, ml_fq_min, fq_min_g1;
+             tail_pipe_max, ml_fq_min, fq_min_g1,
+             msm_lds_sort_min,       /* MSMs below this many terms use the lane-per-term digit sort instead of the LDS-tile sort (default 0: never) */
+             msm_chunk_min;          /* host-slice MSMs from this many G1 bases (half as many G2 bases) run as two halves on two streams (default 2^20) */
 } ripp_config;
 int32_t ripp_config_default(ripp_config* cfg);      /* the built-in defaults of this build; needs no device */
 int32_t ripp_configure(const ripp_config* cfg);     /* NULL: back to the defaults */

@@ -231,7 +231,7 @@ struct Engine {
     DevBuf fix_flags, scale_flags;        // one byte per lane of a carry-free G2 fold / table / scaling kernel: lanes with an exceptional addition, redone by the *_fix kernel behind it
     const void* tab_owner = nullptr;
     size_t msm_chunk_min = (size_t)1 << 20;                               // host-slice MSMs of >= this many G1 bases (half as many G2 bases: the same bytes) run as two halves on two streams (msm_impl: the second half's upload beside the first half's additions)
-    size_t msm_lds_sort_min = (size_t)1 << 19;                            // MSMs of >= this many terms (after the GLV / GLS split) sort through LDS tiles (msm.hpp k_msm_hist_lds / k_msm_scatter_lds)
+    size_t msm_lds_sort_min = 0;                                          // MSMs of >= this many terms (after the GLV / GLS split) sort through LDS tiles (msm.hpp k_msm_hist_lds / k_msm_scatter_lds); the lane-per-term sort below it (A/B)
     const void* g2tab_hi = nullptr; size_t g2tab_half = 0;               // in-round G2 fold tables built ahead of the challenge (fold_g2_table_build): the vector half they were built over
     size_t vm_scale_max = (size_t)1 << 14;                                // per-element G1 scalings of <= this many elements run on the VM (measured: direct product 6.1 -> 3.8 ms at 2^13, 7.1 -> 6.2 ms at 2^14, level at 2^15)
     size_t vm_joint_max = (size_t)1 << 13;                                // folds with <= this many outputs (and more than vm_fold_max) use the joint one-group-per-element VM forms
@@ -268,7 +268,7 @@ struct Engine {
     struct Switches { bool no_vm = false, no_precompute = false, no_fold_tables = false, no_msm_glv = false, lp_one_lane = false, no_endo = false, no_fq = false, no_xscale = false, no_share = false, no_fuse = false, no_prebuild = false, fuse_tables = false; } sw;
     // crossover sizes: the member initialisers above are the defaults, the environment overrides them PER CALL (a test or
     // an A/B run flips them on a live engine)
-    struct Sizes { size_t vm_lines_max, vm_fold_max, vm_tree_max, gls_split_max, msm_vm_merge_max, fold_tab_min, fq_min, lp_fq_min, vm_joint_max, vm_scale_max, tail_pipe_max, ml_fq_min, fq_min_g1; } defaults{};
+    struct Sizes { size_t vm_lines_max, vm_fold_max, vm_tree_max, gls_split_max, msm_vm_merge_max, fold_tab_min, fq_min, lp_fq_min, vm_joint_max, vm_scale_max, tail_pipe_max, ml_fq_min, fq_min_g1, msm_lds_sort_min, msm_chunk_min; } defaults{};
     MsmTune msm_tune;
     // the hash-window look-ahead plan and a few whole-call choices (ripp_config: look_eighths, ranks_per_device, look_static, quiet_waits, agg_sequential, scale_no_fq)
     double cal_ms_per_pair = 0, cal_hash_bytes_per_ms = 0;        // look_plan's rates as measured by the last large proof of this process (0: not yet)
@@ -279,7 +279,7 @@ struct Engine {
         msm_tune = MsmTune();
         vm_lines_max = defaults.vm_lines_max; vm_fold_max = defaults.vm_fold_max; vm_tree_max = defaults.vm_tree_max; gls_split_max = defaults.gls_split_max;
         msm_vm_merge_max = defaults.msm_vm_merge_max; fold_tab_min = defaults.fold_tab_min; fq_min = defaults.fq_min; lp_fq_min = defaults.lp_fq_min; vm_joint_max = defaults.vm_joint_max;
-        vm_scale_max = defaults.vm_scale_max; tail_pipe_max = defaults.tail_pipe_max; ml_fq_min = defaults.ml_fq_min; fq_min_g1 = defaults.fq_min_g1;
+        vm_scale_max = defaults.vm_scale_max; tail_pipe_max = defaults.tail_pipe_max; ml_fq_min = defaults.ml_fq_min; fq_min_g1 = defaults.fq_min_g1; msm_lds_sort_min = defaults.msm_lds_sort_min; msm_chunk_min = defaults.msm_chunk_min;
         sw = Switches(); look_eighths = -1; ranks_per_device = 1.0; look_static = quiet_waits_cfg = agg_sequential = scale_no_fq = false;
         if (g_cfg_set) {
             const ripp_config& c = g_cfg;
@@ -288,15 +288,14 @@ struct Engine {
             look_eighths = c.look_eighths; ranks_per_device = c.ranks_per_device > 1 ? (double)c.ranks_per_device : 1.0;
             msm_tune.c = c.msm_c; msm_tune.ch = c.msm_ch; msm_tune.gmin = c.msm_gmin; sw.no_prebuild = c.no_prebuild;
             vm_lines_max = c.vm_lines_max; vm_fold_max = c.vm_fold_max; vm_tree_max = c.vm_tree_max; gls_split_max = c.gls_split_max; msm_vm_merge_max = c.msm_vm_merge_max; fold_tab_min = c.fold_tab_min;
-            fq_min = c.fq_min; lp_fq_min = c.lp_fq_min; vm_joint_max = c.vm_joint_max; vm_scale_max = c.vm_scale_max; tail_pipe_max = c.tail_pipe_max; ml_fq_min = c.ml_fq_min; fq_min_g1 = c.fq_min_g1;
+            fq_min = c.fq_min; lp_fq_min = c.lp_fq_min; vm_joint_max = c.vm_joint_max; vm_scale_max = c.vm_scale_max; tail_pipe_max = c.tail_pipe_max; ml_fq_min = c.ml_fq_min; fq_min_g1 = c.fq_min_g1; msm_lds_sort_min = c.msm_lds_sort_min; msm_chunk_min = c.msm_chunk_min;
         }
         { const char* s; if ((s = std::getenv("RIPP_MSM_C"))) msm_tune.c = std::atoi(s); if ((s = std::getenv("RIPP_MSM_CH"))) msm_tune.ch = (uint32_t)std::strtoul(s, nullptr, 10); if ((s = std::getenv("RIPP_MSM_GMIN"))) msm_tune.gmin = (uint32_t)std::strtoul(s, nullptr, 10); }
         auto env_sz = [](const char* k, size_t& v) { if (const char* s = std::getenv(k)) v = (size_t)std::strtoull(s, nullptr, 10); };
         env_sz("RIPP_VM_LINES_MAX", vm_lines_max); env_sz("RIPP_VM_FOLD_MAX", vm_fold_max); env_sz("RIPP_VM_TREE_MAX", vm_tree_max);
         env_sz("RIPP_GLS_SPLIT_MAX", gls_split_max); env_sz("RIPP_MSM_VM_MERGE_MAX", msm_vm_merge_max); env_sz("RIPP_FOLD_TAB_MIN", fold_tab_min);
         env_sz("RIPP_FQ_MIN", fq_min); env_sz("RIPP_LP_FQ_MIN", lp_fq_min); env_sz("RIPP_VM_JOINT_MAX", vm_joint_max);
-        msm_lds_sort_min = (size_t)1 << 19; env_sz("RIPP_MSM_LDS_SORT_MIN", msm_lds_sort_min);
-        msm_chunk_min = (size_t)1 << 20; env_sz("RIPP_MSM_CHUNK_MIN", msm_chunk_min);
+        env_sz("RIPP_MSM_LDS_SORT_MIN", msm_lds_sort_min); env_sz("RIPP_MSM_CHUNK_MIN", msm_chunk_min);
         env_sz("RIPP_VM_SCALE_MAX", vm_scale_max); env_sz("RIPP_TAIL_PIPE_MAX", tail_pipe_max); env_sz("RIPP_ML_FQ_MIN", ml_fq_min); env_sz("RIPP_FQ_MIN_G1", fq_min_g1);
         auto env_on = [](const char* k, bool& v) { if (std::getenv(k)) v = true; };
         env_on("RIPP_NO_VM", sw.no_vm); env_on("RIPP_NO_PRECOMPUTE", sw.no_precompute); env_on("RIPP_NO_FOLD_TABLES", sw.no_fold_tables); env_on("RIPP_NO_MSM_GLV", sw.no_msm_glv);
@@ -331,7 +330,7 @@ struct Engine {
         HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_join3, hipEventDisableTiming));
         HIPCHK(hipEventCreate(&ev_t0)); HIPCHK(hipEventCreate(&ev_t1));
         { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n_simd = pr.multiProcessorCount * 4; }
-        defaults = Sizes{vm_lines_max, vm_fold_max, vm_tree_max, gls_split_max, msm_vm_merge_max, fold_tab_min, fq_min, lp_fq_min, vm_joint_max, vm_scale_max, tail_pipe_max, ml_fq_min, fq_min_g1};
+        defaults = Sizes{vm_lines_max, vm_fold_max, vm_tree_max, gls_split_max, msm_vm_merge_max, fold_tab_min, fq_min, lp_fq_min, vm_joint_max, vm_scale_max, tail_pipe_max, ml_fq_min, fq_min_g1, msm_lds_sort_min, msm_chunk_min};
         refresh_switches();
         device = dev;
         return RIPP_OK;
@@ -450,7 +449,7 @@ struct Engine {
             (rc = ms.seg2.reserve((size_t)p.nwin * ((nseg + MSM_SEG_FAN - 1) / MSM_SEG_FAN) * sizeof(Jac<F>))) ||
             (rc = ms.win.reserve(64 * sizeof(Jac<F>))) || (rc = ms.out.reserve(sizeof(Jac<F>)))) return rc;
         HIPCHK(hipMemsetAsync(ms.hist.p, 0, nwb * 4, st));
-        const bool lds_sort = n >= msm_lds_sort_min;                   // large sorts count and rank through LDS (msm.hpp)
+        const bool lds_sort = n >= msm_lds_sort_min && p.nb <= 8192;   // count and rank through LDS tiles (msm.hpp; measured no slower at any size, 2.3 ms faster at n = 2^20)
         const uint32_t tile = msm_sort_tile(p);
         hipLaunchKernelGGL(k_msm_digits, dim3(nblk(nreal, 256)), dim3(256), 0, st, scalars, p, ms.digits.as<uint16_t>(), lds_sort ? nullptr : ms.hist.as<uint32_t>());
         if (lds_sort) hipLaunchKernelGGL(k_msm_hist_lds, dim3(nblk(n, tile), p.nwin), dim3(MSM_SORT_BLOCK), 0, st, ms.digits.as<uint16_t>(), p, tile, ms.hist.as<uint32_t>());
@@ -2273,11 +2272,11 @@ static void config_from_engine(const Engine* e, ripp_config* c) {
     c->no_endo = e->sw.no_endo; c->no_fq = e->sw.no_fq; c->no_xscale = e->sw.no_xscale; c->no_share = e->sw.no_share; c->no_fuse = e->sw.no_fuse; c->fuse_tables = e->sw.fuse_tables; c->scale_no_fq = e->scale_no_fq; c->agg_sequential = e->agg_sequential; c->look_static = e->look_static; c->quiet_waits = e->quiet_waits_cfg;
     c->look_eighths = e->look_eighths; c->ranks_per_device = (int32_t)e->ranks_per_device; c->msm_c = e->msm_tune.c; c->msm_ch = e->msm_tune.ch; c->msm_gmin = e->msm_tune.gmin; c->no_prebuild = e->sw.no_prebuild;
     c->vm_lines_max = e->vm_lines_max; c->vm_fold_max = e->vm_fold_max; c->vm_tree_max = e->vm_tree_max; c->gls_split_max = e->gls_split_max; c->msm_vm_merge_max = e->msm_vm_merge_max; c->fold_tab_min = e->fold_tab_min;
-    c->fq_min = e->fq_min; c->lp_fq_min = e->lp_fq_min; c->vm_joint_max = e->vm_joint_max; c->vm_scale_max = e->vm_scale_max; c->tail_pipe_max = e->tail_pipe_max; c->ml_fq_min = e->ml_fq_min; c->fq_min_g1 = e->fq_min_g1;
+    c->fq_min = e->fq_min; c->lp_fq_min = e->lp_fq_min; c->vm_joint_max = e->vm_joint_max; c->vm_scale_max = e->vm_scale_max; c->tail_pipe_max = e->tail_pipe_max; c->ml_fq_min = e->ml_fq_min; c->fq_min_g1 = e->fq_min_g1; c->msm_lds_sort_min = e->msm_lds_sort_min; c->msm_chunk_min = e->msm_chunk_min;
 }
 API int32_t ripp_config_default(ripp_config* cfg) {            // the built-in defaults of this build (needs no device: a throw-away Engine object is never initialised)
     if (!cfg) return RIPP_ERR_ARG;
-    Engine tmp; tmp.defaults = Engine::Sizes{tmp.vm_lines_max, tmp.vm_fold_max, tmp.vm_tree_max, tmp.gls_split_max, tmp.msm_vm_merge_max, tmp.fold_tab_min, tmp.fq_min, tmp.lp_fq_min, tmp.vm_joint_max, tmp.vm_scale_max, tmp.tail_pipe_max, tmp.ml_fq_min, tmp.fq_min_g1};
+    Engine tmp; tmp.defaults = Engine::Sizes{tmp.vm_lines_max, tmp.vm_fold_max, tmp.vm_tree_max, tmp.gls_split_max, tmp.msm_vm_merge_max, tmp.fold_tab_min, tmp.fq_min, tmp.lp_fq_min, tmp.vm_joint_max, tmp.vm_scale_max, tmp.tail_pipe_max, tmp.ml_fq_min, tmp.fq_min_g1, tmp.msm_lds_sort_min, tmp.msm_chunk_min};
     config_from_engine(&tmp, cfg); cfg->look_eighths = -1; cfg->ranks_per_device = 1;
     return RIPP_OK;
 }

@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(256) k_msm_scatter(const uint16_t* __restrict_
     }
 }
 
-// Large sorts (n >= 2^19 terms): histogram and scatter through LDS, one block per (tile of terms, window).  The lane-per-term forms above issue one
+// The default sort (RIPP_MSM_LDS_SORT_MIN selects the lane-per-term form above below a size, for A/B): histogram and scatter through LDS, one block per (tile of terms, window).  The lane-per-term forms above issue one
 // device-scope atomic and one lone 4-byte store per term and window -- 21 M of each at n = 2^20, and the counters show every one of them leaving
 // the chip as its own 32 / 64-byte HBM write (0.71 + 1.25 GB per MSM against 42 + 84 MB of digits and indices: profiles/r04_msm_2p20_hbm_traffic_pmc.csv).
 // Here a block counts its tile's digits in LDS (nb <= 8192 counters), adds each non-empty count to the window's histogram / reserves a run of that

@@ -38,11 +38,11 @@ pub struct RippConfig {
     pub no_xscale: u32, pub scale_no_fq: u32, pub agg_sequential: u32, pub look_static: u32, pub quiet_waits: u32, pub no_share: u32, pub no_fuse: u32, pub fuse_tables: u32,
     pub look_eighths: i32, pub ranks_per_device: i32, pub msm_c: i32, pub msm_ch: u32, pub msm_gmin: u32, pub no_prebuild: u32,
     pub vm_lines_max: u64, pub vm_fold_max: u64, pub vm_tree_max: u64, pub gls_split_max: u64, pub msm_vm_merge_max: u64, pub fold_tab_min: u64,
-    pub fq_min: u64, pub lp_fq_min: u64, pub vm_joint_max: u64, pub vm_scale_max: u64, pub tail_pipe_max: u64, pub ml_fq_min: u64, pub fq_min_g1: u64,
+    pub fq_min: u64, pub lp_fq_min: u64, pub vm_joint_max: u64, pub vm_scale_max: u64, pub tail_pipe_max: u64, pub ml_fq_min: u64, pub fq_min_g1: u64, pub msm_lds_sort_min: u64, pub msm_chunk_min: u64,
 }
 /// `RIPP_ABI_VERSION` of include/ripp_hip.h this binding was written against; `abi_check()` compares it (and the size of `RippStats`, which
 /// the library writes in full through every stats pointer) with the loaded library.
-pub const RIPP_ABI_VERSION: i32 = 4;
+pub const RIPP_ABI_VERSION: i32 = 5;
 #[cfg(feature = "ffi")]
 pub fn abi_check() -> bool { unsafe { ripp_abi_version() == RIPP_ABI_VERSION && ripp_stats_size() == core::mem::size_of::<RippStats>() } }
 

@@ -130,11 +130,12 @@ def test_msm_vs_oracle(engine, orc, n):
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 33, 1000, (1 << 12) + 5, 1 << 16])
-def test_msm_large_forms_vs_oracle(engine, orc, n):
-    """The forms MSMs of >= 2^19 terms take, forced at sizes the oracle finishes in seconds: the digit sort through LDS tiles (msm.hpp k_msm_hist_lds /
-    k_msm_scatter_lds; RIPP_MSM_LDS_SORT_MIN) and the host-slice call in two halves on two streams, the second half's bases uploading beside the first
-    half's additions (engine.hip msm_impl; RIPP_MSM_CHUNK_MIN) -- affine and projective inputs, skewed scalars (every term in one bucket per window),
-    an identity among the bases and a zero scalar."""
+def test_msm_sort_and_two_stream_forms_vs_oracle(engine, orc, n):
+    """Both digit sorts and the two-stream form of large host-slice MSMs at sizes the oracle finishes in seconds: the lane-per-term sort (k_msm_digits'
+    atomics + k_msm_scatter; RIPP_MSM_LDS_SORT_MIN above n -- the default is the sort through LDS tiles, msm.hpp k_msm_hist_lds / k_msm_scatter_lds, which
+    every other MSM test runs) and the call in two halves on two streams, the second half's bases uploading beside the first half's additions
+    (engine.hip msm_impl; RIPP_MSM_CHUNK_MIN; default from 96 MB of bases) -- affine and projective inputs, skewed scalars (every term in one bucket
+    per window), an identity among the bases and a zero scalar."""
     import os
     s = orc.gen_scalars(23, n); b1, b2 = orc.gen_g1(7, n), orc.gen_g2(8, n)
     if n >= 33:
@@ -142,7 +143,7 @@ def test_msm_large_forms_vs_oracle(engine, orc, n):
     e1, e2 = orc.g1_to_affine(orc.msm_g1_a(b1, s)).reshape(1, 12), (orc.g2_to_affine(orc.msm_g2_a(b2, s)).reshape(1, 24) if n <= 1 << 12 else None)
     same = np.repeat(orc.fr_array([0x1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF % orc.R]), n, axis=0)
     es = orc.g1_to_affine(orc.msm_g1_a(b1, same)).reshape(1, 12)
-    for env in ({"RIPP_MSM_LDS_SORT_MIN": "1"}, {"RIPP_MSM_CHUNK_MIN": "1"}, {"RIPP_MSM_LDS_SORT_MIN": "1", "RIPP_MSM_CHUNK_MIN": "1"}):
+    for env in ({"RIPP_MSM_LDS_SORT_MIN": "4000000000"}, {"RIPP_MSM_CHUNK_MIN": "1"}, {"RIPP_MSM_LDS_SORT_MIN": "4000000000", "RIPP_MSM_CHUNK_MIN": "1"}):
         os.environ.update(env)
         try:
             assert np.array_equal(engine.normalize_batch_g1(engine.MultiexponentiationInnerProductG1.inner_product(orc.blind_g1(b1, 9), s)), e1), env
