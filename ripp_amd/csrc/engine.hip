@@ -230,6 +230,10 @@ struct Engine {
     DevBuf fold_tab1, fold_mult, fold_tab, fold_jac1, fold_jac2;
     DevBuf fix_flags, scale_flags;        // one byte per lane of a carry-free G2 fold / table / scaling kernel: lanes with an exceptional addition, redone by the *_fix kernel behind it
     const void* tab_owner = nullptr;
+    // Device and pinned buffers of the last ONE-SHOT proof (ripp_sipp_prove[_sharded]), adopted by the next one: hipMalloc / hipFree of ~1 GB and four
+    // pinned staging buffers per call cost ~10 ms of every host-slice proof -- most of it the frees, AFTER the digest, where nothing hides them
+    // (host slices 442.6 ms against 430.3 ms for the same proof on a resident job).  Freed by ripp_release_scratch / ripp_shutdown like the other scratch.
+    struct JobBufCache { DevBuf d[15]; PinBuf p[4]; bool full = false; void release() { for (DevBuf& b : d) b.release(); for (PinBuf& b : p) b.release(); full = false; } } job_cache;
     size_t msm_chunk_min = (size_t)1 << 20;                               // host-slice MSMs of >= this many G1 bases (half as many G2 bases: the same bytes) run as two halves on two streams (msm_impl: the second half's upload beside the first half's additions)
     size_t msm_lds_sort_min = 0;                                          // MSMs of >= this many terms (after the GLV / GLS split) sort through LDS tiles (msm.hpp k_msm_hist_lds / k_msm_scatter_lds); the lane-per-term sort below it (A/B)
     const void* g2tab_hi = nullptr; size_t g2tab_half = 0;               // in-round G2 fold tables built ahead of the challenge (fold_g2_table_build): the vector half they were built over
@@ -265,7 +269,7 @@ struct Engine {
         return aux;
     }
     // run-time switches: read from the environment ONCE per C-ABI call (get_engine), never inside round loops
-    struct Switches { bool no_vm = false, no_precompute = false, no_fold_tables = false, no_msm_glv = false, lp_one_lane = false, no_endo = false, no_fq = false, no_xscale = false, no_share = false, no_fuse = false, no_prebuild = false, fuse_tables = false; } sw;
+    struct Switches { bool no_vm = false, no_precompute = false, no_fold_tables = false, no_msm_glv = false, lp_one_lane = false, no_endo = false, no_fq = false, no_xscale = false, no_share = false, no_fuse = false, no_prebuild = false, fuse_tables = false, no_job_cache = false; } sw;
     // crossover sizes: the member initialisers above are the defaults, the environment overrides them PER CALL (a test or
     // an A/B run flips them on a live engine)
     struct Sizes { size_t vm_lines_max, vm_fold_max, vm_tree_max, gls_split_max, msm_vm_merge_max, fold_tab_min, fq_min, lp_fq_min, vm_joint_max, vm_scale_max, tail_pipe_max, ml_fq_min, fq_min_g1, msm_lds_sort_min, msm_chunk_min; } defaults{};
@@ -304,6 +308,7 @@ struct Engine {
         env_on("RIPP_NO_XSCALE", sw.no_xscale);        // G2 folds always on the plain vector with the full-width x^-1
         env_on("RIPP_NO_FQ", sw.no_fq);                // the 12 x 32-bit forms of the kernels that have a carry-free twin (fq_curve.hpp)
         env_on("RIPP_FUSE_TABLES", sw.fuse_tables);    // build the three-quarter tables whatever the look-ahead plan (tests: round 0 then folds ALONE over them when x1 is late)
+        env_on("RIPP_NO_JOB_CACHE", sw.no_job_cache);  // (A/B only, not in ripp_config: an allocator cache, not a form of the computation) one-shot proofs allocate and free their job buffers per call
         env_on("RIPP_NO_PREBUILD", sw.no_prebuild);    // in-round G2 fold tables after the challenge (fold_g2_table), not in the host phase before it (job_prebuild_g2_tables)
         env_on("RIPP_NO_FUSE", sw.no_fuse);            // rounds 0 and 1 always fold one after the other (no three-quarter tables, no job_fold_fused)
         env_on("RIPP_NO_SHARE", sw.no_share);          // every pairing product walks its own G2 chain (no ChainSets grouping, no merged round 0 + look-ahead)
@@ -338,7 +343,7 @@ struct Engine {
     void destroy() {
         if (aux) { aux->destroy(); delete aux; aux = nullptr; }
         for (DevBuf* b : {&lines, &partA, &partB, &jacG1, &jacG2, &tmpA, &tmpB, &tmpR, &affG1, &affG2, &qtab, &vm_flag, &scale_tab, &fold_tab1, &fold_mult, &fold_tab, &fold_jac1, &fold_jac2, &fix_flags, &scale_flags}) b->release();
-        msm_scratch[0].release(); msm_scratch[1].release(); kzg_q[0].release(); kzg_q[1].release(); kzg_bases[0].release(); kzg_bases[1].release();
+        msm_scratch[0].release(); msm_scratch[1].release(); kzg_q[0].release(); kzg_q[1].release(); kzg_bases[0].release(); kzg_bases[1].release(); job_cache.release();
         if (stream3) (void)hipStreamDestroy(stream3);
         if (stream4) (void)hipStreamDestroy(stream4); if (ev_join4) (void)hipEventDestroy(ev_join4);
         if (stream5) (void)hipStreamDestroy(stream5); if (ev_join5) (void)hipEventDestroy(ev_join5);
@@ -1358,7 +1363,7 @@ API int32_t ripp_release_scratch(void) {
     for (DevBuf* b : {&e->lines, &e->partA, &e->partB, &e->jacG1, &e->jacG2, &e->tmpA, &e->tmpB, &e->tmpR, &e->affG1, &e->affG2, &e->qtab, &e->scale_tab, &e->fold_tab1, &e->fold_mult, &e->fold_tab, &e->fold_jac1, &e->fold_jac2, &e->fix_flags, &e->scale_flags}) b->release();
     e->msm_scratch[0].release(); e->msm_scratch[1].release(); e->kzg_q[0].release(); e->kzg_q[1].release(); e->kzg_bases[0].release(); e->kzg_bases[1].release();
     for (PinBuf& pb : e->stage) pb.release();             // pinned host staging (up to 2 x 32 MB after a verifier call at n = 2^20)
-    e->tab_owner = nullptr; e->g2tab_hi = nullptr;
+    e->tab_owner = nullptr; e->g2tab_hi = nullptr; e->job_cache.release();
     if (e->aux) { e->aux->destroy(); delete e->aux; e->aux = nullptr; }
     return RIPP_OK;
 }
@@ -1677,11 +1682,24 @@ API int32_t ripp_sipp_verify(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr
 // borrow_value != nullptr: one-shot proof -- the caller's (16-byte aligned) buffers outlive the job, so the statement hash runs on them
 // in place and starts BEFORE the upload (it is the critical path: ~0.3 s at n = 2^20) instead of after a 336 MB host copy
 // (full_a / full_b / full_r, n_full): the statement the hash runs over -- the shard itself for world == 1, the FULL statement on rank 0 of a sharded one-shot proof
+static void job_buffers(ripp_sipp_job* j, DevBuf* (&d)[15], PinBuf* (&p)[4]) {
+    DevBuf* dl[15] = {&j->a0, &j->b0, &j->r0, &j->a, &j->b, &j->a_next, &j->b_next, &j->jac1, &j->jac2, &j->a_pow, &j->b_pow, &j->a_pow_h, &j->b_pow_h, &j->parts1, &j->parts2};
+    PinBuf* pl[4] = {&j->tp_rows[0], &j->tp_rows[1], &j->look_rows[0], &j->look_rows[1]};
+    for (int i = 0; i < 15; ++i) d[i] = dl[i];
+    for (int i = 0; i < 4; ++i) p[i] = pl[i];
+}
+static void job_release_buffers(ripp_sipp_job* j) { DevBuf* d[15]; PinBuf* p[4]; job_buffers(j, d, p); for (DevBuf* b : d) b->release(); for (PinBuf* b : p) b->release(); }
 static int32_t sipp_job_create_impl(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr* r, size_t n_local, int32_t rank, int32_t world, const ripp_gt* borrow_value, ripp_sipp_job** job,
-                                    const ripp_g1a* full_a = nullptr, const ripp_g2a* full_b = nullptr, const ripp_fr* full_r = nullptr, size_t n_full = 0) {
+                                    const ripp_g1a* full_a = nullptr, const ripp_g2a* full_b = nullptr, const ripp_fr* full_r = nullptr, size_t n_full = 0, bool one_shot = false) {
     LOCK; ENGINE; if (!a || !b || !r || !job || n_local == 0 || world < 1 || rank < 0 || rank >= world) return RIPP_ERR_ARG;
     if (n_local & (n_local - 1)) return RIPP_ERR_POW2;
     ripp_sipp_job* j = new ripp_sipp_job();
+    if (one_shot && e->job_cache.full) {                      // the buffers the previous one-shot proof left behind (sipp_job_retire)
+        DevBuf* d[15]; PinBuf* p[4]; job_buffers(j, d, p);
+        for (int i = 0; i < 15; ++i) std::swap(*d[i], e->job_cache.d[i]);
+        for (int i = 0; i < 4; ++i) std::swap(*p[i], e->job_cache.p[i]);
+        e->job_cache.full = false;
+    }
     struct Live { bool keep = false; Live() { ++g_live_handles; } ~Live() { if (!keep) --g_live_handles; } } live;
     j->n_local = n_local; j->rank = rank; j->world = world; j->world0 = world;
     if (world == 1 && !full_a) { full_a = a; full_b = b; full_r = r; n_full = n_local; }
@@ -1692,7 +1710,7 @@ static int32_t sipp_job_create_impl(const ripp_g1a* a, const ripp_g2a* b, const 
         job_start_hash(j, v); j->hash_prestarted = true;
     }
     int32_t rc;
-    if ((rc = j->a0.reserve(n_local * sizeof(G1A))) || (rc = j->b0.reserve(n_local * sizeof(G2A))) || (rc = j->r0.reserve(n_local * sizeof(Fr)))) { if (j->hash_thread.joinable()) j->hash_thread.join(); for (DevBuf* d : {&j->a0, &j->b0, &j->r0}) d->release(); delete j; return rc; }
+    if ((rc = j->a0.reserve(n_local * sizeof(G1A))) || (rc = j->b0.reserve(n_local * sizeof(G2A))) || (rc = j->r0.reserve(n_local * sizeof(Fr)))) { if (j->hash_thread.joinable()) j->hash_thread.join(); job_release_buffers(j); delete j; return rc; }
     {   // on failure: join the hash thread (it reads the CALLER's buffers in borrow mode) and free the job before returning
         hipError_t he = hipMemcpyAsync(j->a0.p, a, n_local * sizeof(G1A), hipMemcpyHostToDevice, e->stream);
         if (he == hipSuccess) he = hipMemcpyAsync(j->b0.p, b, n_local * sizeof(G2A), hipMemcpyHostToDevice, e->stream);
@@ -1700,7 +1718,7 @@ static int32_t sipp_job_create_impl(const ripp_g1a* a, const ripp_g2a* b, const 
         if (he != hipSuccess) {
             set_err(std::string("statement upload: ") + hipGetErrorString(he));
             if (j->hash_thread.joinable()) j->hash_thread.join();
-            for (DevBuf* d : {&j->a0, &j->b0, &j->r0}) d->release();
+            job_release_buffers(j);
             delete j; return RIPP_ERR_DEVICE;
         }
     }
@@ -1708,7 +1726,7 @@ static int32_t sipp_job_create_impl(const ripp_g1a* a, const ripp_g2a* b, const 
         j->ha.resize(n_local); j->hb.resize(n_local); j->hr.resize(n_local);
         std::memcpy(j->ha.data(), a, n_local * sizeof(G1A)); std::memcpy(j->hb.data(), b, n_local * sizeof(G2A)); std::memcpy(j->hr.data(), r, n_local * sizeof(Fr));
     }
-    if ((rc = e->sync())) { if (j->hash_thread.joinable()) j->hash_thread.join(); for (DevBuf* d : {&j->a0, &j->b0, &j->r0}) d->release(); delete j; return rc; }
+    if ((rc = e->sync())) { if (j->hash_thread.joinable()) j->hash_thread.join(); job_release_buffers(j); delete j; return rc; }
     live.keep = true;
     *job = j; return RIPP_OK;
 }
@@ -1718,10 +1736,27 @@ API int32_t ripp_sipp_job_create(const ripp_g1a* a, const ripp_g2a* b, const rip
 API void ripp_sipp_job_destroy(ripp_sipp_job* j) {
     if (!j) return; LOCK;
     if (j->hash_thread.joinable()) j->hash_thread.join();
-    for (DevBuf* b : {&j->a0, &j->b0, &j->r0, &j->a, &j->b, &j->a_next, &j->b_next, &j->jac1, &j->jac2, &j->a_pow, &j->b_pow, &j->a_pow_h, &j->b_pow_h, &j->parts1, &j->parts2}) b->release();
-    j->tp_rows[0].release(); j->tp_rows[1].release(); j->look_rows[0].release(); j->look_rows[1].release();
+    job_release_buffers(j);
     if (g_engine && g_engine->tab_owner == j) g_engine->tab_owner = nullptr;
     delete j; --g_live_handles;
+}
+// the end of a one-shot proof: the job goes, its buffers stay with the engine for the next one-shot call (Engine::job_cache)
+static void sipp_job_retire(ripp_sipp_job* j) {
+    if (!j) return;
+    {   LOCK;
+        if (j->hash_thread.joinable()) j->hash_thread.join();
+        Engine* e = g_engine;
+        if (e && !e->job_cache.full && !e->sw.no_job_cache) {
+            DevBuf* d[15]; PinBuf* p[4]; job_buffers(j, d, p);
+            bool idle = true; for (PinBuf* b : p) if (b->wait() != RIPP_OK) idle = false;      // (nothing is in flight after a proof: sipp_prove_core's Quiesce)
+            if (idle) {
+                for (int i = 0; i < 15; ++i) std::swap(*d[i], e->job_cache.d[i]);
+                for (int i = 0; i < 4; ++i) std::swap(*p[i], e->job_cache.p[i]);
+                e->job_cache.full = true;
+            }
+        }
+    }
+    ripp_sipp_job_destroy(j);
 }
 API int32_t ripp_sipp_job_begin(ripp_sipp_job* j) { LOCK; ENGINE; if (!j) return RIPP_ERR_ARG; return job_begin(e, j); }
 API size_t ripp_sipp_job_rounds_left(const ripp_sipp_job* j) { if (!j) return 0; size_t total = j->len * (size_t)j->world, r = 0; while (total > 1) { total >>= 1; ++r; } return r; }
@@ -2306,9 +2341,9 @@ API int32_t ripp_sipp_prove(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr*
     if (n == 0 || (n & (n - 1))) return RIPP_ERR_POW2;
     if (!value) return RIPP_ERR_ARG;
     ripp_sipp_job* j = nullptr;
-    int32_t rc = sipp_job_create_impl(a, b, r, n, 0, 1, value, &j); if (rc) return rc;
+    int32_t rc = sipp_job_create_impl(a, b, r, n, 0, 1, value, &j, nullptr, nullptr, nullptr, 0, true); if (rc) return rc;
     rc = ripp_sipp_job_prove(j, value, proof, challenges, st);
-    ripp_sipp_job_destroy(j);
+    sipp_job_retire(j);
     return rc;
 }
 

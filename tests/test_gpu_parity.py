@@ -129,6 +129,33 @@ def test_msm_vs_oracle(engine, orc, n):
         assert np.array_equal(engine.normalize_batch_g2(engine.MultiexponentiationInnerProductG2.inner_product(orc.blind_g2(b2, 9), s)), orc.g2_to_affine(orc.msm_g2_a(b2, s)).reshape(1, 24))
 
 
+def test_one_shot_proofs_reuse_their_buffers(engine, orc):
+    """ripp_sipp_prove hands the device / pinned buffers of its job to the engine when it returns and the next one-shot call adopts them (Engine::job_cache:
+    the hipMalloc / hipFree of ~1 GB per call were ~10 ms of every host-slice proof at n = 2^20).  A larger, a smaller and an equal statement after one
+    another, a resident job's proof in between, and a proof after ripp_release_scratch (which frees the cache): every proof is the oracle's."""
+    import ctypes
+    from ripp_amd._lib import lib
+    stmts = {}
+    for lg in (12, 4, 15, 12, 1):
+        n = 1 << lg
+        if n not in stmts:
+            a, b, r = engine.synth_g1(300 + lg, n), engine.synth_g2(400 + lg, n), engine.synth_fr(500 + lg, n)
+            v = engine.product_of_pairings_with_coeffs(a, b, r)
+            rc, ep, ech = orc.sipp_prove(a, b, r, v); assert rc == 0
+            stmts[n] = (a, b, r, v, ep, ech)
+        a, b, r, v, ep, ech = stmts[n]
+        p, ch, _ = engine.SIPP.prove_one_shot(a, b, r, v)
+        assert np.array_equal(p, ep) and np.array_equal(ch, ech), n
+        if lg == 15:                                   # a resident job between two one-shot calls owns its own buffers
+            job = engine.SippJob(*stmts[1 << 12][:3])
+            try:
+                p2, ch2, _ = job.prove(stmts[1 << 12][3]); assert np.array_equal(p2, stmts[1 << 12][4])
+                assert lib().ripp_release_scratch() == 0             # frees the cached buffers; the job keeps its own
+                p2, ch2, _ = job.prove(stmts[1 << 12][3]); assert np.array_equal(p2, stmts[1 << 12][4])
+            finally:
+                job.close()
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 33, 1000, (1 << 12) + 5, 1 << 16])
 def test_msm_sort_and_two_stream_forms_vs_oracle(engine, orc, n):
     """Both digit sorts and the two-stream form of large host-slice MSMs at sizes the oracle finishes in seconds: the lane-per-term sort (k_msm_digits'
