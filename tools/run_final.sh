@@ -14,4 +14,4 @@ timeout 400 python3 tools/stress_sharded.py 41 90 2 14 4 > $O/stress_world4.txt 
 timeout 400 python3 tools/stress_sharded.py 81 90 3 14 8 > $O/stress_world8.txt 2>&1
 timeout 200 python3 tools/stress_tail.py 5 60 1 12 > $O/stress_tail.txt 2>&1
 timeout 300 python3 tools/poly_commit_bench.py 2 8 > $O/poly_commit_bench.csv 2> $O/poly_commit.err
-ls -la $O $O/c377; tail -3 $O/scaling_ipp.log; cat $O/aggregate_2p14.json | head -30; cat $O/bench_n2_single_device_gloo.json | cut -c1-300; tail -2 $O/stress_world4.txt $O/stress_world8.txt $O/stress_tail.txt
+ls -la $O $O/c377; tail -3 $O/scaling_ipp.log; cat $O/aggregate_2p14.json | head -30; cat $O/bench_n2_single_device_gloo.json | cut -c1-300; for f in stress_world4 stress_world8 stress_tail; do tail -n 2 $O/$f.txt; done
