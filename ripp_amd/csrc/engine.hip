@@ -918,6 +918,7 @@ struct ripp_sipp_job {
         std::vector<std::future<Fp12>> fe, pend;    // final exponentiations still running; GT powers of the level being applied (3 per output)
     };
     std::vector<LookItem> look; PinBuf look_rows[2];
+    double look_deadline = 0;      // ranks that do NOT hash: the time (now_ms) at which rank 0 expects the digest -- they size their look-ahead against it with their OWN measured pairing rate
     std::atomic<uint64_t> hash_done{0}; uint64_t hash_total = 0; double hash_t0 = 0;      // progress of the statement hash (bytes), for the adaptive look-ahead
     bool no_window = false;                         // sharded proofs: rank 0 was handed the digest, nobody hashes, nothing to hide work behind
     size_t hash_n = 0;                              // length of the statement ha_ext / hb_ext / hr_ext point to (the FULL statement on rank 0 of a sharded proof)
@@ -1928,7 +1929,10 @@ static int look_plan(const Engine* e, size_t n_local, int world, bool window) {
 static int32_t job_lookahead(Engine* e, ripp_sipp_job* j, int eighths, bool forced, double ms_per_pair, int first_item = 0) {
     if (first_item == 0) j->look.clear();
     const bool adaptive = !forced && j->hash_total > 0 && !j->no_window && eighths > 0 && !e->look_static;
-    const int items = adaptive ? std::min(2 * LOOK_MAX_R, eighths / 8 + 2) : (eighths + 7) / 8;      // adaptive: at most one whole item beyond what the static model expects
+    // ranks that do not hash the statement themselves: rank 0 told them when it expects the digest (SippPlanMsg::hash_left_ms, its measured hash rate); they cut or
+    // extend the plan it sent by THEIR clock and THEIR measured pairing rate -- a slower or a time-sliced device no longer overruns the window, a faster one uses it
+    const bool by_deadline = !forced && !adaptive && j->look_deadline > 0 && !j->no_window && eighths > 0 && !e->look_static;
+    const int items = (adaptive || by_deadline) ? std::min(2 * LOOK_MAX_R, eighths / 8 + 2) : (eighths + 7) / 8;      // adaptive: at most one whole item beyond what the static model expects
     if (items <= 0 || (j->digest_ready.load() && !forced)) return RIPP_OK;      // the hash is already done: nothing to hide the work behind (forced: RIPP_LOOK_ITEMS, tests)
     const double t0 = now_ms();
     const size_t len = j->len;
@@ -1939,18 +1943,20 @@ static int32_t job_lookahead(Engine* e, ripp_sipp_job* j, int eighths, bool forc
         const size_t qblk = len >> (R + 1);
         if (qblk == 0 || qblk > e->max_pairs_per_batch) break;
         int frac = std::min(8, eighths - 8 * it);                        // static plan: the last item may be partial (the first frac/8 of every block's pairs)
-        if (adaptive) {
+        if (adaptive || by_deadline) {
             if (qblk < 1024) break;
             if ((rc = e->sync())) return rc;                             // the fold tables / the previous item have left the device: what follows starts now
-            const uint64_t done = j->hash_done.load(std::memory_order_relaxed);
-            if (j->digest_ready.load() || done == 0) break;
-            const double elapsed = now_ms() - j->hash_t0;
-            double room = elapsed * (double)(j->hash_total - std::min(done, j->hash_total)) / (double)done - 3.0;      // ms the hash still needs, minus the item's host work
+            const uint64_t done = adaptive ? j->hash_done.load(std::memory_order_relaxed) : 1;
+            if (adaptive && (j->digest_ready.load() || done == 0)) break;
+            const double elapsed = adaptive ? now_ms() - j->hash_t0 : 0;
+            double room = adaptive ? elapsed * (double)(j->hash_total - std::min(done, j->hash_total)) / (double)done - 3.0      // ms the hash still needs, minus the item's host work
+                                   : j->look_deadline - now_ms() - 3.0;                                                            // ... by rank 0's estimate
             // the extrapolation is only trusted inside what a sequential Blake2s can plausibly need in total (0.9 - 1.25 GB/s): a progress counter that
             // lags (the hash thread descheduled, a burst of serialisation waits) must not make the window look longer than it can be
-            room = std::min(room, (double)j->hash_total / 0.9e6 - elapsed);
+            if (adaptive) room = std::min(room, (double)j->hash_total / 0.9e6 - elapsed);
             const double cost = (double)qblk * (double)((size_t)1 << (2 * R)) * std::max(ms_per_pair, 5.0e-5);
-            if (trace_on()) fprintf(stderr, "[ripp] look-ahead item (%d,%c): hash %.0f %% after %.1f ms, room %.1f ms, item %.1f ms\n", R, side ? 'r' : 'l', 100.0 * (double)done / (double)j->hash_total, elapsed, room, cost);
+            if (trace_on() && adaptive) fprintf(stderr, "[ripp] look-ahead item (%d,%c): hash %.0f %% after %.1f ms, room %.1f ms, item %.1f ms\n", R, side ? 'r' : 'l', 100.0 * (double)done / (double)j->hash_total, elapsed, room, cost);
+            if (trace_on() && by_deadline) fprintf(stderr, "[ripp] rank %d look-ahead item (%d,%c): %.1f ms to rank 0's expected digest, item %.1f ms\n", j->rank, R, side ? 'r' : 'l', room, cost);
             if (room <= 0) break;                                        // the window is over (or the clamp above says it must be): nothing more fits
             frac = room >= cost ? 8 : -(int)(32.0 * room / cost);        // adaptive: 32nds (negative = in 32nds)
             if (frac < 0 && frac > -6) break;
@@ -2083,7 +2089,7 @@ static bool test_fail_hit(int rank, size_t round) {
     set_err("injected failure (ripp_test_inject_failure) in the fold of round " + std::to_string(round) + " on rank " + std::to_string(rank));
     return true;
 }
-struct SippPlanMsg { uint64_t n_local; int32_t world, rank, look_items, window, rc, pad; };
+struct SippPlanMsg { uint64_t n_local; int32_t world, rank, look_items, window, rc, pad; double hash_left_ms; };      // hash_left_ms (rank 0): what its statement hash still needs, by its measured rate
 struct SippRoundMsg { Fp12 z[2]; uint8_t digest[32]; int32_t rc, pad[3]; };
 struct SippTailMsg { G1A a; G2A b; int32_t rc, pad[3]; };
 static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, const uint8_t* seed_digest, ripp_gt* proof, ripp_fr* challenges, ripp_stats* st) {
@@ -2107,9 +2113,11 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
     }
     const bool look_forced = e->look_eighths >= 0;
     int look_items = (rank == 0 || look_forced) ? look_plan(e, j->n_local, world0, window || look_forced) : 0;
-    j->no_window = !window;
+    j->no_window = !window; j->look_deadline = 0;
     if (world0 > 1) {
-        SippPlanMsg mine{(uint64_t)j->n_local, world0, rank, look_items, window ? 1 : 0, RIPP_OK, 0};
+        double hash_left = 0;
+        if (window && j->hash_total > 0) hash_left = std::max(0.0, (double)j->hash_total / (e->cal_hash_bytes_per_ms > 0 ? e->cal_hash_bytes_per_ms : 1.12e6) - (now_ms() - j->hash_t0));
+        SippPlanMsg mine{(uint64_t)j->n_local, world0, rank, look_items, window ? 1 : 0, RIPP_OK, 0, hash_left};
         std::vector<SippPlanMsg> all((size_t)world0);
         const double tx = now_ms();
         int32_t rc = comm_allgather(e, &mine, all.data(), sizeof mine); if (rc) return rc;
@@ -2119,6 +2127,7 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
             if (all[w].n_local != (uint64_t)j->n_local || all[w].world != world0 || all[w].rank != w) { set_err("sharded SIPP proof: the ranks disagree on the shard size / world size / rank order"); return RIPP_ERR_ARG; }
         }
         look_items = all[0].look_items; j->no_window = !all[0].window;
+        if (rank != 0 && all[0].window && all[0].hash_left_ms > 0) j->look_deadline = now_ms() + all[0].hash_left_ms;      // (durations, not clocks: every rank leaves the all-gather at about the same time)
     }
     struct HotOff { ~HotOff() { host_pool().set_hot(false); } } hot_off;       // whatever the exit path, the workers go back to sleeping waits
     struct QuietOff { Engine* e; ~QuietOff() { e->quiet_waits = false; } } quiet_off{e};
