@@ -1336,12 +1336,14 @@ API int32_t ripp_abi_version(void) { return RIPP_ABI_VERSION; }
 API size_t ripp_stats_size(void) { return sizeof(ripp_stats); }
 API void ripp_statement_hash_times(double* hash_ms, double* wait_ms) { if (hash_ms) *hash_ms = g_digest_hash_ms; if (wait_ms) *wait_ms = g_digest_wait_ms; }
 API int32_t ripp_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+extern "C++" { static void vec_caches_release(); }      // tipa_api.inc: the parked device buffers of the GIPA / TIPA vector sets (they belong to the engine's device)
 API int32_t ripp_init(int32_t dev) {
     LOCK;
     if (g_engine) {
         if (g_engine->device == dev) return RIPP_OK;
         // re-binding to another device would free the engine's streams under live job / SRS handles: refuse instead
         if (g_live_handles.load() > 0) { set_err("ripp_init: " + std::to_string(g_live_handles.load()) + " job / SRS handle(s) are alive on device " + std::to_string(g_engine->device) + "; destroy them before re-binding the engine"); return RIPP_ERR_ARG; }
+        vec_caches_release();
         g_engine->destroy(); delete g_engine; g_engine = nullptr;
     }
     Engine* e = new Engine(); int32_t rc = e->init(dev);
@@ -1353,6 +1355,7 @@ API void ripp_shutdown(void) {
     // job / SRS / vector handles hold device memory and refer to this engine's streams and tables: tearing it down under them would let the
     // next call create a fresh engine (possibly on another device) that those handles then run on.  Refuse, like ripp_init does.
     if (g_live_handles.load() > 0) { set_err("ripp_shutdown: " + std::to_string(g_live_handles.load()) + " job / SRS / vector handle(s) are still alive; destroy them first"); fprintf(stderr, "[ripp] %s\n", g_err.c_str()); return; }
+    vec_caches_release();
     g_engine->destroy(); delete g_engine; g_engine = nullptr;
 }
 // frees the engine's grow-only scratch (line buffer, fold tables -- ~19 GB after an n = 2^20 proof --, MSM scratch): the next call re-allocates
@@ -1364,7 +1367,7 @@ API int32_t ripp_release_scratch(void) {
     for (DevBuf* b : {&e->lines, &e->partA, &e->partB, &e->jacG1, &e->jacG2, &e->tmpA, &e->tmpB, &e->tmpR, &e->affG1, &e->affG2, &e->qtab, &e->scale_tab, &e->fold_tab1, &e->fold_mult, &e->fold_tab, &e->fold_jac1, &e->fold_jac2, &e->fix_flags, &e->scale_flags}) b->release();
     e->msm_scratch[0].release(); e->msm_scratch[1].release(); e->kzg_q[0].release(); e->kzg_q[1].release(); e->kzg_bases[0].release(); e->kzg_bases[1].release();
     for (PinBuf& pb : e->stage) pb.release();             // pinned host staging (up to 2 x 32 MB after a verifier call at n = 2^20)
-    e->tab_owner = nullptr; e->g2tab_hi = nullptr; e->job_cache.release();
+    e->tab_owner = nullptr; e->g2tab_hi = nullptr; e->job_cache.release(); vec_caches_release();
     if (e->aux) { e->aux->destroy(); delete e->aux; e->aux = nullptr; }
     return RIPP_OK;
 }
