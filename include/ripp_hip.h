@@ -223,6 +223,16 @@ void    ripp_comm_destroy(void);
 int32_t ripp_comm_rank(void);
 int32_t ripp_comm_world(void);
 int32_t ripp_comm_allgather(const void* send, void* recv, size_t bytes);     /* host buffers; recv: world x bytes */
+/* Transport "replay" (MEASUREMENT rig, no counterpart in the reference): a proof is deterministic, so the blocks a rank receives are too.
+ * ripp_comm_record(1) on a live communicator keeps every exchange since the start of the last sharded proof (gathered blocks + this rank's
+ * gap = its own time between the previous exchange and its arrival at this one); ripp_comm_recording_save writes them to a file.
+ * ripp_comm_init_replay makes THIS process rank `rank` of `world` with the peers' blocks served from such a file: alone on its GPU, at full
+ * speed, each all-gather completing no earlier than the slowest peer whose gaps the file holds would have arrived, plus latency_us.  The
+ * rank's own blocks and gaps replace the recorded ones (save again to hand them to the next pass).  tools/replay_ranks.py; DESIGN.md section 6. */
+int32_t ripp_comm_record(int32_t on);
+int32_t ripp_comm_recording_save(const char* path);
+int32_t ripp_comm_init_replay(int32_t rank, int32_t world, const char* path, double latency_us);
+int32_t ripp_comm_replay_info(uint64_t* served, uint64_t* own_differs, double* waited_ms);
 /* InnerProduct implementations over vectors sharded by index residue (element i on rank i mod world); every rank passes ITS shard
  * and receives the full result.  Same status codes as the single-GPU forms (inner_products/src/lib.rs:61-73, 128-141). */
 int32_t ripp_pairing_product_sharded_j(const ripp_g1j* left, size_t nl, const ripp_g2j* right, size_t nr, ripp_gt* out);

@@ -2099,6 +2099,7 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
     const int world0 = j->world0, rank = j->rank;
     const double t_start = now_ms();
     double exchange_ms = 0;
+    comm_mark_proof();
     // whatever the exit path -- the plan exchange below included: nothing enqueued by this proof may still be running when the caller gets control
     // back (engine scratch, tp_rows and the job's vectors are reused by the next call), no prepared state may leak into the next proof, and the hash
     // thread, which reads the CALLER's buffers (borrowed statement), is never left running behind a return.  Constructed BEFORE the thread starts.

@@ -218,6 +218,63 @@ class NativeComm:
         from ._lib import lib
         lib().ripp_comm_destroy()
 
+    # measurement rig (include/ripp_hip.h, transport "replay"): keep the exchanges of the proofs that follow / write the last proof's to a file
+    def record(self, on=True):
+        from ._lib import lib
+        from . import api
+        api._check(lib().ripp_comm_record(1 if on else 0))
+
+    def save_recording(self, path):
+        from ._lib import lib
+        from . import api
+        api._check(lib().ripp_comm_recording_save(os.fsencode(path)))
+
+
+class ReplayComm:
+    """ripp_comm_init_replay: THIS process is rank `rank` of `world`, alone on its GPU; the peers' blocks of every all-gather come from the
+    recording at `path` and arrive when the recorded gaps (where measured) say the slowest peer would have.  No torch.distributed involved."""
+
+    transport = "replay"
+
+    def __init__(self, rank, world, path, latency_us=0.0):
+        import ctypes
+        from ._lib import lib
+        from . import api
+        self.rank, self.world = rank, world
+        api._check(lib().ripp_comm_init_replay(ctypes.c_int32(rank), ctypes.c_int32(world), os.fsencode(path), ctypes.c_double(latency_us)))
+
+    def info(self):
+        import ctypes
+        from ._lib import lib
+        served, differs, waited = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_double()
+        lib().ripp_comm_replay_info(ctypes.byref(served), ctypes.byref(differs), ctypes.byref(waited))
+        return {"exchanges_served": served.value, "own_blocks_differing": differs.value, "waited_ms": waited.value}
+
+    save_recording = NativeComm.save_recording
+    close = NativeComm.close
+
+
+def read_recording(path):
+    """Parse a recording file: (world, [(bytes_per_rank, gaps[world] (NaN = not measured), blocks (world, bytes) uint8), ...])."""
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"RIPPREC1", path
+    world, count = (int(v) for v in np.frombuffer(raw, dtype=np.uint32, count=2, offset=8))
+    off, out = 16, []
+    for _ in range(count):
+        nbytes = int(np.frombuffer(raw, dtype=np.uint32, count=1, offset=off)[0]); off += 8
+        gaps = np.frombuffer(raw, dtype=np.float64, count=world, offset=off).copy(); off += 8 * world
+        blocks = np.frombuffer(raw, dtype=np.uint8, count=world * nbytes, offset=off).reshape(world, nbytes).copy(); off += world * nbytes
+        out.append((nbytes, gaps, blocks))
+    assert off == len(raw), path
+    return world, out
+
+
+def write_recording(path, world, exchanges):
+    with open(path, "wb") as f:
+        f.write(b"RIPPREC1"); f.write(np.array([world, len(exchanges)], dtype=np.uint32).tobytes())
+        for nbytes, gaps, blocks in exchanges:
+            f.write(np.array([nbytes, 0], dtype=np.uint32).tobytes()); f.write(np.asarray(gaps, dtype=np.float64).tobytes()); f.write(np.ascontiguousarray(blocks, dtype=np.uint8).tobytes())
+
 
 def native_sipp_job_prove(job, value, full=None, seed_digest=None):
     """ripp_sipp_job_prove_sharded: SIPP::prove (sipp/src/lib.rs:42-106) across the library's communicator on a resident shard.

@@ -218,39 +218,86 @@ def _native_worker(rank, world, port, n, env, ret):
         dist.destroy_process_group()
 
 
+SPAWN_LOG_ROOT = os.path.join(os.path.dirname(HERE), "gpurun_out", "spawn_failures")
+# what a failed START-UP of the rank processes looks like (gloo rendezvous over a TCP store on 127.0.0.1): the only failures that get a second attempt
+RENDEZVOUS_ERRORS = ("Address already in use", "EADDRINUSE", "TCPStore", "DistNetworkError", "DistStoreError", "Connection reset by peer", "Connection refused",
+                     "connect() timed out", "Socket Timeout", "store->get", "Timed out waiting for clients", "timed out after")
+
+
+def _entry(rank, fn, logdir, *args):
+    """Child side of _spawn_once: everything the rank writes to stdout / stderr (Python tracebacks, the library's messages, HIP / HSA runtime
+    aborts) goes to logdir/rank<k>.log, so that a failure that happens once in a hundred runs leaves its evidence behind."""
+    fd = os.open(os.path.join(logdir, f"rank{rank}.log"), os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    sys.stdout.flush(); sys.stderr.flush()
+    os.dup2(fd, 1); os.dup2(fd, 2); os.close(fd)
+    import faulthandler
+    faulthandler.enable()                                   # a SIGSEGV / SIGABRT inside the library leaves the Python stack of the call in the log
+    fn(rank, *args)
+
+
+class SpawnFailure(Exception):
+    def __init__(self, msg, logdir, exitcodes, text):
+        super().__init__(msg); self.logdir, self.exitcodes, self.text = logdir, exitcodes, text
+
+
 def _spawn_once(fn, world, args, timeout):
+    import shutil
+    import tempfile
     import time
     import torch.multiprocessing as mp
+    os.makedirs(SPAWN_LOG_ROOT, exist_ok=True)
+    logdir = tempfile.mkdtemp(prefix=time.strftime("%H%M%S_") + f"{fn.__name__}_w{world}_", dir=SPAWN_LOG_ROOT)
     mgr = mp.Manager(); ret = mgr.dict()
-    ctx = mp.spawn(fn, args=(world, _free_port()) + tuple(args) + (ret,), nprocs=world, join=False)
+    ctx = mp.spawn(_entry, args=(fn, logdir, world, _free_port()) + tuple(args) + (ret,), nprocs=world, join=False)
     deadline = time.time() + timeout
+    err = None
     try:
         while not ctx.join(timeout=5):
             if time.time() > deadline:
-                raise TimeoutError(f"{world} ranks did not finish within {timeout} s: a rank hangs in a collective")
+                err = TimeoutError(f"{world} ranks did not finish within {timeout} s: a rank hangs in a collective (logs: {logdir})")
+                break
+    except Exception as exc:                                # ProcessRaisedException / ProcessExitedException of torch.multiprocessing
+        err = exc
     finally:
         for pr in ctx.processes:
             if pr.is_alive():
                 pr.kill()
-    return dict(ret)
+        for pr in ctx.processes:
+            pr.join(10)
+    if err is None:
+        shutil.rmtree(logdir, ignore_errors=True)
+        return dict(ret)
+    # keep the evidence: exit code of every rank + its output
+    codes = [pr.exitcode for pr in ctx.processes]
+    tails = []
+    for rank in range(world):
+        try:
+            tails.append(f"---- rank {rank} (exit code {codes[rank]}) ----\n" + open(os.path.join(logdir, f"rank{rank}.log"), errors="replace").read()[-3000:])
+        except OSError:
+            tails.append(f"---- rank {rank} (exit code {codes[rank]}): no log ----")
+    text = f"{type(err).__name__}: {err}\n" + "\n".join(tails)
+    with open(os.path.join(logdir, "failure.txt"), "w") as f:
+        f.write(f"exit codes: {codes}\n{text}\n")
+    if isinstance(err, TimeoutError):
+        raise err
+    raise SpawnFailure(f"{world} ranks of {fn.__name__} failed; exit codes {codes}; logs kept in {logdir}\n{text[-6000:]}", logdir, codes, text)
 
 
 def _spawn(fn, world, args, timeout=900):
     """mp.spawn with a deadline: a hung collective fails the test instead of the session (the children are ended by PID, never by pattern).
-    A child that dies of something other than a wrong result gets ONE retry with FRESH processes and a fresh port, and the first error is printed
-    (the 8-rank aggregate case failed once in ~70 runs on a busy box, in a run whose output was not kept; alone it passed 20 times in a row --
-    a rendezvous / start-up failure of eight processes on 16 CPUs is the suspect, and a deterministic fault fails the retry as well).  Hangs (TimeoutError) and wrong results (the workers assert, and the callers compare what the ranks return) are never retried."""
-    import sys
+    Every rank's output and exit code are kept under gpurun_out/spawn_failures/ when anything goes wrong.  ONE retry with fresh processes and a
+    fresh port is granted only to a failed START-UP: an error text that names the rendezvous (RENDEZVOUS_ERRORS), no rank killed by a signal, no
+    assertion, no status from the library.  A crash of a rank (SIGSEGV / SIGABRT / a GPU memory fault), a non-zero library status, a wrong result
+    and a hang all fail the test at once -- the blanket retry of build round 4 would have hidden exactly those."""
     try:
         return _spawn_once(fn, world, args, timeout)
-    except TimeoutError:
-        raise
-    except AssertionError:
-        raise
-    except Exception as exc:                                    # ProcessRaisedException / ProcessExitedException of torch.multiprocessing
-        if "AssertionError" in str(exc):
+    except SpawnFailure as exc:
+        by_signal = any(c is not None and c < 0 for c in exc.exitcodes)
+        rendezvous = any(k in exc.text for k in RENDEZVOUS_ERRORS)
+        ours = any(k in exc.text for k in ("AssertionError", "DeviceError", "InnerProductError", "[ripp]", "libripp_hip", "HSA_STATUS", "Memory access fault", "hipError"))
+        if by_signal or ours or not rendezvous:
             raise
-        print(f"[test_sharded_gloo] {world} ranks: first attempt failed with {type(exc).__name__}: {str(exc)[-2000:]} -- retrying once with fresh processes", file=sys.stderr)
+        print(f"[test_sharded_gloo] {world} ranks: rendezvous failed ({exc.logdir}) -- one retry with fresh processes", file=sys.stderr)
         return _spawn_once(fn, world, args, timeout)
 
 
