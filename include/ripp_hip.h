@@ -54,11 +54,15 @@ typedef struct {
     /* the statement hash of THIS call (appended in build round 4; 0 on ranks that did not hash): Blake2s itself / waiting for the serialisation workers */
     double statement_hash_ms, statement_hash_wait_ms;
     uint64_t chains_lines;                                            /* G2 chains the carry-free stage-1 kernel walked (<= pairs_lines: products over one Q vector share a chain) */
+    /* memory-aware degradation (appended in build round 5): the deepest fall-back the call took -- 0 none, 1 half-vector round-0 tables instead of the
+     * three-quarter / eight-multiple ones, 2 pre-doubled bases only, 3 no round-0 precomputation; +8 when the line buffer (pairs per launch) was cut --
+     * and the device memory the library holds at the end of the call */
+    uint64_t mem_tier, device_bytes;
 } ripp_stats;
 /* ABI guard.  The library WRITES sizeof(ripp_stats) bytes through every `ripp_stats*` it is given, and the struct has grown twice: a caller
  * compiled against an older header would be overrun.  Bindings must check at load time that RIPP_ABI_VERSION == ripp_abi_version() and
  * sizeof(their ripp_stats) == ripp_stats_size() (ripp_amd/_lib.py and rust/ripp-hip do). */
-#define RIPP_ABI_VERSION 5
+#define RIPP_ABI_VERSION 6
 int32_t ripp_abi_version(void);
 size_t  ripp_stats_size(void);
 
@@ -91,6 +95,12 @@ typedef struct {
              tail_pipe_max, ml_fq_min, fq_min_g1,
              msm_lds_sort_min,       /* MSMs below this many terms use the lane-per-term digit sort instead of the LDS-tile sort (default 0: never) */
              msm_chunk_min;          /* host-slice MSMs from this many G1 bases (half as many G2 bases) run as two halves on two streams (default 2^20) */
+    /* appended in build round 5 (ABI version 6) */
+    uint64_t mem_cap_bytes;          /* device memory the library may hold in all (scratch, tables, jobs, SRS / vector handles); 0 = automatic: what hipMemGetInfo
+                                      * reports free, less a margin.  Short of it the engine cuts the line buffer (pairs per launch), then steps the round-0 fold
+                                      * tables down (ripp_stats.mem_tier); the proof bytes are the same in every tier */
+    uint32_t hot_workers;            /* polling host workers after the digest: 0 automatic (CPUs of the process tree / ranks >= 8), 1 always, 2 never */
+    uint32_t no_job_cache;           /* one-shot proofs free their job buffers (~1 KB per element + four pinned row buffers) instead of parking them for the next call */
 } ripp_config;
 int32_t ripp_config_default(ripp_config* cfg);      /* the built-in defaults of this build; needs no device */
 int32_t ripp_configure(const ripp_config* cfg);     /* NULL: back to the defaults */

@@ -14,6 +14,7 @@
 #include <memory>
 #include <future>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
@@ -158,14 +159,15 @@ inline unsigned nblk(size_t n, unsigned b) { return (unsigned)((n + b - 1) / b);
 inline uint32_t pow2_floor(uint32_t v) { uint32_t p = 1; while ((p << 1) <= v && (p << 1) != 0) p <<= 1; return p; }
 
 // A grow-only device buffer
+std::atomic<size_t> g_dev_bytes{0};      // device memory this library holds through DevBuf (scratch, tables, jobs, SRS / vector handles): what ripp_config.mem_cap_bytes bounds
 struct DevBuf {
     void* p = nullptr; size_t cap = 0;
     int32_t reserve(size_t bytes) {
         if (bytes <= cap) return RIPP_OK;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        HIPCHK(hipMalloc(&p, bytes)); cap = bytes; return RIPP_OK;
+        release();
+        HIPCHK(hipMalloc(&p, bytes)); cap = bytes; g_dev_bytes.fetch_add(bytes, std::memory_order_relaxed); return RIPP_OK;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p) { (void)hipFree(p); g_dev_bytes.fetch_sub(cap, std::memory_order_relaxed); } p = nullptr; cap = 0; }
     template <class T> T* as() { return reinterpret_cast<T*>(p); }
 };
 
@@ -258,7 +260,33 @@ struct Engine {
     DevBuf vm_flag;
     size_t vm_lines_max = (size_t)1 << 15;                                // launches with <= this many pairs use the 16-lanes-per-pair VM line kernel (measured crossover)
     size_t gls_split_max = (size_t)1 << 14;                               // rounds with <= this many outputs use the 4-lane GLS fold
-    size_t max_pairs_per_batch = (size_t)1 << 19;                        // lines buffer cap: 2^19 pairs * 19.6 KB = 10.3 GB
+    size_t max_pairs_per_batch = (size_t)1 << 19;                        // lines buffer cap: 2^19 pairs * 19.6 KB = 10.3 GB (pairs_cap() lowers it when the device is short of memory)
+    // ---- memory-aware degradation (ripp_config.mem_cap_bytes) --------------------------------------------------------------
+    // The optional structures of a large proof are sized against what the device can still give: the line buffer first (without it nothing runs:
+    // pairs_cap halves the batch until it fits), then the round-0 fold tables (13.6 KB per element in the three-quarter form: job_precompute_round0
+    // steps down to half-vector tables of four multiples, then to the two pre-doubled bases, then to nothing), the in-round G2 tables
+    // (fold_g2_table_pays).  Every tier computes the same group elements.  mem_cap = 0: what hipMemGetInfo reports free, less a margin.
+    size_t mem_cap = 0;
+    int mem_tier = 0;                     // the deepest fall-back this call took: 0 none, 1 half-vector tables, 2 pre-doubled bases only, 3 no round-0 precomputation; +8: the line buffer was cut
+    bool mem_fits(size_t need, size_t held) const {
+        if (need <= held) return true;
+        const size_t extra = need - held;
+        if (mem_cap) return g_dev_bytes.load(std::memory_order_relaxed) + extra <= mem_cap;
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess) return true;
+        return extra + std::max<size_t>((size_t)2 << 30, tot / 50) <= fr;
+    }
+    // pairs one launch may take through the line buffer (<= want): probes the device only when the buffer would have to grow
+    size_t pairs_cap(size_t want) {
+        want = std::max<size_t>(1, std::min(want, max_pairs_per_batch));
+        const size_t per = (size_t)N_LINES * LINE_CHUNKS * sizeof(uint4);
+        auto bytes = [per](size_t pairs) { return ((pairs + 63) & ~(size_t)63) * per + 8 * 64 * per; };      // (+ the stride rounding of up to MAX_PRODUCTS products)
+        if (bytes(want) <= lines.cap) return want;
+        size_t w = want;
+        while (w > 4096 && !mem_fits(bytes(w), lines.cap)) w = (w + 1) / 2;
+        if (w < want) mem_tier |= 8;
+        return w;
+    }
     ripp_stats stats{};
     // A second set of streams and scratch on the SAME device: two independent latency-bound provers of one call (aggregate_proofs' TIPP and
     // TIPAWithSSM sub-proofs) run side by side, each driven by its own host thread, instead of taking turns waiting for host and device.
@@ -277,6 +305,7 @@ struct Engine {
     // the hash-window look-ahead plan and a few whole-call choices (ripp_config: look_eighths, ranks_per_device, look_static, quiet_waits, agg_sequential, scale_no_fq)
     double cal_ms_per_pair = 0, cal_hash_bytes_per_ms = 0;        // look_plan's rates as measured by the last large proof of this process (0: not yet)
     int look_eighths = -1; double ranks_per_device = 1.0; bool look_static = false, quiet_waits_cfg = false, agg_sequential = false, scale_no_fq = false;
+    int hot_workers_cfg = 0;               // 0 automatic, 1 always, 2 never (ripp_config.hot_workers / RIPP_HOT_WORKERS)
     // Precedence: built-in defaults < ripp_configure() < environment variables (a debug / A-B override).  This function is the ONLY place of the
     // library that reads RIPP_* configuration from the environment (RIPP_TRACE aside), once per C-ABI call (get_engine) -- never inside a proof.
     void refresh_switches() {
@@ -284,13 +313,14 @@ struct Engine {
         vm_lines_max = defaults.vm_lines_max; vm_fold_max = defaults.vm_fold_max; vm_tree_max = defaults.vm_tree_max; gls_split_max = defaults.gls_split_max;
         msm_vm_merge_max = defaults.msm_vm_merge_max; fold_tab_min = defaults.fold_tab_min; fq_min = defaults.fq_min; lp_fq_min = defaults.lp_fq_min; vm_joint_max = defaults.vm_joint_max;
         vm_scale_max = defaults.vm_scale_max; tail_pipe_max = defaults.tail_pipe_max; ml_fq_min = defaults.ml_fq_min; fq_min_g1 = defaults.fq_min_g1; msm_lds_sort_min = defaults.msm_lds_sort_min; msm_chunk_min = defaults.msm_chunk_min;
-        sw = Switches(); look_eighths = -1; ranks_per_device = 1.0; look_static = quiet_waits_cfg = agg_sequential = scale_no_fq = false;
+        sw = Switches(); look_eighths = -1; ranks_per_device = 1.0; look_static = quiet_waits_cfg = agg_sequential = scale_no_fq = false; mem_cap = 0; hot_workers_cfg = 0;
         if (g_cfg_set) {
             const ripp_config& c = g_cfg;
             sw.no_vm = c.no_vm; sw.no_precompute = c.no_precompute; sw.no_fold_tables = c.no_fold_tables; sw.no_msm_glv = c.no_msm_glv; sw.lp_one_lane = c.lp_one_lane;
             sw.no_endo = c.no_endo; sw.no_fq = c.no_fq; sw.no_xscale = c.no_xscale; sw.no_share = c.no_share; sw.no_fuse = c.no_fuse; sw.fuse_tables = c.fuse_tables; scale_no_fq = c.scale_no_fq; agg_sequential = c.agg_sequential; look_static = c.look_static; quiet_waits_cfg = c.quiet_waits;
             look_eighths = c.look_eighths; ranks_per_device = c.ranks_per_device > 1 ? (double)c.ranks_per_device : 1.0;
             msm_tune.c = c.msm_c; msm_tune.ch = c.msm_ch; msm_tune.gmin = c.msm_gmin; sw.no_prebuild = c.no_prebuild;
+            mem_cap = (size_t)c.mem_cap_bytes; hot_workers_cfg = (int)c.hot_workers; sw.no_job_cache = c.no_job_cache != 0;
             vm_lines_max = c.vm_lines_max; vm_fold_max = c.vm_fold_max; vm_tree_max = c.vm_tree_max; gls_split_max = c.gls_split_max; msm_vm_merge_max = c.msm_vm_merge_max; fold_tab_min = c.fold_tab_min;
             fq_min = c.fq_min; lp_fq_min = c.lp_fq_min; vm_joint_max = c.vm_joint_max; vm_scale_max = c.vm_scale_max; tail_pipe_max = c.tail_pipe_max; ml_fq_min = c.ml_fq_min; fq_min_g1 = c.fq_min_g1; msm_lds_sort_min = c.msm_lds_sort_min; msm_chunk_min = c.msm_chunk_min;
         }
@@ -308,7 +338,9 @@ struct Engine {
         env_on("RIPP_NO_XSCALE", sw.no_xscale);        // G2 folds always on the plain vector with the full-width x^-1
         env_on("RIPP_NO_FQ", sw.no_fq);                // the 12 x 32-bit forms of the kernels that have a carry-free twin (fq_curve.hpp)
         env_on("RIPP_FUSE_TABLES", sw.fuse_tables);    // build the three-quarter tables whatever the look-ahead plan (tests: round 0 then folds ALONE over them when x1 is late)
-        env_on("RIPP_NO_JOB_CACHE", sw.no_job_cache);  // (A/B only, not in ripp_config: an allocator cache, not a form of the computation) one-shot proofs allocate and free their job buffers per call
+        env_on("RIPP_NO_JOB_CACHE", sw.no_job_cache);  // one-shot proofs allocate and free their job buffers per call (ripp_config.no_job_cache)
+        env_sz("RIPP_MEM_CAP_BYTES", mem_cap);         // device memory the library may hold (ripp_config.mem_cap_bytes; 0 = automatic)
+        if (const char* s = std::getenv("RIPP_HOT_WORKERS")) hot_workers_cfg = std::atoi(s) ? 1 : 2;
         env_on("RIPP_NO_PREBUILD", sw.no_prebuild);    // in-round G2 fold tables after the challenge (fold_g2_table), not in the host phase before it (job_prebuild_g2_tables)
         env_on("RIPP_NO_FUSE", sw.no_fuse);            // rounds 0 and 1 always fold one after the other (no three-quarter tables, no job_fold_fused)
         env_on("RIPP_NO_SHARE", sw.no_share);          // every pairing product walks its own G2 chain (no ChainSets grouping, no merged round 0 + look-ahead)
@@ -622,7 +654,7 @@ struct Engine {
         int32_t rc;
         if ((rc = ensure_pinned_rows(nrows)) != RIPP_OK) return rc;
         if (nprod > MAX_PRODUCTS) return RIPP_ERR_ARG;
-        const size_t batch = std::min(M, std::max<size_t>(1, max_pairs_per_batch / nprod));
+        const size_t batch = std::min(M, std::max<size_t>(1, pairs_cap(std::min(max_pairs_per_batch, M * (size_t)nprod)) / nprod));
         for (size_t off = 0; off < M; off += batch) {
             const size_t m = std::min(batch, M - off);
             if ((rc = enqueue_products(a, b, nprod, off, m, pinned_rows)) != RIPP_OK) return rc;
@@ -974,7 +1006,12 @@ int32_t job_round_partials(Engine* e, ripp_sipp_job* j, Fp12* rows /* [2][68] */
     return rc;
 }
 
-bool fold_g2_table_pays(const Engine* e, size_t half) { return half >= e->fold_tab_min && half > e->gls_split_max && !e->sw.no_fold_tables; }
+bool fold_g2_table_pays(const Engine* e, size_t half) {
+    if (!(half >= e->fold_tab_min && half > e->gls_split_max && !e->sw.no_fold_tables)) return false;
+    // (M + 4 M) affine rows + (M - 1) Jacobian rows per element, M = 4 (fold_g2_table_build): only where the device can hold them
+    const size_t need = half * (5 * 4 * sizeof(G2A) + 3 * sizeof(G2J)), held = e->fold_mult.cap + e->fold_tab.cap + e->fold_jac2.cap;
+    return need <= held || e->mem_fits(need, held);
+}
 // rounds whose G2 fold runs on the x-scaled vector (see ripp_sipp_job::bs): the table folds of a proof driven by sipp_prove_core (every rank of a
 // sharded proof scales ITS shard: z^bs -> z is a homomorphism, so the ranks' corrected partial values multiply to the same group element)
 bool xscale_round(const Engine* e, const ripp_sipp_job* j, size_t half) {
@@ -1013,9 +1050,29 @@ int32_t job_precompute_round0(Engine* e, ripp_sipp_job* j, bool fuse = false) {
     const size_t half = j->len / 2, q = j->len / 4;
     if (half < ((size_t)1 << 16) || j->digest_ready.load() || j->no_window || e->sw.no_precompute) return RIPP_OK;
     int32_t rc;
-    const bool tables = !e->sw.no_fold_tables;
-    if ((rc = j->a_pow.reserve(half * sizeof(G1A))) || (rc = j->b_pow.reserve(half * sizeof(G2A))) || (rc = j->jac1.reserve(half * sizeof(G1J))) || (rc = j->jac2.reserve(half * sizeof(G2J)))) return rc;
+    bool tables = !e->sw.no_fold_tables;
     j->tab_ready = false; j->tab_fused = false;
+    // What the device can hold decides the form (Engine::mem_fits; every form folds to the same group elements):
+    //   three-quarter tables, 4 multiples (13.6 KB per element of the vector)  >  half-vector tables, FOLD_TAB_M multiples (18.4 KB; the plan without
+    //   a fused fold)  >  half-vector tables, 4 multiples (9.1 KB)  >  the two pre-doubled bases (0.43 KB)  >  nothing (the folds run their full chains)
+    auto tab_bytes = [](size_t M, size_t cnt) { return cnt * (4 * M * (sizeof(G1A) + sizeof(G2A)) + 16 * M * sizeof(G2A) + (M - 1) * (sizeof(G1J) + sizeof(G2J)) + 4) + 65536; };
+    const size_t tab_held = e->fold_tab1.cap + e->fold_mult.cap + e->fold_tab.cap + e->fold_jac1.cap + e->fold_jac2.cap + e->fix_flags.cap;
+    size_t M_half = FOLD_TAB_M;
+    if (tables) {
+        const bool want_fuse = fuse && xscale_round(e, j, half) && !e->sw.no_fq && !e->sw.no_fuse && q >= e->fq_min;
+        if (want_fuse && !e->mem_fits(tab_bytes(4, 3 * q), tab_held)) { fuse = false; e->mem_tier = std::max(e->mem_tier & 7, 1) | (e->mem_tier & 8); }
+        if (!(want_fuse && fuse)) {
+            if (!e->mem_fits(tab_bytes(M_half, half), tab_held)) { M_half = 4; e->mem_tier = std::max(e->mem_tier & 7, 1) | (e->mem_tier & 8); }
+            if (!e->mem_fits(tab_bytes(M_half, half), tab_held)) { tables = false; e->mem_tier = std::max(e->mem_tier & 7, 2) | (e->mem_tier & 8); }
+        }
+    }
+    if (!tables && !e->mem_fits(half * (sizeof(G1A) + sizeof(G2A) + sizeof(G1J) + sizeof(G2J)), j->a_pow.cap + j->b_pow.cap + j->jac1.cap + j->jac2.cap)) {
+        e->mem_tier = 3 | (e->mem_tier & 8);
+        if (trace_on()) fprintf(stderr, "[ripp] round-0 precomputation skipped: the device is short of memory\n");
+        return RIPP_OK;
+    }
+    if (trace_on() && (e->mem_tier & 7)) fprintf(stderr, "[ripp] round-0 tables: memory tier %d (%s)\n", e->mem_tier & 7, tables ? "half-vector tables" : "pre-doubled bases only");
+    if ((rc = j->a_pow.reserve(half * sizeof(G1A))) || (rc = j->b_pow.reserve(half * sizeof(G2A))) || (rc = j->jac1.reserve(half * sizeof(G1J))) || (rc = j->jac2.reserve(half * sizeof(G2J)))) return rc;
     if (!tables) {                                              // two-base form: 2^64 a_r, 2^32 b_r
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pow2_mul<Fp>), dim3(nblk(half, 256)), dim3(256), 0, e->stream, j->a.as<G1A>() + half, (uint32_t)half, 64, j->jac1.as<G1J>());
         HIPCHK(hipGetLastError());
@@ -1030,7 +1087,7 @@ int32_t job_precompute_round0(Engine* e, ripp_sipp_job* j, bool fuse = false) {
     // tab1 / mult2 hold [M b + m][cnt]; row M b is base b itself, written by the doubling chain's normalisation.
     j->tab_on_lo = xscale_round(e, j, half);                    // scaled fold: x multiplies the LOW half
     fuse = fuse && j->tab_on_lo && !e->sw.no_fq && !e->sw.no_fuse && q >= e->fq_min;
-    const size_t M = fuse ? 4 : FOLD_TAB_M;
+    const size_t M = fuse ? 4 : M_half;
     const size_t cnt = fuse ? 3 * q : half;
     const size_t qstride = (cnt + 63) & ~(size_t)63;
     const size_t njt = (M - 1) * cnt;
@@ -1331,7 +1388,7 @@ extern "C" {
 #define ENGINE Engine* e; { int32_t rc_ = get_engine(&e); if (rc_ != RIPP_OK) return rc_; }
 
 API const char* ripp_last_error(void) { return g_err.c_str(); }
-static_assert(sizeof(ripp_stats) == 22 * 8, "ripp_stats changed: bump RIPP_ABI_VERSION (include/ripp_hip.h) and the bindings (ripp_amd/_lib.py, rust/ripp-hip/src/ffi.rs)");
+static_assert(sizeof(ripp_stats) == 24 * 8, "ripp_stats changed: bump RIPP_ABI_VERSION (include/ripp_hip.h) and the bindings (ripp_amd/_lib.py, rust/ripp-hip/src/ffi.rs)");
 API int32_t ripp_abi_version(void) { return RIPP_ABI_VERSION; }
 API size_t ripp_stats_size(void) { return sizeof(ripp_stats); }
 API void ripp_statement_hash_times(double* hash_ms, double* wait_ms) { if (hash_ms) *hash_ms = g_digest_hash_ms; if (wait_ms) *wait_ms = g_digest_wait_ms; }
@@ -1944,7 +2001,7 @@ static int32_t job_lookahead(Engine* e, ripp_sipp_job* j, int eighths, bool forc
     for (int it = first_item; it < items; ++it) {
         const int R = it / 2 + 1, side = it & 1;
         const size_t qblk = len >> (R + 1);
-        if (qblk == 0 || qblk > e->max_pairs_per_batch) break;
+        if (qblk == 0 || qblk > e->pairs_cap(std::min(e->max_pairs_per_batch, qblk * (size_t)MAX_PRODUCTS))) break;
         int frac = std::min(8, eighths - 8 * it);                        // static plan: the last item may be partial (the first frac/8 of every block's pairs)
         if (adaptive || by_deadline) {
             if (qblk < 1024) break;
@@ -1957,12 +2014,28 @@ static int32_t job_lookahead(Engine* e, ripp_sipp_job* j, int eighths, bool forc
             // the extrapolation is only trusted inside what a sequential Blake2s can plausibly need in total (0.9 - 1.25 GB/s): a progress counter that
             // lags (the hash thread descheduled, a burst of serialisation waits) must not make the window look longer than it can be
             if (adaptive) room = std::min(room, (double)j->hash_total / 0.9e6 - elapsed);
-            const double cost = (double)qblk * (double)((size_t)1 << (2 * R)) * std::max(ms_per_pair, 5.0e-5);
+            // Cost of the item over q pairs per block: 4^R products of q pairs at the measured pairing rate -- or, when its launches leave stage 1
+            // under-occupied (few chains, each walked for 2^R line sets: a lone wave needs ~3.5 ms + 0.3 ms per line set, up to MAX_SHARE of them, per launch whatever q is), that floor per
+            // launch plus the rest of the pipeline (58 % of a pair evaluation).  Measured with recorded peers (profiles/r05_rank0_of_{2,8}_timeline.txt): item
+            // (3,l) on 8 192-pair blocks took 59 ms where the rate alone says 37; 11/32 of it on 32 768-pair blocks 62 ms instead of 46 -- the overrun of
+            // the two-rank window in build round 4's plan.
+            const double mpp = std::max(ms_per_pair, 5.0e-5), nprod = (double)((size_t)1 << (2 * R));
+            auto item_cost = [&](size_t qq) {
+                const size_t per_launch = std::min<size_t>(MAX_PRODUCTS, std::max<size_t>(1, e->max_pairs_per_batch / std::max<size_t>(qq, 1)));
+                const double launches = std::ceil(nprod / (double)per_launch), var = nprod * (double)qq * mpp;
+                return std::max(var, launches * (3.5 + 0.3 * (double)std::min(1 << R, (int)MAX_SHARE)) + 0.58 * var);
+            };
+            const double cost = item_cost(qblk);
             if (trace_on() && adaptive) fprintf(stderr, "[ripp] look-ahead item (%d,%c): hash %.0f %% after %.1f ms, room %.1f ms, item %.1f ms\n", R, side ? 'r' : 'l', 100.0 * (double)done / (double)j->hash_total, elapsed, room, cost);
             if (trace_on() && by_deadline) fprintf(stderr, "[ripp] rank %d look-ahead item (%d,%c): %.1f ms to rank 0's expected digest, item %.1f ms\n", j->rank, R, side ? 'r' : 'l', room, cost);
             if (room <= 0) break;                                        // the window is over (or the clamp above says it must be): nothing more fits
-            frac = room >= cost ? 8 : -(int)(32.0 * room / cost);        // adaptive: 32nds (negative = in 32nds)
-            if (frac < 0 && frac > -6) break;
+            if (room >= cost) frac = 8;
+            else {                                                       // adaptive: the 32nds of the blocks that still fit (negative = in 32nds)
+                int f32 = (int)(32.0 * room / cost);
+                while (f32 > 0 && item_cost((qblk * (size_t)f32 / 32) & ~(size_t)63) > room) --f32;
+                frac = -f32;
+            }
+            if (frac <= 0 && frac > -6) break;
         }
         const size_t q = frac >= 8 ? qblk : frac < 0 ? (qblk * (size_t)(-frac) / 32) & ~(size_t)63 : (qblk * (size_t)frac / 8) & ~(size_t)63;
         if (q == 0) break;
@@ -1977,7 +2050,7 @@ static int32_t job_lookahead(Engine* e, ripp_sipp_job* j, int eighths, bool forc
             prods.push_back({a + ia * qblk, b + ib * qblk, g});
         }
         std::vector<Fp12> grows((size_t)ngroups * N_LINES); std::vector<char> gset((size_t)ngroups, 0);
-        const size_t cmax = std::min<size_t>(MAX_PRODUCTS, std::max<size_t>(1, e->max_pairs_per_batch / q));
+        const size_t cmax = std::min<size_t>(MAX_PRODUCTS, std::max<size_t>(1, e->pairs_cap(std::min(e->max_pairs_per_batch, q * (size_t)MAX_PRODUCTS)) / q));
         const size_t nch = (prods.size() + cmax - 1) / cmax;
         auto absorb = [&](size_t c) -> int32_t {                 // chunk c's per-step values into their groups (the device is busy with chunk c + 1)
             PinBuf& buf = j->look_rows[c & 1];
@@ -2100,6 +2173,7 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
     const double t_start = now_ms();
     double exchange_ms = 0;
     comm_mark_proof();
+    e->mem_tier = 0;
     // whatever the exit path -- the plan exchange below included: nothing enqueued by this proof may still be running when the caller gets control
     // back (engine scratch, tp_rows and the job's vectors are reused by the next call), no prepared state may leak into the next proof, and the hash
     // thread, which reads the CALLER's buffers (borrowed statement), is never left running behind a return.  Constructed BEFORE the thread starts.
@@ -2270,7 +2344,7 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
         if (!j->seeded) {
             j->rng.from_digest(j->digest); j->seeded = true;
             e->quiet_waits = false;
-            host_pool().set_hot(hot_workers_pay(world0));      // the remaining rounds hand 0.1-0.6 ms tasks to the workers every ~2 ms
+            host_pool().set_hot(e->hot_workers_cfg ? e->hot_workers_cfg == 1 : hot_workers_pay(world0));      // the remaining rounds hand 0.1-0.6 ms tasks to the workers every ~2 ms
         }
         const Fr x = fs::sipp_challenge(j->rng, zl, zr);
         x_prev = x;
@@ -2306,6 +2380,7 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
     if ((rc = e->sync())) return rc; HIPCHK(hipStreamSynchronize(e->stream2)); HIPCHK(hipStreamSynchronize(e->stream3));      // the pipelined tail does not wait for its folds
     e->collect_kernel_stats();
     e->stats.exchange_ms = exchange_ms;
+    e->stats.mem_tier = (uint64_t)e->mem_tier; e->stats.device_bytes = g_dev_bytes.load();
     e->stats.statement_hash_ms = window ? g_digest_hash_ms : 0; e->stats.statement_hash_wait_ms = window ? g_digest_wait_ms : 0;      // this call's hash (the thread has been joined)
     if (window && j->hash_total >= ((uint64_t)336 << 16) && g_digest_hash_ms + g_digest_wait_ms > 1.0) e->cal_hash_bytes_per_ms = (double)j->hash_total / (g_digest_hash_ms + g_digest_wait_ms);
     e->stats.total_ms = now_ms() - t_start;
@@ -2321,6 +2396,7 @@ static void config_from_engine(const Engine* e, ripp_config* c) {
     c->look_eighths = e->look_eighths; c->ranks_per_device = (int32_t)e->ranks_per_device; c->msm_c = e->msm_tune.c; c->msm_ch = e->msm_tune.ch; c->msm_gmin = e->msm_tune.gmin; c->no_prebuild = e->sw.no_prebuild;
     c->vm_lines_max = e->vm_lines_max; c->vm_fold_max = e->vm_fold_max; c->vm_tree_max = e->vm_tree_max; c->gls_split_max = e->gls_split_max; c->msm_vm_merge_max = e->msm_vm_merge_max; c->fold_tab_min = e->fold_tab_min;
     c->fq_min = e->fq_min; c->lp_fq_min = e->lp_fq_min; c->vm_joint_max = e->vm_joint_max; c->vm_scale_max = e->vm_scale_max; c->tail_pipe_max = e->tail_pipe_max; c->ml_fq_min = e->ml_fq_min; c->fq_min_g1 = e->fq_min_g1; c->msm_lds_sort_min = e->msm_lds_sort_min; c->msm_chunk_min = e->msm_chunk_min;
+    c->mem_cap_bytes = e->mem_cap; c->hot_workers = (uint32_t)e->hot_workers_cfg; c->no_job_cache = e->sw.no_job_cache;
 }
 API int32_t ripp_config_default(ripp_config* cfg) {            // the built-in defaults of this build (needs no device: a throw-away Engine object is never initialised)
     if (!cfg) return RIPP_ERR_ARG;

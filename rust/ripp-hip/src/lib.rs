@@ -4,6 +4,8 @@
 //! * `DoublyHomomorphicCommitment` (dh_commitments/src/lib.rs:20-55): `HipAFGHOCommitmentG1/G2`, `HipPedersenCommitmentG1/G2`
 //! * `TIPACompatibleSetup` (ip_proofs/src/tipa/mod.rs:25-29) for all of them
 //! * `sipp`: `hip_sipp_prove` / `hip_sipp_verify` / `hip_product_of_pairings[_with_coeffs]` (sipp/src/lib.rs:42-224)
+//! * `fused`: the library's one-call provers returning the REFERENCE's proof types -- `hip_tipa_prove_with_srs_shift`, `hip_tipa_ssm_prove`,
+//!   `hip_aggregate_proofs[_sharded]`, the verifiers, `HipSrs`, `HipVec`, `HipSippJob`, `hip_sipp_prove_sharded` (fused.rs)
 //!
 //! GIPA / TIPA are generic over the two traits (ip_proofs/src/gipa.rs:79-96), so
 //! `GIPA<HipPairingInnerProduct, HipAFGHOCommitmentG1, HipAFGHOCommitmentG2, IdentityCommitment<..>, Blake2b>` runs every pairing
@@ -12,6 +14,8 @@
 #![cfg(feature = "ffi")]
 pub mod convert;
 pub mod ffi;
+pub mod fused;
+pub use fused::*;
 
 use ark_bls12_381::{Bls12_381, Fr, G1Affine, G1Projective, G2Affine, G2Projective};
 use ark_dh_commitments::{random_generators, DoublyHomomorphicCommitment};
@@ -172,6 +176,31 @@ mod tests {
         assert_eq!(HipMultiexpInnerProductG1::inner_product(&l, &s).unwrap(), ark_inner_products::MultiexponentiationInnerProduct::<G1Projective>::inner_product(&l, &s).unwrap());
         assert_eq!(HipMultiexpInnerProductG2::inner_product(&r, &s).unwrap(), ark_inner_products::MultiexponentiationInnerProduct::<G2Projective>::inner_product(&r, &s).unwrap());
         assert!(HipPairingInnerProduct::inner_product(&l[..5], &r[..4]).is_err());
+    }
+
+    /// the fused TIPA prover's proof is a `TIPAProof` of the reference and its UNMODIFIED verifier accepts it (tipa/mod.rs:242-301; the test
+    /// mirrors ip_proofs/src/tipa/mod.rs `pairing_inner_product_test`)
+    #[test]
+    fn fused_tipa_proof_is_accepted_by_the_reference_verifier() {
+        use ark_dh_commitments::afgho16::{AFGHOCommitmentG1, AFGHOCommitmentG2};
+        use ark_inner_products::PairingInnerProduct;
+        use ark_ip_proofs::tipa::TIPA;
+        type RefIPC = IdentityCommitment<PairingOutput<Bls12_381>, Fr>;
+        type RefTIPA = TIPA<PairingInnerProduct<Bls12_381>, AFGHOCommitmentG1<Bls12_381>, AFGHOCommitmentG2<Bls12_381>, RefIPC, Bls12_381, Blake2b>;
+        let mut rng = StdRng::seed_from_u64(0u64);
+        let (srs, ck_t) = RefTIPA::setup(&mut rng, TEST_SIZE).unwrap();
+        let (ck_a, ck_b) = srs.get_commitment_keys();
+        let v_srs = srs.get_verifier_key();
+        let m_a: Vec<G1Projective> = random_generators(&mut rng, TEST_SIZE);
+        let m_b: Vec<G2Projective> = random_generators(&mut rng, TEST_SIZE);
+        let com_a = HipAFGHOCommitmentG1::commit(&ck_a, &m_a).unwrap();
+        let com_b = HipAFGHOCommitmentG2::commit(&ck_b, &m_b).unwrap();
+        let t = vec![HipPairingInnerProduct::inner_product(&m_a, &m_b).unwrap()];
+        let com_t = RefIPC::commit(&vec![ck_t.clone()], &t).unwrap();
+        let hsrs = HipSrs::new(&srs).unwrap();
+        let proof = hip_tipa_prove(&hsrs, (&m_a, &m_b), (&ck_a, &ck_b)).unwrap();
+        assert!(RefTIPA::verify(&v_srs, &ck_t, (&com_a, &com_b, &com_t), &proof).unwrap());
+        assert!(hip_tipa_verify_with_srs_shift(&v_srs, (&com_a, &com_b, &com_t.0[0]), &proof, &ark_ff::One::one()).unwrap());
     }
 
     #[test]

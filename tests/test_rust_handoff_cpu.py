@@ -9,7 +9,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RUST = os.path.join(ROOT, "rust", "ripp-hip")
-FILES = ["examples/dump_kat.rs", "examples/dump_kat_377.rs", "src/lib.rs", "src/convert.rs", "src/ffi.rs"]
+FILES = ["examples/dump_kat.rs", "examples/dump_kat_377.rs", "src/lib.rs", "src/convert.rs", "src/ffi.rs", "src/fused.rs"]
 REF = "/root/reference"
 
 # fields that are private / pub(crate) in the reference: sipp::Proof (sipp/src/lib.rs:32-34), GIPAProof / GIPAAux (gipa.rs:24-77: pub(crate)),
