@@ -75,6 +75,9 @@ int32_t ripp_device_count(void);
  * ripp_release_scratch frees the engine's grow-only scratch (line buffer, fold tables, MSM scratch: ~19 GB after an n = 2^20 proof);
  * the next call re-allocates what it needs. */
 int32_t ripp_release_scratch(void);
+/* device memory the library holds right now through its own buffers (scratch, tables, job / SRS / vector handles): the quantity
+ * ripp_config.mem_cap_bytes bounds and ripp_stats.device_bytes reports at the end of a proof */
+size_t  ripp_device_bytes(void);
 const char* ripp_last_error(void);   /* message of the calling thread's last failed call (thread-local, errno-style) */
 
 /* ---- configuration (no counterpart in the reference: its tuning knobs are cargo features and rayon's thread count) --------------------------
@@ -173,7 +176,10 @@ int32_t ripp_vec_fold(const ripp_vec* hi, const ripp_vec* lo, const ripp_fr* s, 
 
 /* ---- SIPP prover  -- SIPP::<Bls12_381, Blake2s>::prove, sipp/src/lib.rs:42-106 ---------------------------- */
 /* proof: 2*log2(n) GT elements, (z_l, z_r) per round in round order (Proof::gt_elems, sipp/src/lib.rs:32-34).
- * challenges (optional, may be NULL): log2(n) Fr values x of sipp/src/lib.rs:85. */
+ * challenges (optional, may be NULL): log2(n) Fr values x of sipp/src/lib.rs:85.
+ * RETENTION: a one-shot call parks its job buffers (~1 KB of device memory per element and four pinned row buffers: ~1 GB after an n = 2^20
+ * proof) for the next one-shot call, beside the engine's grow-only scratch (line buffer, fold tables: ~19 GB at n = 2^20).  ripp_release_scratch
+ * / ripp_shutdown free both; ripp_config.no_job_cache turns the parking off; ripp_config.mem_cap_bytes bounds the total. */
 int32_t ripp_sipp_prove(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr* r, size_t n, const ripp_gt* value,
                         ripp_gt* proof, ripp_fr* challenges, ripp_stats* stats);
 /* SIPP::verify, sipp/src/lib.rs:109-180.  *accept = 1/0. */
@@ -250,6 +256,8 @@ int32_t ripp_msm_g1_sharded_j(const ripp_g1j* bases, size_t nl, const ripp_fr* s
 int32_t ripp_msm_g2_sharded_j(const ripp_g2j* bases, size_t nl, const ripp_fr* scalars, size_t nr, ripp_g2j* out);
 /* SIPP::prove (sipp/src/lib.rs:42-106) across the communicator: a, b, r = this rank's shard (local j <-> global j * world + rank).
  * Rank 0 passes the full statement (hashed on a host thread while round 0 runs) or its precomputed digest; other ranks pass NULL. */
+/* Argument errors (NULL pointers, a shard size that is no power of two, rank 0 with neither statement nor digest) are returned before the first
+ * exchange and must be symmetric across ranks; every later failure of one rank travels with its next message and makes ALL ranks return non-zero. */
 int32_t ripp_sipp_prove_sharded(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr* r, size_t n_local, const ripp_gt* value,
                                 const ripp_g1a* full_a, const ripp_g2a* full_b, const ripp_fr* full_r, const uint8_t* seed_digest,
                                 ripp_gt* proof, ripp_fr* challenges, ripp_stats* stats);

@@ -117,7 +117,7 @@ def load_library(path):
         raise RuntimeError(f"{path}: ABI mismatch (this binding: version {RIPP_ABI_VERSION}, ripp_stats of {ctypes.sizeof(RippStats)} bytes); rebuild the library")
     L.ripp_last_error.restype = ctypes.c_char_p
     L.ripp_test_inject_failure.restype = None
-    for name in ("ripp_ser_gt", "ripp_ser_g1", "ripp_ser_g2", "ripp_ser_fr", "ripp_sipp_job_rounds_left", "ripp_sipp_job_local_len", "ripp_vec_len"):
+    for name in ("ripp_ser_gt", "ripp_ser_g1", "ripp_ser_g2", "ripp_ser_fr", "ripp_sipp_job_rounds_left", "ripp_sipp_job_local_len", "ripp_vec_len", "ripp_device_bytes"):
         getattr(L, name).restype = ctypes.c_size_t
     L.ripp_vec_free.restype = None; L.ripp_vec_free.argtypes = [ctypes.c_void_p]
     L.ripp_statement_hash_times.restype = None

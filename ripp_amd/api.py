@@ -93,6 +93,16 @@ def device_count():
     return int(lib().ripp_device_count())
 
 
+def release_scratch():
+    """ripp_release_scratch: free the engine's grow-only scratch (line buffer, fold tables, MSM scratch, parked one-shot buffers)."""
+    _check(lib().ripp_release_scratch())
+
+
+def device_bytes():
+    """ripp_device_bytes: device memory the library holds right now (what ripp_config.mem_cap_bytes bounds)."""
+    return int(lib().ripp_device_bytes())
+
+
 # ------------------------------------------------------------------ InnerProduct implementations
 # ------------------------------------------------------------------ device-resident vectors (ripp_vec_*, SURVEY.md section 8b)
 _FP_ONE = None

@@ -177,11 +177,13 @@ struct DevBuf {
 // steps of 10 ms (measured on the n = 2^13..2^14 SIPP verifier: 13.7 ms became 30-50 ms; tools/kdev/verify_lat2.py).
 struct PinBuf {
     void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool pending = false;
-    bool blocking = false;               // set before the first reserve(): waits SLEEP instead of spinning (buffers that are only waited for while the statement hash runs)
+    bool blocking = false;               // set before reserve(): waits SLEEP instead of spinning (buffers that are only waited for while the statement hash runs)
+    bool ev_blocking = false;            // the flag `ev` was created with
     int32_t wait() { if (pending) { HIPCHK(hipEventSynchronize(ev)); pending = false; } return RIPP_OK; }      // the previous copy out of this buffer has landed
     int32_t reserve(size_t bytes) {
         int32_t rc = wait(); if (rc) return rc;
-        if (!ev) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming | (blocking ? hipEventBlockingSync : 0)));
+        if (ev && ev_blocking != blocking) { (void)hipEventDestroy(ev); ev = nullptr; }      // (a parked buffer adopted by a call that waits differently)
+        if (!ev) { HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming | (blocking ? hipEventBlockingSync : 0))); ev_blocking = blocking; }
         if (bytes <= cap) return RIPP_OK;
         if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
         HIPCHK(hipHostMalloc(&p, bytes, hipHostMallocDefault)); cap = bytes; return RIPP_OK;
@@ -1428,6 +1430,9 @@ API int32_t ripp_release_scratch(void) {
     if (e->aux) { e->aux->destroy(); delete e->aux; e->aux = nullptr; }
     return RIPP_OK;
 }
+
+// device memory the library holds right now through its own buffers (scratch, tables, jobs, SRS / vector handles): what ripp_config.mem_cap_bytes bounds
+API size_t ripp_device_bytes(void) { return g_dev_bytes.load(std::memory_order_relaxed); }
 
 // ---- normalisation / scaling / folds on host slices ---------------------------------------------------------
 API int32_t ripp_normalize_g1(const ripp_g1j* in, size_t n, ripp_g1a* out) {

@@ -90,6 +90,7 @@ extern "C" {
     pub fn ripp_shutdown();
     pub fn ripp_device_count() -> i32;
     pub fn ripp_release_scratch() -> i32;
+    pub fn ripp_device_bytes() -> usize;
     pub fn ripp_last_error() -> *const core::ffi::c_char;
     pub fn ripp_config_default(cfg: *mut RippConfig) -> i32;
     pub fn ripp_configure(cfg: *const RippConfig) -> i32;

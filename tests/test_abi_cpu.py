@@ -60,7 +60,9 @@ def test_abi_guard_and_config_defaults_need_no_device(hiplib):
     assert c.struct_size == ctypes.sizeof(RippConfig) and c.look_eighths == -1 and c.ranks_per_device == 1
     assert c.tail_pipe_max == 1 << 11 and c.fold_tab_min == 32768 and c.no_vm == 0 and c.no_precompute == 0 and c.lp_fq_min == 0
     assert c.msm_chunk_min == 1 << 20 and c.msm_lds_sort_min == 0 and c.no_prebuild == 0 and c.fq_min_g1 == 1 << 12       # (members added in build round 4: the layout of the binding follows the header)
-    assert ctypes.sizeof(RippConfig) == 4 * 22 + 8 * 15
+    assert c.mem_cap_bytes == 0 and c.hot_workers == 0 and c.no_job_cache == 0                                              # (build round 5, ABI version 6)
+    assert ctypes.sizeof(RippConfig) == 4 * 22 + 8 * 16 + 4 * 2 and ctypes.sizeof(RippStats) == 24 * 8
+    assert hiplib.ripp_device_bytes() == 0                                                                                  # nothing allocated before the first device call
     bad = RippConfig(); bad.struct_size = 8
     assert hiplib.ripp_configure(ctypes.byref(bad)) == 4             # RIPP_ERR_ARG
     assert hiplib.ripp_configure(ctypes.byref(c)) == 0 and hiplib.ripp_configure(None) == 0

@@ -473,10 +473,11 @@ def test_native_rccl_transport_single_rank(engine):
 
 
 # ---------------------------------------------------------------- sharded GIPA / aggregate_proofs (config 5 across ranks)
-def _agg_worker(rank, world, port, path, ret):
+def _agg_worker(rank, world, port, path, env, ret):
     """One rank of the sharded GIPA / TIPP prover and of ripp_aggregate_proofs_sharded on the instance the parent prepared (`path`);
     hands every output back to the parent."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), RIPP_RANKS_PER_DEVICE=str(world))
+    os.environ.update(env)
     for p in (os.path.dirname(HERE), HERE, os.path.join(HERE, "model")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -505,11 +506,14 @@ def _agg_worker(rank, world, port, path, ret):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,n", [(2, 2), (2, 8), (2, 256), (2, 1 << 14), (4, 4), (4, 8), (4, 256), (4, 1 << 14), (8, 8), (8, 16), (8, 256), (8, 1 << 14)])
-def test_sharded_gipa_and_aggregate(engine, orc, tmp_path, world, n):
+@pytest.mark.parametrize("world,n,env", [(2, 2, {}), (2, 8, {}), (2, 256, {}), (2, 1 << 14, {}), (4, 4, {}), (4, 8, {}), (4, 256, {}), (4, 1 << 14, {}), (8, 8, {}), (8, 16, {}), (8, 256, {}), (8, 1 << 14, {}),
+                                         (2, 256, {"RIPP_AGG_SEQUENTIAL": "1"}), (8, 1 << 14, {"RIPP_AGG_SEQUENTIAL": "1"})])
+def test_sharded_gipa_and_aggregate(engine, orc, tmp_path, world, n, env):
     """ripp_gipa_tipp_prove_sharded / ripp_aggregate_proofs_sharded with 2, 4 and 8 ranks (callback transport on cuda:0; n == world: every rank
     holds ONE proof): commitments of every round, transcripts, base cases, KZG openings and every member of the aggregate -- on EVERY rank --
-    equal the oracle's on the unsharded vectors, and the oracle's verifier accepts.  2^14 is config 5's size (groth16_aggregation.rs:77-160)."""
+    equal the oracle's on the unsharded vectors, and the oracle's verifier accepts.  2^14 is config 5's size (groth16_aggregation.rs:77-160).
+    Default: the TIPP and TIPAWithSSM sub-proofs run SIDE BY SIDE on every rank, their k-th exchanges paired in one all-gather (CommMux, build
+    round 5); RIPP_AGG_SEQUENTIAL=1: one after the other, as in build round 4 -- the same bytes."""
     import helpers as h
     from ripp_amd._lib import AggregateProof
     o = orc
@@ -519,7 +523,7 @@ def test_sharded_gipa_and_aggregate(engine, orc, tmp_path, world, n):
     vk, pub, a, b, c = h.fake_groth16(n, 2, seed=n)
     path = str(tmp_path / "instance.npz")
     np.savez(path, m_a=m_a, m_b=m_b, ck_a=ck_a, ck_b=ck_b, gap=osrs[0], hbp=osrs[1], g_beta=osrs[2], h_alpha=osrs[3], a=a, b=b, c=c)
-    got = _spawn(_agg_worker, world, (path,), timeout=1200)
+    got = _spawn(_agg_worker, world, (path, env), timeout=1200)
     assert sorted(got) == list(range(world))
     rc, esteps, etr, eba, ebb, eka, ekb = o.gipa_tipp_prove(m_a, m_b, ck_a, ck_b)
     assert rc == 0
@@ -575,3 +579,23 @@ def test_bench_ranks_on_one_device_reports_the_hash_excluded_figures(engine, gpu
     assert 0 < out["roofline"]["frac"] <= 1
     assert set(out["look_ahead"]) >= {"items", "pairs"}
     assert "cpu_baseline" not in out                                  # rank 0 at N = 1 only
+
+
+@pytest.mark.gpu
+def test_recorded_peer_transport_one_rank_alone_equals_the_oracle(engine, tmp_path):
+    """Transport "replay" (ripp_comm_record / ripp_comm_init_replay; tools/replay_ranks.py): a two-rank proof is recorded on cuda:0, then rank 0 and
+    rank 1 each prove ALONE with the peer's blocks served from the recording -- two passes each, the second one against the peer's measured gaps.
+    The tool compares every recorded and every replayed proof with the CPU oracle's and fails otherwise."""
+    import json
+    import subprocess
+    out = str(tmp_path / "replay")
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "tools", "replay_ranks.py"), "all", "--world", "2", "--log-n", "13", "--steps", "2", "--warmup", "1",
+                        "--out-dir", out], capture_output=True, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-4000:]
+    passes = json.load(open(os.path.join(out, "w2_n13_passes.json")))
+    assert len(passes) == 4 and all(q["proof_equals_oracle"] and q["replay"]["exchanges_served"] > 0 for q in passes)
+    assert [q["rank"] for q in passes] == [0, 1, 0, 1]
+    # a GT value a rank sends is deterministic: only the plan message (timing fields) may differ from the recording, once per proof
+    assert all(q["replay"]["own_blocks_differing"] <= q["steps"] + q["warmup"] for q in passes), [q["replay"] for q in passes]
+    # the non-hashing rank waited for rank 0's digest in the second pass (rank 0's gaps were known by then)
+    assert passes[1]["replay"]["waited_ms"] > 0
