@@ -91,10 +91,11 @@ def cpu_baseline(log_n_sample, statement=None):
         a, b, r = o.gen_g1(1000, n), o.gen_g2(2000, n), o.gen_scalars(0, n)
         value = o.product_of_pairings_with_coeffs(a, b, r)
     t0 = time.perf_counter()
-    rc, _, _ = o.sipp_prove(a, b, r, value)
+    rc, eproof, _ = o.sipp_prove(a, b, r, value)
     dt = time.perf_counter() - t0
     assert rc == 0
-    out = {"value": n / dt, "unit": "pairs/s", "cores": int(o.lib().orc_num_threads()), "kind": "port",
+    out = {"_proof": eproof if statement is not None and len(statement[0]) == n else None,      # (the oracle's proof of the bench statement itself: compared with the GPU's below)
+           "value": n / dt, "unit": "pairs/s", "cores": int(o.lib().orc_num_threads()), "kind": "port",
            "sample": f"oracle sipp_prove, n=2^{log_n_sample} (the headline statement itself when 20), same synthetic generator (seeds 1000/2000/0), one run of {dt:.2f} s"}
     # the per-core figure BASELINE.md section 2 asks for: the same prover on ONE thread, on a smaller sample of the same statement
     n1 = 1 << min(log_n_sample, 14)
@@ -300,9 +301,17 @@ def main():
         out["post_hash_ms"] = ms_per_step - hash_ms
         out["post_hash_ms_resident"] = resident_ms - sum(st["statement_hash_ms"] + st["statement_hash_wait_ms"] for st in stats_res) / len(stats_res)
         out["look_ahead"] = {"items": int(stats["look_items"]), "pairs": int(stats["look_pairs"]), "order": "(1,l) (1,r) (2,l) (2,r) (3,l) (3,r)"}
+        parity_ok = True
         if world == 1 and args.cpu_log_n > 0:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_log_n, (a, b, r, value))
+            cb = cpu_baseline(args.cpu_log_n, (a, b, r, value))
+            eproof = cb.pop("_proof")
+            if eproof is not None:          # the CPU baseline ran the oracle's prover on the bench statement: a live full-size parity check in every default run
+                parity_ok = bool(np.array_equal(eproof, ref_proof))
+                cb["proof_equals_gpu"] = parity_ok
+            out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
+        if not parity_ok:
+            sys.exit("bench.py: the GPU proof differs from the CPU oracle's proof of the same statement")
     if dist is not None:
         dist.barrier(); comm.close(); dist.destroy_process_group()
 

@@ -55,7 +55,8 @@ typedef struct {
     double statement_hash_ms, statement_hash_wait_ms;
     uint64_t chains_lines;                                            /* G2 chains the carry-free stage-1 kernel walked (<= pairs_lines: products over one Q vector share a chain) */
     /* memory-aware degradation (appended in build round 5): the deepest fall-back the call took -- 0 none, 1 half-vector round-0 tables instead of the
-     * three-quarter / eight-multiple ones, 2 pre-doubled bases only, 3 no round-0 precomputation; +8 when the line buffer (pairs per launch) was cut --
+     * three-quarter / eight-multiple ones, 2 pre-doubled bases only, 3 no round-0 precomputation; +8 when the line buffer (pairs per launch) was cut,
+     * +16 when an in-round G2 table fold ran in the 4-lane split form for lack of room --
      * and the device memory the library holds at the end of the call */
     uint64_t mem_tier, device_bytes;
 } ripp_stats;

@@ -18,7 +18,7 @@ __all__ = ["InnerProductError", "DeviceError", "Vec", "PairingInnerProduct", "Mu
            "PedersenCommitmentG2", "SIPP", "SippJob", "GIPA_TIPP", "SRS", "TIPA_TIPP", "TIPAWithSSM", "aggregate_proofs", "aggregate_proofs_sharded", "gipa_tipp_prove_sharded", "verify_aggregate_proof", "AggregateProof", "ser_tipa_tipp_proof", "de_tipa_tipp_proof", "ser_tipa_ssm_proof", "de_tipa_ssm_proof", "ser_g1_compressed", "ser_g2_compressed", "product_of_pairings", "product_of_pairings_with_coeffs",
            "normalize_batch_g1", "normalize_batch_g2", "fold_g1_affine", "fold_g2_affine", "fold_g1", "fold_g2",
            "scale_g1_affine", "synth_g1", "synth_g2", "synth_fr", "init", "device_count", "final_exponentiation",
-           "ser_gt", "ser_g1", "ser_g2", "ser_fr", "sipp_seed_digest", "gt_mul", "statement_hash_times", "configure", "config_default", "config_get"]
+           "ser_gt", "ser_g1", "ser_g2", "ser_fr", "sipp_seed_digest", "gt_mul", "statement_hash_times", "configure", "config_default", "config_get", "release_scratch", "device_bytes"]
 
 
 class InnerProductError(Exception):

@@ -269,7 +269,7 @@ struct Engine {
     // steps down to half-vector tables of four multiples, then to the two pre-doubled bases, then to nothing), the in-round G2 tables
     // (fold_g2_table_pays).  Every tier computes the same group elements.  mem_cap = 0: what hipMemGetInfo reports free, less a margin.
     size_t mem_cap = 0;
-    int mem_tier = 0;                     // the deepest fall-back this call took: 0 none, 1 half-vector tables, 2 pre-doubled bases only, 3 no round-0 precomputation; +8: the line buffer was cut
+    int mem_tier = 0;                     // the deepest fall-back this call took: 0 none, 1 half-vector tables, 2 pre-doubled bases only, 3 no round-0 precomputation; +8: the line buffer was cut; +16: an in-round G2 table fold took the split form
     bool mem_fits(size_t need, size_t held) const {
         if (need <= held) return true;
         const size_t extra = need - held;
@@ -1008,10 +1008,12 @@ int32_t job_round_partials(Engine* e, ripp_sipp_job* j, Fp12* rows /* [2][68] */
     return rc;
 }
 
-bool fold_g2_table_pays(const Engine* e, size_t half) {
-    if (!(half >= e->fold_tab_min && half > e->gls_split_max && !e->sw.no_fold_tables)) return false;
-    // (M + 4 M) affine rows + (M - 1) Jacobian rows per element, M = 4 (fold_g2_table_build): only where the device can hold them
-    const size_t need = half * (5 * 4 * sizeof(G2A) + 3 * sizeof(G2J)), held = e->fold_mult.cap + e->fold_tab.cap + e->fold_jac2.cap;
+bool fold_g2_table_pays(const Engine* e, size_t half) { return half >= e->fold_tab_min && half > e->gls_split_max && !e->sw.no_fold_tables; }
+// ... and the device can hold them: (M + 4 M) affine rows + (M - 1) Jacobian rows per element, M = 4 (fold_g2_table_build).  NOT part of fold_g2_table_pays:
+// that predicate decides whether the vector is x-scaled and must give the same answer every time it is asked within a round; a round whose tables do not
+// fit runs the SAME fold (same halves, same scalar) through the 4-lane split form instead (job_fold), whatever the x-scaling.
+bool fold_g2_table_fits(const Engine* e, size_t half) {
+    const size_t need = half * (5 * 4 * sizeof(G2A) + 3 * sizeof(G2J)) + 65536, held = e->fold_mult.cap + e->fold_tab.cap + e->fold_jac2.cap;
     return need <= held || e->mem_fits(need, held);
 }
 // rounds whose G2 fold runs on the x-scaled vector (see ripp_sipp_job::bs): the table folds of a proof driven by sipp_prove_core (every rank of a
@@ -1067,6 +1069,9 @@ int32_t job_precompute_round0(Engine* e, ripp_sipp_job* j, bool fuse = false) {
             if (!e->mem_fits(tab_bytes(M_half, half), tab_held)) { M_half = 4; e->mem_tier = std::max(e->mem_tier & 7, 1) | (e->mem_tier & 8); }
             if (!e->mem_fits(tab_bytes(M_half, half), tab_held)) { tables = false; e->mem_tier = std::max(e->mem_tier & 7, 2) | (e->mem_tier & 8); }
         }
+        // no room for round-0 tables: the rest of THIS call runs the table-free form as a whole (the RIPP_NO_FOLD_TABLES / no_fold_tables path the 2^17 switch
+        // test pins) -- the x-scaled G2 vector and the in-round tables of rounds 1-4 go with them; the switches are re-read at the next C-ABI call
+        if (!tables) e->sw.no_fold_tables = true;
     }
     if (!tables && !e->mem_fits(half * (sizeof(G1A) + sizeof(G2A) + sizeof(G1J) + sizeof(G2J)), j->a_pow.cap + j->b_pow.cap + j->jac1.cap + j->jac2.cap)) {
         e->mem_tier = 3 | (e->mem_tier & 8);
@@ -1190,6 +1195,7 @@ int32_t job_prebuild_g2_tables(Engine* e, ripp_sipp_job* j) {
     if (vm_form || j->pre_ready || j->pre_vm_ready || (j->tab_ready && e->tab_owner == j) || !fold_g2_table_pays(e, half)) return RIPP_OK;
     const bool xs = xscale_round(e, j, half);               // (challenges of SIPP are 128-bit: fits_128 holds)
     if (j->bs_on && !xs) return RIPP_OK;                    // the un-scaling fold takes no tables
+    if (!fold_g2_table_fits(e, half)) return RIPP_OK;      // short of memory: job_fold takes the split form
     const G2A* b = j->b.as<G2A>();
     return fold_g2_table_build(e, e->stream, xs ? b : b + half, half);
 }
@@ -1296,7 +1302,7 @@ int32_t job_fold(Engine* e, ripp_sipp_job* j, const Fr& x, bool allow_vm = true,
     if (e->sw.no_endo) {               // no psi on this build / switch: the 255-bit NAF fold (x^-1 is full width)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fold_affine_naf<Fp2>), dim3(nblk(half, 256)), dim3(256), 0, e->stream, b + half, b, (uint32_t)half, naf_digits(x_inv), j->jac2.as<G2J>());
     } else
-    if (half <= e->gls_split_max) {     // latency-bound round: 4 lanes per element
+    if (half <= e->gls_split_max || (fold_g2_table_pays(e, half) && !(e->g2tab_hi && e->g2tab_half == half) && !fold_g2_table_fits(e, half) && ((e->mem_tier |= 16), true))) {     // latency-bound round: 4 lanes per element (also: a table round whose tables the device cannot hold, mem_tier + 16)
         if ((rc = e->qtab.reserve(std::max<size_t>(4 * G2A_CHUNKS * qstride * sizeof(uint4), 4 * half * sizeof(G2J)))) != RIPP_OK) return rc;
         if (!e->sw.no_fq) {
             if ((rc = e->fix_flags.reserve(4 * half + 16))) return rc;

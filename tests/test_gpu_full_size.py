@@ -141,8 +141,9 @@ def test_sipp_prove_2p20_bls12_377_host_slices_vs_oracle():
     a, b, r = R7.synth_g1(1000, N), R7.synth_g2(2000, N), R7.synth_fr(0, N)
     value = R7.product_of_pairings_with_coeffs(a, b, r)
     assert np.array_equal(value, o7.product_of_pairings_with_coeffs(a, b, r))
-    rc, eproof, ech = o7.sipp_prove(a, b, r, value)
-    assert rc == 0
+    from conftest import _oracle_proof_2p20
+    evalue, eproof, ech = _oracle_proof_2p20("377", o7, a, b, r)      # the oracle's proof: committed output of one run, or live with RIPP_TEST_LIVE_ORACLE=1
+    assert np.array_equal(value, evalue)
     proof, ch, st = R7.SIPP.prove_one_shot(a, b, r, value)
     assert proof.shape == (40, 72) and np.array_equal(proof, eproof) and np.array_equal(ch, ech)
     assert R7.SIPP.verify(a, b, r, value, proof) and o7.sipp_verify(a, b, r, value, proof) == 1
