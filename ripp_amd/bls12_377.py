@@ -6,8 +6,8 @@ reference's own SIPP test and `scaling-ipp` example (sipp/src/lib.rs:229, sipp/e
 
 Same C ABI, same array layouts (12 x u32 Fp limbs, 8 x u32 Fr limbs, Montgomery form with R = 2^384 / 2^256); group elements and scalars are
 BLS12-377's.  That build has the GLV / GLS constants and the field-VM programs of its own tower (tools/gen_params.py, tools/vmgen.py) and runs the same
-schedule; its throughput kernels are the 12 x 32-bit forms (the carry-free ones are written for u^2 = -1 and the M-type twist), with the D-type twist's
-line placement; TIPA / aggregate_proofs work on it too, the wire format is ark-ec's generic SWFlags layout (wire.hpp).  No CPU fallback either: a missing library or device fails loudly."""
+schedule on the same carry-free 14 x 28-bit throughput kernels (since build round 4: fq_curve2.hpp FQ2_BETA for u^2 = -5, the D-type twist's line placement in
+fq_miller.hpp / fq_line_products.hpp); TIPA / aggregate_proofs work on it too, the wire format is ark-ec's generic SWFlags layout (wire.hpp).  No CPU fallback either: a missing library or device fails loudly."""
 import importlib.util
 import os
 import sys

@@ -1,5 +1,10 @@
-"""Multi-GPU SIPP prover: one process per GPU, vectors sharded by index residue, partial GT products combined over
-RCCL (torch.distributed backend "nccl" on ROCm) -- the host logic of SURVEY.md section 8(e).
+"""Host-side plumbing of the multi-GPU provers.  PRODUCTION PATH: the NATIVE drivers at the bottom of this file
+(NativeComm / ReplayComm + native_sipp_prove / native_sipp_job_prove / native_pairing_inner_product / native_msm): round loop and collectives
+live inside libripp_hip.so, Python only hands the RCCL id over.  The Python-level prover at the top (TorchComm, ShardedSippProver,
+sharded_pairing_inner_product, sharded_msm) is the CPU TEST VEHICLE of tests/test_sharded_gloo.py: the same protocol with an injectable
+oracle-backed job, so the N > 1 control flow runs on boxes without a GPU (gloo, world sizes 2 / 4 / 8).
+
+One process per GPU, vectors sharded by index residue, partial GT products combined by all-gather + local multiply.
 
 Sharding: global element i lives on rank i mod G at local index i div G.  Every halving round pairs (i, i + L/2);
 while L/2 is a multiple of G both partners have the same residue, so the fold is 100% local and each rank simply
