@@ -270,6 +270,9 @@ def main():
             # the step is bound by the HOST's sequential Blake2s of the 336 B x n statement, whose speed differs by a few per cent from box to box: read `value` next to it
             "statement_hash_ms": round(hash_ms, 3), "ms_per_step_median": ms_median, "value_median": n / (ms_median * 1e-3),
             "ms_per_step_all": [round(t * 1e3, 3) for t in times],
+            # the hash of the SAME calls, step by step: a slow step is a slow hash (the core's clock / a neighbour on its L3), not a slow GPU -- read the two lists side by side
+            "statement_hash_ms_all": [round(h, 3) for h in hash_ms_steps],
+            "post_hash_ms_all": [round(t * 1e3 - h, 3) for t, h in zip(times, hash_ms_steps)],
             "value_resident": n / (resident_ms * 1e-3), "ms_per_step_resident": resident_ms,
             "roofline": {"bound": "hbm", "kernel": dom[3], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
