@@ -158,7 +158,7 @@ def main():
     # the prover hashes ALL of it (sipp/src/lib.rs:56-59).  `value` (the claimed product) is part of the statement.
     # The host copies are ordinary (pageable) numpy arrays -- what a caller of the trait surface hands over; the HIP runtime pins them for the upload
     # and caches the registration.  RIPP_BENCH_PINNED=1 places them in hipHostMalloc'ed memory instead (section 8d's wording): measured SLOWER on the
-    # pool's boxes, 457.4 against 443.8 ms per proof on the same box (profiles/r04_bench_pinned_vs_pageable.txt) -- the CPU side of the proof, the
+    # pool's boxes, 457.4 against 443.8 ms per proof on the same box (build round 4; the A/B record itself was not kept: re-run with RIPP_BENCH_PINNED=1 to repeat it) -- the CPU side of the proof, the
     # sequential hash and the serialisation workers, reads the statement more slowly from that mapping (hash 319.6 against 316.6 ms) and so does
     # everything behind it.
     def pinned(arr):

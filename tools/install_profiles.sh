@@ -1,5 +1,5 @@
 # Copy the summaries collected by tools/run_profiles.sh <tag> (gpurun_out/prof_<tag>/) into profiles/ under the round's names.
-TAG=${1:-r04}; R=${2:-r04}
+TAG=${1:-r05}; R=${2:-r05}
 S=gpurun_out/prof_$TAG
 cp $S/kstats/k_kernel_stats.csv profiles/${R}_bench_kernel_stats_rocprofv3.csv
 cp $S/bench_n1.json profiles/${R}_bench_n1.json
@@ -25,4 +25,5 @@ if [ -d $F ]; then
   [ -s $F/post_hash_timeline.txt ] && cp $F/post_hash_timeline.txt profiles/${R}_post_hash_timeline.txt
   for f in stress_world4 stress_world8 stress_tail; do [ -s $F/$f.txt ] && tail -3 $F/$f.txt > profiles/${R}_$f.txt; done
   [ -s $F/poly_commit_bench.csv ] && cp $F/poly_commit_bench.csv profiles/${R}_poly_commit_bench.csv
+  for G in 2 4 8; do for K in 0 1; do for X in bench.json timeline.txt; do [ -s $F/replay/rank${K}_of_${G}_$X ] && cp $F/replay/rank${K}_of_${G}_$X profiles/${R}_rank${K}_of_${G}_$X; done; done; [ -s $F/replay/w${G}_n20_passes.json ] && cp $F/replay/w${G}_n20_passes.json profiles/${R}_replay_w${G}_passes.json; done
 fi

@@ -1,6 +1,6 @@
 # End-of-round measurement set on the CURRENT build (GPU box): bash tools/run_final.sh <tag>
 set -x
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 bash tools/run_profiles.sh $TAG > gpurun_out/prof_$TAG.log 2>&1
 O=gpurun_out/final_$TAG; mkdir -p $O
@@ -14,4 +14,7 @@ timeout 400 python3 tools/stress_sharded.py 41 90 2 14 4 > $O/stress_world4.txt 
 timeout 400 python3 tools/stress_sharded.py 81 90 3 14 8 > $O/stress_world8.txt 2>&1
 timeout 200 python3 tools/stress_tail.py 5 60 1 12 > $O/stress_tail.txt 2>&1
 timeout 300 python3 tools/poly_commit_bench.py 2 8 > $O/poly_commit_bench.csv 2> $O/poly_commit.err
+# one rank of G alone on this GPU with recorded peers: rank{0,1}_of_{2,4,8}_{bench.json,timeline.txt}
+for G in 2 4; do timeout 500 python3 tools/replay_ranks.py all --world $G --log-n 20 --out-dir $O/replay > $O/replay_w$G.log 2>&1; done
+RIPP_HOT_WORKERS=1 timeout 500 python3 tools/replay_ranks.py all --world 8 --log-n 20 --out-dir $O/replay > $O/replay_w8.log 2>&1
 ls -la $O $O/c377; tail -3 $O/scaling_ipp.log; cat $O/aggregate_2p14.json | head -30; cat $O/bench_n2_single_device_gloo.json | cut -c1-300; for f in stress_world4 stress_world8 stress_tail; do tail -n 2 $O/$f.txt; done

@@ -1,6 +1,6 @@
 # Collects every profile the bench line and DESIGN.md quote, on the CURRENT build.  Usage (GPU box): bash tools/run_profiles.sh <tag>
 set -x
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT

@@ -136,7 +136,19 @@ static double run(fn_t f, const std::vector<uint8_t>& buf, uint32_t out[8]) {
     double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     memcpy(out, h, 32); return s;
 }
+// core clock under this kind of load: a chain of dependent 1-cycle adds (16 per iteration), timed
+static double core_ghz() {
+    uint64_t x = 1; const uint64_t n = 200000000ull;
+    auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t i = 0; i < n; ++i)
+        asm volatile("add %0, %0\n add %0, %0\n add %0, %0\n add %0, %0\n add %0, %0\n add %0, %0\n add %0, %0\n add %0, %0\n"
+                     "add %0, %0\n add %0, %0\n add %0, %0\n add %0, %0\n add %0, %0\n add %0, %0\n add %0, %0\n add %0, %0\n" : "+r"(x));
+    double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return 16.0 * (double)n / s / 1e9;
+}
 int main() {
+    const double ghz = core_ghz();
+    printf("core clock (dependent-add chain): %.2f GHz -> cycles per byte below = GHz / (GB/s)\n", ghz);
     std::vector<uint8_t> buf((size_t)64 << 20);
     uint64_t x = 88172645463325252ull; for (auto& b : buf) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; b = (uint8_t)x; }
     struct { const char* name; fn_t f; } vs[] = {{"v0 loop+table", compress_v0}, {"v1 unrolled", compress_v1}, {"v2 unrolled interleaved", compress_v2}, {"v4 v2 + (a+m)+b", compress_v4}, {"v5 pairs + (a+m)+b", compress_v5}};
@@ -145,13 +157,14 @@ int main() {
         uint32_t out[8]; double best = 1e9;
         for (int rep = 0; rep < 3; ++rep) { double s = run(v.f, buf, out); if (s < best) best = s; }
         if (v.f == compress_v0) memcpy(ref, out, 32);
-        printf("%-28s %8.1f MB/s   %s\n", v.name, buf.size() / best / 1e6, memcmp(ref, out, 32) ? "MISMATCH" : "ok");
+        printf("%-28s %8.1f MB/s  %5.2f c/B  %s\n", v.name, buf.size() / best / 1e6, ghz * 1e9 * best / buf.size(), memcmp(ref, out, 32) ? "MISMATCH" : "ok");
     }
     struct { const char* name; bulk_t f; } bs[] = {{"v6 asm seq (bulk)", blake2s_blocks_seq}, {"v6 asm lock (bulk)", blake2s_blocks_lock}, {"v6 asm lock3first (bulk)", blake2s_blocks_lock3first}};
     for (auto& v : bs) {
         uint32_t out[8]; double best = 1e9;
         for (int rep = 0; rep < 3; ++rep) { double s = run_bulk(v.f, buf, out); if (s < best) best = s; }
-        printf("%-28s %8.1f MB/s   %s\n", v.name, buf.size() / best / 1e6, memcmp(ref, out, 32) ? "MISMATCH" : "ok");
+        printf("%-28s %8.1f MB/s  %5.2f c/B  %s\n", v.name, buf.size() / best / 1e6, ghz * 1e9 * best / buf.size(), memcmp(ref, out, 32) ? "MISMATCH" : "ok");
     }
+    printf("core clock after: %.2f GHz\n", core_ghz());
     return 0;
 }
