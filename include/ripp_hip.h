@@ -390,6 +390,8 @@ size_t  ripp_ser_g1_compressed(const ripp_g1a* p, uint8_t out[48]);
 size_t  ripp_ser_g2_compressed(const ripp_g2a* p, uint8_t out[96]);
 
 /* ---- host-side helpers (no device needed): what the host code around the kernels computes ---------------- */
+/* BLAKE2s-256 (RFC 7693; `blake2::Blake2s` of sipp/src/lib.rs:230) of a host buffer: the implementation the statement hash runs, exposed for tests */
+int32_t ripp_blake2s(const uint8_t* in, size_t len, uint8_t out[32]);
 int32_t ripp_final_exp(const ripp_gt* miller_value, ripp_gt* out);                 /* Pairing::final_exponentiation */
 int32_t ripp_miller_combine(const ripp_gt* step_products /* [68] */, ripp_gt* out); /* stage (3) of pairing.hpp */
 /* out[k] = ripp_final_exp(ripp_miller_combine(step_products + 68 k)), k < count, the way the provers compute it between two kernels: the 63 bits

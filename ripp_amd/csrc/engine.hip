@@ -2463,6 +2463,11 @@ API int32_t ripp_sipp_seed_digest(const ripp_g1a* a, const ripp_g2a* b, const ri
 }
 
 // ---- host helpers ----------------------------------------------------------------------------------------------------
+// BLAKE2s-256 of a host buffer (the digest of sipp/src/rng.rs:14; RFC 7693) -- the library's own implementation incl. its x86-64 assembly bulk path, exposed for tests
+API int32_t ripp_blake2s(const uint8_t* in, size_t len, uint8_t out[32]) {
+    if ((!in && len) || !out) return RIPP_ERR_ARG;
+    fs::Blake2s h; h.update(in, len); h.finish(out); return RIPP_OK;
+}
 API int32_t ripp_final_exp(const ripp_gt* f, ripp_gt* out) { if (!f || !out) return RIPP_ERR_ARG; Fp12 x; std::memcpy(&x, f, sizeof x); const Fp12 r = final_exponentiation(x); std::memcpy(out, &r, sizeof r); return RIPP_OK; }
 API int32_t ripp_pairing_values(const ripp_gt* rows, int32_t count, int32_t parts, ripp_gt* out) {
     if (!rows || !out || count < 0 || parts < 0 || parts > 63) return RIPP_ERR_ARG;

@@ -183,6 +183,7 @@ extern "C" {
     pub fn ripp_de_tipa_ssm_proof(in_: *const u8, len: usize, compress: i32, max_rounds: usize, rounds: *mut usize, com_gt: *mut RippGt, com_g1: *mut RippG1J, base_a: *mut RippG1J, base_b: *mut RippFr, final_ck_a: *mut RippG2J, opening_a: *mut RippG2J) -> i32;
     pub fn ripp_ser_g1_compressed(p: *const RippG1A, out: *mut u8) -> usize;
     pub fn ripp_ser_g2_compressed(p: *const RippG2A, out: *mut u8) -> usize;
+    pub fn ripp_blake2s(in_: *const u8, len: usize, out: *mut u8) -> i32;
     pub fn ripp_final_exp(miller_value: *const RippGt, out: *mut RippGt) -> i32;
     pub fn ripp_miller_combine(step_products: *const RippGt, out: *mut RippGt) -> i32;
     pub fn ripp_pairing_values(step_products: *const RippGt, count: i32, parts: i32, out: *mut RippGt) -> i32;

@@ -194,3 +194,36 @@ def test_library_point_encoding_matches_public_literals(hiplib, orc):
     assert R.ser_g1(g1).hex() == "%096x%096x" % (G1_X, G1_Y)
     assert R.ser_g2(g2).hex() == "%096x%096x%096x%096x" % (G2_X1, G2_X0, G2_Y1, G2_Y0)
     assert R.ser_g1_compressed(np.zeros(12, dtype=np.uint64)).hex() == "c0" + "00" * 47      # infinity: compression + infinity bits
+
+
+def test_blake2s_matches_hashlib_at_every_length_class(hiplib):
+    """The statement hash's Blake2s (host_fs.hpp + the generated x86-64 bulk loop blake2s_x64.S, which handles n / 64 - 1 blocks of a call and stages
+    64 bytes ahead) against hashlib.blake2s: every length 0..700 -- below, at and above the 192-byte threshold of the assembly path, every residue
+    mod 64 -- a few large odd sizes, unaligned starts, and a buffer that ends exactly at the end of a page-aligned mapping (an overread would fault)."""
+    import ctypes.util
+    import hashlib
+    import mmap
+    rng = np.random.default_rng(7)
+    data = rng.integers(0, 256, size=(1 << 20) + 777, dtype=np.uint8)
+    out = np.zeros(32, dtype=np.uint8)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    for n in list(range(0, 701)) + [4095, 4096, 4097, 65536 + 13, (1 << 20) + 777]:
+        for off in ((0, 1, 7) if n < 800 else (0, 3)):
+            if off + n > len(data):
+                continue
+            view = data[off:off + n]
+            assert hiplib.ripp_blake2s(p(view) if n else None, ctypes.c_size_t(n), p(out)) == 0
+            assert bytes(out) == hashlib.blake2s(view.tobytes()).digest(), (n, off)
+    # the buffer's last byte is the last byte of a mapping followed by an unmapped page
+    mm = mmap.mmap(-1, 2 * mmap.PAGESIZE)
+    buf = (ctypes.c_uint8 * (2 * mmap.PAGESIZE)).from_buffer(mm)
+    base = ctypes.addressof(buf)
+    libc = ctypes.CDLL(ctypes.util.find_library("c"), use_errno=True)
+    assert libc.mprotect(ctypes.c_void_p(base + mmap.PAGESIZE), ctypes.c_size_t(mmap.PAGESIZE), 0) == 0          # PROT_NONE on the second page
+    for n in (192, 200, 256, 1000, mmap.PAGESIZE):
+        src = rng.integers(0, 256, size=n, dtype=np.uint8)
+        ctypes.memmove(base + mmap.PAGESIZE - n, src.ctypes.data, n)
+        assert hiplib.ripp_blake2s(ctypes.c_void_p(base + mmap.PAGESIZE - n), ctypes.c_size_t(n), p(out)) == 0
+        assert bytes(out) == hashlib.blake2s(src.tobytes()).digest(), n
+    libc.mprotect(ctypes.c_void_p(base + mmap.PAGESIZE), ctypes.c_size_t(mmap.PAGESIZE), 3)
+    del buf; mm.close()

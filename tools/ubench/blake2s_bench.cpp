@@ -114,9 +114,7 @@ static void compress_v5(uint32_t h[8], const uint8_t* blk, uint64_t t, bool last
 //  1.11 GB/s on the EPYC 9575F against 1.14 GB/s for V2 as compiled by clang -O3: V2 already sits at the dependency-chain floor.)
 
 // V6: hand-allocated x86-64 assembly over MANY blocks per call (gen_blake2s_x64.py: fifteen registers of state, a2 / a3 in rsp-relative slots)
-extern "C" void blake2s_blocks_seq(uint32_t h[8], const uint8_t* in, size_t nblocks, uint64_t t);
-extern "C" void blake2s_blocks_lock(uint32_t h[8], const uint8_t* in, size_t nblocks, uint64_t t);
-extern "C" void blake2s_blocks_lock3first(uint32_t h[8], const uint8_t* in, size_t nblocks, uint64_t t);
+#include "build/b2s_list.h"      // generated: one entry per build/b2s_*.S (gen_blake2s_x64.py <order> [keep_h] [early_copy])
 typedef void (*fn_t)(uint32_t*, const uint8_t*, uint64_t, bool);
 typedef void (*bulk_t)(uint32_t*, const uint8_t*, size_t, uint64_t);
 static double run_bulk(bulk_t f, const std::vector<uint8_t>& buf, uint32_t out[8]) {
@@ -149,7 +147,7 @@ static double core_ghz() {
 int main() {
     const double ghz = core_ghz();
     printf("core clock (dependent-add chain): %.2f GHz -> cycles per byte below = GHz / (GB/s)\n", ghz);
-    std::vector<uint8_t> buf((size_t)64 << 20);
+    std::vector<uint8_t> buf((size_t)64 << 20); buf.reserve(buf.size() + 64);      // (early_copy forms stage 64 bytes beyond the last block they process: the final block follows in this buffer)
     uint64_t x = 88172645463325252ull; for (auto& b : buf) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; b = (uint8_t)x; }
     struct { const char* name; fn_t f; } vs[] = {{"v0 loop+table", compress_v0}, {"v1 unrolled", compress_v1}, {"v2 unrolled interleaved", compress_v2}, {"v4 v2 + (a+m)+b", compress_v4}, {"v5 pairs + (a+m)+b", compress_v5}};
     uint32_t ref[8];
@@ -159,8 +157,7 @@ int main() {
         if (v.f == compress_v0) memcpy(ref, out, 32);
         printf("%-28s %8.1f MB/s  %5.2f c/B  %s\n", v.name, buf.size() / best / 1e6, ghz * 1e9 * best / buf.size(), memcmp(ref, out, 32) ? "MISMATCH" : "ok");
     }
-    struct { const char* name; bulk_t f; } bs[] = {{"v6 asm seq (bulk)", blake2s_blocks_seq}, {"v6 asm lock (bulk)", blake2s_blocks_lock}, {"v6 asm lock3first (bulk)", blake2s_blocks_lock3first}};
-    for (auto& v : bs) {
+    for (auto& v : B2S_ASM) {
         uint32_t out[8]; double best = 1e9;
         for (int rep = 0; rep < 3; ++rep) { double s = run_bulk(v.f, buf, out); if (s < best) best = s; }
         printf("%-28s %8.1f MB/s  %5.2f c/B  %s\n", v.name, buf.size() / best / 1e6, ghz * 1e9 * best / buf.size(), memcmp(ref, out, 32) ? "MISMATCH" : "ok");

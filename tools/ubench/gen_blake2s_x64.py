@@ -30,28 +30,45 @@ D = ["r12d", "r13d", "r14d", "r15d"]
 M, A2, A3, H, IN, N, TT, HP, FRAME = 0, 64, 68, 72, 104, 112, 120, 128, 136
 
 
-def g_ops(k, half, x, y):
-    """the 14 (16 for stack-resident a) instructions of one G as a list; k = G index 0..3"""
+XMM_HOME = False          # argv option "xmm": a2 / a3 live in xmm4 / xmm5 (movd both ways) instead of stack slots
+
+
+def ld_a(k): return f"movd {T}, xmm{k + 2}" if XMM_HOME else f"mov {T}, [rsp+{A2 if k == 2 else A3}]"
+def st_a(k): return f"movd xmm{k + 2}, {T}" if XMM_HOME else f"mov [rsp+{A2 if k == 2 else A3}], {T}"
+
+
+def g_ops(k, half, x, y, immediate=False):
+    """the 14 (16 for stack-resident a) instructions of one G as a list; k = G index 0..3.
+    immediate: a stack-resident a goes back to its slot right after EACH update (T is free again at once, so such G's can be interleaved)"""
     a = A[k]
     if half == 0:
         b, c, d = B[k], C[k], D[k]
     else:
         b, c, d = B[(k + 1) % 4], C[(k + 2) % 4], D[(k + 3) % 4]
     ops = []
-    if a is None:
-        slot = A2 if k == 2 else A3
+    mem = a is None
+    slot = A2 if k == 2 else A3
+    if mem:
         a = T
-        ops.append(f"mov {a}, [rsp+{slot}]")
-    ops += [f"add {a}, [rsp+{M + 4 * x}]", f"add {a}, {b}", f"xor {d}, {a}", f"ror {d}, 16", f"add {c}, {d}", f"xor {b}, {c}", f"ror {b}, 12",
-            f"add {a}, [rsp+{M + 4 * y}]", f"add {a}, {b}", f"xor {d}, {a}", f"ror {d}, 8"]
-    if A[k] is None:
-        ops.append(f"mov [rsp+{A2 if k == 2 else A3}], {a}")
+        ops.append(ld_a(k))
+    ops += [f"add {a}, [rsp+{M + 4 * x}]", f"add {a}, {b}"]
+    if mem and immediate:
+        ops.append(st_a(k))
+    ops += [f"xor {d}, {a}", f"ror {d}, 16", f"add {c}, {d}", f"xor {b}, {c}", f"ror {b}, 12"]
+    if mem and immediate:
+        ops.append(ld_a(k))
+    ops += [f"add {a}, [rsp+{M + 4 * y}]", f"add {a}, {b}"]
+    if mem and immediate:
+        ops.append(st_a(k))
+    ops += [f"xor {d}, {a}", f"ror {d}, 8"]
+    if mem and not immediate:
+        ops.append(st_a(k))
     ops += [f"add {c}, {d}", f"xor {b}, {c}", f"ror {b}, 7"]
     return ops
 
 
 def interleave(lists):
-    out, i = [], 0
+    out = []
     while any(lists):
         for l in lists:
             if l:
@@ -59,8 +76,35 @@ def interleave(lists):
     return out
 
 
+def interleave_units(lists, unit):
+    """lockstep in units of `unit` instructions per G (keeps an immediate G's load-add-add-store / its T lifetime contiguous)"""
+    out = []
+    while any(lists):
+        for l in lists:
+            for _ in range(unit):
+                if l:
+                    out.append(l.pop(0))
+    return out
+
+
 def half_round(r, half, variant):
     s = SIGMA[r][8 * half: 8 * half + 8]
+    if variant == "lock4m":                         # all four in lockstep; a2 / a3 return to their slots after every update (T lives 4 instructions)
+        g = [g_ops(k, half, s[2 * k], s[2 * k + 1], immediate=True) for k in range(4)]
+        # phases of a G: [a-update][d][c][b][a-update][d][c][b]; emit phase by phase across the four G's, the stack-resident ones first
+        def phases(ops, mem):
+            cut = [5, 1, 1, 2, 5, 1, 1, 2] if mem else [3, 1, 1, 2, 3, 1, 1, 2]      # (the xor that consumes T stays with the update: T is dead at every phase boundary)
+            out, i = [], 0
+            for c in cut:
+                out.append(ops[i:i + c]); i += c
+            assert i == len(ops), (i, len(ops))
+            return out
+        ph = [phases(g[k], A[k] is None) for k in range(4)]
+        out = []
+        for p in range(8):
+            for k in (3, 2, 0, 1):
+                out += ph[k][p]
+        return out
     g = [g_ops(k, half, s[2 * k], s[2 * k + 1]) for k in range(4)]
     if variant == "seq":
         return interleave([g[0], g[1]]) + g[2] + g[3]
@@ -68,36 +112,71 @@ def half_round(r, half, variant):
         return interleave([g[0], g[1], g[2]]) + g[3]
     if variant == "lock3first":                     # the lone stack-resident G FIRST in program order (oldest-first pick favours it), then three in lockstep
         return g[3] + interleave([g[0], g[1], g[2]])
+    if variant == "l3f_u2":                          # as lock3first, the lockstep in units of two instructions per G
+        return g[3] + interleave_units([g[0], g[1], g[2]], 2)
+    if variant == "l3f_u3":
+        return g[3] + interleave_units([g[0], g[1], g[2]], 3)
+    if variant == "l3f_201":                         # as lock3first, the stack-resident G2 leading the lockstep
+        return g[3] + interleave([g[2], g[0], g[1]])
+    if variant == "l3f_half":                        # G3's first half-G, the other three's first half-G's in lockstep, then the second halves likewise
+        h3 = len(g[3]) // 2
+        a3, b3 = g[3][:8], g[3][8:]
+        firsts = [x[:7] for x in (g[0], g[1])] + [g[2][:8]]
+        seconds = [x[7:] for x in (g[0], g[1])] + [g[2][8:]]
+        return a3 + interleave(firsts) + b3 + interleave(seconds)
+    if variant == "g32first":                       # both stack-resident G's first, then the two register G's in lockstep
+        return g[3] + g[2] + interleave([g[0], g[1]])
     raise SystemExit("variant?")
 
 
 def main():
     variant = sys.argv[1] if len(sys.argv) > 1 else "lock"
-    name = "blake2s_blocks_" + variant
-    o = [".intel_syntax noprefix", ".text", f".globl {name}", f".type {name}, @function", f"{name}:",
+    opts = set(sys.argv[2:])
+    keep_h, early = "keep_h" in opts, "early_copy" in opts
+    global XMM_HOME
+    XMM_HOME = "xmm" in opts
+    name = next((o[5:] for o in opts if o.startswith("name=")), None)
+    opts = {o for o in opts if not o.startswith("name=")}
+    name = name or "blake2s_blocks_" + "_".join([variant] + sorted(opts))
+    copy_msg = lambda reg: [f"movdqu xmm0, [{reg}]", f"movdqu xmm1, [{reg}+16]", f"movdqu xmm2, [{reg}+32]", f"movdqu xmm3, [{reg}+48]",
+                            f"movdqu [rsp+{M}], xmm0", f"movdqu [rsp+{M + 16}], xmm1", f"movdqu [rsp+{M + 32}], xmm2", f"movdqu [rsp+{M + 48}], xmm3"]
+    load_ab = [f"mov {A[0]}, [rsp+{H}]", f"mov {A[1]}, [rsp+{H + 4}]", f"mov {T}, [rsp+{H + 8}]", st_a(2), f"mov {T}, [rsp+{H + 12}]", st_a(3)] + \
+              [f"mov {B[i]}, [rsp+{H + 16 + 4 * i}]" for i in range(4)]
+    o = [f"# GENERATED by tools/ubench/gen_blake2s_x64.py {' '.join(sys.argv[1:])} -- do not edit; see that script for the design and tools/ubench/blake2s_bench.cpp for the measurements",
+         ".intel_syntax noprefix", ".text", f".globl {name}", f".hidden {name}", f".type {name}, @function", f"{name}:",
          "# void f(uint32_t h[8] /*rdi*/, const uint8_t* in /*rsi*/, size_t nblocks /*rdx*/, uint64_t t /*rcx: bytes hashed before the first block*/)",
+         "# early_copy forms read 64 bytes BEYOND the last block they process (the next block's message is staged during the current one)",
          "push rbx", "push rbp", "push r12", "push r13", "push r14", "push r15", f"sub rsp, {FRAME}",
          "test rdx, rdx", "jz 9f",
          f"mov [rsp+{HP}], rdi", f"mov [rsp+{IN}], rsi", f"mov [rsp+{N}], rdx", f"mov [rsp+{TT}], rcx"]
     for i in range(0, 8, 2):
         o += [f"mov rax, [rdi+{4 * i}]", f"mov [rsp+{H + 4 * i}], rax"]
-    o.append("1:")
-    # block prologue: copy the message, bump t, load the state
-    o += [f"mov rsi, [rsp+{IN}]", "movdqu xmm0, [rsi]", "movdqu xmm1, [rsi+16]", "movdqu xmm2, [rsi+32]", "movdqu xmm3, [rsi+48]",
-          f"movdqu [rsp+{M}], xmm0", f"movdqu [rsp+{M + 16}], xmm1", f"movdqu [rsp+{M + 32}], xmm2", f"movdqu [rsp+{M + 48}], xmm3",
-          "add rsi, 64", f"mov [rsp+{IN}], rsi", f"mov rcx, [rsp+{TT}]", "add rcx, 64", f"mov [rsp+{TT}], rcx"]
-    # v0..v3 = h0..h3 (a row), v4..7 = h4..7 (b), v8..11 = IV0..3 (c), v12 = IV4 ^ t_lo, v13 = IV5 ^ t_hi, v14 = IV6, v15 = IV7 (d)
+    if early:
+        o += copy_msg("rsi") + ["add rsi, 64", f"mov [rsp+{IN}], rsi"]
+    if keep_h:
+        o += load_ab
+    o += [".p2align 6", "1:"]
+    if not early:
+        o += [f"mov rcx, [rsp+{IN}]"] + copy_msg("rcx") + ["add rcx, 64", f"mov [rsp+{IN}], rcx"]
+    o += [f"mov rcx, [rsp+{TT}]", "add rcx, 64", f"mov [rsp+{TT}], rcx"]
     o += [f"mov {D[0]}, ecx", f"xor {D[0]}, {IV[4]}", "shr rcx, 32", f"mov {D[1]}, ecx", f"xor {D[1]}, {IV[5]}", f"mov {D[2]}, {IV[6]}", f"mov {D[3]}, {IV[7]}"]
-    o += [f"mov {A[0]}, [rsp+{H}]", f"mov {A[1]}, [rsp+{H + 4}]", f"mov {T}, [rsp+{H + 8}]", f"mov [rsp+{A2}], {T}", f"mov {T}, [rsp+{H + 12}]", f"mov [rsp+{A3}], {T}"]
-    o += [f"mov {B[i]}, [rsp+{H + 16 + 4 * i}]" for i in range(4)]
+    if not keep_h:
+        o += load_ab
     o += [f"mov {C[i]}, {IV[i]}" for i in range(4)]
     for r in range(10):
         for half in (0, 1):
             o += half_round(r, half, variant)
-    # h[i] ^= v[i] ^ v[i+8]
-    o += [f"xor {A[0]}, {C[0]}", f"xor [rsp+{H}], {A[0]}", f"xor {A[1]}, {C[1]}", f"xor [rsp+{H + 4}], {A[1]}",
-          f"mov {T}, [rsp+{A2}]", f"xor {T}, {C[2]}", f"xor [rsp+{H + 8}], {T}", f"mov {T}, [rsp+{A3}]", f"xor {T}, {C[3]}", f"xor [rsp+{H + 12}], {T}"]
-    o += [x for i in range(4) for x in (f"xor {B[i]}, {D[i]}", f"xor [rsp+{H + 16 + 4 * i}], {B[i]}")]
+    if early:       # stage the NEXT block's message behind the last round's loads (program order keeps them on the old words); rcx is free here
+        o += [f"mov rcx, [rsp+{IN}]"] + copy_msg("rcx") + ["add rcx, 64", f"mov [rsp+{IN}], rcx"]
+    if keep_h:      # new h in the registers the next block starts from; the frame copy is updated off the chain
+        o += [x for k in (0, 1) for x in (f"xor {A[k]}, {C[k]}", f"xor {A[k]}, [rsp+{H + 4 * k}]", f"mov [rsp+{H + 4 * k}], {A[k]}")]
+        for k, slot in ((2, A2), (3, A3)):
+            o += [ld_a(k), f"xor {T}, {C[k]}", f"xor {T}, [rsp+{H + 4 * k}]", st_a(k), f"mov [rsp+{H + 4 * k}], {T}"]
+        o += [x for i in range(4) for x in (f"xor {B[i]}, {D[i]}", f"xor {B[i]}, [rsp+{H + 16 + 4 * i}]", f"mov [rsp+{H + 16 + 4 * i}], {B[i]}")]
+    else:
+        o += [f"xor {A[0]}, {C[0]}", f"xor [rsp+{H}], {A[0]}", f"xor {A[1]}, {C[1]}", f"xor [rsp+{H + 4}], {A[1]}",
+              ld_a(2), f"xor {T}, {C[2]}", f"xor [rsp+{H + 8}], {T}", ld_a(3), f"xor {T}, {C[3]}", f"xor [rsp+{H + 12}], {T}"]
+        o += [x for i in range(4) for x in (f"xor {B[i]}, {D[i]}", f"xor [rsp+{H + 16 + 4 * i}], {B[i]}")]
     o += [f"dec qword ptr [rsp+{N}]", "jnz 1b"]
     o += [f"mov rdi, [rsp+{HP}]"]
     for i in range(0, 8, 2):
