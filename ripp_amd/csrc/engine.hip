@@ -1972,12 +1972,12 @@ static int look_plan(const Engine* e, size_t n_local, int world, bool window) {
     const double nl = (double)n_local * share, n = (double)n_local * world;
     if (n < (double)((size_t)1 << 17)) return 0;                    // small statements: the hash is done long before the GPU is
     // Rates: compiled-in for the FIRST proof of a process (2^20 pairs through lines + products ~80 ms with the carry-free kernels; the statement hash
-    // 313-317 ms at n = 2^20 = 1.06-1.12 GB/s of Blake2s in situ), MEASURED afterwards: sipp_prove_core records this box's hash rate and this device's
+    // 286 ms at n = 2^20 = 1.17 GB/s of Blake2s in situ with the x86-64 bulk loop, build round 5; 313-317 ms = 1.06-1.12 GB/s before), MEASURED afterwards: sipp_prove_core records this box's hash rate and this device's
     // pairing rate at the end of every large proof that hashed (Engine::cal_*), so the static plan the non-hashing ranks follow is priced with what
     // rank 0's box and GPU really do (boxes differ by +-3 % / +-5 %).  Scaling and the fold tables move with the GPU factor.
     const double ms_per_pair = e->cal_ms_per_pair > 0 ? e->cal_ms_per_pair : 6.7e-5;      // (shared G2 chains: 138 ms for the 2^21 pair evaluations of round 0 + (1,l) at n = 2^20)
     const double gpu_f = ms_per_pair / 6.7e-5;
-    const double hash_ms = n * 336.0 / (e->cal_hash_bytes_per_ms > 0 ? e->cal_hash_bytes_per_ms : 1.12e6);
+    const double hash_ms = n * 336.0 / (e->cal_hash_bytes_per_ms > 0 ? e->cal_hash_bytes_per_ms : 1.17e6);
     double budget = hash_ms - (nl * (3.2e-5 * gpu_f + ms_per_pair + 5.3e-5 * gpu_f) + 1.0);      // scaling, round 0, fold tables (measured at n = 2^20: 33 + 80 + 55 ms)
     int items = 0;
     for (int it = 0; it < 2 * LOOK_MAX_R; ++it) {
@@ -2205,7 +2205,7 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
     j->no_window = !window; j->look_deadline = 0;
     if (world0 > 1) {
         double hash_left = 0;
-        if (window && j->hash_total > 0) hash_left = std::max(0.0, (double)j->hash_total / (e->cal_hash_bytes_per_ms > 0 ? e->cal_hash_bytes_per_ms : 1.12e6) - (now_ms() - j->hash_t0));
+        if (window && j->hash_total > 0) hash_left = std::max(0.0, (double)j->hash_total / (e->cal_hash_bytes_per_ms > 0 ? e->cal_hash_bytes_per_ms : 1.17e6) - (now_ms() - j->hash_t0));
         SippPlanMsg mine{(uint64_t)j->n_local, world0, rank, look_items, window ? 1 : 0, RIPP_OK, 0, hash_left};
         std::vector<SippPlanMsg> all((size_t)world0);
         const double tx = now_ms();
