@@ -1081,10 +1081,12 @@ int32_t job_precompute_round0(Engine* e, ripp_sipp_job* j, bool fuse = false) {
     if (trace_on() && (e->mem_tier & 7)) fprintf(stderr, "[ripp] round-0 tables: memory tier %d (%s)\n", e->mem_tier & 7, tables ? "half-vector tables" : "pre-doubled bases only");
     if ((rc = j->a_pow.reserve(half * sizeof(G1A))) || (rc = j->b_pow.reserve(half * sizeof(G2A))) || (rc = j->jac1.reserve(half * sizeof(G1J))) || (rc = j->jac2.reserve(half * sizeof(G2J)))) return rc;
     if (!tables) {                                              // two-base form: 2^64 a_r, 2^32 b_r
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pow2_mul<Fp>), dim3(nblk(half, 256)), dim3(256), 0, e->stream, j->a.as<G1A>() + half, (uint32_t)half, 64, j->jac1.as<G1J>());
+        if (!e->sw.no_fq) hipLaunchKernelGGL(k_pow2_mul_g1_q, dim3(nblk(half, 256)), dim3(256), 0, e->stream, j->a.as<G1A>() + half, (uint32_t)half, 64, j->jac1.as<G1J>());
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pow2_mul<Fp>), dim3(nblk(half, 256)), dim3(256), 0, e->stream, j->a.as<G1A>() + half, (uint32_t)half, 64, j->jac1.as<G1J>());
         HIPCHK(hipGetLastError());
         if ((rc = e->normalize_dev<Fp>(j->jac1.as<G1J>(), half, j->a_pow.as<G1A>()))) return rc;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pow2_mul<Fp2>), dim3(nblk(half, 256)), dim3(256), 0, e->stream, j->b.as<G2A>() + half, (uint32_t)half, 32, j->jac2.as<G2J>());
+        if (!e->sw.no_fq) hipLaunchKernelGGL(k_pow2_mul_g2_q, dim3(nblk(half, 64)), dim3(64), 0, e->stream, j->b.as<G2A>() + half, (uint32_t)half, 32, j->jac2.as<G2J>());
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pow2_mul<Fp2>), dim3(nblk(half, 256)), dim3(256), 0, e->stream, j->b.as<G2A>() + half, (uint32_t)half, 32, j->jac2.as<G2J>());
         HIPCHK(hipGetLastError());
         if ((rc = e->normalize_dev<Fp2>(j->jac2.as<G2J>(), half, j->b_pow.as<G2A>()))) return rc;
         j->pre_ready = true;
@@ -1108,10 +1110,12 @@ int32_t job_precompute_round0(Engine* e, ripp_sipp_job* j, bool fuse = false) {
     for (int b = 0; b < 4; ++b) {
         G1A* base1 = t1 + M * b * cnt; G2A* base2 = t2 + M * b * cnt;
         if (b > 0) {
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pow2_mul<Fp>), dim3(nblk(cnt, 256)), dim3(256), 0, e->stream, base1 - M * cnt, (uint32_t)cnt, 32, sj1);
+            if (!e->sw.no_fq) hipLaunchKernelGGL(k_pow2_mul_g1_q, dim3(nblk(cnt, 256)), dim3(256), 0, e->stream, base1 - M * cnt, (uint32_t)cnt, 32, sj1);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pow2_mul<Fp>), dim3(nblk(cnt, 256)), dim3(256), 0, e->stream, base1 - M * cnt, (uint32_t)cnt, 32, sj1);
             HIPCHK(hipGetLastError());
             if ((rc = e->normalize_dev<Fp>(sj1, cnt, base1))) return rc;
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pow2_mul<Fp2>), dim3(nblk(cnt, 256)), dim3(256), 0, e->stream, base2 - M * cnt, (uint32_t)cnt, 16, sj2);
+            if (!e->sw.no_fq) hipLaunchKernelGGL(k_pow2_mul_g2_q, dim3(nblk(cnt, 64)), dim3(64), 0, e->stream, base2 - M * cnt, (uint32_t)cnt, 16, sj2);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pow2_mul<Fp2>), dim3(nblk(cnt, 256)), dim3(256), 0, e->stream, base2 - M * cnt, (uint32_t)cnt, 16, sj2);
             HIPCHK(hipGetLastError());
             if ((rc = e->normalize_dev<Fp2>(sj2, cnt, base2))) return rc;
         }
@@ -2040,7 +2044,9 @@ static int32_t job_lookahead(Engine* e, ripp_sipp_job* j, int eighths, bool forc
             if (trace_on() && adaptive) fprintf(stderr, "[ripp] look-ahead item (%d,%c): hash %.0f %% after %.1f ms, room %.1f ms, item %.1f ms\n", R, side ? 'r' : 'l', 100.0 * (double)done / (double)j->hash_total, elapsed, room, cost);
             if (trace_on() && by_deadline) fprintf(stderr, "[ripp] rank %d look-ahead item (%d,%c): %.1f ms to rank 0's expected digest, item %.1f ms\n", j->rank, R, side ? 'r' : 'l', room, cost);
             if (room <= 0) break;                                        // the window is over (or the clamp above says it must be): nothing more fits
-            if (room >= cost) frac = 8;
+            // item (1,r) is completed when at least 80 % of it fits: the missing part costs 4 x as much here as after the fold, but BOTH values of round 1
+            // known at the digest is what lets rounds 0 and 1 fold in one pass (-8.5 ms): an overrun of up to ~14 ms pays
+            if (room >= cost || (it == 1 && room >= 0.8 * cost)) frac = 8;
             else {                                                       // adaptive: the 32nds of the blocks that still fit (negative = in 32nds)
                 int f32 = (int)(32.0 * room / cost);
                 while (f32 > 0 && item_cost((qblk * (size_t)f32 / 32) & ~(size_t)63) > room) --f32;
@@ -2306,10 +2312,14 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
             // asynchronous, during the host work below: the challenge-independent half of this round's G2 table fold (rounds of 2^16 and more elements)
             if (round >= 1 && !fuse_pending && !tp_round && (rc = job_prebuild_g2_tables(e, j))) return rc;
             // asynchronous: overlaps the host work below and the hash.  Both items of round 1 planned in full: tables over three quarters for the fused fold
-            if (round == 0 && !j->seeded && (rc = job_precompute_round0(e, j, (look_items >= 16 || e->sw.fuse_tables) && j->len >= 4))) return rc;
+            // Three-quarter tables (fused fold of rounds 0 + 1) as soon as the plan expects at least HALF of item (1,r) to fit: the adaptive planner completes
+            // that item when >= 80 % of it fits (job_lookahead), and a forced full plan measured 409 ms against 416-418 ms for the cautious one on a 289 ms-hash
+            // box (profiles/r05_plan_threshold_ab.txt) -- since the x86-64 Blake2s loop the window is ~20 ms shorter than the work that used to fill it.
+            const bool plan_fuse = look_forced ? look_items >= 16 : look_items >= 12;
+            if (round == 0 && !j->seeded && (rc = job_precompute_round0(e, j, (plan_fuse || e->sw.fuse_tables) && j->len >= 4))) return rc;
             if (!j->pre_vm_ready && (rc = job_precompute_vm(e, j))) return rc;                   // small rounds: the same on the VM, during the host phase
             // entry into the pipelined tail -- unless the look-ahead has (round 0: is about to get) both values of the next round
-            const bool next_known = round == 0 ? (look_items >= 16 && j->len >= 4 && (look_forced || !j->digest_ready.load())) : look_full(j, round + 1);
+            const bool next_known = round == 0 ? (plan_fuse && j->len >= 4 && (look_forced || !j->digest_ready.load())) : look_full(j, round + 1);
             if (!tp_round && !next_known && tail_pipe_ok(e, j) && (rc = job_tail_enqueue(e, j, round + 1))) return rc;
             t0 = now_ms();
             if (tp_round) { if ((rc = job_tail_values(j, round, x_prev, &zl, &zr))) return rc; }

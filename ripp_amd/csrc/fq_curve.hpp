@@ -253,4 +253,21 @@ __global__ void __launch_bounds__(64) k_fold_g1_fused_fix(const G1A* __restrict_
     for_flagged(flag, q, [&](uint32_t i) { out[i] = fold_g1_fused_complete(tab, tstride, M, lo[i], q, i, dg); });
 }
 
+// 2^k * in[i] (Jacobian out): the carry-free twin of kernels.hpp's k_pow2_mul<Fp> -- the pre-doubled bases of the round-0 fold tables (engine.hip:
+// job_precompute_round0, three launches of 32 doublings over three quarters of the vector at n = 2^20: 10 ms of the hash window on the 12 x 32-bit form).
+// A doubling has no exceptional case on a group of odd order; the identity stays the identity (Z = 0).
+__global__ void __launch_bounds__(256, 2) k_pow2_mul_g1_q(const G1A* __restrict__ in, uint32_t n, int k, G1J* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const G1A p = in[i];
+    if (is_inf(p)) { out[i] = jac_inf<Fp>(); return; }
+    const AffQ q = affq_from(p);
+    JacQ acc; acc.x = fq_coord(q.x); acc.y = fq_coord(q.y); acc.z = fq_coord(fq_one());
+#pragma unroll 1
+    for (int t = 0; t < k; ++t) jdbl_q(acc);
+    out[i] = jacq_to_g1j(acc);
+#endif
+}
+
 }  // namespace ripp

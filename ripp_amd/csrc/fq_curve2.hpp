@@ -396,4 +396,20 @@ __global__ void __launch_bounds__(64) k_fold_g2_gls_split_fix(const G2A* __restr
     for_flagged(flag, 4 * half, [&](uint32_t f) { const int j = (int)(f / half); const uint32_t i = f - (uint32_t)j * half; parts[f] = fold_g2_gls_split_complete(gls_image(hi[i], j), dg, j); });
 }
 
+// 2^k * in[i] on G2 (Jacobian out): the carry-free twin of k_pow2_mul<Fp2> (16 doublings per table base, 32 for the pre-doubled second base)
+__global__ void __launch_bounds__(64, 2) k_pow2_mul_g2_q(const G2A* __restrict__ in, uint32_t n, int k, G2J* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const G2A* bp = in + i;
+    bool inf; { const G2A b = *bp; inf = is_inf(b); }
+    if (inf) { out[i] = jac_inf<Fp2>(); return; }
+    JacQ2 d; d.x = f2_to_coord(f2_from(opaque(bp)->x)); d.y = f2_to_coord(f2_from(opaque(bp)->y)); d.z = f2_to_coord(Fq2n{fq_one(), fq_zero()});
+    f2_pin(d.z);
+#pragma unroll 1
+    for (int t = 0; t < k; ++t) jdbl2_q(d);
+    out[i] = G2J{f2_to(d.x), f2_to(d.y), f2_to(d.z)};
+#endif
+}
+
 }  // namespace ripp

@@ -635,6 +635,10 @@ __global__ void __launch_bounds__(256) k_normalize(const Jac<F>* __restrict__ in
     }
 }
 
+// (Build round 5 tried an LDS-transposing twin -- a wave copies 64 consecutive structs as one contiguous run of 16-byte chunks, lanes pick theirs out of
+// LDS at an odd chunk pitch, results leave the same way.  Measured on the proof's launch mix: 1.17 ms per average G2 launch against 0.51 ms for this
+// kernel -- six barriers per step and one wave per 19 KB of LDS cost more than the uncoalesced struct accesses, which the L2 absorbs.  Not kept.)
+
 // ---- per-element scalar multiplication, either group: out[i] = k[i] * base[i * base_stride]
 // (a_r = a_i * r^i and ck_1_r = ck_i * r^-i of groth16_aggregation.rs:119-131; base_stride = 0 broadcasts one base,
 //  which is structured_generators_scalar_power of tipa/mod.rs:372-391).  Plain MSB-first double-and-add: every lane
