@@ -51,6 +51,86 @@ def statement(R, rank, world, n):
     return a, b, r, full
 
 
+# ---- workload "aggregate": config 5 (aggregate_proofs, groth16_aggregation.rs:77-160) across the ranks ---------------------------------------------
+def agg_statement(R, o, n):
+    alpha, beta = o.fr_array([0xa1fa0001])[0], o.fr_array([0xbe7a0001])[0]
+    return R.SRS.from_trapdoors(alpha, beta, n), R.synth_g1(101, n), R.synth_g2(202, n), R.synth_g1(303, n)
+
+
+def agg_expected(log_n, out_dir):
+    """the ORACLE's aggregate of the synthetic instance (cached per out_dir): the members compared bit for bit"""
+    import numpy as np
+    path = os.path.join(out_dir, f"oracle_aggregate_n{log_n}.npz")
+    if not os.path.exists(path):
+        import orclib as o
+        import ripp_amd as R
+        R.init(0)
+        srs, a, b, c = agg_statement(R, o, 1 << log_n)
+        rc, exp = o.aggregate_proofs(srs.g_alpha_powers, srs.h_beta_powers, a, b, c)
+        assert rc == 0
+        d = {k: np.array(exp.field(k)) for k in ("com_a", "com_b", "com_c", "ip_ab", "r", "ab_kzg_c", "c_base_b", "c_kzg_c")}
+        d.update({k: np.array(getattr(exp, k)) for k in ("ab_com_steps", "ab_transcript", "c_com_gt", "c_transcript")})
+        np.savez(path, **d)
+    return dict(np.load(path))
+
+
+def agg_check(got, exp, who):
+    import numpy as np
+    for k in ("com_a", "com_b", "com_c", "ip_ab", "r", "ab_kzg_c", "c_base_b", "c_kzg_c"):
+        assert np.array_equal(np.array(got.field(k)), exp[k]), f"{who}: aggregate member {k} differs from the oracle's"
+    for k in ("ab_com_steps", "ab_transcript", "c_com_gt", "c_transcript"):
+        assert np.array_equal(np.array(getattr(got, k)), exp[k]), f"{who}: aggregate member {k} differs from the oracle's"
+
+
+def agg_record_worker(args):
+    import torch.distributed as dist
+    import orclib as o
+    import ripp_amd as R
+    from ripp_amd.sharded import NativeComm, shard
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    exp = agg_expected(args.log_n, args.out_dir)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    R.init(0)
+    comm = NativeComm("callback")
+    srs, a, b, c = agg_statement(R, o, 1 << args.log_n)
+    if rank == 0:
+        comm.record(True)
+    got, _ = R.aggregate_proofs_sharded(srs, shard(a, rank, world), shard(b, rank, world), shard(c, rank, world))
+    agg_check(got, exp, f"recording run, rank {rank}")
+    if rank == 0:
+        comm.save_recording(args.rec)
+    dist.barrier(); comm.close(); dist.destroy_process_group()
+
+
+def agg_replay_worker(args):
+    import torch
+    import orclib as o
+    import ripp_amd as R
+    from ripp_amd.sharded import ReplayComm, shard
+    rank, world = args.rank, args.world
+    exp = agg_expected(args.log_n, args.out_dir)
+    torch.cuda.set_device(0); R.init(0)
+    srs, a, b, c = agg_statement(R, o, 1 << args.log_n)
+    t_one = []
+    for _ in range(args.warmup + args.steps):                      # the same instance unsharded, for the comparison on this box
+        t0 = time.perf_counter(); got1, _ = R.aggregate_proofs(srs, a, b, c); t_one.append((time.perf_counter() - t0) * 1e3)
+    agg_check(got1, exp, "unsharded")
+    comm = ReplayComm(rank, world, args.rec, args.latency_us)
+    sa, sb, sc = shard(a, rank, world), shard(b, rank, world), shard(c, rank, world)
+    times = []
+    for it in range(args.warmup + args.steps):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        got, st = R.aggregate_proofs_sharded(srs, sa, sb, sc)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) * 1e3
+        agg_check(got, exp, f"replayed rank {rank} of {world}")
+        if it >= args.warmup:
+            times.append(dt)
+    info = comm.info(); comm.close()
+    print(json.dumps({"what": f"aggregate_proofs, n = 2^{args.log_n}: rank {rank} of {world} alone on one MI355X, peers replayed (instant, + {args.latency_us} us per exchange)",
+                      "ms_per_call_sharded": sum(times) / len(times), "ms_all": [round(t, 2) for t in times],
+                      "ms_per_call_unsharded_same_box": sum(t_one[args.warmup:]) / args.steps, "replay": info, "members_equal_oracle": True}), flush=True)
+
+
 def record_worker(args):
     """One of the G recording processes (all on cuda:0, gloo carries the all-gather)."""
     import numpy as np
@@ -121,7 +201,7 @@ def run_record(args, world, rec):
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RIPP_RANKS_PER_DEVICE=str(world),
                    HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "_record", "--log-n", str(args.log_n), "--out-dir", args.out_dir, "--rec", rec], env=env))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "_record", "--log-n", str(args.log_n), "--out-dir", args.out_dir, "--rec", rec, "--workload", args.workload], env=env))
     deadline = time.time() + 900
     rcs = []
     for p in procs:
@@ -138,7 +218,7 @@ def run_record(args, world, rec):
 
 def run_replay(args, world, rank, rec, tag):
     cmd = [sys.executable, os.path.abspath(__file__), "_replay", "--log-n", str(args.log_n), "--out-dir", args.out_dir, "--rec", rec, "--world", str(world),
-           "--rank", str(rank), "--steps", str(args.steps), "--warmup", str(args.warmup), "--latency-us", str(args.latency_us)]
+           "--rank", str(rank), "--steps", str(args.steps), "--warmup", str(args.warmup), "--latency-us", str(args.latency_us), "--workload", args.workload]
     env = dict(os.environ, RIPP_TRACE="1", OMP_NUM_THREADS="1")
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     if p.returncode:
@@ -169,15 +249,33 @@ def main():
     ap.add_argument("--latency-us", type=float, default=20.0, help="fixed cost added to every replayed exchange (a small RCCL all-gather over xGMI: ~15-30 us)")
     ap.add_argument("--out-dir", default=os.path.join(ROOT, "gpurun_out", "replay"))
     ap.add_argument("--rec", default=None)
+    ap.add_argument("--workload", choices=["sipp", "aggregate"], default="sipp", help="aggregate: config 5 (use --log-n 14); one pass of rank 0 with instant peers (the ranks are symmetric)")
     ap.add_argument("--passes", type=int, default=2, help="rank 0 / rank 1 rounds of the fixed-point iteration")
     args = ap.parse_args()
     os.makedirs(args.out_dir, exist_ok=True)
     if args.mode == "_record":
-        return record_worker(args)
+        return agg_record_worker(args) if args.workload == "aggregate" else record_worker(args)
     if args.mode == "_replay":
-        return replay_worker(args)
+        return agg_replay_worker(args) if args.workload == "aggregate" else replay_worker(args)
     import numpy as np
     from ripp_amd.sharded import read_recording, write_recording
+    if args.workload == "aggregate":
+        world = args.world
+        rec = os.path.join(args.out_dir, f"agg_w{world}_n{args.log_n}.rec")
+        p = subprocess.run([sys.executable, "-c", f"import sys; sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tools')!r}); import replay_ranks as r; r.agg_expected({args.log_n}, {args.out_dir!r})"])
+        assert p.returncode == 0
+        run_record(args, world, rec)
+        w, ex = read_recording(rec)
+        write_recording(rec, world, [(nb, np.full(world, np.nan), bl) for nb, _, bl in ex])
+        cmd = [sys.executable, os.path.abspath(__file__), "_replay", "--log-n", str(args.log_n), "--out-dir", args.out_dir, "--rec", rec, "--world", str(world), "--rank", "0",
+               "--steps", str(args.steps), "--warmup", str(args.warmup), "--latency-us", str(args.latency_us), "--workload", "aggregate"]
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        if p.returncode:
+            sys.stderr.write(p.stderr[-4000:]); raise SystemExit("aggregate replay failed")
+        res = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]); res["exchanges_per_call"] = len(ex)
+        json.dump(res, open(os.path.join(args.out_dir, f"aggregate_rank0_of_{world}.json"), "w"), indent=1)
+        print(f"aggregate n = 2^{args.log_n}, rank 0 of {world}: {res['ms_per_call_sharded']:.1f} ms sharded ({len(ex)} exchanges) against {res['ms_per_call_unsharded_same_box']:.1f} ms on one GPU", flush=True)
+        return
     oracle_proof(args.log_n, args.out_dir)
     world = args.world
     rec = os.path.join(args.out_dir, f"w{world}_n{args.log_n}.rec")

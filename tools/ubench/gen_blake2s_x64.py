@@ -182,6 +182,17 @@ def main():
     for i in range(0, 8, 2):
         o += [f"mov rax, [rsp+{H + 4 * i}]", f"mov [rdi+{4 * i}], rax"]
     o += ["9:", f"add rsp, {FRAME}", "pop r15", "pop r14", "pop r13", "pop r12", "pop rbp", "pop rbx", "ret", f".size {name}, .-{name}", '.section .note.GNU-stack,"",@progbits']
+    import re
+    if "rorx" in opts:          # BMI2 rotate: no flags written
+        o = [re.sub(r"^ror (\w+), (\d+)$", lambda m: f"rorx {m.group(1)}, {m.group(1)}, {m.group(2)}", x) for x in o]
+    if "lea" in opts:           # register-register adds as lea: no flags written
+        def lea(x):
+            m = re.match(r"^add (e\w+|r\d+d), (e\w+|r\d+d)$", x)
+            if not m:
+                return x
+            r64 = lambda r: ("r" + r[1:]) if r.startswith("e") else r[:-1]
+            return f"lea {m.group(1)}, [{r64(m.group(1))}+{r64(m.group(2))}]"
+        o = [lea(x) for x in o]
     print("\n".join(("    " + x) if not x.endswith(":") and not x.startswith(".") and not x.startswith("#") else x for x in o))
 
 
