@@ -282,7 +282,7 @@ struct Engine {
     size_t pairs_cap(size_t want) {
         want = std::max<size_t>(1, std::min(want, max_pairs_per_batch));
         const size_t per = (size_t)N_LINES * LINE_CHUNKS * sizeof(uint4);
-        auto bytes = [per](size_t pairs) { return ((pairs + 63) & ~(size_t)63) * per + 8 * 64 * per; };      // (+ the stride rounding of up to MAX_PRODUCTS products)
+        auto bytes = [per](size_t pairs) { return ((pairs + 63) & ~(size_t)63) * per + (size_t)MAX_PRODUCTS * 64 * per; };      // (+ the stride rounding of up to MAX_PRODUCTS products)
         if (bytes(want) <= lines.cap) return want;
         size_t w = want;
         while (w > 4096 && !mem_fits(bytes(w), lines.cap)) w = (w + 1) / 2;
@@ -596,12 +596,21 @@ struct Engine {
         // EIGHT products 20 % (3 * 544 = 1 632 of 2 048 slots: k_line_products_q then takes 25 % longer per pair -- measured on the first shared
         // round-0 launches of build round 4, where it ate the whole gain of the shared G2 chains).  Throughput-sized launches of 8 / 7 / 4 products
         // are therefore split 6 + 2 / 5 + 2 / 2 + 2; the lines of all products still come from ONE stage-1 launch.
-        int pieces[3] = {nprod, 0, 0};
-        if (m * (size_t)nprod >= ((size_t)1 << 17) && !sw.lp_one_lane) {
+        // More than 8 products (a deep look-ahead item: 16, 32 or 64 block products): greedily the piece sizes k for which 68 k rows x an integer number of
+        // waves per row fill the 2 048 slots (30 -> 1 wave per row, 15 -> 2, 10 -> 3, 6 -> 5, 5 -> 6, 3 -> 10, 2 -> 15, 1 -> 30): 16 = 15 + 1, 32 = 30 + 2, 64 = 30 + 30 + 3 + 1.
+        // (One piece of 16 products left half the chip idle in stage 2: item (2,l) of a 4-rank proof 46 ms where the rate says 34.)
+        int pieces[8] = {nprod, 0, 0, 0, 0, 0, 0, 0};
+        if (nprod > 8) {
+            static const int fill[8] = {30, 15, 10, 6, 5, 3, 2, 1};
+            int left = nprod, k = 0;
+            while (left > 0 && k < 8) { int f = 0; while (fill[f] > left) ++f; pieces[k++] = fill[f]; left -= fill[f]; }
+            if (left > 0) pieces[7] += left;
+        }
+        else if (m * (size_t)nprod >= ((size_t)1 << 17) && !sw.lp_one_lane) {
             if (nprod == 8) { pieces[0] = 6; pieces[1] = 2; } else if (nprod == 7) { pieces[0] = 5; pieces[1] = 2; } else if (nprod == 4) { pieces[0] = 2; pieces[1] = 2; }
         }
         int p_lo = 0;
-        for (int pc = 0; pc < 3 && pieces[pc] > 0; p_lo += pieces[pc], ++pc)
+        for (int pc = 0; pc < 8 && pieces[pc] > 0; p_lo += pieces[pc], ++pc)
             if ((rc = enqueue_stage2(p_lo, pieces[pc], m, stride, dst_pinned)) != RIPP_OK) return rc;
         return RIPP_OK;
     }

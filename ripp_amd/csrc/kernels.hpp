@@ -49,7 +49,8 @@ __device__ __forceinline__ T load_chunks(const uint4* buf, size_t row, size_t st
 // ---- stage 1: line elements --------------------------------------------------------------------------------
 // grid.y = product index p: pairs (a[p][i], b[p][i]), i < M, rows p*68 .. p*68+67 of lines[rows][18][stride].
 // Pairs with a point at infinity emit the unit line.  Both pairing products of a SIPP round go in ONE launch.
-constexpr int MAX_PRODUCTS = 8;     // pairing products sharing one launch (2 per SIPP round, 6 per GIPA/TIPP round, 8 quarter products of a pipelined SIPP tail round)
+constexpr int MAX_PRODUCTS = 64;    // pairing products sharing one stage-1 launch (2 per SIPP round, 6 per GIPA/TIPP round, 8 quarter products of a pipelined SIPP tail round;
+                                    // up to the 64 block products of a round-3 look-ahead item: build round 5 -- eight launches of 8 left stage 1 at a lone wave's latency)
 struct PairSets { const G1A* a[MAX_PRODUCTS]; const G2A* b[MAX_PRODUCTS]; };
 // The same products grouped into CHAINS (fq_miller.hpp k_miller_lines_q): chain g walks b[g] once and emits the lines of the np[g] consecutive
 // products first[g] .. first[g] + np[g] - 1, whose P vectors are a[first[g]] ..  (a chain of one product is the plain form).
