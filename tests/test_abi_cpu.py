@@ -227,3 +227,16 @@ def test_blake2s_matches_hashlib_at_every_length_class(hiplib):
         assert bytes(out) == hashlib.blake2s(src.tobytes()).digest(), n
     libc.mprotect(ctypes.c_void_p(base + mmap.PAGESIZE), ctypes.c_size_t(mmap.PAGESIZE), 3)
     del buf; mm.close()
+
+
+def test_blake2s_assembly_is_the_generators_output():
+    """ripp_amd/csrc/blake2s_x64.S is generated (tools/ubench/gen_blake2s_x64.py); its first line records the arguments: regenerating must reproduce it."""
+    import subprocess
+    import sys
+    path = os.path.join(ROOT, "ripp_amd", "csrc", "blake2s_x64.S")
+    text = open(path).read()
+    first = text.splitlines()[0]
+    assert first.startswith("# GENERATED by tools/ubench/gen_blake2s_x64.py ")
+    args = first.split("gen_blake2s_x64.py ", 1)[1].split(" -- ")[0].split()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ubench", "gen_blake2s_x64.py")] + args, capture_output=True, text=True, check=True).stdout
+    assert out == text, "ripp_amd/csrc/blake2s_x64.S is stale: regenerate it with the arguments on its first line"
