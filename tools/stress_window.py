@@ -15,7 +15,7 @@ lo = int(sys.argv[3]) if len(sys.argv) > 3 else 17
 hi = int(sys.argv[4]) if len(sys.argv) > 4 else 18
 rng = np.random.default_rng(seed)
 SW = ["RIPP_FUSE_TABLES", "RIPP_NO_FUSE", "RIPP_NO_SHARE", "RIPP_NO_XSCALE", "RIPP_NO_FOLD_TABLES", "RIPP_NO_PREBUILD"]
-bad = cnt = 0; t0 = time.time()
+bad = cnt = capped = 0; t0 = time.time()
 while time.time() - t0 < seconds:
     n = 1 << int(rng.integers(lo, hi + 1)); q = n // 4
     sa, sb, sr = (int(x) for x in rng.integers(1, 1 << 30, 3))
@@ -35,6 +35,9 @@ while time.time() - t0 < seconds:
         env = {"RIPP_LOOK_EIGHTHS": str(int(rng.integers(0, 49)))}
         for s in SW:
             if rng.random() < 0.25: env[s] = "1"
+        if rng.random() < 0.3:                                 # a random device-memory cap (build round 5): the scratch is released first so that the cap binds and the tiers of job_precompute_round0 / pairs_cap are taken
+            env["RIPP_MEM_CAP_BYTES"] = str(int(rng.integers(12, 80)) * 100_000_000 + R.device_bytes() * 0)
+            R.release_scratch(); capped += 1
         os.environ.update(env)
         try:
             p, ch, st = job.prove(v)
@@ -44,4 +47,4 @@ while time.time() - t0 < seconds:
         if not (rc == 0 and np.array_equal(p, ep) and np.array_equal(ch, ech)):
             bad += 1; print("MISMATCH", n, sa, sb, sr, env, flush=True)
     job.close()
-print("proofs", cnt, "mismatches", bad, "(n = 2^%d .. 2^%d, random look-ahead plans and switches %s)" % (lo, hi, " ".join(SW)))
+print("proofs", cnt, "mismatches", bad, "(n = 2^%d .. 2^%d, random look-ahead plans and switches %s; %d proofs under a random RIPP_MEM_CAP_BYTES of 1.2 - 8 GB)" % (lo, hi, " ".join(SW), capped))
