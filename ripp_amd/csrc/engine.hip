@@ -31,6 +31,7 @@
 #include "fq_curve.hpp"
 #include "fq_curve2.hpp"
 #include "fq_line_products.hpp"
+#include "fq_line_products_k.hpp"
 #include "fq_miller.hpp"
 #include "fq_scale.hpp"
 #include "fq_msm.hpp"
@@ -299,7 +300,7 @@ struct Engine {
         return aux;
     }
     // run-time switches: read from the environment ONCE per C-ABI call (get_engine), never inside round loops
-    struct Switches { bool no_vm = false, no_precompute = false, no_fold_tables = false, no_msm_glv = false, lp_one_lane = false, no_endo = false, no_fq = false, no_xscale = false, no_share = false, no_fuse = false, no_prebuild = false, fuse_tables = false, no_job_cache = false; } sw;
+    struct Switches { bool no_vm = false, no_precompute = false, no_fold_tables = false, no_msm_glv = false, lp_one_lane = false, no_endo = false, no_fq = false, no_xscale = false, no_share = false, no_fuse = false, no_prebuild = false, fuse_tables = false, no_job_cache = false, no_lp_kara = false; } sw;
     // crossover sizes: the member initialisers above are the defaults, the environment overrides them PER CALL (a test or
     // an A/B run flips them on a live engine)
     struct Sizes { size_t vm_lines_max, vm_fold_max, vm_tree_max, gls_split_max, msm_vm_merge_max, fold_tab_min, fq_min, lp_fq_min, vm_joint_max, vm_scale_max, tail_pipe_max, ml_fq_min, fq_min_g1, msm_lds_sort_min, msm_chunk_min; } defaults{};
@@ -338,6 +339,7 @@ struct Engine {
         env_on("RIPP_LP_ONE_LANE", sw.lp_one_lane);
         env_on("RIPP_NO_ENDO", sw.no_endo);            // plain scalar multiplications in the folds / scaling (no GLV, no psi)
         env_on("RIPP_NO_XSCALE", sw.no_xscale);        // G2 folds always on the plain vector with the full-width x^-1
+        env_on("RIPP_NO_LP_KARA", sw.no_lp_kara);      // stage 2 of the pairing product with the six-product sums of k_line_products_q instead of the Karatsuba form (BLS12-381)
         env_on("RIPP_NO_FQ", sw.no_fq);                // the 12 x 32-bit forms of the kernels that have a carry-free twin (fq_curve.hpp)
         env_on("RIPP_FUSE_TABLES", sw.fuse_tables);    // build the three-quarter tables whatever the look-ahead plan (tests: round 0 then folds ALONE over them when x1 is late)
         env_on("RIPP_NO_JOB_CACHE", sw.no_job_cache);  // one-shot proofs allocate and free their job buffers per call (ripp_config.no_job_cache)
@@ -623,7 +625,13 @@ struct Engine {
         // one resident batch: rows * T / 64 waves <= SIMDs * RIPP_OCC, so no partially filled second batch
         // T accumulators per row.  Spill-free form (line_products.hpp): 3 lanes per accumulator, 21 accumulators per wave;
         // RIPP_LP_ONE_LANE=1 selects the one-lane-per-accumulator kernel (A/B builds only).
-        const uint32_t per_wave = sw.lp_one_lane ? 64 : LP_GROUPS_PER_WAVE;
+        // BLS12-381, throughput-sized launches: the Karatsuba form (fq_line_products_k.hpp: six lanes per accumulator, 10 accumulators per wave)
+#if !defined(RIPP_BLS12_377)
+        const bool lp_kara = !sw.no_fq && !sw.no_lp_kara && !sw.lp_one_lane && m * (size_t)np2 >= lp_fq_min;
+#else
+        const bool lp_kara = false;
+#endif
+        const uint32_t per_wave = sw.lp_one_lane ? 64 : lp_kara ? LK_GROUPS_PER_WAVE : LP_GROUPS_PER_WAVE;
         uint32_t T = (uint32_t)std::max<size_t>(per_wave, ((size_t)n_simd * RIPP_OCC_PROD / nrows) * per_wave);
         if (T > m) T = (uint32_t)m;
         if ((rc = partA.reserve(nrows * FP12_CHUNKS * (size_t)T * sizeof(uint4))) != RIPP_OK) return rc;
@@ -632,6 +640,11 @@ struct Engine {
 #if defined(RIPP_AB_KERNELS) && !defined(RIPP_BLS12_377)
         if (sw.lp_one_lane)           // build round 1's one-lane-per-accumulator form: A/B builds only (-DRIPP_AB_KERNELS; it spills 1 248 B per lane)
             hipLaunchKernelGGL(k_line_products1, dim3(nblk(T, 64), (unsigned)nrows), dim3(64), 0, stream, lrows, stride, (uint32_t)m, partA.as<uint4>(), T);
+        else
+#endif
+#if !defined(RIPP_BLS12_377)
+        if (lp_kara)
+            hipLaunchKernelGGL(k_line_products_k, dim3(nblk(T, LK_GROUPS_PER_WAVE), (unsigned)nrows), dim3(64), 0, stream, lrows, stride, (uint32_t)m, partA.as<uint4>(), T);
         else
 #endif
         if (!sw.no_fq && m * (size_t)np2 >= lp_fq_min)          // throughput-sized launches: the carry-free twin (fq_line_products.hpp), both curves

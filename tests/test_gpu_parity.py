@@ -348,6 +348,7 @@ def test_sipp_prove_2p17_vs_oracle_with_precomputed_round0(engine, orc):
     big = str((1 << 32) - 1)
     for env in ({"RIPP_NO_FOLD_TABLES": "1"}, {"RIPP_NO_XSCALE": "1"}, {"RIPP_FQ_MIN": "4096", "RIPP_LP_FQ_MIN": "1"},
                 {"RIPP_FQ_MIN": "4096", "RIPP_NO_XSCALE": "1"}, {"RIPP_NO_FQ": "1"}, {"RIPP_LP_FQ_MIN": big}, {"RIPP_ML_FQ_MIN": big},
+                {"RIPP_NO_LP_KARA": "1"}, {"RIPP_NO_LP_KARA": "1", "RIPP_LOOK_EIGHTHS": "48"},     # stage 2 with the six-product sums (k_line_products_q) instead of the Karatsuba form (k_line_products_k, the default on BLS12-381)
                 {"RIPP_LOOK_EIGHTHS": "11"}, {"RIPP_LOOK_EIGHTHS": "5"}, {"RIPP_LOOK_EIGHTHS": "20", "RIPP_NO_XSCALE": "1"},
                 {"RIPP_LOOK_EIGHTHS": "48"}, {"RIPP_LOOK_EIGHTHS": "48", "RIPP_NO_SHARE": "1"}, {"RIPP_LOOK_EIGHTHS": "24", "RIPP_ML_FQ_MIN": big},      # shared G2 chains (fq_miller.hpp) / every product its own chain
                 # >= 16 eighths: both values of round 1 come from the look-ahead, so rounds 0 and 1 fold in ONE pass over three-quarter tables (job_fold_fused:
