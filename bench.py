@@ -33,7 +33,8 @@ HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 #   k_line_products_q  68 lines x 3 lanes x 5 488 (12 lazily reduced six-product sums of 196 each + their 196-MAD reductions, fq_line_products.hpp)
 #   k_miller_lines_q   63 doubling steps x 9 800 (6 Fp2 squares of 784, 3 Fp2 products of 1 176, 2 Fp2 x Fp of 784) + 5 addition steps x 16 072 (fq_miller.hpp)
 #   k_line_products    68 x 3 x 8 064, k_miller_lines (63 x 25 + 5 x 41) Fp products x 288: the 12 x 32-bit forms (BLS12-377, RIPP_NO_FQ), every MAD followed by a carry capture
-MADS_PER_PAIR = {"k_line_products_q": 68 * 3 * 5488, "k_miller_lines_q": 63 * 9800 + 5 * 16072,
+#   k_line_products_k  68 lines x 6 lanes x 2 156 (per Fp2 output 9 products + 2 reductions: Karatsuba inside the lazily reduced sums, fq_line_products_k.hpp; build round 6, BLS12-381)
+MADS_PER_PAIR = {"k_line_products_q": 68 * 3 * 5488, "k_miller_lines_q": 63 * 9800 + 5 * 16072, "k_line_products_k": 68 * 6 * 2156,
                  "k_line_products": 68 * 3 * 8064, "k_miller_lines": (63 * 25 + 5 * 41) * 288}
 MAD_ISSUE_PEAK_T = 34.72          # T lane-MAD/s, the hardware's measured v_mad_u64_u32 issue rate (profiles/r01_ubench_valu_rates.txt)
 # what an isolated multiplier chain reaches, in the same unit: carry-free 14 x 28-bit product 78.5 G/s x 392 MADs (profiles/r03_fqbench.txt);
@@ -110,6 +111,52 @@ def cpu_baseline(log_n_sample, statement=None):
     return out
 
 
+def config_figures(R, np, with_oracle):
+    """BASELINE.json's configs 2 and 3 beside the headline (outside its timed region): PairingInnerProduct::inner_product at n = 2^16 on Jacobian inputs
+    (SURVEY.md section 8d's "raw P1 throughput") and the G1 / G2 MultiexponentiationInnerProduct at n = 2^20, each on HOST slices (upload inside), best of 3
+    after one warm-up, with the algorithmic bytes of section 8(d) against the HBM peak and the CPU oracle's time for the same call on this box."""
+    from ripp_amd import api
+    o = None
+    if with_oracle:                     # the CPU leg: the oracle supplies the randomised Jacobian representatives and the expected values
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import orclib as o
+    one = api._fp_one()
+
+    def jac1(p): return np.ascontiguousarray(np.concatenate([p, np.tile(one, (len(p), 1))], axis=1))                                             # (x, y, 1)
+    def jac2(p): return np.ascontiguousarray(np.concatenate([p, np.tile(np.concatenate([one, np.zeros(6, dtype=np.uint64)]), (len(p), 1))], axis=1))
+    out = {}
+    n2 = 1 << 16
+    a2, b2 = R.synth_g1(1000, n2), R.synth_g2(2000, n2)
+    aj, bj = (o.blind_g1(a2, 1), o.blind_g2(b2, 1)) if o else (jac1(a2), jac2(b2))
+
+    def best(fn, reps=3):
+        fn(); ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter(); v = fn(); ts.append(time.perf_counter() - t0)
+        return min(ts), v
+    t, got = best(lambda: R.PairingInnerProduct.inner_product(aj, bj))
+    fig = {"ms": t * 1e3, "pairs_per_s": n2 / t, "algorithmic_GBps": n2 * (144 + 288) / t / 1e9, "frac": n2 * (144 + 288) / t / 1e9 / HBM_PEAK_GBS,
+           "call": "ripp_pairing_product_j, n = 2^16 Jacobian inputs (144 + 288 B per pair), host slices"}
+    if with_oracle:
+        t0 = time.perf_counter(); rc, exp = o.pairing_product_j(aj, bj); fig["cpu_oracle_ms"] = (time.perf_counter() - t0) * 1e3
+        fig["equals_oracle"] = bool(rc == 0 and np.array_equal(got, exp))
+    out["pairing_product_2p16"] = fig
+    n3 = 1 << 20
+    a, b, r = R.synth_g1(1000, n3), R.synth_g2(2000, n3), R.synth_fr(0, n3)
+    for name, bases, ip, norm, per_term, shape in (("msm_g1_2p20", jac1(a), R.MultiexponentiationInnerProductG1, R.normalize_batch_g1, 144 + 32, (1, 12)),
+                                                   ("msm_g2_2p20", jac2(b), R.MultiexponentiationInnerProductG2, R.normalize_batch_g2, 288 + 32, (1, 24))):
+        t, got = best(lambda: ip.inner_product(bases, r))
+        fig = {"ms": t * 1e3, "terms_per_s": n3 / t, "algorithmic_GBps": n3 * per_term / t / 1e9, "frac": n3 * per_term / t / 1e9 / HBM_PEAK_GBS,
+               "call": "ripp_%s_j, n = 2^20 Jacobian bases (%d B per term with its scalar), host slices" % (name[:6], per_term)}
+        if with_oracle:
+            t0 = time.perf_counter()
+            exp = (o.g1_to_affine(o.msm_g1_a(a, r)) if name == "msm_g1_2p20" else o.g2_to_affine(o.msm_g2_a(b, r))).reshape(shape)
+            fig["cpu_oracle_ms"] = (time.perf_counter() - t0) * 1e3
+            fig["equals_oracle"] = bool(np.array_equal(norm(got), exp))
+        out[name] = fig
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -145,7 +192,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend, rank=rank, world_size=world)     # rendezvous + barriers; "nccl" IS RCCL on ROCm
+        import datetime
+        # a rank that DIES must end the job, not hang it: the process group's collectives (and through them the callback transport) give up after this long;
+        # the library's own RCCL exchanges poll against ripp_config.comm_timeout_ms (60 s).  A failing rank exits non-zero -- nothing here re-executes a process.
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=int(os.environ.get("RIPP_BENCH_DIST_TIMEOUT_S", "120"))))     # rendezvous + barriers; "nccl" IS RCCL on ROCm
         # the proof's collectives run INSIDE libripp_hip.so: its own RCCL communicator over xGMI (id handed over through torch.distributed),
         # or -- single-device test mode -- an all-gather callback over gloo
         comm = NativeComm("rccl" if backend == "nccl" else "callback")
@@ -208,7 +258,16 @@ def main():
         return total, times, stats_all, ref_proof
 
     # ---- the timed region: the section 8(d) call.  HOST slices in, proof bytes out; upload of the statement (shard) inside the call
+    kill_rank = int(os.environ.get("RIPP_BENCH_KILL_RANK", "-1"))       # test hook (tests/test_sharded_gloo.py): this rank kills itself in round 3 of its second proof
+    host_calls = [0]
+
     def host_step():
+        host_calls[0] += 1
+        if world > 1 and rank == kill_rank and host_calls[0] == 2:
+            import ctypes
+            from ripp_amd._lib import lib as _lib
+            _lib().ripp_test_inject_failure.restype = None
+            _lib().ripp_test_inject_failure(ctypes.c_int32(rank), ctypes.c_int32(1003))
         if world == 1:
             proof, ch, st = R.SIPP.prove_one_shot(a, b, r, value)       # ripp_sipp_prove: hashing starts on the caller's buffers, overlaps the upload and the first kernels
         else:
@@ -237,7 +296,7 @@ def main():
         # dominant kernel of the path on this rank, from HIP events recorded on the engine's own stream
         # the kernels the engine launches for throughput-sized products: the carry-free twins unless switched off
         no_fq = bool(os.environ.get("RIPP_NO_FQ"))
-        lp_name = "k_line_products" if no_fq or int(os.environ.get("RIPP_LP_FQ_MIN", "0")) > (1 << 19) else "k_line_products_q"
+        lp_name = "k_line_products" if no_fq or int(os.environ.get("RIPP_LP_FQ_MIN", "0")) > (1 << 19) else "k_line_products_q" if os.environ.get("RIPP_NO_LP_KARA") else "k_line_products_k"
         ml_name = "k_miller_lines" if no_fq or int(os.environ.get("RIPP_ML_FQ_MIN", "0")) > (1 << 19) else "k_miller_lines_q"
         k_lines = (stats["kernel_miller_lines_ms_sum"], stats["kernel_miller_lines_launches"], stats["pairs_lines"], ml_name)
         k_prod = (stats["kernel_line_products_ms_sum"], stats["kernel_line_products_launches"], stats["pairs_products"], lp_name)
@@ -257,7 +316,8 @@ def main():
             traffic = None
         mads = MADS_PER_PAIR[dom[3]]
         mad_rate_t = dom[2] * mads / (dom[0] * 1e-3) / 1e12 if dom[0] > 0 else 0.0            # T multiply-adds per second inside the kernel
-        mult_peak_t = MULTIPLIER_PEAK_T["q" if dom[3].endswith("_q") else "32"]
+        carry_free = dom[3].endswith(("_q", "_k"))
+        mult_peak_t = MULTIPLIER_PEAK_T["q" if carry_free else "32"]
         hash_ms = sum(hash_ms_steps) / len(hash_ms_steps)
         out = {
             "metric": "SIPP prover pairing-products/sec at n=2^%d BLS12-381" % args.log_n,
@@ -274,7 +334,8 @@ def main():
             "statement_hash_ms_all": [round(h, 3) for h in hash_ms_steps],
             "post_hash_ms_all": [round(t * 1e3 - h, 3) for t, h in zip(times, hash_ms_steps)],
             "value_resident": n / (resident_ms * 1e-3), "ms_per_step_resident": resident_ms,
-            "roofline": {"bound": "hbm", "kernel": dom[3], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # `bound` / `achieved` / `peak` / `frac` are the byte roofline the bench contract asks for; `binding` names the roof that actually limits the kernel
+            "roofline": {"bound": "hbm", "binding": "int_alu", "kernel": dom[3], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": dom[2] * ALG_BYTES_PER_PAIR / max(dom[1], 1),
                          "avg_launch_ms": dom[0] / max(dom[1], 1), "launches_per_step": dom[1], "pairs_per_step": dom[2],
@@ -284,8 +345,12 @@ def main():
                          # runs at 2 waves per SIMD: a lone wave issues one v_mad_u64_u32 per 3.99 ns, two waves one per 2.11 ns, eight one per 1.89 ns.
                          "int_alu": {"unit": "T MAD/s", "achieved": mad_rate_t, "peak": MAD_ISSUE_PEAK_T, "peak_kind": "measured v_mad_u64_u32 issue rate of the chip",
                                      "frac": mad_rate_t / MAD_ISSUE_PEAK_T, "mads_per_pair": mads,
-                                     "multiplier_peak": mult_peak_t, "multiplier_kind": "isolated %s Montgomery product chain, MADs/s" % ("14 x 28-bit carry-free" if dom[3].endswith("_q") else "12 x 32-bit"),
+                                     "multiplier_peak": mult_peak_t, "multiplier_kind": "isolated %s Montgomery product chain, MADs/s" % ("14 x 28-bit carry-free" if carry_free else "12 x 32-bit"),
                                      "frac_of_multiplier": mad_rate_t / mult_peak_t,
+                                     # the same launches priced at build round 5's multiply-add count for this stage (k_line_products_q: 1 119 552 per pair): the
+                                     # Karatsuba form executes 21 % fewer multiply-adds per pair, so its EXECUTED rate is lower at a higher pair rate -- compare this one across rounds
+                                     "achieved_at_r05_count": (dom[2] * MADS_PER_PAIR["k_line_products_q"] / (dom[0] * 1e-3) / 1e12) if dom[3] == "k_line_products_k" and dom[0] > 0 else None,
+                                     "ns_per_pair": dom[0] * 1e6 / dom[2] if dom[2] else None,
                                      "occupancy_ceiling": {"waves_per_simd": 2, "frac_of_issue_roof": round(1.89 / 2.11, 3)}},
                          "note": "integer-ALU bound (381-bit Montgomery arithmetic, ~1.8 M multiply-adds per 288 input bytes); see DESIGN.md"},
             "phase_ms": {k: round(v, 3) for k, v in stats.items() if k.endswith("_ms")},
@@ -304,6 +369,9 @@ def main():
         out["post_hash_ms"] = ms_per_step - hash_ms
         out["post_hash_ms_resident"] = resident_ms - sum(st["statement_hash_ms"] + st["statement_hash_wait_ms"] for st in stats_res) / len(stats_res)
         out["look_ahead"] = {"items": int(stats["look_items"]), "pairs": int(stats["look_pairs"]), "order": "(1,l) (1,r) (2,l) (2,r) (3,l) (3,r)"}
+        out["miller_loops_per_s"] = 2 * (n - 1) / (ms_per_step * 1e-3)            # the 2 (n - 1) Miller loops of the reference's prover per second of the step
+        if world == 1 and args.log_n == 20 and not os.environ.get("RIPP_BENCH_NO_CONFIGS"):
+            out.update(config_figures(R, np, args.cpu_log_n > 0))
         parity_ok = True
         if world == 1 and args.cpu_log_n > 0:
             cb = cpu_baseline(args.cpu_log_n, (a, b, r, value))

@@ -63,7 +63,7 @@ typedef struct {
 /* ABI guard.  The library WRITES sizeof(ripp_stats) bytes through every `ripp_stats*` it is given, and the struct has grown twice: a caller
  * compiled against an older header would be overrun.  Bindings must check at load time that RIPP_ABI_VERSION == ripp_abi_version() and
  * sizeof(their ripp_stats) == ripp_stats_size() (ripp_amd/_lib.py and rust/ripp-hip do). */
-#define RIPP_ABI_VERSION 6
+#define RIPP_ABI_VERSION 7
 int32_t ripp_abi_version(void);
 size_t  ripp_stats_size(void);
 
@@ -100,11 +100,17 @@ typedef struct {
              msm_lds_sort_min,       /* MSMs below this many terms use the lane-per-term digit sort instead of the LDS-tile sort (default 0: never) */
              msm_chunk_min;          /* host-slice MSMs from this many G1 bases (half as many G2 bases) run as two halves on two streams (default 2^20) */
     /* appended in build round 5 (ABI version 6) */
-    uint64_t mem_cap_bytes;          /* device memory the library may hold in all (scratch, tables, jobs, SRS / vector handles); 0 = automatic: what hipMemGetInfo
+    uint64_t mem_cap_bytes;          /* a BUDGET for the device memory the library holds (scratch, tables, jobs, SRS / vector handles: ripp_device_bytes()), consulted where an
+                                      * OPTIONAL structure is sized -- a caller's own uploads are never refused because of it; 0 = automatic: what hipMemGetInfo
                                       * reports free, less a margin.  Short of it the engine cuts the line buffer (pairs per launch), then steps the round-0 fold
                                       * tables down (ripp_stats.mem_tier); the proof bytes are the same in every tier */
     uint32_t hot_workers;            /* polling host workers after the digest: 0 automatic (CPUs of the process tree / ranks >= 8), 1 always, 2 never */
     uint32_t no_job_cache;           /* one-shot proofs free their job buffers (~1 KB per element + four pinned row buffers) instead of parking them for the next call */
+    /* appended in build round 6 (ABI version 7) */
+    uint32_t no_lp_karatsuba;        /* (selector) stage 2 of the pairing product with the six-product sums of k_line_products_q instead of the Karatsuba form k_line_products_k (BLS12-381) */
+    uint32_t comm_timeout_ms;        /* deadline of one exchange of the RCCL transport; 0 = 60 000.  On expiry the call returns RIPP_ERR_DEVICE and the communicator is unusable */
+    uint32_t plan_derate_pct;        /* the look-ahead planner prices the GPU this many per cent SLOWER than measured (tests of the plan on a slow device; 0 = as measured) */
+    uint32_t n_devices;              /* stateless trait calls (pairing products, MSMs on host slices) split over this many devices IN THIS PROCESS; 0 / 1 = the bound device only */
 } ripp_config;
 int32_t ripp_config_default(ripp_config* cfg);      /* the built-in defaults of this build; needs no device */
 int32_t ripp_configure(const ripp_config* cfg);     /* NULL: back to the defaults */
@@ -267,7 +273,8 @@ int32_t ripp_sipp_job_prove_sharded(ripp_sipp_job* job, const ripp_gt* value, co
                                     const uint8_t* seed_digest, ripp_gt* proof, ripp_fr* challenges, ripp_stats* stats);
 /* TEST HOOK (no counterpart in the reference): the fold of round `round` on rank `rank` of this process's NEXT SIPP proof reports
  * RIPP_ERR_DEVICE instead of running -- a local failure in the middle of a sharded proof.  One shot; (-1, -1) disarms.  Every rank
- * of the proof must then return non-zero from the same exchange (tests/test_sharded_gloo.py::test_collective_error_exit_*). */
+ * of the proof must then return non-zero from the same exchange (tests/test_sharded_gloo.py::test_collective_error_exit_*).
+ * round + 1000: the process KILLS ITSELF there (SIGKILL) -- a rank that dies in the middle of a proof; the survivors' exchange runs into its deadline. */
 void    ripp_test_inject_failure(int32_t rank, int32_t round);
 
 /* ---- GIPA prover, TIPP instantiation  -- GIPA::prove_with_aux / _prove, ip_proofs/src/gipa.rs:162-312 ------------

@@ -10,7 +10,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RIPP_HIP_LIB") or os.path.join(PKG_DIR, "lib", "libripp_hip.so")      # RIPP_HIP_LIB: another build of the same library (A/B runs)
 
 RIPP_OK, RIPP_ERR_LENGTH, RIPP_ERR_POW2, RIPP_ERR_DEVICE, RIPP_ERR_ARG = 0, 1, 2, 3, 4
-RIPP_ABI_VERSION = 6              # include/ripp_hip.h; checked against the library at load time together with sizeof(ripp_stats)
+RIPP_ABI_VERSION = 7              # include/ripp_hip.h; checked against the library at load time together with sizeof(ripp_stats)
 
 
 class RippStats(ctypes.Structure):
@@ -33,7 +33,8 @@ class RippConfig(ctypes.Structure):
         ("look_eighths", ctypes.c_int32), ("ranks_per_device", ctypes.c_int32), ("msm_c", ctypes.c_int32), ("msm_ch", ctypes.c_uint32), ("msm_gmin", ctypes.c_uint32), ("no_prebuild", ctypes.c_uint32)] + [
         (n, ctypes.c_uint64) for n in ("vm_lines_max", "vm_fold_max", "vm_tree_max", "gls_split_max", "msm_vm_merge_max", "fold_tab_min", "fq_min", "lp_fq_min", "vm_joint_max",
                                        "vm_scale_max", "tail_pipe_max", "ml_fq_min", "fq_min_g1", "msm_lds_sort_min", "msm_chunk_min", "mem_cap_bytes")] + [
-        ("hot_workers", ctypes.c_uint32), ("no_job_cache", ctypes.c_uint32)]
+        ("hot_workers", ctypes.c_uint32), ("no_job_cache", ctypes.c_uint32),
+        ("no_lp_karatsuba", ctypes.c_uint32), ("comm_timeout_ms", ctypes.c_uint32), ("plan_derate_pct", ctypes.c_uint32), ("n_devices", ctypes.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

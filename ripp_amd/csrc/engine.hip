@@ -7,6 +7,7 @@
 // sipp/src/lib.rs:56-60,80-85,94.
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <csignal>
 #include <sched.h>
 #include <condition_variable>
 #include <deque>
@@ -22,6 +23,9 @@
 #include <string>
 #include <thread>
 #include <vector>
+#ifndef RIPP_BUILD_STAMP
+#define RIPP_BUILD_STAMP __DATE__ " " __TIME__       // (the Makefile passes a hash of the sources)
+#endif
 #include "../../include/ripp_hip.h"
 #include "kernels.hpp"
 #include "line_products.hpp"
@@ -293,6 +297,9 @@ struct Engine {
     ripp_stats stats{};
     // A second set of streams and scratch on the SAME device: two independent latency-bound provers of one call (aggregate_proofs' TIPP and
     // TIPAWithSSM sub-proofs) run side by side, each driven by its own host thread, instead of taking turns waiting for host and device.
+    // In-process multi-device dispatch of the stateless trait calls (ripp_config.n_devices): one more Engine per extra device, each driven by its own host
+    // thread for the duration of one call (device_slots / run_on_devices below).  RIPP_VIRTUAL_DEVICES=G (one-GPU test rig): G slots, all on the bound device.
+    std::vector<Engine*> peers; bool virtual_devices = false;
     Engine* aux = nullptr;
     Engine* aux_engine() {
         if (!aux) { Engine* a = new Engine(); if (a->init(device) != RIPP_OK) { delete a; return nullptr; } aux = a; }
@@ -309,6 +316,7 @@ struct Engine {
     double cal_ms_per_pair = 0, cal_hash_bytes_per_ms = 0;        // look_plan's rates as measured by the last large proof of this process (0: not yet)
     int look_eighths = -1; double ranks_per_device = 1.0; bool look_static = false, quiet_waits_cfg = false, agg_sequential = false, scale_no_fq = false;
     int hot_workers_cfg = 0;               // 0 automatic, 1 always, 2 never (ripp_config.hot_workers / RIPP_HOT_WORKERS)
+    uint32_t comm_timeout_ms = 0, plan_derate_pct = 0, n_devices_cfg = 0;      // ripp_config members of the same names (RIPP_COMM_TIMEOUT_MS, RIPP_PLAN_DERATE_PCT, RIPP_N_DEVICES)
     // Precedence: built-in defaults < ripp_configure() < environment variables (a debug / A-B override).  This function is the ONLY place of the
     // library that reads RIPP_* configuration from the environment (RIPP_TRACE aside), once per C-ABI call (get_engine) -- never inside a proof.
     void refresh_switches() {
@@ -316,7 +324,7 @@ struct Engine {
         vm_lines_max = defaults.vm_lines_max; vm_fold_max = defaults.vm_fold_max; vm_tree_max = defaults.vm_tree_max; gls_split_max = defaults.gls_split_max;
         msm_vm_merge_max = defaults.msm_vm_merge_max; fold_tab_min = defaults.fold_tab_min; fq_min = defaults.fq_min; lp_fq_min = defaults.lp_fq_min; vm_joint_max = defaults.vm_joint_max;
         vm_scale_max = defaults.vm_scale_max; tail_pipe_max = defaults.tail_pipe_max; ml_fq_min = defaults.ml_fq_min; fq_min_g1 = defaults.fq_min_g1; msm_lds_sort_min = defaults.msm_lds_sort_min; msm_chunk_min = defaults.msm_chunk_min;
-        sw = Switches(); look_eighths = -1; ranks_per_device = 1.0; look_static = quiet_waits_cfg = agg_sequential = scale_no_fq = false; mem_cap = 0; hot_workers_cfg = 0;
+        sw = Switches(); look_eighths = -1; ranks_per_device = 1.0; look_static = quiet_waits_cfg = agg_sequential = scale_no_fq = false; mem_cap = 0; hot_workers_cfg = 0; comm_timeout_ms = plan_derate_pct = n_devices_cfg = 0;
         if (g_cfg_set) {
             const ripp_config& c = g_cfg;
             sw.no_vm = c.no_vm; sw.no_precompute = c.no_precompute; sw.no_fold_tables = c.no_fold_tables; sw.no_msm_glv = c.no_msm_glv; sw.lp_one_lane = c.lp_one_lane;
@@ -324,6 +332,7 @@ struct Engine {
             look_eighths = c.look_eighths; ranks_per_device = c.ranks_per_device > 1 ? (double)c.ranks_per_device : 1.0;
             msm_tune.c = c.msm_c; msm_tune.ch = c.msm_ch; msm_tune.gmin = c.msm_gmin; sw.no_prebuild = c.no_prebuild;
             mem_cap = (size_t)c.mem_cap_bytes; hot_workers_cfg = (int)c.hot_workers; sw.no_job_cache = c.no_job_cache != 0;
+            sw.no_lp_kara = c.no_lp_karatsuba != 0; comm_timeout_ms = c.comm_timeout_ms; plan_derate_pct = c.plan_derate_pct; n_devices_cfg = c.n_devices;
             vm_lines_max = c.vm_lines_max; vm_fold_max = c.vm_fold_max; vm_tree_max = c.vm_tree_max; gls_split_max = c.gls_split_max; msm_vm_merge_max = c.msm_vm_merge_max; fold_tab_min = c.fold_tab_min;
             fq_min = c.fq_min; lp_fq_min = c.lp_fq_min; vm_joint_max = c.vm_joint_max; vm_scale_max = c.vm_scale_max; tail_pipe_max = c.tail_pipe_max; ml_fq_min = c.ml_fq_min; fq_min_g1 = c.fq_min_g1; msm_lds_sort_min = c.msm_lds_sort_min; msm_chunk_min = c.msm_chunk_min;
         }
@@ -345,6 +354,9 @@ struct Engine {
         env_on("RIPP_NO_JOB_CACHE", sw.no_job_cache);  // one-shot proofs allocate and free their job buffers per call (ripp_config.no_job_cache)
         env_sz("RIPP_MEM_CAP_BYTES", mem_cap);         // device memory the library may hold (ripp_config.mem_cap_bytes; 0 = automatic)
         if (const char* s = std::getenv("RIPP_HOT_WORKERS")) hot_workers_cfg = std::atoi(s) ? 1 : 2;
+        { auto env_u32 = [](const char* k, uint32_t& v) { if (const char* s = std::getenv(k)) v = (uint32_t)std::strtoul(s, nullptr, 10); };
+          env_u32("RIPP_COMM_TIMEOUT_MS", comm_timeout_ms); env_u32("RIPP_PLAN_DERATE_PCT", plan_derate_pct); env_u32("RIPP_N_DEVICES", n_devices_cfg);
+          virtual_devices = false; if (const char* s = std::getenv("RIPP_VIRTUAL_DEVICES")) { n_devices_cfg = (uint32_t)std::strtoul(s, nullptr, 10); virtual_devices = true; } }
         env_on("RIPP_NO_PREBUILD", sw.no_prebuild);    // in-round G2 fold tables after the challenge (fold_g2_table), not in the host phase before it (job_prebuild_g2_tables)
         env_on("RIPP_NO_FUSE", sw.no_fuse);            // rounds 0 and 1 always fold one after the other (no three-quarter tables, no job_fold_fused)
         env_on("RIPP_NO_SHARE", sw.no_share);          // every pairing product walks its own G2 chain (no ChainSets grouping, no merged round 0 + look-ahead)
@@ -378,6 +390,8 @@ struct Engine {
     }
     void destroy() {
         if (aux) { aux->destroy(); delete aux; aux = nullptr; }
+        for (Engine* p : peers) { (void)hipSetDevice(p->device); p->destroy(); delete p; }
+        if (!peers.empty()) { peers.clear(); (void)hipSetDevice(device); }
         for (DevBuf* b : {&lines, &partA, &partB, &jacG1, &jacG2, &tmpA, &tmpB, &tmpR, &affG1, &affG2, &qtab, &vm_flag, &scale_tab, &fold_tab1, &fold_mult, &fold_tab, &fold_jac1, &fold_jac2, &fix_flags, &scale_flags}) b->release();
         msm_scratch[0].release(); msm_scratch[1].release(); kzg_q[0].release(); kzg_q[1].release(); kzg_bases[0].release(); kzg_bases[1].release(); job_cache.release();
         if (stream3) (void)hipStreamDestroy(stream3);
@@ -1460,6 +1474,8 @@ API int32_t ripp_release_scratch(void) {
     for (PinBuf& pb : e->stage) pb.release();             // pinned host staging (up to 2 x 32 MB after a verifier call at n = 2^20)
     e->tab_owner = nullptr; e->g2tab_hi = nullptr; e->job_cache.release(); vec_caches_release();
     if (e->aux) { e->aux->destroy(); delete e->aux; e->aux = nullptr; }
+    for (Engine* p : e->peers) { (void)hipSetDevice(p->device); p->destroy(); delete p; }
+    if (!e->peers.empty()) { e->peers.clear(); (void)hipSetDevice(e->device); }
     return RIPP_OK;
 }
 
@@ -1552,6 +1568,56 @@ API int32_t ripp_fold_fr(const ripp_fr* hi, const ripp_fr* lo, size_t half, cons
     return e->sync();
 }
 
+// ---- in-process multi-device dispatch (ripp_config.n_devices) --------------------------------------------------------------------------------
+// The reference's traits are static, stateless calls of ONE process (inner_products/src/lib.rs:45-48), so an unmodified caller of PairingInnerProduct /
+// MultiexponentiationInnerProduct can only ever reach the devices this process drives.  With n_devices = D > 1 a host-slice call is cut into D contiguous
+// index ranges; range d runs on its own Engine (device bound + d; streams, scratch, line buffer of its own) under its own host thread, the D partial results
+// -- 68 per-step Fp12 products, or one group element -- come back by plain D2H copies, and the host combines them and runs the ONE final exponentiation.
+// No communicator, no RCCL: the host needs the value anyway.  The result is the single-device call's value (a projective MSM result
+// is another representative of the same point).  UNMEASURED on a multi-GPU node; tested on one GPU with RIPP_VIRTUAL_DEVICES.
+extern "C++" {
+struct DevSlot { Engine* e; size_t off, cnt; };
+static int32_t device_slots(Engine* e, size_t n, size_t min_units, std::vector<DevSlot>* out) {
+    size_t D = e->n_devices_cfg > 1 ? e->n_devices_cfg : 1;
+    if (min_units && D > n / min_units) D = std::max<size_t>(1, n / min_units);
+    out->clear();
+    if (D > 1) {
+        int count = 0; (void)hipGetDeviceCount(&count);
+        for (size_t d = 1; d < D; ++d) {
+            const int phys = e->virtual_devices ? e->device : e->device + (int)d;
+            if (phys >= count) { set_err("n_devices = " + std::to_string(e->n_devices_cfg) + ": device " + std::to_string(phys) + " does not exist (" + std::to_string(count) + " visible)"); (void)hipSetDevice(e->device); return RIPP_ERR_ARG; }
+            if (e->peers.size() < d) {
+                Engine* p = new Engine(); const int32_t rc = p->init(phys);
+                (void)hipSetDevice(e->device);
+                if (rc != RIPP_OK) { delete p; return rc; }
+                e->peers.push_back(p);
+            } else if (e->peers[d - 1]->device != phys) { set_err("n_devices: the device mapping changed under live peer engines (ripp_release_scratch first)"); return RIPP_ERR_ARG; }
+            e->peers[d - 1]->refresh_switches(); e->peers[d - 1]->stats = ripp_stats{};
+        }
+    }
+    for (size_t d = 0; d < D; ++d) { const size_t lo = n * d / D, hi = n * (d + 1) / D; out->push_back({d == 0 ? e : e->peers[d - 1], lo, hi - lo}); }
+    return RIPP_OK;
+}
+// fn(engine, offset, count, slot) on every slot: slot 0 on the calling thread, the others on threads of their own (HIP's current device is per thread)
+template <class FN> static int32_t run_on_devices(Engine* e, const std::vector<DevSlot>& sl, FN fn) {
+    if (sl.size() == 1) return fn(sl[0].e, sl[0].off, sl[0].cnt, 0);
+    std::vector<int32_t> rcs(sl.size(), RIPP_OK); std::vector<std::string> errs(sl.size());
+    std::vector<std::thread> th;
+    for (size_t d = 1; d < sl.size(); ++d)
+        th.emplace_back([&, d]() {
+            if (hipSetDevice(sl[d].e->device) != hipSuccess) { rcs[d] = RIPP_ERR_DEVICE; errs[d] = "hipSetDevice failed"; return; }
+            rcs[d] = fn(sl[d].e, sl[d].off, sl[d].cnt, (int)d);
+            if (rcs[d]) errs[d] = g_err;
+        });
+    rcs[0] = fn(sl[0].e, sl[0].off, sl[0].cnt, 0); if (rcs[0]) errs[0] = g_err;
+    for (std::thread& t : th) t.join();
+    (void)hipSetDevice(e->device);
+    for (size_t d = 0; d < sl.size(); ++d) if (rcs[d]) { set_err("device slot " + std::to_string(d) + " of " + std::to_string(sl.size()) + ": " + errs[d]); return rcs[d]; }
+    return RIPP_OK;
+}
+constexpr size_t PAIRS_PER_DEVICE_MIN = 4096, MSM_TERMS_PER_DEVICE_MIN = (size_t)1 << 15;
+}  // extern "C++"
+
 // ---- pairing products ------------------------------------------------------------------------------------------
 static int32_t pairing_product_dev(Engine* e, const G1A* da, const G2A* db, size_t n, ripp_gt* out) {
     Fp12 rows[N_LINES];
@@ -1562,24 +1628,38 @@ static int32_t pairing_product_dev(Engine* e, const G1A* da, const G2A* db, size
     e->collect_kernel_stats();
     return RIPP_OK;
 }
+extern "C++" {
+// per-step products of one slot's pairs, then the product over the slots, the 63 squarings and ONE final exponentiation on the host
+template <class ROWS> static int32_t pairing_product_slots(Engine* e, size_t n, ripp_gt* out, ROWS rows_of /* (engine, off, cnt, Fp12 rows[68]) */) {
+    std::vector<DevSlot> sl; int32_t rc = device_slots(e, n, PAIRS_PER_DEVICE_MIN, &sl); if (rc) return rc;
+    std::vector<Fp12> rows(sl.size() * N_LINES);
+    if ((rc = run_on_devices(e, sl, [&](Engine* ee, size_t off, size_t cnt, int d) { return rows_of(ee, off, cnt, rows.data() + (size_t)d * N_LINES); }))) return rc;
+    for (size_t d = 1; d < sl.size(); ++d) for (int s = 0; s < N_LINES; ++s) rows[s] = mul(rows[s], rows[d * N_LINES + s]);
+    Fp12 z; pairing_values(rows.data(), 1, &z);
+    std::memcpy(out, &z, sizeof(Fp12));
+    e->collect_kernel_stats();
+    return RIPP_OK;
+}
+}
 API int32_t ripp_pairing_product_a(const ripp_g1a* a, const ripp_g2a* b, size_t n, ripp_gt* out) {
     LOCK; ENGINE; if (!out || (n && (!a || !b))) return RIPP_ERR_ARG;
-    G1A* da; G2A* db; int32_t rc;
-    if ((rc = upload<G1A>(e, e->tmpA, a, n, &da))) return rc;
-    if ((rc = upload<G2A>(e, e->tmpB, b, n, &db))) return rc;
-    return pairing_product_dev(e, da, db, n, out);
+    return pairing_product_slots(e, n, out, [&](Engine* ee, size_t off, size_t cnt, Fp12* rows) -> int32_t {
+        G1A* da; G2A* db; int32_t rc;
+        if ((rc = upload<G1A>(ee, ee->tmpA, a + off, cnt, &da)) || (rc = upload<G2A>(ee, ee->tmpB, b + off, cnt, &db))) return rc;
+        const G1A* as[1] = {da}; const G2A* bs[1] = {db};
+        return ee->step_products(as, bs, 1, cnt, rows); });
 }
 API int32_t ripp_pairing_product_j(const ripp_g1j* l, size_t nl, const ripp_g2j* r, size_t nr, ripp_gt* out) {
     if (nl != nr) { set_err("left length, right length: " + std::to_string(nl) + ", " + std::to_string(nr)); return RIPP_ERR_LENGTH; }
     LOCK; ENGINE; if (!out || (nl && (!l || !r))) return RIPP_ERR_ARG;
-    G1J* dl; G2J* dr; int32_t rc;
-    if ((rc = upload<G1J>(e, e->jacG1, l, nl, &dl))) return rc;
-    if ((rc = upload<G2J>(e, e->jacG2, r, nr, &dr))) return rc;
-    if ((rc = e->affG1.reserve(std::max<size_t>(nl, 1) * sizeof(G1A)))) return rc;
-    if ((rc = e->affG2.reserve(std::max<size_t>(nl, 1) * sizeof(G2A)))) return rc;
-    if ((rc = e->normalize_dev<Fp>(dl, nl, e->affG1.as<G1A>()))) return rc;       // inner_products/src/lib.rs:80-81
-    if ((rc = e->normalize_dev<Fp2>(dr, nr, e->affG2.as<G2A>()))) return rc;
-    return pairing_product_dev(e, e->affG1.as<G1A>(), e->affG2.as<G2A>(), nl, out);
+    return pairing_product_slots(e, nl, out, [&](Engine* ee, size_t off, size_t cnt, Fp12* rows) -> int32_t {
+        G1J* dl; G2J* dr; int32_t rc;
+        if ((rc = upload<G1J>(ee, ee->jacG1, l + off, cnt, &dl)) || (rc = upload<G2J>(ee, ee->jacG2, r + off, cnt, &dr))) return rc;
+        if ((rc = ee->affG1.reserve(std::max<size_t>(cnt, 1) * sizeof(G1A))) || (rc = ee->affG2.reserve(std::max<size_t>(cnt, 1) * sizeof(G2A)))) return rc;
+        if ((rc = ee->normalize_dev<Fp>(dl, cnt, ee->affG1.as<G1A>()))) return rc;       // inner_products/src/lib.rs:80-81
+        if ((rc = ee->normalize_dev<Fp2>(dr, cnt, ee->affG2.as<G2A>()))) return rc;
+        const G1A* as[1] = {ee->affG1.as<G1A>()}; const G2A* bs[1] = {ee->affG2.as<G2A>()};
+        return ee->step_products(as, bs, 1, cnt, rows); });
 }
 // this rank's share of a sharded pairing product: the Miller value of its pairs, BEFORE the final exponentiation.
 // prod over ranks of these (ripp_combine_partials), then ONE ripp_final_exp, equals ripp_pairing_product_j of the whole vectors.
@@ -1616,9 +1696,7 @@ API int32_t ripp_pairing_product_coeffs_a(const ripp_g1a* a, const ripp_g2a* b, 
 
 // ---- MSM -----------------------------------------------------------------------------------------------------------
 extern "C++" {
-template <class F, bool JAC> static int32_t msm_impl(const void* bases, size_t nl, const ripp_fr* scalars, size_t nr, void* out) {
-    if (nl != nr) { set_err("left length, right length: " + std::to_string(nl) + ", " + std::to_string(nr)); return RIPP_ERR_LENGTH; }
-    LOCK; ENGINE; if (!out || (nl && (!bases || !scalars))) return RIPP_ERR_ARG;
+template <class F, bool JAC> static int32_t msm_on(Engine* e, const void* bases, const ripp_fr* scalars, size_t nl, Jac<F>* out) {      // the MSM of nl terms on engine e (its device is current)
     Jac<F> res = jac_inf<F>();
     if (nl) {
         int32_t rc; Fr* ds;
@@ -1663,6 +1741,18 @@ template <class F, bool JAC> static int32_t msm_impl(const void* bases, size_t n
         }
         else if ((rc = e->msm_dev<F>(db, ds, nl, &res, &bases_arrive))) return rc;
     }
+    *out = res;
+    return RIPP_OK;
+}
+template <class F, bool JAC> static int32_t msm_impl(const void* bases, size_t nl, const ripp_fr* scalars, size_t nr, void* out) {
+    if (nl != nr) { set_err("left length, right length: " + std::to_string(nl) + ", " + std::to_string(nr)); return RIPP_ERR_LENGTH; }
+    LOCK; ENGINE; if (!out || (nl && (!bases || !scalars))) return RIPP_ERR_ARG;
+    std::vector<DevSlot> sl; int32_t rc = device_slots(e, nl, MSM_TERMS_PER_DEVICE_MIN, &sl); if (rc) return rc;
+    std::vector<Jac<F>> part(sl.size());
+    using B = typename std::conditional<JAC, Jac<F>, Affine<F>>::type;
+    if ((rc = run_on_devices(e, sl, [&](Engine* ee, size_t off, size_t cnt, int d) { return msm_on<F, JAC>(ee, static_cast<const B*>(bases) + off, scalars + off, cnt, &part[(size_t)d]); }))) return rc;
+    Jac<F> res = part[0];
+    for (size_t d = 1; d < sl.size(); ++d) res = add(res, part[d]);
     std::memcpy(out, &res, sizeof(Jac<F>));
     return RIPP_OK;
 }
@@ -2001,7 +2091,7 @@ static int look_plan(const Engine* e, size_t n_local, int world, bool window) {
     // 286 ms at n = 2^20 = 1.17 GB/s of Blake2s in situ with the x86-64 bulk loop, build round 5; 313-317 ms = 1.06-1.12 GB/s before), MEASURED afterwards: sipp_prove_core records this box's hash rate and this device's
     // pairing rate at the end of every large proof that hashed (Engine::cal_*), so the static plan the non-hashing ranks follow is priced with what
     // rank 0's box and GPU really do (boxes differ by +-3 % / +-5 %).  Scaling and the fold tables move with the GPU factor.
-    const double ms_per_pair = e->cal_ms_per_pair > 0 ? e->cal_ms_per_pair : 6.7e-5;      // (shared G2 chains: 138 ms for the 2^21 pair evaluations of round 0 + (1,l) at n = 2^20)
+    const double ms_per_pair = (e->cal_ms_per_pair > 0 ? e->cal_ms_per_pair : 6.7e-5) * (1.0 + 0.01 * e->plan_derate_pct);      // (shared G2 chains: 138 ms for the 2^21 pair evaluations of round 0 + (1,l) at n = 2^20; plan_derate_pct: ripp_config, the plan of a slower device)
     const double gpu_f = ms_per_pair / 6.7e-5;
     const double hash_ms = n * 336.0 / (e->cal_hash_bytes_per_ms > 0 ? e->cal_hash_bytes_per_ms : 1.17e6);
     double budget = hash_ms - (nl * (3.2e-5 * gpu_f + ms_per_pair + 5.3e-5 * gpu_f) + 1.0);      // scaling, round 0, fold tables (measured at n = 2^20: 33 + 80 + 55 ms)
@@ -2056,7 +2146,7 @@ static int32_t job_lookahead(Engine* e, ripp_sipp_job* j, int eighths, bool forc
             // launch plus the rest of the pipeline (58 % of a pair evaluation).  Measured with recorded peers (profiles/r05_rank0_of_{2,8}_timeline.txt): item
             // (3,l) on 8 192-pair blocks took 59 ms where the rate alone says 37; 11/32 of it on 32 768-pair blocks 62 ms instead of 46 -- the overrun of
             // the two-rank window in build round 4's plan.
-            const double mpp = std::max(ms_per_pair, 5.0e-5), nprod = (double)((size_t)1 << (2 * R));
+            const double mpp = std::max(ms_per_pair, 5.0e-5) * (1.0 + 0.01 * e->plan_derate_pct), nprod = (double)((size_t)1 << (2 * R));
             auto item_cost = [&](size_t qq) {
                 const size_t per_launch = std::min<size_t>(MAX_PRODUCTS, std::max<size_t>(1, e->max_pairs_per_batch / std::max<size_t>(qq, 1)));
                 const double launches = std::ceil(nprod / (double)per_launch), var = nprod * (double)qq * mpp;
@@ -2199,6 +2289,7 @@ static int32_t job_round0_shared(Engine* e, ripp_sipp_job* j, Fp12* rows) {
 // running -- what an allocation or launch failure in the middle of a proof looks like to the protocol.  One shot: consumed when it fires.
 static std::atomic<int> g_fail_rank{-1}, g_fail_round{-1};
 static bool test_fail_hit(int rank, size_t round) {
+    if (g_fail_rank.load(std::memory_order_relaxed) == rank && g_fail_round.load(std::memory_order_relaxed) == 1000 + (int)round) raise(SIGKILL);      // (round + 1000: the rank DIES there)
     if (g_fail_rank.load(std::memory_order_relaxed) != rank || g_fail_round.load(std::memory_order_relaxed) != (int)round) return false;
     g_fail_rank = -1; g_fail_round = -1;
     set_err("injected failure (ripp_test_inject_failure) in the fold of round " + std::to_string(round) + " on rank " + std::to_string(rank));
@@ -2440,6 +2531,7 @@ static void config_from_engine(const Engine* e, ripp_config* c) {
     c->vm_lines_max = e->vm_lines_max; c->vm_fold_max = e->vm_fold_max; c->vm_tree_max = e->vm_tree_max; c->gls_split_max = e->gls_split_max; c->msm_vm_merge_max = e->msm_vm_merge_max; c->fold_tab_min = e->fold_tab_min;
     c->fq_min = e->fq_min; c->lp_fq_min = e->lp_fq_min; c->vm_joint_max = e->vm_joint_max; c->vm_scale_max = e->vm_scale_max; c->tail_pipe_max = e->tail_pipe_max; c->ml_fq_min = e->ml_fq_min; c->fq_min_g1 = e->fq_min_g1; c->msm_lds_sort_min = e->msm_lds_sort_min; c->msm_chunk_min = e->msm_chunk_min;
     c->mem_cap_bytes = e->mem_cap; c->hot_workers = (uint32_t)e->hot_workers_cfg; c->no_job_cache = e->sw.no_job_cache;
+    c->no_lp_karatsuba = e->sw.no_lp_kara; c->comm_timeout_ms = e->comm_timeout_ms; c->plan_derate_pct = e->plan_derate_pct; c->n_devices = e->n_devices_cfg;
 }
 API int32_t ripp_config_default(ripp_config* cfg) {            // the built-in defaults of this build (needs no device: a throw-away Engine object is never initialised)
     if (!cfg) return RIPP_ERR_ARG;

@@ -51,6 +51,10 @@ pub const RIPP_ERR_LENGTH: i32 = 1;
 pub const RIPP_ERR_POW2: i32 = 2;
 pub const RIPP_ERR_DEVICE: i32 = 3;
 pub const RIPP_ERR_ARG: i32 = 4;
+/// `ripp_vec_kind`: what a device-resident vector holds (include/ripp_hip.h: RIPP_VEC_*); `ripp_vec_download` writes ripp_g1a / ripp_g2a / ripp_fr elements accordingly
+pub const RIPP_VEC_G1: i32 = 1;
+pub const RIPP_VEC_G2: i32 = 2;
+pub const RIPP_VEC_FR: i32 = 3;
 
 #[repr(C)] #[derive(Copy, Clone, Default, Debug)]
 pub struct RippStats {
@@ -74,10 +78,11 @@ pub struct RippConfig {
     pub vm_lines_max: u64, pub vm_fold_max: u64, pub vm_tree_max: u64, pub gls_split_max: u64, pub msm_vm_merge_max: u64, pub fold_tab_min: u64,
     pub fq_min: u64, pub lp_fq_min: u64, pub vm_joint_max: u64, pub vm_scale_max: u64, pub tail_pipe_max: u64, pub ml_fq_min: u64, pub fq_min_g1: u64, pub msm_lds_sort_min: u64, pub msm_chunk_min: u64,
     pub mem_cap_bytes: u64, pub hot_workers: u32, pub no_job_cache: u32,
+    pub no_lp_karatsuba: u32, pub comm_timeout_ms: u32, pub plan_derate_pct: u32, pub n_devices: u32,
 }
 /// `RIPP_ABI_VERSION` of include/ripp_hip.h this binding was written against; `abi_check()` compares it (and the size of `RippStats`, which
 /// the library writes in full through every stats pointer) with the loaded library.
-pub const RIPP_ABI_VERSION: i32 = 6;
+pub const RIPP_ABI_VERSION: i32 = 7;
 #[cfg(feature = "ffi")]
 pub fn abi_check() -> bool { unsafe { ripp_abi_version() == RIPP_ABI_VERSION && ripp_stats_size() == core::mem::size_of::<RippStats>() } }
 

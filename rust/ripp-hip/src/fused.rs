@@ -268,9 +268,17 @@ impl HipVec {
     pub fn msm_g1(bases: &HipVec, scalars: &HipVec) -> Result<G1Projective, Error> { let mut out = RippG1J::default(); check(unsafe { ripp_vec_msm(bases.h, scalars.h, &mut out as *mut RippG1J as *mut core::ffi::c_void) })?; Ok(un_g1j(&out)) }
     pub fn msm_g2(bases: &HipVec, scalars: &HipVec) -> Result<G2Projective, Error> { let mut out = RippG2J::default(); check(unsafe { ripp_vec_msm(bases.h, scalars.h, &mut out as *mut RippG2J as *mut core::ffi::c_void) })?; Ok(un_g2j(&out)) }
     pub fn scalar_inner_product(l: &HipVec, r: &HipVec) -> Result<Fr, Error> { let mut out = RippFr::default(); check(unsafe { ripp_vec_scalar_inner_product(l.h, r.h, &mut out) })?; Ok(un_fr(&out)) }
-    pub fn download_g1(&self) -> Result<Vec<G1Projective>, Error> { let mut v = vec![RippG1J::default(); self.len()]; check(unsafe { ripp_vec_download(self.h, v.as_mut_ptr() as *mut core::ffi::c_void) })?; Ok(v.iter().map(un_g1j).collect()) }
-    pub fn download_g2(&self) -> Result<Vec<G2Projective>, Error> { let mut v = vec![RippG2J::default(); self.len()]; check(unsafe { ripp_vec_download(self.h, v.as_mut_ptr() as *mut core::ffi::c_void) })?; Ok(v.iter().map(un_g2j).collect()) }
-    pub fn download_fr(&self) -> Result<Vec<Fr>, Error> { let mut v = vec![RippFr::default(); self.len()]; check(unsafe { ripp_vec_download(self.h, v.as_mut_ptr() as *mut core::ffi::c_void) })?; Ok(v.iter().map(un_fr).collect()) }
+    /// `ripp_vec_download` writes AFFINE elements (96 / 192 bytes) or scalars (32 bytes) according to the vector's kind: the buffer is typed by kind, and a
+    /// handle of another kind is refused HERE (a 32 n-byte buffer handed over for a G1 vector would be overrun by 96 n bytes).
+    fn want_kind(&self, kind: i32, what: &str) -> Result<(), Error> {
+        if self.kind() == kind { Ok(()) } else { Err(format!("HipVec::{what}: the vector holds kind {} (1 = G1, 2 = G2, 3 = Fr), not kind {kind}", self.kind()).into()) }
+    }
+    pub fn download_g1a(&self) -> Result<Vec<G1Affine>, Error> { self.want_kind(RIPP_VEC_G1, "download_g1a")?; let mut v = vec![RippG1A::default(); self.len()]; check(unsafe { ripp_vec_download(self.h, v.as_mut_ptr() as *mut core::ffi::c_void) })?; Ok(v.iter().map(un_g1a).collect()) }
+    pub fn download_g2a(&self) -> Result<Vec<G2Affine>, Error> { self.want_kind(RIPP_VEC_G2, "download_g2a")?; let mut v = vec![RippG2A::default(); self.len()]; check(unsafe { ripp_vec_download(self.h, v.as_mut_ptr() as *mut core::ffi::c_void) })?; Ok(v.iter().map(un_g2a).collect()) }
+    /// the projective types the reference's GIPA carries (`.into()` of the affine elements the device holds)
+    pub fn download_g1(&self) -> Result<Vec<G1Projective>, Error> { Ok(self.download_g1a()?.into_iter().map(Into::into).collect()) }
+    pub fn download_g2(&self) -> Result<Vec<G2Projective>, Error> { Ok(self.download_g2a()?.into_iter().map(Into::into).collect()) }
+    pub fn download_fr(&self) -> Result<Vec<Fr>, Error> { self.want_kind(RIPP_VEC_FR, "download_fr")?; let mut v = vec![RippFr::default(); self.len()]; check(unsafe { ripp_vec_download(self.h, v.as_mut_ptr() as *mut core::ffi::c_void) })?; Ok(v.iter().map(un_fr).collect()) }
 }
 impl Drop for HipVec { fn drop(&mut self) { unsafe { ripp_vec_free(self.h) } } }
 

@@ -58,6 +58,14 @@ def _oracle_proof_2p20(tag, o, a, b, r):
         assert rc == 0
         return value, proof, ch
     z = np.load(path)
+    # the fixture is a cache of THIS oracle's output: its canary (the same generators and prover at n = 2^10, tests/golden/gen_sipp_2p20_oracle_proofs.py) must still
+    # come out of the oracle as loaded -- a stale file fails here instead of passing or failing for the wrong reason
+    m = 1 << 10
+    ca, cb, cr = o.gen_g1(1000, m), o.gen_g2(2000, m), o.gen_scalars(0, m)
+    cv = o.product_of_pairings_with_coeffs(ca, cb, cr)
+    rc, cproof, cch = o.sipp_prove(ca, cb, cr, cv)
+    assert rc == 0 and np.array_equal(cv, z["canary_value_" + tag]) and np.array_equal(cproof, z["canary_proof_" + tag]) and np.array_equal(cch, z["canary_ch_" + tag]), \
+        "tests/golden/sipp_2p20_oracle_proofs.npz is stale for BLS12-" + tag + ": regenerate it (tests/golden/gen_sipp_2p20_oracle_proofs.py)"
     return z["value_" + tag], z["proof_" + tag], z["ch_" + tag]
 
 

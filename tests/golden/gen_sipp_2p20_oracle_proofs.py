@@ -17,19 +17,33 @@ sys.path.insert(0, os.path.dirname(HERE))
 import numpy as np
 
 
+CANARY_N = 1 << 10
+
+
+def statement_proof(o, n):
+    """The oracle's proof of bench.py's statement generators at size n: (value, proof, challenges).  ONE code path for the fixture and its canary."""
+    a, b, r = o.gen_g1(1000, n), o.gen_g2(2000, n), o.gen_scalars(0, n)
+    value = o.product_of_pairings_with_coeffs(a, b, r)
+    rc, proof, ch = o.sipp_prove(a, b, r, value)
+    assert rc == 0 and o.sipp_verify(a, b, r, value, proof) == 1
+    return value, proof, ch
+
+
 def main():
-    n = 1 << 20
-    out = {}
+    """Default: everything (~6 min).  --canary-only: keep the n = 2^20 proofs of the existing file and recompute the n = 2^10 canaries only -- for use
+    after an oracle edit that is KNOWN not to change any output; tests/test_oracle_cpu.py::test_full_size_fixture_is_current then says whether it did."""
+    path = os.path.join(HERE, "sipp_2p20_oracle_proofs.npz")
+    out = dict(np.load(path)) if "--canary-only" in sys.argv else {}
     for tag, modname in (("381", "orclib"), ("377", "orclib377")):
         o = __import__(modname)
-        t0 = time.time()
-        a, b, r = o.gen_g1(1000, n), o.gen_g2(2000, n), o.gen_scalars(0, n)
-        value = o.product_of_pairings_with_coeffs(a, b, r)
-        rc, proof, ch = o.sipp_prove(a, b, r, value)
-        assert rc == 0 and o.sipp_verify(a, b, r, value, proof) == 1
-        out["value_" + tag], out["proof_" + tag], out["ch_" + tag] = value, proof, ch
-        print(f"BLS12-{tag}: oracle proof of the n = 2^20 statement in {time.time() - t0:.0f} s", flush=True)
-    np.savez_compressed(os.path.join(HERE, "sipp_2p20_oracle_proofs.npz"), **out)
+        if "--canary-only" not in sys.argv:
+            t0 = time.time()
+            out["value_" + tag], out["proof_" + tag], out["ch_" + tag] = statement_proof(o, 1 << 20)
+            print(f"BLS12-{tag}: oracle proof of the n = 2^20 statement in {time.time() - t0:.0f} s", flush=True)
+        # the canary: the same generators and the same prover at n = 2^10, recomputed by the CPU suite in a second -- an oracle (or generator) edit that changes
+        # outputs without a refresh of this file fails there, for both curves
+        out["canary_value_" + tag], out["canary_proof_" + tag], out["canary_ch_" + tag] = statement_proof(o, CANARY_N)
+    np.savez_compressed(path, **out)
 
 
 if __name__ == "__main__":

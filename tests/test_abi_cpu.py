@@ -61,7 +61,8 @@ def test_abi_guard_and_config_defaults_need_no_device(hiplib):
     assert c.tail_pipe_max == 1 << 11 and c.fold_tab_min == 32768 and c.no_vm == 0 and c.no_precompute == 0 and c.lp_fq_min == 0
     assert c.msm_chunk_min == 1 << 20 and c.msm_lds_sort_min == 0 and c.no_prebuild == 0 and c.fq_min_g1 == 1 << 12       # (members added in build round 4: the layout of the binding follows the header)
     assert c.mem_cap_bytes == 0 and c.hot_workers == 0 and c.no_job_cache == 0                                              # (build round 5, ABI version 6)
-    assert ctypes.sizeof(RippConfig) == 4 * 22 + 8 * 16 + 4 * 2 and ctypes.sizeof(RippStats) == 24 * 8
+    assert c.no_lp_karatsuba == 0 and c.comm_timeout_ms == 0 and c.plan_derate_pct == 0 and c.n_devices == 0                 # (build round 6, ABI version 7)
+    assert ctypes.sizeof(RippConfig) == 4 * 22 + 8 * 16 + 4 * 2 + 4 * 4 and ctypes.sizeof(RippStats) == 24 * 8
     assert hiplib.ripp_device_bytes() == 0                                                                                  # nothing allocated before the first device call
     bad = RippConfig(); bad.struct_size = 8
     assert hiplib.ripp_configure(ctypes.byref(bad)) == 4             # RIPP_ERR_ARG

@@ -9,7 +9,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RUST = os.path.join(ROOT, "rust", "ripp-hip")
-FILES = ["examples/dump_kat.rs", "examples/dump_kat_377.rs", "src/lib.rs", "src/convert.rs", "src/ffi.rs", "src/fused.rs"]
+FILES = ["examples/dump_kat.rs", "examples/dump_kat_377.rs", "src/lib.rs", "src/convert.rs", "src/ffi.rs", "src/fused.rs", "tests/vec_roundtrip.rs"]
 REF = "/root/reference"
 
 # fields that are private / pub(crate) in the reference: sipp::Proof (sipp/src/lib.rs:32-34), GIPAProof / GIPAAux (gipa.rs:24-77: pub(crate)),
@@ -65,7 +65,7 @@ def test_every_item_imported_from_the_reference_is_public_there(rel):
     # fully qualified uses in expressions (ark_inner_products::PairingInnerProduct::<..>)
     for m in re.finditer(r"\b(ark_(?:sipp|inner_products|dh_commitments|ip_proofs))::([A-Za-z_][A-Za-z0-9_]*)\b", code):
         paths.append(m.group(1) + "::" + m.group(2))
-    assert paths or rel.endswith(("ffi.rs", "convert.rs"))
+    assert paths or rel.endswith(("ffi.rs", "convert.rs", "vec_roundtrip.rs"))
     for path in sorted(set(paths)):
         parts = path.split("::")
         src_dir = os.path.join(REF, CRATE_DIR[parts[0]], "src")
@@ -83,3 +83,22 @@ def test_design_does_not_call_the_handoff_compiled():
     """DESIGN.md section 5 must say the hand-off has never been through a compiler (there is none here)."""
     text = open(os.path.join(ROOT, "DESIGN.md")).read()
     assert "never been through a compiler" in text or "has not been compiled" in text
+
+
+def test_vector_downloads_are_typed_by_kind():
+    """ripp_vec_download writes AFFINE group elements (vec_api.inc: vec_elem_size = sizeof(G1A) / sizeof(G2A) / sizeof(Fr)).  The Rust wrapper must size its
+    buffer with the affine FFI structs and refuse a handle of another kind before the call: a projective buffer decodes garbage, a scalar buffer handed
+    over for a G1 vector is overrun by 64 n bytes.  (Source-level: there is no Rust toolchain here; rust/ripp-hip/tests/vec_roundtrip.rs is the run-time test.)"""
+    code = strip_comments(open(os.path.join(RUST, "src", "fused.rs")).read())
+    for fn, buf, kind in (("download_g1a", "RippG1A", "RIPP_VEC_G1"), ("download_g2a", "RippG2A", "RIPP_VEC_G2"), ("download_fr", "RippFr", "RIPP_VEC_FR")):
+        m = re.search(r"pub fn %s\(&self\)[^{]*\{(.*?)\n" % fn, code, flags=re.S)
+        assert m, fn
+        body = m.group(1)
+        assert "want_kind(%s" % kind in body and body.index("want_kind") < body.index("ripp_vec_download"), fn
+        assert "vec![%s::default(); self.len()]" % buf in body, fn
+    # no download may allocate projective elements for ripp_vec_download
+    assert not re.search(r"vec!\[RippG[12]J::default\(\); self\.len\(\)\][^;]*;[^;]*ripp_vec_download", code)
+    hdr = open(os.path.join(ROOT, "include", "ripp_hip.h")).read()
+    ffi = open(os.path.join(RUST, "src", "ffi.rs")).read()
+    for name, val in re.findall(r"(RIPP_VEC_[A-Z0-9]+) = (\d+)", hdr):
+        assert re.search(r"pub const %s: i32 = %s;" % (name, val), ffi), name

@@ -460,6 +460,135 @@ def test_collective_error_exit_no_rank_hangs(engine, orc, world, n, fail_rank, f
         assert np.array_equal(got[rank]["proof"], eproof) and np.array_equal(got[rank]["ch"], ech), f"rank {rank}: the proof after the failure differs"
 
 
+# ---------------------------------------------------------------- communicator self-test, a rank that DIES
+def _selftest_worker(rank, world, port, claim, ret):
+    """ripp_comm_init_callback over gloo with rank `claim[rank]` announced to the library (no device needed: the callback transport is host code)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    for p in (os.path.dirname(HERE), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import ctypes
+    import datetime
+    import torch
+    import torch.distributed as dist
+    from ripp_amd._lib import lib
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        FN = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
+
+        def allgather(_user, send, recv, nbytes):
+            try:
+                src = np.ctypeslib.as_array(ctypes.cast(send, ctypes.POINTER(ctypes.c_uint8)), shape=(nbytes,))
+                t = torch.from_numpy(src.copy()); outs = [torch.empty_like(t) for _ in range(world)]
+                dist.all_gather(outs, t)
+                np.ctypeslib.as_array(ctypes.cast(recv, ctypes.POINTER(ctypes.c_uint8)), shape=(nbytes * world,))[:] = torch.cat(outs).numpy()
+                return 0
+            except Exception:
+                return 1
+        cb = FN(allgather)
+        L = lib(); L.ripp_last_error.restype = ctypes.c_char_p
+        rc = L.ripp_comm_init_callback(ctypes.c_int32(claim[rank]), ctypes.c_int32(world), cb, None)
+        ret[rank] = {"rc": rc, "err": L.ripp_last_error().decode() if rc else "", "world": L.ripp_comm_world()}
+        L.ripp_comm_destroy()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,claim", [(2, (0, 1)), (2, (0, 0)), (4, (0, 1, 3, 2))])
+def test_comm_selftest_names_the_miswired_rank(world, claim):
+    """ripp_comm_init[_callback] ends with ONE all-gather of (rank, world, ABI version, build fingerprint) that every rank checks: a bring-up in which two
+    processes claim the same rank, or the ranks are permuted against the transport's order, is an error STRING on every rank -- not a first proof that
+    hangs or is wrong.  Runs without a GPU (callback transport over gloo)."""
+    got = _spawn(_selftest_worker, world, (claim,), timeout=240)
+    assert sorted(got) == list(range(world))
+    for rank in range(world):
+        if tuple(claim) == tuple(range(world)):
+            assert got[rank]["rc"] == 0 and got[rank]["world"] == world, got[rank]
+        else:
+            assert got[rank]["rc"] == 4 and "self-test" in got[rank]["err"] and "introduced itself as rank" in got[rank]["err"], got[rank]
+            assert got[rank]["world"] == 1                       # the communicator was not kept
+
+
+def _kill_worker(rank, world, port, n, kill_rank, kill_round, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), RIPP_RANKS_PER_DEVICE=str(world))
+    for p in (os.path.dirname(HERE), HERE, os.path.join(HERE, "model")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import ctypes
+    import datetime
+    import time
+    import torch.distributed as dist
+    import ripp_amd as R
+    from ripp_amd._lib import lib
+    from ripp_amd.sharded import NativeComm, shard, native_sipp_job_prove
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=20))      # the callback transport's deadline is the process group's
+    R.init(0)
+    comm = NativeComm("callback")
+    a, b, r = R.synth_g1(123, n), R.synth_g2(456, n), R.synth_fr(7, n)
+    value = R.product_of_pairings_with_coeffs(a, b, r)
+    job = R.SippJob(shard(a, rank, world), shard(b, rank, world), shard(r, rank, world), rank=rank, world=world)
+    proof, ch, _ = native_sipp_job_prove(job, value, full=(a, b, r) if rank == 0 else None)           # a complete proof first: everything is in step
+    lib().ripp_test_inject_failure.restype = None
+    if rank == kill_rank:
+        lib().ripp_test_inject_failure(ctypes.c_int32(kill_rank), ctypes.c_int32(1000 + kill_round))      # SIGKILL inside the library, in the fold of that round
+    t0 = time.time(); err = None
+    try:
+        native_sipp_job_prove(job, value, full=(a, b, r) if rank == 0 else None)
+    except Exception as exc:
+        err = str(exc)
+    ret[rank] = {"err": err, "seconds": time.time() - t0, "proof": proof}
+    # no clean-up collectives: the group has lost a member (the process ends here)
+    os._exit(0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n,kill_rank,kill_round", [(2, 1 << 12, 1, 2), (4, 1 << 12, 2, 0)])
+def test_killed_rank_ends_the_survivors_within_the_deadline(engine, orc, world, n, kill_rank, kill_round):
+    """ONE rank is killed (SIGKILL, raised inside the library in the fold of round r) in the middle of a sharded proof.  It never sends its next block:
+    the survivors' exchange fails when the transport's deadline passes (here gloo's 20 s; the RCCL transport polls its stream against
+    ripp_config.comm_timeout_ms) and every survivor returns an error naming the exchange -- nothing waits for the driver's own limit."""
+    import time
+    import torch.multiprocessing as mp
+    mgr = mp.Manager(); ret = mgr.dict()
+    ctx = mp.spawn(_kill_worker, args=(world, _free_port(), n, kill_rank, kill_round, ret), nprocs=world, join=False)
+    t0 = time.time()
+    while any(pr.is_alive() for pr in ctx.processes) and time.time() - t0 < 150:
+        time.sleep(0.5)
+    alive = [pr.is_alive() for pr in ctx.processes]
+    for pr in ctx.processes:
+        if pr.is_alive():
+            pr.kill()
+    for pr in ctx.processes:
+        pr.join(10)
+    assert not any(alive), f"ranks still running after 150 s: {alive}"
+    codes = [pr.exitcode for pr in ctx.processes]
+    assert codes[kill_rank] == -9, codes
+    got = dict(ret)
+    rc, eproof, _ = orc.sipp_prove(orc.gen_g1(123, n), orc.gen_g2(456, n), orc.gen_scalars(7, n), orc.product_of_pairings_with_coeffs(orc.gen_g1(123, n), orc.gen_g2(456, n), orc.gen_scalars(7, n)))
+    for rank in range(world):
+        if rank == kill_rank:
+            assert rank not in got
+            continue
+        assert codes[rank] == 0 and rank in got, (rank, codes)
+        assert got[rank]["err"] and "all-gather" in got[rank]["err"] and f"rank {rank} of {world}" in got[rank]["err"], got[rank]["err"]
+        assert got[rank]["seconds"] < 90, got[rank]["seconds"]
+        assert np.array_equal(got[rank]["proof"], eproof)           # (the proof before the kill was the oracle's)
+
+
+@pytest.mark.gpu
+def test_bench_exits_non_zero_when_a_rank_dies(engine):
+    """`bench.py --gpus 2` (ranks on cuda:0, collectives over gloo) with rank 1 killed in the middle of the timed proofs (RIPP_BENCH_KILL_RANK): the job
+    ends with a non-zero exit code in well under 90 s -- never a re-exec, never a hang until the driver's limit."""
+    import subprocess
+    import time
+    env = dict(os.environ, RIPP_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", RIPP_BENCH_KILL_RANK="1", RIPP_BENCH_DIST_TIMEOUT_S="20")
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--log-n", "14"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0, p.stdout[-2000:]
+    assert time.time() - t0 < 90, time.time() - t0
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]          # no result line from a job that lost a rank
+
+
 _RCCL_SCRIPT = r"""
 import os, sys
 import numpy as np
