@@ -129,6 +129,12 @@ int32_t ripp_msm_g2_j(const ripp_g2j* bases, size_t n_left, const ripp_fr* scala
 /* VariableBaseMSM::msm on affine bases (sipp/src/lib.rs:174-175) */
 int32_t ripp_msm_g1_a(const ripp_g1a* bases, const ripp_fr* scalars, size_t n, ripp_g1j* out);
 int32_t ripp_msm_g2_a(const ripp_g2a* bases, const ripp_fr* scalars, size_t n, ripp_g2j* out);
+/* In-process multi-device dispatch (ripp_config.n_devices = D > 1, no communicator): the pairing products and MSMs on host slices above cut their index range
+ * into D contiguous parts, one per device (bound device + d), each on its own engine and host thread; the host multiplies / adds the D partial results and runs
+ * the one final exponentiation.  The value is the single-device call's (an MSM result may be another projective representative of the same point).  Parts below
+ * 4 096 pairs / 32 768 terms are not split off.  ripp_device_slots_used: how many parts the LAST such call of this process used (1 = not split).
+ * RIPP_VIRTUAL_DEVICES=D in the environment maps all D slots onto the bound device (a one-GPU test rig).  Proofs (SIPP, GIPA, TIPA) shard across PROCESSES. */
+int32_t ripp_device_slots_used(void);
 /* ScalarInnerProduct::inner_product (inner_products/src/lib.rs:144-166): sum_i l_i * r_i in Fr; RIPP_ERR_LENGTH as above */
 int32_t ripp_scalar_inner_product(const ripp_fr* left, size_t nl, const ripp_fr* right, size_t nr, ripp_fr* out);
 /* Sharded evaluation (vectors partitioned by index residue, one process per GPU): this rank's share of a
@@ -256,6 +262,10 @@ int32_t ripp_comm_record(int32_t on);
 int32_t ripp_comm_recording_save(const char* path);
 int32_t ripp_comm_init_replay(int32_t rank, int32_t world, const char* path, double latency_us);
 int32_t ripp_comm_replay_info(uint64_t* served, uint64_t* own_differs, double* waited_ms);
+/* the replay's verdict, called after the proofs: own blocks whose BYTES differed from the recording (clock readings of the plan message, Miller values before the
+ * final exponentiation, projective representatives of partial MSM sums do, legitimately) are compared by what they MEAN; *mismatches > 0 (and RIPP_ERR_ARG,
+ * the first one named in ripp_last_error) says the live run left the recorded protocol -- the measurement is void */
+int32_t ripp_comm_replay_check(uint64_t* differing, uint64_t* mismatches);
 /* InnerProduct implementations over vectors sharded by index residue (element i on rank i mod world); every rank passes ITS shard
  * and receives the full result.  Same status codes as the single-GPU forms (inner_products/src/lib.rs:61-73, 128-141). */
 int32_t ripp_pairing_product_sharded_j(const ripp_g1j* left, size_t nl, const ripp_g2j* right, size_t nr, ripp_gt* out);

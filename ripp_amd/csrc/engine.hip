@@ -158,6 +158,7 @@ std::atomic<int> g_live_handles{0};       // ripp_sipp_job / ripp_srs objects ho
 
 #define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_err(std::string(#expr) + ": " + hipGetErrorString(e_)); return RIPP_ERR_DEVICE; } } while (0)
 void set_err(const std::string& s) { g_err = s; }
+bool trace_on();
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 inline unsigned nblk(size_t n, unsigned b) { return (unsigned)((n + b - 1) / b); }
@@ -165,12 +166,28 @@ inline uint32_t pow2_floor(uint32_t v) { uint32_t p = 1; while ((p << 1) <= v &&
 
 // A grow-only device buffer
 std::atomic<size_t> g_dev_bytes{0};      // device memory this library holds through DevBuf (scratch, tables, jobs, SRS / vector handles): what ripp_config.mem_cap_bytes bounds
+// Out of device memory: before a reserve() gives up, the engine of the calling thread frees its IDLE scratch -- the grow-only line buffer, fold tables and
+// partial-product buffers that no reserve() of the CURRENT C-ABI call has touched (Engine::evict_idle) -- and the allocation is tried once more.  Found by the
+// uncapped n = 2^24 proof (tools/sipp_2p24.py): the prover legitimately fills the device (281 of 288 GB held), and the verifier called next failed in hipMalloc.
+std::atomic<uint64_t> g_call_epoch{1};                  // one tick per C-ABI call that takes the engine (get_engine)
+struct Engine;
+thread_local Engine* t_engine = nullptr;                // the engine this thread drives (get_engine; the threads of the auxiliary / peer engines set their own)
+size_t evict_idle_scratch(Engine* e);
 struct DevBuf {
-    void* p = nullptr; size_t cap = 0;
+    void* p = nullptr; size_t cap = 0; uint64_t epoch = 0;      // epoch: the call that last reserved this buffer
     int32_t reserve(size_t bytes) {
+        epoch = g_call_epoch.load(std::memory_order_relaxed);
         if (bytes <= cap) return RIPP_OK;
         release();
-        HIPCHK(hipMalloc(&p, bytes)); cap = bytes; g_dev_bytes.fetch_add(bytes, std::memory_order_relaxed); return RIPP_OK;
+        hipError_t err = hipMalloc(&p, bytes);
+        if (err == hipErrorOutOfMemory && t_engine) {
+            (void)hipGetLastError();
+            const size_t freed = evict_idle_scratch(t_engine);
+            if (trace_on()) fprintf(stderr, "[ripp] out of device memory for %zu bytes: %zu bytes of idle scratch freed, retrying\n", bytes, freed);
+            err = freed ? hipMalloc(&p, bytes) : err;
+        }
+        if (err != hipSuccess) { p = nullptr; (void)hipGetLastError(); set_err(std::string("hipMalloc(&p, bytes): ") + hipGetErrorString(err) + " (" + std::to_string(bytes) + " bytes wanted, " + std::to_string(g_dev_bytes.load()) + " held by the library)"); return RIPP_ERR_DEVICE; }
+        cap = bytes; g_dev_bytes.fetch_add(bytes, std::memory_order_relaxed); return RIPP_OK;
     }
     void release() { if (p) { (void)hipFree(p); g_dev_bytes.fetch_sub(cap, std::memory_order_relaxed); } p = nullptr; cap = 0; }
     template <class T> T* as() { return reinterpret_cast<T*>(p); }
@@ -712,10 +729,30 @@ int32_t get_engine(Engine** out) {
     }
     if (hipSetDevice(g_engine->device) != hipSuccess) { set_err("hipSetDevice failed"); return RIPP_ERR_DEVICE; }
     g_engine->refresh_switches();
+    g_call_epoch.fetch_add(1, std::memory_order_relaxed); t_engine = g_engine;
     *out = g_engine; return RIPP_OK;
 }
 
 bool trace_on() { static const bool on = std::getenv("RIPP_TRACE") != nullptr; return on; }
+// frees the scratch of engine e that the current call has not touched; only buffers whose contents no later step of a call takes for granted (each is re-reserved --
+// and re-filled -- by the call that uses it; the cached fold tables are disowned so that their next user rebuilds them).  Returns the bytes freed.
+size_t evict_idle_scratch(Engine* e) {
+    const uint64_t now = g_call_epoch.load(std::memory_order_relaxed);
+    (void)hipDeviceSynchronize();
+    const size_t before = g_dev_bytes.load();
+    bool tables = false;
+    for (DevBuf* b : {&e->lines, &e->partA, &e->partB, &e->qtab, &e->scale_tab, &e->jacG1, &e->jacG2, &e->affG1, &e->affG2, &e->tmpA, &e->tmpB, &e->tmpR}) if (b->p && b->epoch != now) b->release();
+    for (DevBuf* b : {&e->fold_tab1, &e->fold_mult, &e->fold_tab, &e->fold_jac1, &e->fold_jac2}) if (b->p && b->epoch != now) { b->release(); tables = true; }
+    if (tables) { e->tab_owner = nullptr; e->g2tab_hi = nullptr; }
+    for (int k = 0; k < 2; ++k) {
+        MsmScratch& ms = e->msm_scratch[k];
+        for (DevBuf* b : {&ms.digits, &ms.hist, &ms.offs, &ms.cursor, &ms.slotoffs, &ms.spw, &ms.sorted, &ms.slots, &ms.buckets, &ms.seg, &ms.seg2, &ms.win, &ms.ext, &ms.flags}) if (b->p && b->epoch != now) b->release();
+        for (DevBuf* b : {&e->kzg_q[k], &e->kzg_bases[k]}) if (b->p && b->epoch != now) b->release();
+    }
+    if (e->job_cache.full) e->job_cache.release();                        // buffers a finished one-shot proof parked for the next one
+    const size_t after = g_dev_bytes.load();
+    return before > after ? before - after : 0;
+}
 
 ScalarBits scalar_bits(const Fr& s_mont) {
     const Fr c = from_mont(s_mont);
@@ -1576,6 +1613,7 @@ API int32_t ripp_fold_fr(const ripp_fr* hi, const ripp_fr* lo, size_t half, cons
 // No communicator, no RCCL: the host needs the value anyway.  The result is the single-device call's value (a projective MSM result
 // is another representative of the same point).  UNMEASURED on a multi-GPU node; tested on one GPU with RIPP_VIRTUAL_DEVICES.
 extern "C++" {
+static std::atomic<int32_t> g_last_slots{1};
 struct DevSlot { Engine* e; size_t off, cnt; };
 static int32_t device_slots(Engine* e, size_t n, size_t min_units, std::vector<DevSlot>* out) {
     size_t D = e->n_devices_cfg > 1 ? e->n_devices_cfg : 1;
@@ -1596,6 +1634,7 @@ static int32_t device_slots(Engine* e, size_t n, size_t min_units, std::vector<D
         }
     }
     for (size_t d = 0; d < D; ++d) { const size_t lo = n * d / D, hi = n * (d + 1) / D; out->push_back({d == 0 ? e : e->peers[d - 1], lo, hi - lo}); }
+    g_last_slots = (int32_t)D;
     return RIPP_OK;
 }
 // fn(engine, offset, count, slot) on every slot: slot 0 on the calling thread, the others on threads of their own (HIP's current device is per thread)
@@ -1606,6 +1645,7 @@ template <class FN> static int32_t run_on_devices(Engine* e, const std::vector<D
     for (size_t d = 1; d < sl.size(); ++d)
         th.emplace_back([&, d]() {
             if (hipSetDevice(sl[d].e->device) != hipSuccess) { rcs[d] = RIPP_ERR_DEVICE; errs[d] = "hipSetDevice failed"; return; }
+            t_engine = sl[d].e;
             rcs[d] = fn(sl[d].e, sl[d].off, sl[d].cnt, (int)d);
             if (rcs[d]) errs[d] = g_err;
         });
@@ -1617,6 +1657,7 @@ template <class FN> static int32_t run_on_devices(Engine* e, const std::vector<D
 }
 constexpr size_t PAIRS_PER_DEVICE_MIN = 4096, MSM_TERMS_PER_DEVICE_MIN = (size_t)1 << 15;
 }  // extern "C++"
+API int32_t ripp_device_slots_used(void) { return g_last_slots.load(); }
 
 // ---- pairing products ------------------------------------------------------------------------------------------
 static int32_t pairing_product_dev(Engine* e, const G1A* da, const G2A* db, size_t n, ripp_gt* out) {
@@ -2328,6 +2369,7 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
         SippPlanMsg mine{(uint64_t)j->n_local, world0, rank, look_items, window ? 1 : 0, RIPP_OK, 0, hash_left};
         std::vector<SippPlanMsg> all((size_t)world0);
         const double tx = now_ms();
+        t_ex_kind = EX_PLAN;
         int32_t rc = comm_allgather(e, &mine, all.data(), sizeof mine); if (rc) return rc;
         exchange_ms += now_ms() - tx;
         for (int w = 0; w < world0; ++w) {

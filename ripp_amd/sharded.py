@@ -255,6 +255,15 @@ class ReplayComm:
         lib().ripp_comm_replay_info(ctypes.byref(served), ctypes.byref(differs), ctypes.byref(waited))
         return {"exchanges_served": served.value, "own_blocks_differing": differs.value, "waited_ms": waited.value}
 
+    def check(self):
+        """ripp_comm_replay_check: own blocks whose bytes differed from the recording are compared by meaning; raises when one MEANS something else"""
+        import ctypes
+        from ._lib import lib
+        from . import api
+        differing, mismatches = ctypes.c_uint64(), ctypes.c_uint64()
+        api._check(lib().ripp_comm_replay_check(ctypes.byref(differing), ctypes.byref(mismatches)))
+        return {"own_blocks_bytewise_differing": differing.value, "own_blocks_semantic_mismatches": mismatches.value}
+
     save_recording = NativeComm.save_recording
     close = NativeComm.close
 

@@ -107,6 +107,7 @@ extern "C" {
     pub fn ripp_msm_g2_j(bases: *const RippG2J, n_left: usize, scalars: *const RippFr, n_right: usize, out: *mut RippG2J) -> i32;
     pub fn ripp_msm_g1_a(bases: *const RippG1A, scalars: *const RippFr, n: usize, out: *mut RippG1J) -> i32;
     pub fn ripp_msm_g2_a(bases: *const RippG2A, scalars: *const RippFr, n: usize, out: *mut RippG2J) -> i32;
+    pub fn ripp_device_slots_used() -> i32;
     pub fn ripp_scalar_inner_product(left: *const RippFr, nl: usize, right: *const RippFr, nr: usize, out: *mut RippFr) -> i32;
     pub fn ripp_pairing_miller_j(left: *const RippG1J, nl: usize, right: *const RippG2J, nr: usize, miller_value: *mut RippGt) -> i32;
     pub fn ripp_sum_g1_j(pts: *const RippG1J, n: usize, out: *mut RippG1J) -> i32;
@@ -161,6 +162,7 @@ extern "C" {
     pub fn ripp_comm_recording_save(path: *const core::ffi::c_char) -> i32;
     pub fn ripp_comm_init_replay(rank: i32, world: i32, path: *const core::ffi::c_char, latency_us: f64) -> i32;
     pub fn ripp_comm_replay_info(served: *mut u64, own_differs: *mut u64, waited_ms: *mut f64) -> i32;
+    pub fn ripp_comm_replay_check(differing: *mut u64, mismatches: *mut u64) -> i32;
     pub fn ripp_pairing_product_sharded_j(left: *const RippG1J, nl: usize, right: *const RippG2J, nr: usize, out: *mut RippGt) -> i32;
     pub fn ripp_msm_g1_sharded_j(bases: *const RippG1J, nl: usize, scalars: *const RippFr, nr: usize, out: *mut RippG1J) -> i32;
     pub fn ripp_msm_g2_sharded_j(bases: *const RippG2J, nl: usize, scalars: *const RippFr, nr: usize, out: *mut RippG2J) -> i32;

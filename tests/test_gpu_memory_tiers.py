@@ -56,7 +56,8 @@ def test_sipp_prove_2p22_accepted_by_the_oracle_verifier(engine, orc):
     MSMs) and by the engine's -- on WHATEVER memory tier the device's free memory allows (a busy device degrades, it does not fail).  Then the same proof
     again beside a dummy allocation that leaves the library ~60 GB: hipMemGetInfo itself (no mem_cap_bytes) must push the call down the tiers, and the
     proof bytes must not change.  ripp_release_scratch returns the device memory."""
-    import torch
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")                               # the HIP runtime the library is bound to (already mapped): the neighbour's allocation comes from it
     R = engine
     n = 1 << 22
     R.release_scratch()
@@ -73,15 +74,16 @@ def test_sipp_prove_2p22_accepted_by_the_oracle_verifier(engine, orc):
     R.release_scratch()
     assert R.device_bytes() <= base + (1 << 16)
     # a neighbour takes most of the device: what is left (~60 GB) holds the statement and a cut line buffer, not 57 GB of three-quarter tables
-    free, total = torch.cuda.mem_get_info(0)
-    ballast = torch.empty(max(0, free - (60 << 30)), dtype=torch.uint8, device="cuda:0")
+    free, total, ballast = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_void_p()
+    assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+    taken = max(0, free.value - (60 << 30))
+    assert hip.hipMalloc(ctypes.byref(ballast), ctypes.c_size_t(taken)) == 0
     try:
         proof2, ch2, st2 = R.SIPP.prove_one_shot(a, b, r, value)
         assert np.array_equal(proof2, proof) and np.array_equal(ch2, ch), "the proof changed with the memory tier (mem_tier %d)" % st2["mem_tier"]
         assert int(st2["mem_tier"]) > 0, "60 GB cannot hold the three-quarter tables of 2^22 elements: the free memory did not drive the tier"
-        print(f"n = 2^22: free device -> mem_tier {tier_free}, {held_free >> 30} GB held; with {ballast.numel() >> 30} GB taken by a neighbour -> mem_tier {int(st2['mem_tier'])}, {int(st2['device_bytes']) >> 30} GB held")
+        print(f"n = 2^22: free device -> mem_tier {tier_free}, {held_free >> 30} GB held; with {taken >> 30} GB taken by a neighbour -> mem_tier {int(st2['mem_tier'])}, {int(st2['device_bytes']) >> 30} GB held")
     finally:
-        del ballast
-        torch.cuda.empty_cache()
+        hip.hipFree(ballast)
         R.release_scratch()
     assert R.device_bytes() <= base + (1 << 16)

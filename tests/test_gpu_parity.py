@@ -654,3 +654,51 @@ def test_shared_g2_chains_vs_oracle(engine, orc, n, eighths):
     finally:
         engine.configure()
         job.close()
+
+
+def test_in_process_multi_device_dispatch_on_virtual_devices(engine, orc):
+    """ripp_config.n_devices (include/ripp_hip.h): the stateless trait calls on host slices -- PairingInnerProduct, the pairing products of the sipp crate, both
+    MultiexponentiationInnerProducts -- cut their index range into D parts, one per device and host thread of THIS process, and combine the partial results on
+    the host (one final exponentiation).  On a one-GPU box the D slots are mapped onto the bound device (RIPP_VIRTUAL_DEVICES); the values must be the
+    oracle's, ripp_device_slots_used tells that the split really happened, and small inputs are not split."""
+    import ctypes
+    import os
+    from ripp_amd._lib import lib
+    n = 1 << 15
+    a, b, r = orc.gen_g1(71, n), orc.gen_g2(72, n), orc.gen_scalars(73, n)
+    aj, bj = orc.blind_g1(a, 5), orc.blind_g2(b, 6)
+    a[17] = 0; b[n // 2 + 3] = 0                                     # identities in two different parts
+    rc, exp_j = orc.pairing_product_j(aj, bj)
+    assert rc == 0
+    exp_a = orc.product_of_pairings_with_coeffs(a, b, np.ascontiguousarray(np.repeat(orc.fr_array([1]), n, axis=0)))      # (affine inputs with identities)
+    exp_m1, exp_m2 = orc.g1_to_affine(orc.msm_g1_a(a, r)).reshape(1, 12), orc.g2_to_affine(orc.msm_g2_a(b, r)).reshape(1, 24)
+    L = lib(); L.ripp_device_slots_used.restype = ctypes.c_int32
+    for D in (1, 2, 3, 4):
+        os.environ["RIPP_VIRTUAL_DEVICES"] = str(D)
+        try:
+            assert np.array_equal(engine.PairingInnerProduct.inner_product(aj, bj), exp_j) and L.ripp_device_slots_used() == D
+            assert np.array_equal(engine.product_of_pairings(a, b), exp_a) and L.ripp_device_slots_used() == D
+            assert np.array_equal(engine.normalize_batch_g1(engine.MultiexponentiationInnerProductG1.inner_product(orc.to_jac_g1(a), r)), exp_m1) and L.ripp_device_slots_used() == 1   # 2^15 terms: below 2 x 32 768
+            assert np.array_equal(engine.normalize_batch_g2(engine.MultiexponentiationInnerProductG2.inner_product(orc.to_jac_g2(b), r)), exp_m2)
+            # a short vector is not split; the reference's length error comes before any dispatch
+            assert np.array_equal(engine.PairingInnerProduct.inner_product(aj[:1000], bj[:1000]), orc.pairing_product_j(aj[:1000], bj[:1000])[1]) and L.ripp_device_slots_used() == 1
+            with pytest.raises(engine.InnerProductError):
+                engine.PairingInnerProduct.inner_product(aj[:10], bj[:9])
+        finally:
+            del os.environ["RIPP_VIRTUAL_DEVICES"]
+    # the configured form (no environment): n_devices beyond the visible devices is an argument error naming the device, not a crash
+    engine.configure(n_devices=64)
+    try:
+        with pytest.raises(ValueError, match="does not exist"):
+            engine.PairingInnerProduct.inner_product(aj, bj)
+    finally:
+        engine.configure()
+    n2 = 1 << 17                                                     # an MSM large enough to be cut in four
+    a2, r2 = engine.synth_g1(500, n2), engine.synth_fr(3, n2)
+    os.environ["RIPP_VIRTUAL_DEVICES"] = "4"
+    try:
+        got = engine.normalize_batch_g1(engine.MultiexponentiationInnerProductG1.inner_product(orc.to_jac_g1(a2), r2))
+        assert L.ripp_device_slots_used() == 4
+    finally:
+        del os.environ["RIPP_VIRTUAL_DEVICES"]
+    assert np.array_equal(got, orc.g1_to_affine(orc.msm_g1_a(a2, r2)).reshape(1, 12))

@@ -103,6 +103,7 @@ def agg_record_worker(args):
 
 
 def agg_replay_worker(args):
+    pin_cores(args)
     import torch
     import orclib as o
     import ripp_amd as R
@@ -125,7 +126,7 @@ def agg_replay_worker(args):
         agg_check(got, exp, f"replayed rank {rank} of {world}")
         if it >= args.warmup:
             times.append(dt)
-    info = comm.info(); comm.close()
+    info = comm.info(); info.update(comm.check()); comm.close()          # check(): raises when an own block MEANS something else than the recorded one
     print(json.dumps({"what": f"aggregate_proofs, n = 2^{args.log_n}: rank {rank} of {world} alone on one MI355X, peers replayed (instant, + {args.latency_us} us per exchange)",
                       "ms_per_call_sharded": sum(times) / len(times), "ms_all": [round(t, 2) for t in times],
                       "ms_per_call_unsharded_same_box": sum(t_one[args.warmup:]) / args.steps, "replay": info, "members_equal_oracle": True}), flush=True)
@@ -153,8 +154,17 @@ def record_worker(args):
     dist.barrier(); comm.close(); dist.destroy_process_group()
 
 
+def pin_cores(args):
+    """--cores N: this rank may use N host cores only (what it gets on a node where 8 ranks share the CPUs); the library's workers then compete among themselves"""
+    if args.cores > 0:
+        avail = sorted(os.sched_getaffinity(0))
+        os.sched_setaffinity(0, set(avail[:args.cores]))
+        os.environ["RIPP_HOT_WORKERS"] = "0" if args.cores < 4 else os.environ.get("RIPP_HOT_WORKERS", "1")      # polling workers need cores of their own
+
+
 def replay_worker(args):
     """Rank k of G alone on the GPU: the timed call of bench.py with recorded peers; prints one JSON line."""
+    pin_cores(args)
     import numpy as np
     import torch
     import ripp_amd as R
@@ -175,13 +185,13 @@ def replay_worker(args):
             times.append(dt * 1e3); stats_all.append(st)
         print(f"[replay] rank {rank}/{world} proof {it}: {dt * 1e3:.1f} ms", file=sys.stderr, flush=True)
     comm.save_recording(args.rec)
-    info = comm.info()
+    info = comm.info(); info.update(comm.check())                  # raises when an own block MEANS something else than the recorded one: the measurement would be void
     _, ex = read_recording(args.rec)
     comm.close()
     ms = sum(times) / len(times); st = stats_all[-1]
     hash_ms = sum(s["statement_hash_ms"] + s["statement_hash_wait_ms"] for s in stats_all) / len(stats_all)
     out = {"what": f"rank {rank} of {world}, alone on one MI355X, peers replayed from a recording (tools/replay_ranks.py)", "n": n, "rank": rank, "world": world,
-           "steps": args.steps, "warmup": args.warmup, "latency_us_per_exchange": args.latency_us,
+           "steps": args.steps, "warmup": args.warmup, "latency_us_per_exchange": args.latency_us, "host_cores": len(os.sched_getaffinity(0)),
            "ms_per_step": ms, "ms_per_step_median": sorted(times)[len(times) // 2], "ms_per_step_all": [round(t, 3) for t in times],
            "value_if_this_rank_is_the_slowest": n / (ms * 1e-3), "unit": "pairs/s",
            "statement_hash_ms": round(hash_ms, 3) if rank == 0 else None, "post_hash_ms": ms - hash_ms if rank == 0 else None,
@@ -218,7 +228,7 @@ def run_record(args, world, rec):
 
 def run_replay(args, world, rank, rec, tag):
     cmd = [sys.executable, os.path.abspath(__file__), "_replay", "--log-n", str(args.log_n), "--out-dir", args.out_dir, "--rec", rec, "--world", str(world),
-           "--rank", str(rank), "--steps", str(args.steps), "--warmup", str(args.warmup), "--latency-us", str(args.latency_us), "--workload", args.workload]
+           "--rank", str(rank), "--steps", str(args.steps), "--warmup", str(args.warmup), "--latency-us", str(args.latency_us), "--workload", args.workload, "--cores", str(args.cores)]
     env = dict(os.environ, RIPP_TRACE="1", OMP_NUM_THREADS="1")
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     if p.returncode:
@@ -251,6 +261,8 @@ def main():
     ap.add_argument("--rec", default=None)
     ap.add_argument("--workload", choices=["sipp", "aggregate"], default="sipp", help="aggregate: config 5 (use --log-n 14); one pass of rank 0 with instant peers (the ranks are symmetric)")
     ap.add_argument("--passes", type=int, default=2, help="rank 0 / rank 1 rounds of the fixed-point iteration")
+    ap.add_argument("--cores", type=int, default=0, help="host cores the live rank may use (0 = all): 2 = its share of a 16-core node with 8 ranks")
+    ap.add_argument("--sweep-latency-us", default="", help="comma-separated per-exchange latencies: after the passes, rank 0 is replayed once more at each of them")
     args = ap.parse_args()
     os.makedirs(args.out_dir, exist_ok=True)
     if args.mode == "_record":
@@ -297,6 +309,21 @@ def main():
             gaps[2:] = gaps[1]
         write_recording(rec, world, ex)
     json.dump(summary, open(os.path.join(args.out_dir, f"w{world}_n{args.log_n}_passes.json"), "w"), indent=1)
+    if args.sweep_latency_us:
+        # the fixed per-exchange cost is the one free parameter of the model: rank 0 against the measured peers at each value (its own gaps are rewritten each time,
+        # the peers' stay).  Then ONE more run with the rank confined to 2 host cores -- its share of a 16-core node that hosts 8 ranks.
+        sweep = []
+        base_lat, base_cores = args.latency_us, args.cores
+        for lat in [float(x) for x in args.sweep_latency_us.split(",")]:
+            args.latency_us = lat
+            res = run_replay(args, world, 0, rec, f"latency sweep: {lat:g} us per exchange")
+            sweep.append({k: res[k] for k in ("latency_us_per_exchange", "host_cores", "ms_per_step", "ms_per_step_all", "statement_hash_ms", "post_hash_ms", "exchange_ms_per_step", "replay")})
+        args.latency_us, args.cores = base_lat, 2
+        res = run_replay(args, world, 0, rec, "2 host cores for the rank")
+        sweep.append({k: res[k] for k in ("latency_us_per_exchange", "host_cores", "ms_per_step", "ms_per_step_all", "statement_hash_ms", "post_hash_ms", "exchange_ms_per_step", "replay")})
+        args.cores = base_cores
+        json.dump({"what": f"rank 0 of {world}, n = 2^{args.log_n}, peers as measured; per-exchange latency swept, then the rank confined to 2 host cores", "runs": sweep},
+                  open(os.path.join(args.out_dir, f"w{world}_n{args.log_n}_latency_sweep.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
