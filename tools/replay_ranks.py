@@ -318,11 +318,13 @@ def main():
             args.latency_us = lat
             res = run_replay(args, world, 0, rec, f"latency sweep: {lat:g} us per exchange")
             sweep.append({k: res[k] for k in ("latency_us_per_exchange", "host_cores", "ms_per_step", "ms_per_step_all", "statement_hash_ms", "post_hash_ms", "exchange_ms_per_step", "replay")})
-        args.latency_us, args.cores = base_lat, 2
-        res = run_replay(args, world, 0, rec, "2 host cores for the rank")
-        sweep.append({k: res[k] for k in ("latency_us_per_exchange", "host_cores", "ms_per_step", "ms_per_step_all", "statement_hash_ms", "post_hash_ms", "exchange_ms_per_step", "replay")})
+        args.latency_us = base_lat
+        for cores in (8, 4, 2):
+            args.cores = cores
+            res = run_replay(args, world, 0, rec, f"{cores} host cores for the rank")
+            sweep.append({k: res[k] for k in ("latency_us_per_exchange", "host_cores", "ms_per_step", "ms_per_step_all", "statement_hash_ms", "post_hash_ms", "exchange_ms_per_step", "replay")})
         args.cores = base_cores
-        json.dump({"what": f"rank 0 of {world}, n = 2^{args.log_n}, peers as measured; per-exchange latency swept, then the rank confined to 2 host cores", "runs": sweep},
+        json.dump({"what": f"rank 0 of {world}, n = 2^{args.log_n}, peers as measured; per-exchange latency swept, then the rank confined to 8 / 4 / 2 host cores", "runs": sweep},
                   open(os.path.join(args.out_dir, f"w{world}_n{args.log_n}_latency_sweep.json"), "w"), indent=1)
 
 
