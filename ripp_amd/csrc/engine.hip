@@ -66,6 +66,7 @@ class HostPool {
 public:
     explicit HostPool(unsigned n) { for (unsigned i = 0; i < n; ++i) th_.emplace_back([this]() { run(); }); }
     ~HostPool() { { std::lock_guard<std::mutex> lk(mu_); stop_ = true; } cv_.notify_all(); for (auto& t : th_) t.join(); }
+    unsigned size() const { return (unsigned)th_.size(); }
     template <class F> auto submit(F&& f) -> std::future<decltype(f())> {
         auto task = std::make_shared<std::packaged_task<decltype(f())()>>(std::forward<F>(f));
         auto fut = task->get_future();
@@ -111,7 +112,13 @@ private:
     std::vector<std::thread> th_; std::deque<std::function<void()>> q_; std::mutex mu_; std::condition_variable cv_; bool stop_ = false;
     std::atomic<int> pending_{0}, sleepers_{0}; std::atomic<bool> hot_{false};
 };
-HostPool& host_pool() { static HostPool pool(6); return pool; }
+static int effective_cpus();
+// 6 workers (+ the caller's thread); 11 where the process may use 14 CPUs or more: the pipelined tail then cuts each of its six final exponentiations in two
+// bit ranges (job_tail_values) -- 12 tasks of ~0.65 ms instead of 6 of ~0.95 ms on the critical path of the last 12 rounds
+HostPool& host_pool() {      // (RIPP_HOST_WORKERS: A/B override, read once when the pool is created)
+    static HostPool pool([]() -> unsigned { if (const char* s = std::getenv("RIPP_HOST_WORKERS")) { const int v = std::atoi(s); if (v >= 1 && v <= 64) return (unsigned)v; } return effective_cpus() >= 14 ? 11u : 6u; }());
+    return pool;
+}
 // CPUs this PROCESS TREE may use: the affinity mask capped by the cgroup's CPU quota (cpu.max: the GPU pool's boxes give 16).  The ranks of a sharded proof
 // are separate processes on ONE node and share that allowance.
 static int effective_cpus() {
@@ -137,7 +144,7 @@ static bool hot_workers_pay(int ranks_on_node) { return effective_cpus() / std::
 // field element, ~0.57 ms instead of ~0.74 ms per product on the critical path of EVERY round (3 ranges).
 double now_ms(); bool trace_on();
 void pairing_values(const Fp12* rows, int count, Fp12* out, int parts = 0) {
-    if (parts <= 0) parts = count >= 2 ? 3 : 4;
+    if (parts <= 0) parts = host_pool().size() >= 11 ? (count >= 2 ? 5 : 8) : (count >= 2 ? 3 : 4);      // as many ranges as the workers take in one go
     struct Seg { int k, hi, lo; };
     std::vector<Seg> segs;
     for (int k = 0; k < count; ++k) for (int g = 0; g < parts; ++g) segs.push_back({k, 62 - (63 * g) / parts, 62 - (63 * (g + 1)) / parts + 1});
@@ -2082,23 +2089,48 @@ static int32_t job_tail_values(ripp_sipp_job* j, size_t round, const Fr& x_prev,
     j->tp_round[slot] = ~(size_t)0;
     const Fp12* rows = buf.as<Fp12>();
     Fp12 T[6];          // per side: E0 * E3 (one final exponentiation for the pair), E1, E2
-    host_pool().parallel(6, [&](int t) {
+    // each value in `parts` bit ranges of the Miller recurrence, every range with its own final exponentiation on its own worker, joined by cyclotomic
+    // squarings (pairing_values has the identity): 2 ranges where the pool has the workers for 12 tasks
+    const int parts = host_pool().size() >= 11 ? 2 : 1;
+    Fp12 E[6][2];
+    auto range_of = [parts](int g, int* hi, int* lo) { *hi = 62 - (63 * g) / parts; *lo = 62 - (63 * (g + 1)) / parts + 1; };
+    host_pool().parallel(6 * parts, [&](int u) {
+        const int t = u / parts, g = u % parts;
+        int hi, lo; range_of(g, &hi, &lo);
         const Fp12* base = rows + (size_t)(t / 3) * 4 * N_LINES; const int kind = t % 3;
         if (kind == 0) {
+            int s0 = 0; for (int b = 62; b > hi; --b) s0 += 1 + (int)((BLS_X_ABS >> b) & 1);      // the rows this range consumes: [s0, s1)
+            int s1 = s0; for (int b = hi; b >= lo; --b) s1 += 1 + (int)((BLS_X_ABS >> b) & 1);
             Fp12 prod[N_LINES];
-            for (int s2 = 0; s2 < N_LINES; ++s2) prod[s2] = mul(base[s2], base[3 * N_LINES + s2]);
-            T[t] = final_exponentiation(miller_combine(prod));
-        } else T[t] = final_exponentiation(miller_combine(base + (size_t)kind * N_LINES));
+            for (int s2 = s0; s2 < s1; ++s2) prod[s2] = mul(base[s2], base[3 * N_LINES + s2]);
+            E[t][g] = final_exponentiation(miller_combine_range(prod, hi, lo));
+        } else E[t][g] = final_exponentiation(miller_combine_range(base + (size_t)kind * N_LINES, hi, lo));
+    });
+    host_pool().parallel(6, [&](int t) {
+        Fp12 c = E[t][0];
+        for (int g = 1; g < parts; ++g) { int hi, lo; range_of(g, &hi, &lo); for (int b = hi; b >= lo; --b) c = cyclotomic_sqr(c); c = mul(c, E[t][g]); }
+        T[t] = BLS_X_NEG ? conj(c) : c;
     });
     const double tw2 = now_ms();
     // per side: E1^(1/x) as two tasks of two digit strings each (1/x is full width: four strings), E2^x as one (x is 128 bits: two strings)
     const GlsDigits gx = gls_digits(x_prev), gxi = gls_digits(inv(x_prev));
-    Fp12 P[6];
-    host_pool().parallel(6, [&](int t) {
-        const int side = t / 3, part = t % 3;
-        P[t] = part == 2 ? gt_pow_gls_strings(T[3 * side + 2], gx, 15u) : gt_pow_gls_strings(T[3 * side + 1], gxi, part == 0 ? 3u : 12u);
-    });
-    *zl = mul(mul(T[0], P[0]), mul(P[1], P[2])); *zr = mul(mul(T[3], P[3]), mul(P[4], P[5]));
+    if (parts == 1) {
+        Fp12 P[6];
+        host_pool().parallel(6, [&](int t) {
+            const int side = t / 3, part = t % 3;
+            P[t] = part == 2 ? gt_pow_gls_strings(T[3 * side + 2], gx, 15u) : gt_pow_gls_strings(T[3 * side + 1], gxi, part == 0 ? 3u : 12u);
+        });
+        *zl = mul(mul(T[0], P[0]), mul(P[1], P[2])); *zr = mul(mul(T[3], P[3]), mul(P[4], P[5]));
+    } else {            // twelve workers: one digit string of 1/x per task, two tasks for x (whichever of its four strings are in use)
+        Fp12 P[12];
+        static const unsigned mask[6] = {1u, 2u, 4u, 8u, 5u, 10u};
+        host_pool().parallel(12, [&](int t) {
+            const int side = t / 6, part = t % 6;
+            P[t] = part >= 4 ? gt_pow_gls_strings(T[3 * side + 2], gx, mask[part]) : gt_pow_gls_strings(T[3 * side + 1], gxi, mask[part]);
+        });
+        *zl = mul(mul(mul(T[0], P[0]), mul(P[1], P[2])), mul(P[3], mul(P[4], P[5])));
+        *zr = mul(mul(mul(T[3], P[6]), mul(P[7], P[8])), mul(P[9], mul(P[10], P[11])));
+    }
     if (trace_on()) fprintf(stderr, "[ripp] tail values: waited %.2f ms for the device, final exponentiations %.2f ms, powers %.2f ms\n", tw1 - tw0, tw2 - tw1, now_ms() - tw2);
     return RIPP_OK;
 }
@@ -2485,9 +2517,15 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
                 else if (dev[1]) pairing_values(rows + N_LINES, 1, &zd[1]);
                 if (j->bs_on && (dev[0] || dev[1])) {      // the device holds bs * b: what it evaluated is z^bs (look-ahead values came from the plain round-0 blocks)
                     const GlsDigits gsi = gls_digits(inv(j->bs));                     // two tasks of two digit strings per value
+                    if (host_pool().size() >= 11) {                                     // one digit string per task
+                        Fp12 part[8];
+                        host_pool().parallel(8, [&](int t) { if (!dev[t >> 2]) return; part[t] = gt_pow_gls_strings(zd[t >> 2], gsi, 1u << (t & 3)); });
+                        for (int k = 0; k < 2; ++k) if (dev[k]) zd[k] = mul(mul(part[4 * k], part[4 * k + 1]), mul(part[4 * k + 2], part[4 * k + 3]));
+                    } else {
                     Fp12 part[4];
                     host_pool().parallel(4, [&](int t) { if (!dev[t >> 1]) return; part[t] = gt_pow_gls_strings(zd[t >> 1], gsi, (t & 1) ? 12u : 3u); });
                     for (int k = 0; k < 2; ++k) if (dev[k]) zd[k] = mul(part[2 * k], part[2 * k + 1]);
+                    }
                 }
                 zl = zd[0]; zr = zd[1];
                 if (lk_l) { look_finish_level(*lk_l); zl = dev[0] ? mul(lk_l->Z[0], zd[0]) : lk_l->Z[0]; }

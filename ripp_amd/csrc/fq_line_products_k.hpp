@@ -60,6 +60,20 @@ template <int OFF> __device__ __forceinline__ void lk_ld_x(lk_v4i& x0, lk_v4i& x
 template <int OFF> __device__ __forceinline__ void lk_ld_x2(lk_v2i& x0, lk_v2i& x1, uint32_t addr, int64_t& pin) {  // limbs 12, 13
     asm volatile("ds_read_b64 %0, %3 offset:%4\n\tds_read_b64 %1, %3 offset:%5" : "=&v"(x0), "=&v"(x1), "+v"(pin) : "v"(addr), "n"(OFF), "n"(OFF + 64));
 }
+// fetch + wait in ONE statement (hipcc puts an s_nop behind every inline-asm statement): issue the next reads, then wait until at most N reads are in flight --
+// i.e. until the CURRENT operands (cx0, cx1, and a 14-limb value or two) have arrived
+template <int OFF, int N> __device__ __forceinline__ void lk_ld_x_w(lk_v4i& nx0, lk_v4i& nx1, uint32_t addr, int64_t& pin, lk_v4i& cx0, lk_v4i& cx1) {
+    asm volatile("ds_read_b128 %0, %5 offset:%6\n\tds_read_b128 %1, %5 offset:%7\n\ts_waitcnt lgkmcnt(%8)"
+                 : "=&v"(nx0), "=&v"(nx1), "+v"(pin), "+v"(cx0), "+v"(cx1) : "v"(addr), "n"(OFF), "n"(OFF + 64), "n"(N));
+}
+template <int OFF, int N> __device__ __forceinline__ void lk_ld_x2_w(lk_v2i& nx0, lk_v2i& nx1, uint32_t addr, int64_t& pin, lk_v4i& cx0, lk_v4i& cx1) {
+    asm volatile("ds_read_b64 %0, %5 offset:%6\n\tds_read_b64 %1, %5 offset:%7\n\ts_waitcnt lgkmcnt(%8)"
+                 : "=&v"(nx0), "=&v"(nx1), "+v"(pin), "+v"(cx0), "+v"(cx1) : "v"(addr), "n"(OFF), "n"(OFF + 64), "n"(N));
+}
+template <int OFF, int N> __device__ __forceinline__ void lk_ld_x_w2(lk_v4i& nx0, lk_v4i& nx1, uint32_t addr, int64_t& pin, lk_v2i& cx0, lk_v2i& cx1) {      // (waits for the two-limb chunk)
+    asm volatile("ds_read_b128 %0, %5 offset:%6\n\tds_read_b128 %1, %5 offset:%7\n\ts_waitcnt lgkmcnt(%8)"
+                 : "=&v"(nx0), "=&v"(nx1), "+v"(pin), "+v"(cx0), "+v"(cx1) : "v"(addr), "n"(OFF), "n"(OFF + 64), "n"(N));
+}
 // (a sum that is an ordinary expression lets LLVM re-associate  col += x y  into a chain of dependent multiply-adds on a temporary plus one 64-bit add per column)
 #define LK_OPAQUE(X_) asm volatile("" : "+v"(X_))
 #define LK_WAIT_X(n, XA_, XB_) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(XA_), "+v"(XB_))
@@ -229,16 +243,15 @@ __global__ void __launch_bounds__(64, 2) k_line_products_k(const uint4* __restri
 #define LK_AB_TERM(P_, AX_, NEXT_, NW_)                                                                                                   \
             { int32_t Y0[NL], Y1[NL];                                                                                                 \
               NEXT_                                                                                                                    \
-              lk_ld_x<16>(x0[1], x1[1], AX_, U[NL - 1]);                                                                               \
-              LK_WAIT_V(NW_, ya[P_]); LK_WAIT_V(NW_, yc[P_]); LK_WAIT_X(NW_, x0[0], x1[0]);                                            \
+              lk_ld_x_w<16, NW_>(x0[1], x1[1], AX_, U[NL - 1], x0[0], x1[0]); LK_WAIT_V(NW_, ya[P_]); LK_WAIT_V(NW_, yc[P_]);          \
               lk_limbs_of(ya[P_], Y0); lk_limbs_of(yc[P_], Y1);                                                                        \
               lk_mads2<0>(U, V, x0[0], x1[0], Y0, Y1); LK_TIE(U); LK_TIE(V);                                                           \
-              lk_ld_x<32>(x0[0], x1[0], AX_, U[NL - 1]); LK_WAIT_X(2, x0[1], x1[1]);                                                   \
+              lk_ld_x_w<32, 2>(x0[0], x1[0], AX_, U[NL - 1], x0[1], x1[1]);                                                            \
               lk_mads2<1>(U, V, x0[1], x1[1], Y0, Y1); LK_TIE(U); LK_TIE(V);                                                           \
-              lk_ld_x2<48>(xa, xb, AX_, U[NL - 1]); LK_WAIT_X(2, x0[0], x1[0]);                                                        \
+              lk_ld_x2_w<48, 2>(xa, xb, AX_, U[NL - 1], x0[0], x1[0]);                                                                 \
               lk_mads2<2>(U, V, x0[0], x1[0], Y0, Y1); LK_TIE(U); LK_TIE(V);
 #define LK_AB_END(AXN_)                                                                                                                   \
-              lk_ld_x<0>(x0[0], x1[0], AXN_, U[NL - 1]); LK_WAIT_X(2, xa, xb);                                                         \
+              lk_ld_x_w2<0, 2>(x0[0], x1[0], AXN_, U[NL - 1], xa, xb);                                                                 \
               { const lk_v4i a4{xa.x, xa.y, 0, 0}, b4{xb.x, xb.y, 0, 0}; lk_mads2<3>(U, V, a4, b4, Y0, Y1); } LK_TIE(U); LK_TIE(V); }
             LkBuf ys[2];
             LK_AB_TERM(0, ax0, lk_ld_val<0>(ya[1], ay1, U[NL - 1]); lk_ld_val<64>(yc[1], ay1, U[NL - 1]);, 10) LK_AB_END(ax1)
@@ -256,22 +269,25 @@ __global__ void __launch_bounds__(64, 2) k_line_products_k(const uint4* __restri
 #define LK_C_TERM(P_, AX_, NEXT_, NW_)                                                                                                    \
             { int32_t Y[NL];                                                                                                          \
               NEXT_                                                                                                                    \
-              lk_ld_x<16>(x0[1], x1[1], AX_, U[NL - 1]);                                                                               \
-              LK_WAIT_V(NW_, ys[P_]); LK_WAIT_X(NW_, x0[0], x1[0]);                                                                    \
+              lk_ld_x_w<16, NW_>(x0[1], x1[1], AX_, U[NL - 1], x0[0], x1[0]); LK_WAIT_V(NW_, ys[P_]);                                  \
               lk_limbs_of(ys[P_], Y);                                                                                                  \
-              { lk_v4i xs = x0[0] + x1[0]; LK_OPAQUE(xs); lk_mads1<0>(U, xs, Y); } LK_TIE(U);                                                                             \
-              lk_ld_x<32>(x0[0], x1[0], AX_, U[NL - 1]); LK_WAIT_X(2, x0[1], x1[1]);                                                   \
-              { lk_v4i xs = x0[1] + x1[1]; LK_OPAQUE(xs); lk_mads1<1>(U, xs, Y); } LK_TIE(U);                                                                             \
-              lk_ld_x2<48>(xa, xb, AX_, U[NL - 1]); LK_WAIT_X(2, x0[0], x1[0]);                                                        \
-              { lk_v4i xs = x0[0] + x1[0]; LK_OPAQUE(xs); lk_mads1<2>(U, xs, Y); } LK_TIE(U);
-#define LK_C_END(NEXTX_, NL_)                                                                                                             \
-              NEXTX_ LK_WAIT_X(NL_, xa, xb);                                                                                           \
-              { lk_v4i s4{xa.x + xb.x, xa.y + xb.y, 0, 0}; LK_OPAQUE(s4); lk_mads1<3>(U, s4, Y); } LK_TIE(U); }
-            LK_C_TERM(0, ax0, lk_ld_val<128>(ys[1], ay1, U[NL - 1]);, 6) LK_C_END(lk_ld_x<0>(x0[0], x1[0], ax1, U[NL - 1]);, 2)
-            LK_C_TERM(1, ax1, lk_ld_val<128>(ys[0], ay2, U[NL - 1]);, 6) LK_C_END(lk_ld_x<0>(x0[0], x1[0], ax2, U[NL - 1]);, 2)
-            LK_C_TERM(0, ax2, , 2) LK_C_END(, 0)
+              lk_mads1<0>(U, x0[0] + x1[0], Y);                                                                                        \
+              lk_ld_x_w<32, 2>(x0[0], x1[0], AX_, U[NL - 1], x0[1], x1[1]);                                                            \
+              lk_mads1<1>(U, x0[1] + x1[1], Y);                                                                                        \
+              lk_ld_x2_w<48, 2>(xa, xb, AX_, U[NL - 1], x0[0], x1[0]);                                                                 \
+              lk_mads1<2>(U, x0[0] + x1[0], Y);
+#define LK_C_END_NEXT(AXN_)                                                                                                               \
+              lk_ld_x_w2<0, 2>(x0[0], x1[0], AXN_, U[NL - 1], xa, xb);                                                                 \
+              { const lk_v4i s4{xa.x + xb.x, xa.y + xb.y, 0, 0}; lk_mads1<3>(U, s4, Y); } }
+#define LK_C_END_LAST()                                                                                                                   \
+              LK_WAIT_X(0, xa, xb);                                                                                                    \
+              { const lk_v4i s4{xa.x + xb.x, xa.y + xb.y, 0, 0}; lk_mads1<3>(U, s4, Y); } }
+            LK_C_TERM(0, ax0, lk_ld_val<128>(ys[1], ay1, U[NL - 1]);, 6) LK_C_END_NEXT(ax1)
+            LK_C_TERM(1, ax1, lk_ld_val<128>(ys[0], ay2, U[NL - 1]);, 6) LK_C_END_NEXT(ax2)
+            LK_C_TERM(0, ax2, , 2) LK_C_END_LAST()
 #undef LK_C_TERM
-#undef LK_C_END
+#undef LK_C_END_NEXT
+#undef LK_C_END_LAST
             lk_reduce_cols(U, im); LK_TIE14(im);
         }
         __syncthreads();                                                         // every lane of the group has read the old coefficients and the line values

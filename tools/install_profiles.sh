@@ -1,11 +1,12 @@
 # Copy the summaries collected by tools/run_profiles.sh <tag> (gpurun_out/prof_<tag>/) into profiles/ under the round's names.
-TAG=${1:-r05}; R=${2:-r05}
+TAG=${1:-r06}; R=${2:-r06}
 S=gpurun_out/prof_$TAG
 cp $S/kstats/k_kernel_stats.csv profiles/${R}_bench_kernel_stats_rocprofv3.csv
 cp $S/bench_n1.json profiles/${R}_bench_n1.json
 cp $S/fpbench.txt profiles/${R}_fpbench_production.txt
 cp $S/fqbench.txt profiles/${R}_fqbench.txt
 cp $S/invbench.txt profiles/${R}_invbench.txt
+[ -s $S/lpbench.txt ] && cp $S/lpbench.txt profiles/${R}_lpbench.txt
 cp $S/hbm_traffic.csv profiles/${R}_hbm_traffic_pmc.csv
 cp $S/traffic.json profiles/traffic_current.json
 cp $S/msm_sweep.txt profiles/${R}_msm_2p20.txt
@@ -25,5 +26,9 @@ if [ -d $F ]; then
   [ -s $F/post_hash_timeline.txt ] && cp $F/post_hash_timeline.txt profiles/${R}_post_hash_timeline.txt
   for f in stress_world4 stress_world8 stress_tail; do [ -s $F/$f.txt ] && tail -3 $F/$f.txt > profiles/${R}_$f.txt; done
   [ -s $F/poly_commit_bench.csv ] && cp $F/poly_commit_bench.csv profiles/${R}_poly_commit_bench.csv
+  [ -s $F/bench_n1_derated.json ] && cp $F/bench_n1_derated.json profiles/${R}_bench_n1_derated.json
+  [ -s $F/plan_derate_ab.txt ] && cp $F/plan_derate_ab.txt profiles/${R}_plan_derate_ab.txt
+  [ -s $F/replay/w8_n20_latency_sweep.json ] && cp $F/replay/w8_n20_latency_sweep.json profiles/${R}_replay_latency_sweep.json
+  [ -s $F/replay/aggregate_rank0_of_8.json ] && cp $F/replay/aggregate_rank0_of_8.json profiles/${R}_aggregate_2p14_sharded_replay.json
   for G in 2 4 8; do for K in 0 1; do for X in bench.json timeline.txt; do [ -s $F/replay/rank${K}_of_${G}_$X ] && cp $F/replay/rank${K}_of_${G}_$X profiles/${R}_rank${K}_of_${G}_$X; done; done; [ -s $F/replay/w${G}_n20_passes.json ] && cp $F/replay/w${G}_n20_passes.json profiles/${R}_replay_w${G}_passes.json; done
 fi

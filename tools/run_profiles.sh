@@ -1,6 +1,6 @@
 # Collects every profile the bench line and DESIGN.md quote, on the CURRENT build.  Usage (GPU box): bash tools/run_profiles.sh <tag>
 set -x
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
@@ -8,6 +8,8 @@ export TMPDIR=/tmp
 ./tools/ubench/build/fpbench > $OUT/fpbench.txt 2>&1
 ./tools/ubench/build/fqbench > $OUT/fqbench.txt 2>&1
 ./tools/ubench/build/invbench > $OUT/invbench.txt 2>&1
+# stage 2a of the pairing product in isolation: k_line_products_q (six-product sums) against k_line_products_k (Karatsuba), bit-compared
+( ./tools/ubench/build/lpbench 17 2 5; ./tools/ubench/build/lpbench 17 6 3; ./tools/ubench/build/lpbench 15 2 3 ) > $OUT/lpbench.txt 2>&1
 timeout 900 python3 bench.py --steps 5 --warmup 1 > $OUT/bench_n1.json 2> $OUT/bench_n1.err        # incl. the CPU baseline at n = 2^20 (~100 s)
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/kstats -o k --output-format csv -- python3 bench.py --steps 3 --warmup 1 --cpu-log-n 0 > $OUT/kstats.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o f --output-format csv -- python3 bench.py --steps 1 --warmup 0 --cpu-log-n 0 > $OUT/pmc_fetch.log 2>&1
