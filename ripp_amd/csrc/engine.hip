@@ -2558,7 +2558,9 @@ static int32_t sipp_prove_core(Engine* e, ripp_sipp_job* j, const Fp12& val, con
         if (!j->seeded) {
             j->rng.from_digest(j->digest); j->seeded = true;
             e->quiet_waits = false;
-            host_pool().set_hot(e->hot_workers_cfg ? e->hot_workers_cfg == 1 : hot_workers_pay(world0));      // the remaining rounds hand 0.1-0.6 ms tasks to the workers every ~2 ms
+            // polling workers need cores of their own: forced on (ripp_config.hot_workers = 1) with fewer CPUs than workers they would starve the threads that do the work
+            // (measured with recorded peers: rank 0 of 8 confined to 4 cores with polling forced: 349 ms after the digest instead of ~50)
+            host_pool().set_hot(e->hot_workers_cfg ? (e->hot_workers_cfg == 1 && effective_cpus() >= (int)host_pool().size() + 2) : hot_workers_pay(world0));      // the remaining rounds hand 0.1-0.6 ms tasks to the workers every ~2 ms
         }
         const Fr x = fs::sipp_challenge(j->rng, zl, zr);
         x_prev = x;

@@ -324,6 +324,17 @@ pub fn hip_sipp_prove_sharded(a: &[G1Affine], b: &[G2Affine], r: &[Fr], value: &
     check(unsafe { ripp_sipp_prove_sharded(la.as_ptr(), lb.as_ptr(), lr.as_ptr(), la.len(), &gt(value), fa, fb, fr_, null(), proof.as_mut_ptr(), null_mut(), null_mut()) })?;
     Ok(proof[..2 * rounds].chunks(2).map(|p| (un_gt(&p[0]), un_gt(&p[1]))).collect())
 }
+/// Use `n` devices of THIS process for the stateless trait calls (`HipPairingInnerProduct`, `HipMultiexpInnerProductG1/G2` on host slices): the library cuts the index
+/// range into `n` parts, one per device (bound device + d), and combines the partial results on the host -- no communicator, no change to the caller (`ripp_config.n_devices`).
+/// Proofs (SIPP / GIPA / TIPA) shard across processes instead (`hip_comm_init`).  `hip_device_slots_used()` tells how many parts the last such call used.
+pub fn hip_set_devices(n: u32) -> Result<(), Error> {
+    let mut c = core::mem::MaybeUninit::<RippConfig>::zeroed();
+    check(unsafe { ripp_config_get(c.as_mut_ptr()) })?;
+    let mut c = unsafe { c.assume_init() };
+    c.n_devices = n;
+    check(unsafe { ripp_configure(&c) })
+}
+pub fn hip_device_slots_used() -> i32 { unsafe { ripp_device_slots_used() } }
 /// bring the library's RCCL communicator up: rank 0 creates the 128-byte id (`hip_comm_unique_id`), the host's own rendezvous hands it to the others
 pub fn hip_comm_unique_id() -> Result<[u8; 128], Error> { let mut id = [0u8; 128]; check(unsafe { ripp_comm_unique_id(id.as_mut_ptr()) })?; Ok(id) }
 pub fn hip_comm_init(id: &[u8; 128], rank: i32, world: i32) -> Result<(), Error> { check(unsafe { ripp_comm_init(id.as_ptr(), rank, world) }) }

@@ -57,7 +57,12 @@ def test_sipp_prove_2p22_accepted_by_the_oracle_verifier(engine, orc):
     again beside a dummy allocation that leaves the library ~60 GB: hipMemGetInfo itself (no mem_cap_bytes) must push the call down the tiers, and the
     proof bytes must not change.  ripp_release_scratch returns the device memory."""
     import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")                               # the HIP runtime the library is bound to (already mapped): the neighbour's allocation comes from it
+    # the HIP runtime libripp_hip.so is bound to (a process may map two: the ROCm installation's and the copy a PyTorch wheel bundles -- by soname one gets whichever came
+    # first, and the other one has no device context): take the mapped path that is not torch's
+    maps = [ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln]
+    paths = sorted(set(maps), key=lambda q: ("torch" in q, q))
+    assert paths, "libamdhip64 is not mapped?"
+    hip = ctypes.CDLL(paths[0])
     R = engine
     n = 1 << 22
     R.release_scratch()

@@ -159,7 +159,8 @@ def pin_cores(args):
     if args.cores > 0:
         avail = sorted(os.sched_getaffinity(0))
         os.sched_setaffinity(0, set(avail[:args.cores]))
-        os.environ["RIPP_HOT_WORKERS"] = "0" if args.cores < 4 else os.environ.get("RIPP_HOT_WORKERS", "1")      # polling workers need cores of their own
+        if args.cores < 8:
+            os.environ.pop("RIPP_HOT_WORKERS", None)          # polling workers need cores of their own: leave the choice to the library (it counts the CPUs it may use)
 
 
 def replay_worker(args):
