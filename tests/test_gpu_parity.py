@@ -702,3 +702,32 @@ def test_in_process_multi_device_dispatch_on_virtual_devices(engine, orc):
     finally:
         del os.environ["RIPP_VIRTUAL_DEVICES"]
     assert np.array_equal(got, orc.g1_to_affine(orc.msm_g1_a(a2, r2)).reshape(1, 12))
+
+
+@pytest.mark.parametrize("n,D", [(1 << 12, 2), (1 << 12, 4), (1 << 13, 8), (1 << 12, 3)])
+def test_gipa_tipp_prove_on_in_process_ranks(engine, orc, n, D):
+    """The fused GIPA prover with ripp_config.n_devices = D: D in-process ranks (one host thread and engine per device, vectors sharded by index residue, the per-round
+    exchange a copy through host memory -- no communicator) must give the single-device proof, i.e. the oracle's: commitments, challenges, base case.  On a one-GPU
+    box the ranks share the bound device (RIPP_VIRTUAL_DEVICES); D = 3 rounds down to two ranks; a vector too short to be worth a device stays on one."""
+    import ctypes
+    import os
+    from ripp_amd._lib import lib
+    m_a, m_b = orc.blind_g1(orc.gen_g1(11, n), 1), orc.blind_g2(orc.gen_g2(22, n), 2)
+    ck_a, ck_b = orc.blind_g2(orc.gen_g2(33, n), 3), orc.blind_g1(orc.gen_g1(44, n), 4)
+    rc, steps, tr, ba, bb, ka, kb = orc.gipa_tipp_prove(m_a, m_b, ck_a, ck_b)
+    assert rc == 0
+    L = lib(); L.ripp_device_slots_used.restype = ctypes.c_int32
+    os.environ["RIPP_VIRTUAL_DEVICES"] = str(D)
+    try:
+        proof, aux, raw = engine.GIPA_TIPP.prove_with_aux(m_a, m_b, ck_a, ck_b)
+        assert L.ripp_device_slots_used() == (2 if D == 3 else min(D, n // 1024))
+        small = engine.GIPA_TIPP.prove_with_aux(m_a[:64], m_b[:64], ck_a[:64], ck_b[:64])[2]
+        assert L.ripp_device_slots_used() == 1
+    finally:
+        del os.environ["RIPP_VIRTUAL_DEVICES"]
+    assert np.array_equal(raw["round_order_steps"], steps) and np.array_equal(raw["round_order_transcript"], tr)
+    assert np.array_equal(engine.normalize_batch_g1(proof["r_base"][0]), orc.g1_to_affine(ba).reshape(1, 12))
+    assert np.array_equal(engine.normalize_batch_g2(proof["r_base"][1]), orc.g2_to_affine(bb).reshape(1, 24))
+    assert np.array_equal(engine.normalize_batch_g2(aux["ck_base"][0]), orc.g2_to_affine(ka).reshape(1, 24))
+    assert np.array_equal(engine.normalize_batch_g1(aux["ck_base"][1]), orc.g1_to_affine(kb).reshape(1, 12))
+    assert np.array_equal(small["round_order_transcript"], orc.gipa_tipp_prove(m_a[:64], m_b[:64], ck_a[:64], ck_b[:64])[2])
