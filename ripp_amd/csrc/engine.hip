@@ -1925,9 +1925,10 @@ static void job_buffers(ripp_sipp_job* j, DevBuf* (&d)[15], PinBuf* (&p)[4]) {
     for (int i = 0; i < 4; ++i) p[i] = pl[i];
 }
 static void job_release_buffers(ripp_sipp_job* j) { DevBuf* d[15]; PinBuf* p[4]; job_buffers(j, d, p); for (DevBuf* b : d) b->release(); for (PinBuf* b : p) b->release(); }
-static int32_t sipp_job_create_impl(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr* r, size_t n_local, int32_t rank, int32_t world, const ripp_gt* borrow_value, ripp_sipp_job** job,
-                                    const ripp_g1a* full_a = nullptr, const ripp_g2a* full_b = nullptr, const ripp_fr* full_r = nullptr, size_t n_full = 0, bool one_shot = false) {
-    LOCK; ENGINE; if (!a || !b || !r || !job || n_local == 0 || world < 1 || rank < 0 || rank >= world) return RIPP_ERR_ARG;
+// (on engine e, whose device is current and whose caller holds the library's lock: the C-ABI wrapper below, or one in-process rank of sipp_prove_devices)
+static int32_t sipp_job_create_on(Engine* e, const ripp_g1a* a, const ripp_g2a* b, const ripp_fr* r, size_t n_local, int32_t rank, int32_t world, const ripp_gt* borrow_value, ripp_sipp_job** job,
+                                  const ripp_g1a* full_a = nullptr, const ripp_g2a* full_b = nullptr, const ripp_fr* full_r = nullptr, size_t n_full = 0, bool one_shot = false) {
+    if (!a || !b || !r || !job || n_local == 0 || world < 1 || rank < 0 || rank >= world) return RIPP_ERR_ARG;
     if (n_local & (n_local - 1)) return RIPP_ERR_POW2;
     ripp_sipp_job* j = new ripp_sipp_job();
     if (one_shot && e->job_cache.full) {                      // the buffers the previous one-shot proof left behind (sipp_job_retire)
@@ -1966,6 +1967,11 @@ static int32_t sipp_job_create_impl(const ripp_g1a* a, const ripp_g2a* b, const 
     live.keep = true;
     *job = j; return RIPP_OK;
 }
+static int32_t sipp_job_create_impl(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr* r, size_t n_local, int32_t rank, int32_t world, const ripp_gt* borrow_value, ripp_sipp_job** job,
+                                    const ripp_g1a* full_a = nullptr, const ripp_g2a* full_b = nullptr, const ripp_fr* full_r = nullptr, size_t n_full = 0, bool one_shot = false) {
+    LOCK; ENGINE;
+    return sipp_job_create_on(e, a, b, r, n_local, rank, world, borrow_value, job, full_a, full_b, full_r, n_full, one_shot);
+}
 API int32_t ripp_sipp_job_create(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr* r, size_t n_local, int32_t rank, int32_t world, ripp_sipp_job** job) {
     return sipp_job_create_impl(a, b, r, n_local, rank, world, nullptr, job);
 }
@@ -1977,6 +1983,23 @@ API void ripp_sipp_job_destroy(ripp_sipp_job* j) {
     delete j; --g_live_handles;
 }
 // the end of a one-shot proof: the job goes, its buffers stay with the engine for the next one-shot call (Engine::job_cache)
+// the same for a job of engine e whose caller holds the lock (an in-process rank): park the buffers with THAT engine, then free the job
+static void sipp_job_retire_on(Engine* e, ripp_sipp_job* j) {
+    if (!j) return;
+    if (j->hash_thread.joinable()) j->hash_thread.join();
+    if (!e->job_cache.full && !e->sw.no_job_cache) {
+        DevBuf* d[15]; PinBuf* p[4]; job_buffers(j, d, p);
+        bool idle = true; for (PinBuf* b : p) if (b->wait() != RIPP_OK) idle = false;
+        if (idle) {
+            for (int i = 0; i < 15; ++i) std::swap(*d[i], e->job_cache.d[i]);
+            for (int i = 0; i < 4; ++i) std::swap(*p[i], e->job_cache.p[i]);
+            e->job_cache.full = true;
+        }
+    }
+    job_release_buffers(j);
+    if (e->tab_owner == j) e->tab_owner = nullptr;
+    delete j; --g_live_handles;
+}
 static void sipp_job_retire(ripp_sipp_job* j) {
     if (!j) return;
     {   LOCK;
@@ -2643,9 +2666,59 @@ API int32_t ripp_sipp_job_prove(ripp_sipp_job* j, const ripp_gt* value, ripp_gt*
     return sipp_prove_core(e, j, val, nullptr, proof, challenges, st);
 }
 
+// SIPP::prove on D IN-PROCESS RANKS (ripp_config.n_devices = D > 1): one host thread, engine and job per device walk the sharded protocol of sipp_prove_core side by
+// side -- the statement sharded by index residue exactly as across processes, rank 0 hashing the caller's whole statement, the per-round exchange of finished
+// partial GT values a copy through LocalComm (comm_core.inc).  Every rank ends with the same proof; the caller gets rank 0's after they have been compared.
+// The unmodified single-process caller of SIPP::prove thereby reaches every device it drives.  UNMEASURED on a multi-GPU node; tested on RIPP_VIRTUAL_DEVICES.
+extern "C++" {
+static int32_t sipp_prove_devices(Engine* e, std::vector<DevSlot>& sl, const ripp_g1a* a, const ripp_g2a* b, const ripp_fr* r, size_t n, const ripp_gt* value,
+                                  ripp_gt* proof, ripp_fr* challenges, ripp_stats* st) {
+    const size_t D = sl.size(), nl = n / D; size_t rounds = 0; while (((size_t)1 << rounds) < n) ++rounds;
+    LocalComm lc; lc.world = (int)D;
+    Fp12 val; std::memcpy(&val, value, sizeof val);
+    struct Out { std::vector<ripp_gt> proof; std::vector<ripp_fr> ch; ripp_stats st; };
+    std::vector<Out> outs(D);
+    const bool virt = e->virtual_devices;
+    int32_t rc = run_on_devices(e, sl, [&](Engine* ee, size_t, size_t, int d) -> int32_t {
+        t_lcomm = &lc; t_lrank = d;
+        struct Unbind { ~Unbind() { t_lcomm = nullptr; t_lrank = 0; } } unbind;
+        if (virt) ee->ranks_per_device = (double)D;                              // the look-ahead plan prices the window per DEVICE
+        std::vector<G1A> sa(nl); std::vector<G2A> sb(nl); std::vector<Fr> sr(nl);      // this rank's residue class (local j <-> global j D + d)
+        for (size_t i = 0; i < nl; ++i) { std::memcpy(&sa[i], &a[i * D + (size_t)d], sizeof(G1A)); std::memcpy(&sb[i], &b[i * D + (size_t)d], sizeof(G2A)); std::memcpy(&sr[i], &r[i * D + (size_t)d], sizeof(Fr)); }
+        ripp_sipp_job* j = nullptr;
+        int32_t r2 = sipp_job_create_on(ee, reinterpret_cast<const ripp_g1a*>(sa.data()), reinterpret_cast<const ripp_g2a*>(sb.data()), reinterpret_cast<const ripp_fr*>(sr.data()), nl, d, (int32_t)D,
+                                        d == 0 ? value : nullptr, &j, d == 0 ? a : nullptr, d == 0 ? b : nullptr, d == 0 ? r : nullptr, n, true);
+        if (r2) { lc.fail(); return r2; }
+        if (d == 0 && !j->hash_prestarted) {                                    // the caller's buffers do not meet the engine types' alignment: hash a copy
+            j->ha_ext = nullptr; j->ha.resize(n); j->hb.resize(n); j->hr.resize(n);
+            std::memcpy(j->ha.data(), a, n * sizeof(G1A)); std::memcpy(j->hb.data(), b, n * sizeof(G2A)); std::memcpy(j->hr.data(), r, n * sizeof(Fr));
+        }
+        Out& o = outs[(size_t)d]; o.proof.resize(2 * std::max<size_t>(rounds, 1)); o.ch.resize(std::max<size_t>(rounds, 1));
+        r2 = sipp_prove_core(ee, j, val, nullptr, o.proof.data(), o.ch.data(), &o.st);
+        sipp_job_retire_on(ee, j);
+        if (r2) lc.fail();
+        return r2; });
+    if (rc) return rc;
+    for (size_t d = 1; d < D; ++d)
+        if (std::memcmp(outs[d].proof.data(), outs[0].proof.data(), 2 * rounds * sizeof(ripp_gt))) { set_err("in-process ranks: the devices' proofs differ"); return RIPP_ERR_DEVICE; }
+    std::memcpy(proof, outs[0].proof.data(), 2 * rounds * sizeof(ripp_gt));
+    if (challenges) std::memcpy(challenges, outs[0].ch.data(), rounds * sizeof(ripp_fr));
+    if (st) *st = outs[0].st;
+    return RIPP_OK;
+}
+}
 API int32_t ripp_sipp_prove(const ripp_g1a* a, const ripp_g2a* b, const ripp_fr* r, size_t n, const ripp_gt* value, ripp_gt* proof, ripp_fr* challenges, ripp_stats* st) {
     if (n == 0 || (n & (n - 1))) return RIPP_ERR_POW2;
     if (!value) return RIPP_ERR_ARG;
+    {   // more than one device configured for this process, and a statement worth sharding (>= 2^14 elements per device)?
+        LOCK; ENGINE;
+        if (e->n_devices_cfg > 1 && a && b && r && proof) {
+            std::vector<DevSlot> sl; int32_t rc = device_slots(e, n, (size_t)1 << 14, &sl); if (rc) return rc;
+            size_t D = 1; while (2 * D <= sl.size()) D *= 2;
+            g_last_slots = (int32_t)D;
+            if (D > 1) { sl.resize(D); return sipp_prove_devices(e, sl, a, b, r, n, value, proof, challenges, st); }
+        }
+    }
     ripp_sipp_job* j = nullptr;
     int32_t rc = sipp_job_create_impl(a, b, r, n, 0, 1, value, &j, nullptr, nullptr, nullptr, 0, true); if (rc) return rc;
     rc = ripp_sipp_job_prove(j, value, proof, challenges, st);

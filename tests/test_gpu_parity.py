@@ -731,3 +731,31 @@ def test_gipa_tipp_prove_on_in_process_ranks(engine, orc, n, D):
     assert np.array_equal(engine.normalize_batch_g2(aux["ck_base"][0]), orc.g2_to_affine(ka).reshape(1, 24))
     assert np.array_equal(engine.normalize_batch_g1(aux["ck_base"][1]), orc.g1_to_affine(kb).reshape(1, 12))
     assert np.array_equal(small["round_order_transcript"], orc.gipa_tipp_prove(m_a[:64], m_b[:64], ck_a[:64], ck_b[:64])[2])
+
+
+@pytest.mark.parametrize("n,D", [(1 << 15, 2), (1 << 16, 4)])
+def test_sipp_prove_on_in_process_ranks(engine, orc, n, D):
+    """SIPP::prove with ripp_config.n_devices = D: D in-process ranks (one host thread, engine and job per device; the statement sharded by index residue, rank 0 hashing
+    the caller's whole statement, the per-round exchange a copy through host memory) must give the single-device proof -- all 2 log2 n GT values and every challenge
+    equal to the oracle's.  The D slots share the bound device here (RIPP_VIRTUAL_DEVICES); a statement below 2^14 elements per device is not sharded."""
+    import ctypes
+    import os
+    from ripp_amd._lib import lib
+    a, b, r = engine.synth_g1(31, n), engine.synth_g2(32, n), engine.synth_fr(33, n)
+    a[5] = 0; b[n - 3] = 0; r[n // 2] = 0                             # identities and a zero coefficient on different ranks
+    value = engine.product_of_pairings_with_coeffs(a, b, r)
+    rc, eproof, ech = orc.sipp_prove(a, b, r, value)
+    assert rc == 0
+    L = lib(); L.ripp_device_slots_used.restype = ctypes.c_int32
+    os.environ["RIPP_VIRTUAL_DEVICES"] = str(D)
+    try:
+        proof, ch, st = engine.SIPP.prove_one_shot(a, b, r, value)
+        assert L.ripp_device_slots_used() == D
+        proof2, ch2, _ = engine.SIPP.prove_one_shot(a, b, r, value)      # again: the ranks' parked job buffers are adopted
+        small = engine.SIPP.prove_one_shot(a[:4096], b[:4096], r[:4096], engine.product_of_pairings_with_coeffs(a[:4096], b[:4096], r[:4096]))[0]
+        assert L.ripp_device_slots_used() == 1 and small.shape == (24, 72)
+    finally:
+        del os.environ["RIPP_VIRTUAL_DEVICES"]
+    assert np.array_equal(proof, eproof) and np.array_equal(ch, ech)
+    assert np.array_equal(proof2, eproof) and np.array_equal(ch2, ech)
+    assert np.array_equal(engine.SIPP.prove_one_shot(a, b, r, value)[0], eproof)      # and back on one device
