@@ -78,8 +78,22 @@ struct Fq {
 using Fqn = Fq<FQ_LN, 2>;         // what every multiplication returns
 
 __device__ __forceinline__ void mad64(uint64_t& acc, uint32_t x, uint32_t y) { acc += (uint64_t)x * y; }
-#ifndef FQ_NACC
-#define FQ_NACC 1
+// A column is ONE chain of multiply-adds seeded with the previous column's carry.  Left to itself LLVM re-associates the sum: it starts the chain at zero and adds the
+// carry with a 64-bit add behind it (26 v_lshl_add_u64 per product) -- one more instruction per column for a dependence that costs nothing here: a dependent
+// v_mad_u64_u32 issues at the rate of an independent one (profiles/r01_ubench_valu_rates.txt).  An empty asm on the running sum keeps the chain as written.
+#ifndef FQ_CHAIN_TIES
+#define FQ_CHAIN_TIES 2
+#endif
+#if FQ_CHAIN_TIES == 2
+#define FQ_CHAIN(x) asm volatile("" :: "v"(x))
+#elif FQ_CHAIN_TIES
+#define FQ_CHAIN(x) asm("" : "+v"(x))
+#else
+#define FQ_CHAIN(x)
+#endif
+// a square as 105 limb products (the 91 cross terms once, against a doubled operand) instead of 196
+#ifndef FQ_DEDICATED_SQR
+#define FQ_DEDICATED_SQR 1
 #endif
 
 template <uint64_t LM, int VB> __device__ __forceinline__ Fq<LM, VB> fq_const(const fq28::Limbs& c) { Fq<LM, VB> r; for (int i = 0; i < fq28::NL; ++i) r.l[i] = c.l[i]; return r; }
@@ -110,67 +124,80 @@ constexpr bool dot_fits(int NT, uint64_t L1, uint64_t L2) {
 }
 }  // namespace fq28
 
-// sum_t a[t] * b[t] * R'^-1 mod p with ONE Montgomery reduction; result limbs < 2^28, value < 2p
-template <int NT, uint64_t L1, int V1, uint64_t L2, int V2>
-__device__ __forceinline__ Fqn fq_dot(const Fq<L1, V1> (&a)[NT], const Fq<L2, V2> (&b)[NT]) {
+// The Montgomery product over columns: terms(k, acc) adds the limb products of column k (0 <= k < 27) of the integer to be reduced to acc; the m p terms of the
+// reduction follow in the same chain.  Result limbs < 2^28, value < 2p when the integer is < VMAX p^2.
+template <class TERMS>
+__device__ __forceinline__ Fqn fq_montgomery(TERMS&& terms) {
     using namespace fq28;
-    static_assert(dot_fits(NT, L1, L2), "column sum overflows 64 bits: normalise an operand");
-    static_assert((long)NT * V1 * V2 <= VMAX, "value bound: the sum of products must stay below p R'");
     uint32_t m[NL];
     Fqn r;
-    // A dependent v_mad_u64_u32 has a latency of ~6 issue slots: at the 2 waves / SIMD the register-heavy kernels run with, ONE accumulator
-    // chain per column leaves the multiplier idle 40 % of the time.  The terms of a column therefore go round-robin into NACC independent
-    // accumulators (summed once per column); with the compiler interleaving two columns that is 2 NACC chains per wave.
-    constexpr int NACC = FQ_NACC;
     uint64_t carry = 0;
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
-        uint64_t acc[NACC]; int u = 0;
+        uint64_t s = carry;
+        terms(k, s);
 #pragma unroll
-        for (int c = 0; c < NACC; ++c) acc[c] = 0;
-        acc[0] = carry;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-#pragma unroll
-            for (int i = 0; i <= k; ++i) { mad64(acc[u], a[t].l[i], b[t].l[k - i]); u = (u + 1) % NACC; }
-        }
-#pragma unroll
-        for (int i = 0; i < k; ++i) { mad64(acc[u], m[i], P28.l[k - i]); u = (u + 1) % NACC; }
-        uint64_t s = acc[0];
-#pragma unroll
-        for (int c = 1; c < NACC; ++c) s += acc[c];
+        for (int i = 0; i < k; ++i) { mad64(s, m[i], P28.l[k - i]); FQ_CHAIN(s); }
         m[k] = ((uint32_t)s * INV28) & MASK;
         mad64(s, m[k], P28.l[0]);
         carry = s >> W;
     }
 #pragma unroll
     for (int k = NL; k < 2 * NL - 1; ++k) {
-        uint64_t acc[NACC]; int u = 0;
+        uint64_t s = carry;
+        terms(k, s);
 #pragma unroll
-        for (int c = 0; c < NACC; ++c) acc[c] = 0;
-        acc[0] = carry;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-#pragma unroll
-            for (int i = k - NL + 1; i < NL; ++i) { mad64(acc[u], a[t].l[i], b[t].l[k - i]); u = (u + 1) % NACC; }
-        }
-#pragma unroll
-        for (int i = k - NL + 1; i < NL; ++i) { mad64(acc[u], m[i], P28.l[k - i]); u = (u + 1) % NACC; }
-        uint64_t s = acc[0];
-#pragma unroll
-        for (int c = 1; c < NACC; ++c) s += acc[c];
+        for (int i = k - NL + 1; i < NL; ++i) { mad64(s, m[i], P28.l[k - i]); FQ_CHAIN(s); }
         r.l[k - NL] = (uint32_t)s & MASK;
         carry = s >> W;
     }
     r.l[NL - 1] = (uint32_t)carry;        // value < 2p < 2^382: the top limb is < 2^18
     return r;
 }
+
+// sum_t a[t] * b[t] * R'^-1 mod p with ONE Montgomery reduction; result limbs < 2^28, value < 2p
+template <int NT, uint64_t L1, int V1, uint64_t L2, int V2>
+__device__ __forceinline__ Fqn fq_dot(const Fq<L1, V1> (&a)[NT], const Fq<L2, V2> (&b)[NT]) {
+    using namespace fq28;
+    static_assert(dot_fits(NT, L1, L2), "column sum overflows 64 bits: normalise an operand");
+    static_assert((long)NT * V1 * V2 <= VMAX, "value bound: the sum of products must stay below p R'");
+    return fq_montgomery([&](int k, uint64_t& s) __attribute__((always_inline)) {
+        const int lo = k < NL ? 0 : k - NL + 1, hi = k < NL ? k : NL - 1;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int i = lo; i <= hi; ++i) { mad64(s, a[t].l[i], b[t].l[k - i]); FQ_CHAIN(s); }
+        }
+    });
+}
 template <uint64_t L1, int V1, uint64_t L2, int V2>
 __device__ __forceinline__ Fqn fq_mul(const Fq<L1, V1>& a, const Fq<L2, V2>& b) {
     const Fq<L1, V1> aa[1] = {a}; const Fq<L2, V2> bb[1] = {b};
     return fq_dot<1>(aa, bb);
 }
-template <uint64_t L1, int V1> __device__ __forceinline__ Fqn fq_sqr(const Fq<L1, V1>& a) { return fq_mul(a, a); }
+// a^2: column k = sum_(i < j, i + j = k) (2 a_i) a_j + [k even] a_(k/2)^2 -- the same integer as a * a, 105 limb products
+template <uint64_t L1, int V1> __device__ __forceinline__ Fqn fq_sqr(const Fq<L1, V1>& a) {
+#if FQ_DEDICATED_SQR
+    using namespace fq28;
+    static_assert(dot_fits(1, L1, L1), "column sum overflows 64 bits: normalise the operand");
+    static_assert(L1 <= ((uint64_t)1 << 31), "the doubled limbs must fit 32 bits");
+    static_assert((long)V1 * V1 <= VMAX, "value bound");
+    uint32_t d[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) d[i] = a.l[i] << 1;
+    return fq_montgomery([&](int k, uint64_t& s) __attribute__((always_inline)) {
+        const int lo = k < NL ? 0 : k - NL + 1, hi = k < NL ? k : NL - 1;
+#pragma unroll
+        for (int i = lo; i <= hi; ++i) {
+            const int j = k - i;
+            if (i < j) { mad64(s, d[i], a.l[j]); FQ_CHAIN(s); }
+            else if (i == j) { mad64(s, a.l[i], a.l[i]); FQ_CHAIN(s); }
+        }
+    });
+#else
+    return fq_mul(a, a);
+#endif
+}
 
 // limb-wise, no carries
 template <uint64_t L1, int V1, uint64_t L2, int V2>

@@ -1,7 +1,7 @@
 // G1 group law and fold kernels on the carry-free field form (fq28.hpp): the throughput twins of kernels.hpp's k_fold_affine_naf<Fp> /
 // k_fold_g1_tab.  Same formulas (dbl-2009-l, madd-2007-bl), written over lazily bounded values: additions and subtractions are limb-wise
 // (no carry chains, no conditional subtractions), every multiplication is 196 + 196 multiply-adds instead of 288 + 288 with carries, and
-// the compiler checks every bound (fq28.hpp).  Coordinates are carried between group operations as normalised values < 4p.
+// the compiler checks every bound (fq28.hpp).  Coordinates are carried between group operations carry-normalised and UNREDUCED (JacQ below).
 // The low-liveness forms do not cover the exceptional cases (T = +-Q, an operand at infinity): they REPORT them and the kernel recomputes
 // such a lane with the complete formulas of curve.hpp, exactly like k_fold_g2_tab.
 #pragma once
@@ -41,36 +41,59 @@ template <uint64_t LM, int VB> __device__ __forceinline__ FqC fq_coord(const Fq<
     else return fq_widen<FQ_LN, 4>(fq_reduce(a));
 }
 
-struct JacQ { FqC x, y, z; };
+// A Jacobian point between two group operations.  Its coordinates are NOT reduced: they keep the bounds the formulas leave them with -- after a doubling
+// (X, Y, Z) < (36, 19, 4) p, after a mixed addition < (11, 7, 8) p, whatever the bounds of the operands (every input first meets a product) -- and are only
+// carry-normalised: a reduction (quotient estimate + a signed 64-bit carry pass) costs a fifth of a field product, a normalisation a few per cent
+// (tools/ubench/fqgroup.hip), and the group law used four per addition and two per doubling.  The compiler checks every bound (fq28.hpp).
+using JX = Fq<FQ_LN, 36>; using JY = Fq<FQ_LN, 19>; using JZ = Fq<FQ_LN, 8>;
+struct JacQ { JX x; JY y; JZ z; };
 struct AffQ { Fqn x, y; };
+// a value into a coordinate slot: carry-normalised where it is lazy; its bound must fit the slot's (a compile error otherwise, never a silent reduction)
+template <class T, uint64_t LM, int VB> __device__ __forceinline__ T fq_slot(const Fq<LM, VB>& a) {
+    static_assert(VB <= T::VMAXB, "coordinate bound exceeded: reduce the value first");
+    if constexpr (LM <= FQ_LN) return fq_widen<FQ_LN, T::VMAXB>(a);
+    else return fq_widen<FQ_LN, T::VMAXB>(fq_norm(a));
+}
+template <class TX, class TY, class TZ> __device__ __forceinline__ void jq_set(JacQ& a, const TX& x, const TY& y, const TZ& z) { a.x = fq_slot<JX>(x); a.y = fq_slot<JY>(y); a.z = fq_slot<JZ>(z); }
+__device__ __forceinline__ void jq_set_identity(JacQ& a) { jq_set(a, fq_one(), fq_one(), fq_zero()); }
 __device__ __forceinline__ AffQ affq_from(const G1A& p) { return {fq_from_fp(p.x), fq_from_fp(p.y)}; }
 __device__ __forceinline__ G1J jacq_to_g1j(const JacQ& p) { return {fq_to_fp(fq_reduce(p.x)), fq_to_fp(fq_reduce(p.y)), fq_to_fp(fq_reduce(p.z))}; }
 
-// dbl-2009-l (a = 0): 2M + 5S.  Z = 0 maps to Z3 = 0.
+// dbl-2009-l (a = 0): 2M + 5S.  Z = 0 maps to Z3 = 0.  Every product is PINNED where it is written (fq28.hpp fq_pin): the multiply-adds of a product are tied
+// into chains (FQ_CHAIN), and without the pins the compiler starts several products before it finishes one and spills their operands.
+// Bounds out: X3 = E^2 - 2D < (2 + 17 + 17) p, Y3 = E (D - X3) - 8C < (2 + 16 + 1) p, Z3 = 2 Y Z < 4p.
 __device__ __forceinline__ void jdbl_q(JacQ& p) {
-    const Fqn A = fq_sqr(p.x), B = fq_sqr(p.y), C = fq_sqr(B);
-    const auto D = fq_norm(fq_dbl(fq_sub(fq_sub(fq_sqr(fq_add(p.x, B)), A), C)));
+    Fqn A = fq_sqr(p.x); fq_pin(A);
+    Fqn B = fq_sqr(p.y); fq_pin(B);
+    Fqn C = fq_sqr(B); fq_pin(C);
+    Fqn t = fq_sqr(fq_add(p.x, B)); fq_pin(t);
+    auto D = fq_norm(fq_dbl(fq_sub(fq_sub(t, A), C))); fq_pin(D);                   // < 16p
     const auto E = fq_add(fq_dbl(A), A);
-    const Fqn X3 = fq_reduce(fq_sub(fq_sub(fq_sqr(E), D), D));
-    const auto Z3 = fq_dbl(fq_mul(p.y, p.z));
-    p.y = fq_coord(fq_sub(fq_mul(E, fq_sub(D, X3)), fq_dbl(fq_dbl(fq_dbl(C)))));
-    p.x = fq_coord(X3);
-    p.z = fq_coord(Z3);
+    auto X3 = fq_norm(fq_sub(fq_sub(fq_sqr(E), D), D)); fq_pin(X3);
+    Fqn yz = fq_mul(p.y, p.z); fq_pin(yz);
+    p.y = fq_slot<JY>(fq_sub(fq_mul(E, fq_sub(D, X3)), fq_dbl(fq_dbl(fq_dbl(C))))); fq_pin(p.y);
+    p.x = fq_slot<JX>(X3);
+    p.z = fq_slot<JZ>(fq_dbl(yz));
 }
-// madd-2007-bl, q affine and NOT the identity, p NOT the identity.  Returns true when the result is not valid (H = 0: p = +-q).
+// madd-2007-bl, q affine and NOT the identity, p NOT the identity.  Returns true when the result is not valid (H = 0: p = +-q) -- read off H^2, which the
+// formula needs anyway and which is a reduced value (H itself is only normalised; H = 0 mod p iff H^2 = 0 mod p).
+// Bounds out: X3 = r^2 - J - 2V < 11p, Y3 = r (V - X3) - 2 Y1 J < 7p, Z3 = (Z1 + H)^2 - Z1Z1 - HH < 8p.
 __device__ __forceinline__ bool jmadd_q(JacQ& p, const Fqn& x2, const Fqn& y2) {
-    const Fqn Z1Z1 = fq_sqr(p.z);
-    const Fqn H = fq_reduce(fq_sub(fq_mul(x2, Z1Z1), p.x));
-    const bool special = fq_is_zero(H);
-    const auto rr = fq_norm(fq_dbl(fq_sub(fq_mul(fq_mul(y2, p.z), Z1Z1), p.y)));
-    const Fqn HH = fq_sqr(H);
+    Fqn Z1Z1 = fq_sqr(p.z); fq_pin(Z1Z1);
+    auto H = fq_norm(fq_sub(fq_mul(x2, Z1Z1), p.x)); fq_pin(H);                     // < 39p
+    Fqn yz = fq_mul(y2, p.z); fq_pin(yz);
+    auto rr = fq_norm(fq_dbl(fq_sub(fq_mul(yz, Z1Z1), p.y))); fq_pin(rr);            // < 44p
+    Fqn HH = fq_sqr(H); fq_pin(HH);
+    const bool special = fq_is_zero(HH);
     const auto I = fq_dbl(fq_dbl(HH));
-    const Fqn J = fq_mul(H, I), V = fq_mul(p.x, I);
-    const Fqn X3 = fq_reduce(fq_sub(fq_sub(fq_sub(fq_sqr(rr), J), V), V));
-    const auto Z3 = fq_sub(fq_sub(fq_sqr(fq_add(p.z, H)), Z1Z1), HH);
-    p.y = fq_coord(fq_sub(fq_mul(rr, fq_sub(V, X3)), fq_dbl(fq_mul(p.y, J))));
-    p.x = fq_coord(X3);
-    p.z = fq_coord(Z3);
+    Fqn J = fq_mul(H, I); fq_pin(J);
+    Fqn V = fq_mul(p.x, I); fq_pin(V);
+    auto X3 = fq_norm(fq_sub(fq_sub(fq_sub(fq_sqr(rr), J), V), V)); fq_pin(X3);
+    Fqn zh = fq_sqr(fq_add(p.z, H)); fq_pin(zh);
+    p.z = fq_slot<JZ>(fq_sub(fq_sub(zh, Z1Z1), HH)); fq_pin(p.z);
+    Fqn yj = fq_mul(p.y, J); fq_pin(yj);
+    p.y = fq_slot<JY>(fq_sub(fq_mul(rr, fq_sub(V, X3)), fq_dbl(yj))); fq_pin(p.y);
+    p.x = fq_slot<JX>(X3);
     return special;
 }
 #endif
@@ -87,7 +110,7 @@ __global__ void __launch_bounds__(256, 2) k_fold_g1_naf_q(const G1A* __restrict_
     if (pos < 0 || is_inf(p)) { out[i] = to_jac(l); return; }   // s * hi = identity
     const AffQ q = affq_from(p);
     const Fqn ny = fq_reduce(fq_neg(q.y));
-    JacQ acc; acc.x = fq_coord(q.x); acc.y = fq_coord(dg.d[pos] < 0 ? ny : q.y); acc.z = fq_coord(fq_one());
+    JacQ acc; jq_set(acc, q.x, dg.d[pos] < 0 ? ny : q.y, fq_one());
     bool bad = false;
 #pragma unroll 1
     for (--pos; pos >= 0; --pos) {
@@ -121,7 +144,7 @@ __global__ void __launch_bounds__(256, 2) k_fold_g1_glv_q(const G1A* __restrict_
         bx = fq_mul(q.x, fq_from_fp(fp_const(RIPP_GLV_BETA)));             // phi(P) = (beta x, y)
         ny = fq_reduce(fq_neg(q.y));
     }
-    JacQ acc; acc.x = acc.y = fq_coord(fq_one()); acc.z = fq_coord(fq_zero());
+    JacQ acc; jq_set_identity(acc);
     bool inf = true, bad = false;                                         // inf is wave-uniform (shared digit strings)
 #pragma unroll 1
     for (int pos = dg.len - 1; pos >= 0; --pos) {
@@ -131,7 +154,7 @@ __global__ void __launch_bounds__(256, 2) k_fold_g1_glv_q(const G1A* __restrict_
             const int d = h ? dg.d2[pos] : dg.d1[pos];
             if (d == 0) continue;
             const Fqn& x = h ? bx : q.x;
-            if (inf) { acc.x = fq_coord(x); acc.y = fq_coord(d < 0 ? ny : q.y); acc.z = fq_coord(fq_one()); inf = false; }
+            if (inf) { jq_set(acc, x, d < 0 ? ny : q.y, fq_one()); inf = false; }
             else bad |= jmadd_q(acc, x, d < 0 ? ny : q.y);
         }
     }
@@ -159,7 +182,7 @@ __global__ void __launch_bounds__(256, 2) k_fold_g1_tab_q(const G1A* __restrict_
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= half) return;
 #if defined(__HIP_DEVICE_COMPILE__)
-    JacQ acc; acc.x = acc.y = fq_coord(fq_one()); acc.z = fq_coord(fq_zero());
+    JacQ acc; jq_set_identity(acc);
     bool inf = true, bad = false;                               // inf is wave-uniform (shared digit strings); a table point at infinity makes the lane `bad`
 #pragma unroll 1
     for (int pos = dg.len - 1; pos >= 0; --pos) {
@@ -172,7 +195,7 @@ __global__ void __launch_bounds__(256, 2) k_fold_g1_tab_q(const G1A* __restrict_
             bad |= is_inf(qa);
             AffQ q = affq_from(qa);
             if (d < 0) q.y = fq_reduce(fq_neg(q.y));
-            if (inf) { acc.x = fq_coord(q.x); acc.y = fq_coord(q.y); acc.z = fq_coord(fq_one()); inf = false; }
+            if (inf) { jq_set(acc, q.x, q.y, fq_one()); inf = false; }
             else bad |= jmadd_q(acc, q.x, q.y);
         }
     }
@@ -221,7 +244,7 @@ __global__ void __launch_bounds__(256, 2) k_fold_g1_fused_q(const G1A* __restric
     if (i >= q) return;
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr uint32_t betaw[12] = RIPP_GLV_BETA; constexpr fq28::Limbs BETA = fq28::from_mont384(betaw);
-    JacQ acc; acc.x = acc.y = fq_coord(fq_one()); acc.z = fq_coord(fq_zero());
+    JacQ acc; jq_set_identity(acc);
     bool inf = true, bad = false;                               // inf is wave-uniform (shared digit strings); a table point at infinity makes the lane `bad`
 #pragma unroll 1
     for (int pos = dg.len - 1; pos >= 0; --pos) {
@@ -238,7 +261,7 @@ __global__ void __launch_bounds__(256, 2) k_fold_g1_fused_q(const G1A* __restric
             AffQ p = affq_from(qa);
             if (u == 2) p.x = fq_mul(p.x, fq_const<FQ_LN, 1>(BETA));
             if (d < 0) p.y = fq_reduce(fq_neg(p.y));
-            if (inf) { acc.x = fq_coord(p.x); acc.y = fq_coord(p.y); acc.z = fq_coord(fq_one()); inf = false; }
+            if (inf) { jq_set(acc, p.x, p.y, fq_one()); inf = false; }
             else bad |= jmadd_q(acc, p.x, p.y);
         }
     }
@@ -263,7 +286,7 @@ __global__ void __launch_bounds__(256, 2) k_pow2_mul_g1_q(const G1A* __restrict_
     const G1A p = in[i];
     if (is_inf(p)) { out[i] = jac_inf<Fp>(); return; }
     const AffQ q = affq_from(p);
-    JacQ acc; acc.x = fq_coord(q.x); acc.y = fq_coord(q.y); acc.z = fq_coord(fq_one());
+    JacQ acc; jq_set(acc, q.x, q.y, fq_one());
 #pragma unroll 1
     for (int t = 0; t < k; ++t) jdbl_q(acc);
     out[i] = jacq_to_g1j(acc);

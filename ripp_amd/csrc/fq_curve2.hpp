@@ -69,14 +69,41 @@ template <uint64_t L1, int V1> __device__ __forceinline__ Fq2C f2_to_coord(const
 // engine Fp2 (Mont-384) -> carry-free form: times 2^8 is a re-slicing, then one quotient estimate (no Montgomery product)
 __device__ __forceinline__ Fqn fq_from_fp_fast(const Fp& x) { return fq_reduce(fq_unpack_shl8(x.l)); }
 __device__ __forceinline__ Fq2n f2_from(const Fp2& x) { return {fq_from_fp_fast(x.c0), fq_from_fp_fast(x.c1)}; }
-__device__ __forceinline__ Fp2 f2_to(const Fq2C& a) { return {fq_to_fp(fq_reduce(a.c0)), fq_to_fp(fq_reduce(a.c1))}; }
+template <uint64_t L1, int V1> __device__ __forceinline__ Fp2 f2_to(const Fq2T<L1, V1>& a) { return {fq_to_fp(fq_reduce(a.c0)), fq_to_fp(fq_reduce(a.c1))}; }
 
-struct JacQ2 { Fq2C x, y, z; };
+// A Jacobian point of G2 between two group operations.  BLS12-381 (u^2 = -1): a mixed addition leaves (X, Y, Z) < (11, 7, 8) p and these bounds pass every
+// static check of the next operation (an Fp2 square needs 2V (2V + 1) <= 2 500: the widest square is (Z + H)^2 with Z + H < 22p), so its five values that
+// used to be REDUCED (H, r, X3, Y3, Z3: ten quotient estimates + signed carry passes, a fifth of a field product each) are only carry-normalised
+// (fq_curve.hpp JacQ has the G1 side and the measurements).  A doubling still reduces X3 and Y3 (E^2 - 2D < 36p would not fit the next square).
+// BLS12-377 (u^2 = -5: a product's bound carries the factor 5) keeps every coordinate below 4p as before.
+#if defined(RIPP_BLS12_377)
+using Fq2X = Fq2C; using Fq2Y = Fq2C; using Fq2Z = Fq2C;
+#else
+using Fq2X = Fq2T<FQ_LN, 11>; using Fq2Y = Fq2T<FQ_LN, 7>; using Fq2Z = Fq2T<FQ_LN, 8>;
+#endif
+struct JacQ2 { Fq2X x; Fq2Y y; Fq2Z z; };
+// a value into a coordinate slot: widened / carry-normalised when its bound fits the slot's, reduced otherwise
+template <class T, uint64_t LM, int VB> __device__ __forceinline__ T fq_slot_r(const Fq<LM, VB>& a) {
+    if constexpr (VB <= T::VMAXB && LM <= FQ_LN) return fq_widen<FQ_LN, T::VMAXB>(a);
+    else if constexpr (VB <= T::VMAXB) return fq_widen<FQ_LN, T::VMAXB>(fq_norm(a));
+    else return fq_widen<FQ_LN, T::VMAXB>(fq_reduce(a));
+}
+template <class T2, uint64_t L1, int V1> __device__ __forceinline__ T2 f2_slot(const Fq2T<L1, V1>& a) { return {fq_slot_r<decltype(T2::c0)>(a.c0), fq_slot_r<decltype(T2::c1)>(a.c1)}; }
+// the values a mixed addition carries between its products: normalised where the next square's bound allows it (BLS12-381), reduced otherwise
+template <uint64_t L1, int V1> __device__ __forceinline__ auto f2_lazy(const Fq2T<L1, V1>& a) {
+#if defined(RIPP_BLS12_377)
+    return f2_reduce(a);
+#else
+    return f2_norm(a);
+#endif
+}
+template <class TX, class TY, class TZ> __device__ __forceinline__ void j2_set(JacQ2& a, const TX& x, const TY& y, const TZ& z) { a.x = f2_slot<Fq2X>(x); a.y = f2_slot<Fq2Y>(y); a.z = f2_slot<Fq2Z>(z); }
+__device__ __forceinline__ void j2_set_identity(JacQ2& a) { j2_set(a, Fq2n{fq_one(), fq_zero()}, Fq2n{fq_one(), fq_zero()}, Fq2n{fq_zero(), fq_zero()}); }
 // dbl-2009-l / madd-2007-bl in the low-liveness order of kernels.hpp (jdbl_lo / jmadd_lo), every product inlined and PINNED where it is written:
 // with the out-of-line Karatsuba products (f2_mul above) these two kept ~340 dwords per lane in scratch, with inlined products and
 // sched_barriers between them 84 -- the barriers bind only the machine scheduler, the DAG had already interleaved the products.
 __device__ __forceinline__ void jdbl2_q(JacQ2& p) {
-    p.z = f2_to_coord(f2_dbl(f2_muld(p.y, p.z))); f2_pin(p.z);
+    p.z = f2_slot<Fq2Z>(f2_dbl(f2_muld(p.y, p.z))); f2_pin(p.z);
     Fq2n A = f2_sqrd(p.x); f2_pin(A);
     Fq2n B = f2_sqrd(p.y); f2_pin(B);
     Fq2n t = f2_sqrd(f2_norm(f2_add(p.x, B))); f2_pin(t);
@@ -84,18 +111,17 @@ __device__ __forceinline__ void jdbl2_q(JacQ2& p) {
     auto D = f2_norm(f2_dbl(f2_sub(f2_sub(t, A), C))); f2_pin(D);
     auto E = f2_norm(f2_add(f2_dbl(A), A)); f2_pin(E);
     Fq2n X3 = f2_reduce(f2_sub(f2_sub(f2_sqrd(E), D), D)); f2_pin(X3);
-    p.y = f2_to_coord(f2_sub(f2_muld(E, f2_norm(f2_sub(D, X3))), f2_dbl(f2_dbl(f2_dbl(C))))); f2_pin(p.y);
-    p.x = f2_to_coord(X3);
+    p.y = f2_slot<Fq2Y>(f2_sub(f2_muld(E, f2_norm(f2_sub(D, X3))), f2_dbl(f2_dbl(f2_dbl(C))))); f2_pin(p.y);
+    p.x = f2_slot<Fq2X>(X3);
 }
 // loadx / loady fetch the affine addend (Fq2n); park: this lane's LDS column (stride 64 lanes, 7 x 16 B).
 // Returns true when the result is NOT valid (H = 0: T = +-Q).
 template <class LOADX, class LOADY>
 __device__ __forceinline__ bool jmadd2_q(JacQ2& p, LOADX loadx, LOADY loady, uint4* park) {
     Fq2n Z1Z1 = f2_sqrd(p.z); f2_pin(Z1Z1);
-    Fq2n H = f2_reduce(f2_sub(f2_muld(loadx(), Z1Z1), p.x)); f2_pin(H);
+    auto H = f2_lazy(f2_sub(f2_muld(loadx(), Z1Z1), p.x)); f2_pin(H);
     Fq2n t = f2_muld(Z1Z1, p.z); f2_pin(t);
-    Fq2n r = f2_reduce(f2_dbl(f2_sub(f2_muld(loady(), t), p.y))); f2_pin(r);
-    const bool special = f2_is_zero(H);
+    auto r = f2_lazy(f2_dbl(f2_sub(f2_muld(loady(), t), p.y))); f2_pin(r);
     { uint32_t w[28];                                                      // Y1 rests in LDS until the last product
 #pragma unroll
       for (int k = 0; k < 14; ++k) { w[k] = p.y.c0.l[k]; w[14 + k] = p.y.c1.l[k]; }
@@ -103,22 +129,23 @@ __device__ __forceinline__ bool jmadd2_q(JacQ2& p, LOADX loadx, LOADY loady, uin
 #pragma unroll
       for (int k = 0; k < 7; ++k) park[k * 64] = src[k]; }
     Fq2n HH = f2_sqrd(H); f2_pin(HH);
-    p.z = f2_to_coord(f2_sub(f2_sub(f2_sqrd(f2_norm(f2_add(p.z, H))), Z1Z1), HH)); f2_pin(p.z);
+    const bool special = f2_is_zero(HH);                                   // H = 0 iff H^2 = 0: HH is a reduced value, H need not be
+    p.z = f2_slot<Fq2Z>(f2_sub(f2_sub(f2_sqrd(f2_norm(f2_add(p.z, H))), Z1Z1), HH)); f2_pin(p.z);
     const auto I = f2_dbl(f2_dbl(HH));                                     // 4 HH, lazy
     Fq2n J = f2_muld(H, I); f2_pin(J);
     Fq2n V = f2_muld(p.x, I); f2_pin(V);
-    Fq2n X3 = f2_reduce(f2_sub(f2_sub(f2_sub(f2_sqrd(r), J), V), V)); f2_pin(X3);
+    auto X3 = f2_lazy(f2_sub(f2_sub(f2_sub(f2_sqrd(r), J), V), V)); f2_pin(X3);
     Fq2n t2;
     { uint4 q[7];
 #pragma unroll
       for (int k = 0; k < 7; ++k) q[k] = park[k * 64];
       const uint32_t* w = reinterpret_cast<const uint32_t*>(q);
-      Fq2C y1;
+      Fq2Y y1;
 #pragma unroll
       for (int k = 0; k < 14; ++k) { y1.c0.l[k] = w[k]; y1.c1.l[k] = w[14 + k]; }
       t2 = f2_muld(J, y1); f2_pin(t2); }
-    p.y = f2_to_coord(f2_sub(f2_muld(r, f2_norm(f2_sub(V, X3))), f2_dbl(t2))); f2_pin(p.y);
-    p.x = f2_to_coord(X3);
+    p.y = f2_slot<Fq2Y>(f2_sub(f2_muld(r, f2_norm(f2_sub(V, X3))), f2_dbl(t2))); f2_pin(p.y);
+    p.x = f2_slot<Fq2X>(X3);
     return special;
 }
 #endif
@@ -135,7 +162,7 @@ __global__ void __launch_bounds__(64, 2) k_fold_g2_tab_q(const uint4* __restrict
     if (i >= half) return;
 #if defined(__HIP_DEVICE_COMPILE__)
     uint4* park = park_ + threadIdx.x;
-    JacQ2 acc; acc.x = acc.y = f2_coord(Fq2n{fq_one(), fq_zero()}); acc.z = f2_coord(Fq2n{fq_zero(), fq_zero()});
+    JacQ2 acc; j2_set_identity(acc);
     bool inf = true, bad = false;                                        // inf is wave-uniform: the digit strings are shared by the launch
 #pragma unroll 1
     for (int pos = dg.len - 1; pos >= 0; --pos) {
@@ -154,7 +181,7 @@ __global__ void __launch_bounds__(64, 2) k_fold_g2_tab_q(const uint4* __restrict
             if (inf) {                                                    // first addition: acc <- +-Q
                 const Fp2 x0 = ldfp2(0), y0 = ldfp2(6);
                 bad |= x0.is_zero() && y0.is_zero();
-                acc.x = f2_coord(f2_from(x0)); acc.y = f2_coord(f2_from(d < 0 ? neg(y0) : y0)); acc.z = f2_coord(Fq2n{fq_one(), fq_zero()}); inf = false;
+                j2_set(acc, f2_from(x0), f2_from(d < 0 ? neg(y0) : y0), Fq2n{fq_one(), fq_zero()}); inf = false;
             } else {
                 { const Fp2 x0 = ldfp2(0); bad |= x0.is_zero() && ldfp2(6).is_zero(); }      // a table point at infinity
                 bad |= jmadd2_q(acc, loadx, loady, park);
@@ -215,7 +242,7 @@ __global__ void __launch_bounds__(64, 2) k_fold_g2_fused_q(const uint4* __restri
     if (i >= q) return;
 #if defined(__HIP_DEVICE_COMPILE__)
     uint4* park = park_ + threadIdx.x;
-    JacQ2 acc; acc.x = acc.y = f2_coord(Fq2n{fq_one(), fq_zero()}); acc.z = f2_coord(Fq2n{fq_zero(), fq_zero()});
+    JacQ2 acc; j2_set_identity(acc);
     bool inf = true, bad = false;                                        // inf is wave-uniform: the digit strings are shared by the launch
 #pragma unroll 1
     for (int pos = dg.len - 1; pos >= 0; --pos) {
@@ -235,7 +262,7 @@ __global__ void __launch_bounds__(64, 2) k_fold_g2_fused_q(const uint4* __restri
             if (inf) {                                                    // first addition: acc <- +-Q
                 const Fp2 x0 = ldfp2(0), y0 = ldfp2(6);
                 bad |= x0.is_zero() && y0.is_zero();
-                acc.x = f2_coord(f2_from(x0)); acc.y = f2_coord(f2_from(d < 0 ? neg(y0) : y0)); acc.z = f2_coord(Fq2n{fq_one(), fq_zero()}); inf = false;
+                j2_set(acc, f2_from(x0), f2_from(d < 0 ? neg(y0) : y0), Fq2n{fq_one(), fq_zero()}); inf = false;
             } else {
                 { const Fp2 x0 = ldfp2(0); bad |= x0.is_zero() && ldfp2(6).is_zero(); }      // a table point at infinity
                 bad |= jmadd2_q(acc, loadx, loady, park);
@@ -297,7 +324,7 @@ __global__ void __launch_bounds__(64, 2) k_odd_multiples_q(const G2A* __restrict
     uint4* tmp = reinterpret_cast<uint4*>(out + (size_t)(M - 2) * n + i);       // 14 of the slot's 18 chunks: X2, Y2
     JacQ2 t;
     {
-        JacQ2 d; d.x = f2_to_coord(f2_from(opaque(bp)->x)); d.y = f2_to_coord(f2_from(opaque(bp)->y)); d.z = f2_to_coord(Fq2n{fq_one(), fq_zero()});
+        JacQ2 d; j2_set(d, f2_from(opaque(bp)->x), f2_from(opaque(bp)->y), Fq2n{fq_one(), fq_zero()});
         f2_pin(d.z);
         jdbl2_q(d);
         Fq2n Z2 = f2_reduce(d.z); f2_pin(Z2);
@@ -305,16 +332,16 @@ __global__ void __launch_bounds__(64, 2) k_odd_multiples_q(const G2A* __restrict
         st7(zpark, 64, Z2);
         st7(tmp, 1, f2_reduce(d.x)); st7(tmp + 7, 1, f2_reduce(d.y));
         Fq2n zz = f2_sqrd(Z2); f2_pin(zz);
-        { Fq2n px = f2_muld(f2_from(opaque(bp)->x), zz); f2_pin(px); t.x = f2_to_coord(px); }
+        { Fq2n px = f2_muld(f2_from(opaque(bp)->x), zz); f2_pin(px); t.x = f2_slot<Fq2X>(px); }
         Fq2n zzz = f2_muld(zz, Z2); f2_pin(zzz);
-        { Fq2n py = f2_muld(f2_from(opaque(bp)->y), zzz); f2_pin(py); t.y = f2_to_coord(py); }
-        t.z = f2_to_coord(Fq2n{fq_one(), fq_zero()}); f2_pin(t.z);
+        { Fq2n py = f2_muld(f2_from(opaque(bp)->y), zzz); f2_pin(py); t.y = f2_slot<Fq2Y>(py); }
+        t.z = f2_slot<Fq2Z>(Fq2n{fq_one(), fq_zero()}); f2_pin(t.z);
     }
 #pragma unroll 1
     for (int m = 0; m < M - 1; ++m) {
         bad |= jmadd2_q(t, [&]() { return ld7(opaque(tmp), 1); }, [&]() { return ld7(opaque(tmp) + 7, 1); }, park);
         Fq2n zo = f2_muld(t.z, ld7(zpark, 64)); f2_pin(zo);
-        out[(size_t)m * n + i] = G2J{f2_to(t.x), f2_to(t.y), f2_to(f2_to_coord(zo))};
+        out[(size_t)m * n + i] = G2J{f2_to(t.x), f2_to(t.y), f2_to(zo)};
     }
 #if !defined(RIPP_INLINE_FALLBACK)
     flag[i] = bad;
@@ -370,7 +397,7 @@ __global__ void __launch_bounds__(64, 2) k_fold_g2_gls_split_q(const G2A* __rest
         bad = is_inf(q);
         st7(qpark, f2_from(q.x)); st7(qpark + 7 * 64, f2_from(q.y));
     }
-    JacQ2 acc; acc.x = acc.y = f2_to_coord(Fq2n{fq_one(), fq_zero()}); acc.z = f2_to_coord(Fq2n{fq_zero(), fq_zero()});
+    JacQ2 acc; j2_set_identity(acc);
     bool inf = true;                                                    // wave-uniform: one digit string per wave
 #pragma unroll 1
     for (int pos = dg.len - 1; pos >= 0; --pos) {
@@ -379,7 +406,7 @@ __global__ void __launch_bounds__(64, 2) k_fold_g2_gls_split_q(const G2A* __rest
         if (d == 0) continue;
         auto loadx = [&]() { return ld7(qpark); };
         auto loady = [&]() { const Fq2n y = ld7(qpark + 7 * 64); if (d > 0) return y; return Fq2n{fq_reduce(fq_neg(y.c0)), fq_reduce(fq_neg(y.c1))}; };
-        if (inf) { acc.x = f2_to_coord(loadx()); acc.y = f2_to_coord(loady()); acc.z = f2_to_coord(Fq2n{fq_one(), fq_zero()}); f2_pin(acc.z); inf = false; }
+        if (inf) { j2_set(acc, loadx(), loady(), Fq2n{fq_one(), fq_zero()}); f2_pin(acc.z); inf = false; }
         else bad |= jmadd2_q(acc, loadx, loady, park);
     }
 #if !defined(RIPP_INLINE_FALLBACK)
@@ -404,7 +431,7 @@ __global__ void __launch_bounds__(64, 2) k_pow2_mul_g2_q(const G2A* __restrict__
     const G2A* bp = in + i;
     bool inf; { const G2A b = *bp; inf = is_inf(b); }
     if (inf) { out[i] = jac_inf<Fp2>(); return; }
-    JacQ2 d; d.x = f2_to_coord(f2_from(opaque(bp)->x)); d.y = f2_to_coord(f2_from(opaque(bp)->y)); d.z = f2_to_coord(Fq2n{fq_one(), fq_zero()});
+    JacQ2 d; j2_set(d, f2_from(opaque(bp)->x), f2_from(opaque(bp)->y), Fq2n{fq_one(), fq_zero()});
     f2_pin(d.z);
 #pragma unroll 1
     for (int t = 0; t < k; ++t) jdbl2_q(d);

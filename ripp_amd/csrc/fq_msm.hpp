@@ -75,26 +75,26 @@ __global__ void __launch_bounds__(64, 2) k_msm_slot_sum_q(const QAff<F>* __restr
 #if defined(__HIP_DEVICE_COMPILE__)
     bool inf = true, bad = false;
     if constexpr (std::is_same<F, Fp>::value) {
-        JacQ a; a.x = a.y = fq_widen<FQ_LN, 4>(fq_one()); a.z = fq_widen<FQ_LN, 4>(fq_zero());
+        JacQ a; jq_set_identity(a);
 #pragma unroll 1
         for (uint32_t k = begin; k < end; ++k) {
             const QAff<Fp> q = ext[sorted[(size_t)w * p.n + k]];
             if (qfp_zero(q.x) && qfp_zero(q.y)) continue;                                 // the identity among the bases
             const Fqn x = qfp_get(q.x), y = qfp_get(q.y);
-            if (inf) { a.x = fq_widen<FQ_LN, 4>(x); a.y = fq_widen<FQ_LN, 4>(y); a.z = fq_widen<FQ_LN, 4>(fq_one()); inf = false; }
+            if (inf) { jq_set(a, x, y, fq_one()); inf = false; }
             else bad |= jmadd_q(a, x, y);
         }
         if (!inf && !bad) acc = jacq_to_g1j(a);
     } else {
         uint4* park = park_ + threadIdx.x;
-        JacQ2 a; a.x = a.y = f2_to_coord(Fq2n{fq_one(), fq_zero()}); a.z = f2_to_coord(Fq2n{fq_zero(), fq_zero()});
+        JacQ2 a; j2_set_identity(a);
 #pragma unroll 1
         for (uint32_t k = begin; k < end; ++k) {
             const QAff<Fp2>* qp = ext + sorted[(size_t)w * p.n + k];
             { const QAff<Fp2> q = *qp; if (qfp_zero(q.x0) && qfp_zero(q.x1) && qfp_zero(q.y0) && qfp_zero(q.y1)) continue; }
             auto lx = [&]() { const QAff<Fp2>* o = opaque(qp); return Fq2n{qfp_get(o->x0), qfp_get(o->x1)}; };
             auto ly = [&]() { const QAff<Fp2>* o = opaque(qp); return Fq2n{qfp_get(o->y0), qfp_get(o->y1)}; };
-            if (inf) { a.x = f2_to_coord(lx()); a.y = f2_to_coord(ly()); a.z = f2_to_coord(Fq2n{fq_one(), fq_zero()}); inf = false; }
+            if (inf) { j2_set(a, lx(), ly(), Fq2n{fq_one(), fq_zero()}); inf = false; }
             else bad |= jmadd2_q(a, lx, ly, park);
         }
         if (!inf && !bad) acc = G2J{f2_to(a.x), f2_to(a.y), f2_to(a.z)};

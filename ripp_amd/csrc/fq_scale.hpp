@@ -17,8 +17,11 @@ namespace ripp {
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define SBS() __builtin_amdgcn_sched_barrier(0)
-// add-2007-bl (both operands Jacobian, neither the identity) in a low-liveness order.  Returns true when H = 0 (p = +-q): result not valid.
-__device__ __forceinline__ bool jadd_q(JacQ& p, const JacQ& q) {
+// a table entry as the main loop reads it: reduced coordinates (the table stores 12 packed words per coordinate), Y possibly negated (lazily)
+struct JacT { Fqn x; Fq<FQ_LN, 4> y; Fqn z; };
+// add-2007-bl (both operands Jacobian, neither the identity) in a low-liveness order.  Returns true when H = 0 (p = +-q): result not valid (read off (2H)^2).
+// Bounds out: (11, 7, 2) p; nothing is reduced (fq_curve.hpp JacQ).
+__device__ __forceinline__ bool jadd_q(JacQ& p, const JacT& q) {
     const Fqn Z1Z1 = fq_sqr(p.z); SBS();
     const Fqn U2 = fq_mul(q.x, Z1Z1); SBS();
     const Fqn S2 = fq_mul(fq_mul(q.y, p.z), Z1Z1); SBS();
@@ -26,38 +29,37 @@ __device__ __forceinline__ bool jadd_q(JacQ& p, const JacQ& q) {
     const Fqn U1 = fq_mul(p.x, Z2Z2); SBS();
     const Fqn S1 = fq_mul(fq_mul(p.y, q.z), Z2Z2); SBS();
     const auto Zs = fq_norm(fq_sub(fq_sub(fq_sqr(fq_norm(fq_add(p.z, q.z))), Z1Z1), Z2Z2)); SBS();      // 2 Z1 Z2
-    const Fqn H = fq_reduce(fq_sub(U2, U1));
-    const bool special = fq_is_zero(H);
-    p.z = fq_coord(fq_mul(Zs, H)); SBS();
+    const auto H = fq_norm(fq_sub(U2, U1));                                                               // < 5p
+    p.z = fq_slot<JZ>(fq_mul(Zs, H)); SBS();
     const Fqn I = fq_sqr(fq_dbl(H)); SBS();
+    const bool special = fq_is_zero(I);
     const Fqn J = fq_mul(H, I); SBS();
     const auto rr = fq_norm(fq_dbl(fq_sub(S2, S1)));
     const Fqn V = fq_mul(U1, I); SBS();
-    const Fqn X3 = fq_reduce(fq_sub(fq_sub(fq_sub(fq_sqr(rr), J), V), V)); SBS();
-    p.y = fq_coord(fq_sub(fq_mul(rr, fq_norm(fq_sub(V, X3))), fq_dbl(fq_mul(S1, J))));
-    p.x = fq_coord(X3);
+    const auto X3 = fq_norm(fq_sub(fq_sub(fq_sub(fq_sqr(rr), J), V), V)); SBS();
+    p.y = fq_slot<JY>(fq_sub(fq_mul(rr, fq_norm(fq_sub(V, X3))), fq_dbl(fq_mul(S1, J))));
+    p.x = fq_slot<JX>(X3);
     return special;
 }
 #undef SBS
-// a coordinate (< 4p < 2^383, normalised limbs) as 12 words
-__device__ __forceinline__ void fq_pack_c(const FqC& a, uint32_t (&x)[12]) { Fqn t; for (int k = 0; k < fq28::NL; ++k) t.l[k] = a.l[k]; fq_pack(t, x); }
-// one Jacobian table entry: 3 coordinates x 12 packed words = 9 chunks (the layout of scale.hpp's table)
+// one Jacobian table entry: 3 coordinates x 12 packed words = 9 chunks (the layout of scale.hpp's table); the coordinates are reduced here (< 2p < 2^384)
 __device__ __forceinline__ void st_tab_q(uint4* tab, int e, uint32_t n, uint32_t i, const JacQ& t) {
     uint32_t w[36];
-    { uint32_t x[12]; fq_pack_c(t.x, x); for (int k = 0; k < 12; ++k) w[k] = x[k]; }
-    { uint32_t x[12]; fq_pack_c(t.y, x); for (int k = 0; k < 12; ++k) w[12 + k] = x[k]; }
-    { uint32_t x[12]; fq_pack_c(t.z, x); for (int k = 0; k < 12; ++k) w[24 + k] = x[k]; }
+    { uint32_t x[12]; fq_pack(fq_reduce(t.x), x); for (int k = 0; k < 12; ++k) w[k] = x[k]; }
+    { uint32_t x[12]; fq_pack(fq_reduce(t.y), x); for (int k = 0; k < 12; ++k) w[12 + k] = x[k]; }
+    { uint32_t x[12]; fq_pack(fq_reduce(t.z), x); for (int k = 0; k < 12; ++k) w[24 + k] = x[k]; }
 #pragma unroll
     for (int q = 0; q < G1J_CHUNKS; ++q) tab[((size_t)i * SCALE_TAB + e) * G1J_CHUNKS + q] = uint4{w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
 }
-__device__ __forceinline__ JacQ ld_tab_q(const uint4* tab, int e, uint32_t n, uint32_t i) {
+struct JacR { Fqn x, y, z; };
+__device__ __forceinline__ JacR ld_tab_q(const uint4* tab, int e, uint32_t n, uint32_t i) {
     uint32_t w[36];
 #pragma unroll
     for (int q = 0; q < G1J_CHUNKS; ++q) { const uint4 v = tab[((size_t)i * SCALE_TAB + e) * G1J_CHUNKS + q]; w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w; }
     uint32_t a[12], b[12], c[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) { a[k] = w[k]; b[k] = w[12 + k]; c[k] = w[24 + k]; }
-    JacQ r; r.x = fq_widen<FQ_LN, 4>(fq_unpack(a)); r.y = fq_widen<FQ_LN, 4>(fq_unpack(b)); r.z = fq_widen<FQ_LN, 4>(fq_unpack(c));
+    JacR r; r.x = fq_unpack(a); r.y = fq_unpack(b); r.z = fq_unpack(c);
     return r;
 }
 // the complete computation of one lane (exceptional additions): plain MSB-first double-and-add with curve.hpp's formulas
@@ -90,7 +92,7 @@ __global__ void __launch_bounds__(256, 2) k_scale_g1_glv_q(const G1A* __restrict
     bool bad = false;
     {   // multiples 1..8 of the base, Jacobian: 1 doubling + 6 mixed additions
         const AffQ pq = affq_from(p);
-        JacQ t; t.x = fq_widen<FQ_LN, 4>(pq.x); t.y = fq_widen<FQ_LN, 4>(pq.y); t.z = fq_widen<FQ_LN, 4>(fq_one());
+        JacQ t; jq_set(t, pq.x, pq.y, fq_one());
         st_tab_q(tab, 0, n, i, t);
         jdbl_q(t);
         st_tab_q(tab, 1, n, i, t);
@@ -98,7 +100,7 @@ __global__ void __launch_bounds__(256, 2) k_scale_g1_glv_q(const G1A* __restrict
         for (int e = 2; e < SCALE_TAB; ++e) { bad |= jmadd_q(t, pq.x, pq.y); st_tab_q(tab, e, n, i, t); }
     }
     const Fqn beta = fq_from_fp(fp_const(RIPP_GLV_BETA));
-    JacQ acc; acc.x = acc.y = fq_widen<FQ_LN, 4>(fq_one()); acc.z = fq_widen<FQ_LN, 4>(fq_zero());
+    JacQ acc; jq_set_identity(acc);
     bool inf = true;
 #pragma unroll 1
     for (int j = 32; j >= 0; --j) {
@@ -107,10 +109,11 @@ __global__ void __launch_bounds__(256, 2) k_scale_g1_glv_q(const G1A* __restrict
         for (int h = 0; h < 2; ++h) {
             const int d = scale_digit(h ? d2 : d1, j);
             if (d == 0) continue;
-            JacQ t = ld_tab_q(tab, (d < 0 ? -d : d) - 1, n, i);
-            if (d < 0) t.y = fq_coord(fq_neg(t.y));
-            if (h) t.x = fq_widen<FQ_LN, 4>(fq_mul(t.x, beta));                    // phi in Jacobian coordinates: (beta X, Y, Z)
-            if (inf) { acc = t; inf = false; } else bad |= jadd_q(acc, t);
+            const JacR e = ld_tab_q(tab, (d < 0 ? -d : d) - 1, n, i);
+            JacT t; t.x = e.x; t.y = fq_widen<FQ_LN, 4>(e.y); t.z = e.z;
+            if (d < 0) t.y = fq_slot<Fq<FQ_LN, 4>>(fq_neg(e.y));
+            if (h) t.x = fq_mul(e.x, beta);                                        // phi in Jacobian coordinates: (beta X, Y, Z)
+            if (inf) { jq_set(acc, t.x, t.y, t.z); inf = false; } else bad |= jadd_q(acc, t);
         }
     }
     flag[i] = bad;
