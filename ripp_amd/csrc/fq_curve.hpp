@@ -56,7 +56,21 @@ template <class T, uint64_t LM, int VB> __device__ __forceinline__ T fq_slot(con
 }
 template <class TX, class TY, class TZ> __device__ __forceinline__ void jq_set(JacQ& a, const TX& x, const TY& y, const TZ& z) { a.x = fq_slot<JX>(x); a.y = fq_slot<JY>(y); a.z = fq_slot<JZ>(z); }
 __device__ __forceinline__ void jq_set_identity(JacQ& a) { jq_set(a, fq_one(), fq_one(), fq_zero()); }
-__device__ __forceinline__ AffQ affq_from(const G1A& p) { return {fq_from_fp(p.x), fq_from_fp(p.y)}; }
+// engine value (Mont-384) -> carry-free form: times 2^8 is a re-slicing of the words, then one quotient estimate -- a fifth of the Montgomery product by 2^400 that
+// fq_from_fp spends (a table fold converts two coordinates per addition: 2 of its 12 products)
+__device__ __forceinline__ Fqn fq_from_fp_fast(const Fp& x) { return fq_reduce(fq_unpack_shl8(x.l)); }
+__device__ __forceinline__ AffQ affq_from(const G1A& p) { return {fq_from_fp_fast(p.x), fq_from_fp_fast(p.y)}; }
+// A TABLE operand of a mixed addition is not even reduced: the re-sliced words are the value 2^8 x < 256p with normalised limbs, and both products it enters
+// (x2 Z1Z1, y2 Z1) keep V1 V2 <= 2 500 (fq28.hpp VMAX = R' / p), so the Montgomery product absorbs the factor; -y2 is the limb-wise K - y2 (K = 257p).
+using FqTab = Fq<FQ_LN, 256>;
+using FqTabY = Fq<fq28::sub_lm(1, FQ_LN), 258>;                          // y2 or -y2
+__device__ __forceinline__ FqTab fq_tab(const Fp& x) { return fq_unpack_shl8(x.l); }
+__device__ __forceinline__ FqTabY fq_tab_y(const Fp& y, bool negate) {
+    const FqTab v = fq_tab(y);
+    FqTabY r;
+    if (negate) r = fq_neg(v); else r = fq_widen<FqTabY::LMAX, 258>(v);
+    return r;
+}
 __device__ __forceinline__ G1J jacq_to_g1j(const JacQ& p) { return {fq_to_fp(fq_reduce(p.x)), fq_to_fp(fq_reduce(p.y)), fq_to_fp(fq_reduce(p.z))}; }
 
 // dbl-2009-l (a = 0): 2M + 5S.  Z = 0 maps to Z3 = 0.  Every product is PINNED where it is written (fq28.hpp fq_pin): the multiply-adds of a product are tied
@@ -78,7 +92,8 @@ __device__ __forceinline__ void jdbl_q(JacQ& p) {
 // madd-2007-bl, q affine and NOT the identity, p NOT the identity.  Returns true when the result is not valid (H = 0: p = +-q) -- read off H^2, which the
 // formula needs anyway and which is a reduced value (H itself is only normalised; H = 0 mod p iff H^2 = 0 mod p).
 // Bounds out: X3 = r^2 - J - 2V < 11p, Y3 = r (V - X3) - 2 Y1 J < 7p, Z3 = (Z1 + H)^2 - Z1Z1 - HH < 8p.
-__device__ __forceinline__ bool jmadd_q(JacQ& p, const Fqn& x2, const Fqn& y2) {
+template <class TX2, class TY2>
+__device__ __forceinline__ bool jmadd_q(JacQ& p, const TX2& x2, const TY2& y2) {
     Fqn Z1Z1 = fq_sqr(p.z); fq_pin(Z1Z1);
     auto H = fq_norm(fq_sub(fq_mul(x2, Z1Z1), p.x)); fq_pin(H);                     // < 39p
     Fqn yz = fq_mul(y2, p.z); fq_pin(yz);
@@ -193,10 +208,8 @@ __global__ void __launch_bounds__(256, 2) k_fold_g1_tab_q(const G1A* __restrict_
             if (d == 0) continue;
             const G1A qa = tab[(size_t)(M * t + ((d < 0 ? -d : d) >> 1)) * tstride + i];
             bad |= is_inf(qa);
-            AffQ q = affq_from(qa);
-            if (d < 0) q.y = fq_reduce(fq_neg(q.y));
-            if (inf) { jq_set(acc, q.x, q.y, fq_one()); inf = false; }
-            else bad |= jmadd_q(acc, q.x, q.y);
+            if (inf) { AffQ q = affq_from(qa); if (d < 0) q.y = fq_reduce(fq_neg(q.y)); jq_set(acc, q.x, q.y, fq_one()); inf = false; }
+            else bad |= jmadd_q(acc, fq_tab(qa.x), fq_tab_y(qa.y, d < 0));
         }
     }
     const G1A l = lo[i];
@@ -258,11 +271,16 @@ __global__ void __launch_bounds__(256, 2) k_fold_g1_fused_q(const G1A* __restric
             el += u == 0 ? q : u == 3 ? 0u : 2 * q;
             const G1A qa = tab[(size_t)(M * (t & 3) + ((d < 0 ? -d : d) >> 1)) * tstride + el];
             bad |= is_inf(qa);
-            AffQ p = affq_from(qa);
-            if (u == 2) p.x = fq_mul(p.x, fq_const<FQ_LN, 1>(BETA));
-            if (d < 0) p.y = fq_reduce(fq_neg(p.y));
-            if (inf) { jq_set(acc, p.x, p.y, fq_one()); inf = false; }
-            else bad |= jmadd_q(acc, p.x, p.y);
+            if (inf) {
+                AffQ p = affq_from(qa);
+                if (u == 2) p.x = fq_mul(p.x, fq_const<FQ_LN, 1>(BETA));
+                if (d < 0) p.y = fq_reduce(fq_neg(p.y));
+                jq_set(acc, p.x, p.y, fq_one()); inf = false;
+            } else {
+                FqTab px = fq_tab(qa.x);
+                if (u == 2) px = fq_widen<FQ_LN, 256>(fq_mul(px, fq_const<FQ_LN, 1>(BETA)));
+                bad |= jmadd_q(acc, px, fq_tab_y(qa.y, d < 0));
+            }
         }
     }
     const G1A l = lo[i];

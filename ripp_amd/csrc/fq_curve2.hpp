@@ -66,8 +66,7 @@ template <uint64_t L1, int V1, uint64_t L2, int V2>
 __device__ __forceinline__ Fq2n f2_mul_fq(const Fq2T<L1, V1>& a, const Fq<L2, V2>& s) { Fq2n r; r.c0 = fq_mul(a.c0, s); fq_pin(r.c0); r.c1 = fq_mul(a.c1, s); return r; }
 template <uint64_t L1, int V1> __device__ __forceinline__ Fq2C f2_to_coord(const Fq2T<L1, V1>& a) { return {fq_coord(a.c0), fq_coord(a.c1)}; }
 
-// engine Fp2 (Mont-384) -> carry-free form: times 2^8 is a re-slicing, then one quotient estimate (no Montgomery product)
-__device__ __forceinline__ Fqn fq_from_fp_fast(const Fp& x) { return fq_reduce(fq_unpack_shl8(x.l)); }
+// engine Fp2 (Mont-384) -> carry-free form: times 2^8 is a re-slicing, then one quotient estimate (fq_curve.hpp fq_from_fp_fast: no Montgomery product)
 __device__ __forceinline__ Fq2n f2_from(const Fp2& x) { return {fq_from_fp_fast(x.c0), fq_from_fp_fast(x.c1)}; }
 template <uint64_t L1, int V1> __device__ __forceinline__ Fp2 f2_to(const Fq2T<L1, V1>& a) { return {fq_to_fp(fq_reduce(a.c0)), fq_to_fp(fq_reduce(a.c1))}; }
 
@@ -82,6 +81,9 @@ using Fq2X = Fq2C; using Fq2Y = Fq2C; using Fq2Z = Fq2C;
 using Fq2X = Fq2T<FQ_LN, 11>; using Fq2Y = Fq2T<FQ_LN, 7>; using Fq2Z = Fq2T<FQ_LN, 8>;
 #endif
 struct JacQ2 { Fq2X x; Fq2Y y; Fq2Z z; };
+// table operands of a mixed addition (BLS12-381): 2^8 x < 256p re-sliced, -y2 limb-wise (fq_curve.hpp fq_tab / fq_tab_y)
+__device__ __forceinline__ Fq2T<FQ_LN, 256> f2_tab(const Fp2& v) { return {fq_tab(v.c0), fq_tab(v.c1)}; }
+__device__ __forceinline__ Fq2T<FqTabY::LMAX, 258> f2_tab_y(const Fp2& v, bool negate) { return {fq_tab_y(v.c0, negate), fq_tab_y(v.c1, negate)}; }
 // a value into a coordinate slot: widened / carry-normalised when its bound fits the slot's, reduced otherwise
 template <class T, uint64_t LM, int VB> __device__ __forceinline__ T fq_slot_r(const Fq<LM, VB>& a) {
     if constexpr (VB <= T::VMAXB && LM <= FQ_LN) return fq_widen<FQ_LN, T::VMAXB>(a);
@@ -176,8 +178,13 @@ __global__ void __launch_bounds__(64, 2) k_fold_g2_tab_q(const uint4* __restrict
             auto ldfp2 = [&](int q0) { Fp2 v; uint4* dd = reinterpret_cast<uint4*>(&v); const uint4* b2 = opaque(base);      // re-loaded where it is used (merged with the identity check below, x and y stayed alive from the top of the addition)
 #pragma unroll
                 for (int q = 0; q < 6; ++q) dd[q] = b2[(size_t)(q0 + q) * stride]; return v; };
+#if defined(RIPP_BLS12_377)
             auto loadx = [&]() { return f2_from(ldfp2(0)); };
             auto loady = [&]() { const Fp2 y = ldfp2(6); return f2_from(d < 0 ? neg(y) : y); };
+#else
+            auto loadx = [&]() { return f2_tab(ldfp2(0)); };                   // table operands are not reduced (fq_curve.hpp fq_tab): the products absorb the factor 2^8
+            auto loady = [&]() { return f2_tab_y(ldfp2(6), d < 0); };
+#endif
             if (inf) {                                                    // first addition: acc <- +-Q
                 const Fp2 x0 = ldfp2(0), y0 = ldfp2(6);
                 bad |= x0.is_zero() && y0.is_zero();
@@ -257,8 +264,13 @@ __global__ void __launch_bounds__(64, 2) k_fold_g2_fused_q(const uint4* __restri
             auto ldfp2 = [&](int q0) { Fp2 v; uint4* dd = reinterpret_cast<uint4*>(&v); const uint4* b2 = opaque(base);
 #pragma unroll
                 for (int c = 0; c < 6; ++c) dd[c] = b2[(size_t)(q0 + c) * stride]; return v; };
+#if defined(RIPP_BLS12_377)
             auto loadx = [&]() { return f2_from(ldfp2(0)); };
             auto loady = [&]() { const Fp2 y = ldfp2(6); return f2_from(d < 0 ? neg(y) : y); };
+#else
+            auto loadx = [&]() { return f2_tab(ldfp2(0)); };                   // table operands are not reduced (fq_curve.hpp fq_tab): the products absorb the factor 2^8
+            auto loady = [&]() { return f2_tab_y(ldfp2(6), d < 0); };
+#endif
             if (inf) {                                                    // first addition: acc <- +-Q
                 const Fp2 x0 = ldfp2(0), y0 = ldfp2(6);
                 bad |= x0.is_zero() && y0.is_zero();
