@@ -47,6 +47,18 @@ template <uint64_t LM, int VB> __device__ __forceinline__ FqC fq_coord(const Fq<
 // (tools/ubench/fqgroup.hip), and the group law used four per addition and two per doubling.  The compiler checks every bound (fq28.hpp).
 using JX = Fq<FQ_LN, 36>; using JY = Fq<FQ_LN, 19>; using JZ = Fq<FQ_LN, 8>;
 struct JacQ { JX x; JY y; JZ z; };
+// a b - c d with ONE Montgomery reduction: a lazily reduced sum of two products whose second term enters as (K - c) d (K a multiple of p above c, limb-wise).
+// Y3 of the addition formulas is such a difference: one reduction (196 multiply-adds + its glue) less per addition, and the result is a reduced value.
+template <class TA, class TB, class TC, class TD>
+__device__ __forceinline__ Fqn fq_mul_sub(const TA& a, const TB& b, const TC& c, const TD& d) {
+    const auto nc = fq_neg(c);
+    using TN = decltype(nc);
+    constexpr uint64_t L1 = TA::LMAX > TN::LMAX ? TA::LMAX : TN::LMAX, L2 = TB::LMAX > TD::LMAX ? TB::LMAX : TD::LMAX;
+    constexpr int V1 = TA::VMAXB > TN::VMAXB ? TA::VMAXB : TN::VMAXB, V2 = TB::VMAXB > TD::VMAXB ? TB::VMAXB : TD::VMAXB;
+    const Fq<L1, V1> aa[2] = {fq_widen<L1, V1>(a), fq_widen<L1, V1>(nc)};
+    const Fq<L2, V2> bb[2] = {fq_widen<L2, V2>(b), fq_widen<L2, V2>(d)};
+    return fq_dot<2>(aa, bb);
+}
 struct AffQ { Fqn x, y; };
 // a value into a coordinate slot: carry-normalised where it is lazy; its bound must fit the slot's (a compile error otherwise, never a silent reduction)
 template <class T, uint64_t LM, int VB> __device__ __forceinline__ T fq_slot(const Fq<LM, VB>& a) {
@@ -91,7 +103,7 @@ __device__ __forceinline__ void jdbl_q(JacQ& p) {
 }
 // madd-2007-bl, q affine and NOT the identity, p NOT the identity.  Returns true when the result is not valid (H = 0: p = +-q) -- read off H^2, which the
 // formula needs anyway and which is a reduced value (H itself is only normalised; H = 0 mod p iff H^2 = 0 mod p).
-// Bounds out: X3 = r^2 - J - 2V < 11p, Y3 = r (V - X3) - 2 Y1 J < 7p, Z3 = (Z1 + H)^2 - Z1Z1 - HH < 8p.
+// Bounds out: X3 = r^2 - J - 2V < 11p, Y3 = r (V - X3) - 2 Y1 J < 2p (a two-product sum with its own reduction), Z3 = (Z1 + H)^2 - Z1Z1 - HH < 8p.
 template <class TX2, class TY2>
 __device__ __forceinline__ bool jmadd_q(JacQ& p, const TX2& x2, const TY2& y2) {
     Fqn Z1Z1 = fq_sqr(p.z); fq_pin(Z1Z1);
@@ -106,8 +118,7 @@ __device__ __forceinline__ bool jmadd_q(JacQ& p, const TX2& x2, const TY2& y2) {
     auto X3 = fq_norm(fq_sub(fq_sub(fq_sub(fq_sqr(rr), J), V), V)); fq_pin(X3);
     Fqn zh = fq_sqr(fq_add(p.z, H)); fq_pin(zh);
     p.z = fq_slot<JZ>(fq_sub(fq_sub(zh, Z1Z1), HH)); fq_pin(p.z);
-    Fqn yj = fq_mul(p.y, J); fq_pin(yj);
-    p.y = fq_slot<JY>(fq_sub(fq_mul(rr, fq_sub(V, X3)), fq_dbl(yj))); fq_pin(p.y);
+    p.y = fq_slot<JY>(fq_mul_sub(rr, fq_norm(fq_sub(V, X3)), fq_dbl(p.y), J)); fq_pin(p.y);       // r (V - X3) - 2 Y1 J, one reduction
     p.x = fq_slot<JX>(X3);
     return special;
 }

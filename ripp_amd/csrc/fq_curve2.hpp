@@ -99,6 +99,26 @@ template <uint64_t L1, int V1> __device__ __forceinline__ auto f2_lazy(const Fq2
     return f2_norm(a);
 #endif
 }
+#if !defined(RIPP_BLS12_377)
+// a b - c d over Fp2 (u^2 = -1) with ONE reduction per part: two lazily reduced sums of four products (fq_curve.hpp fq_mul_sub has the Fp form)
+template <class TA, class TB, class TC, class TD>
+__device__ __forceinline__ Fq2n f2_muld_sub(const TA& a, const TB& b, const TC& c, const TD& d) {
+    const auto na1 = fq_neg(a.c1); const auto nc0 = fq_neg(c.c0); const auto nc1 = fq_neg(c.c1);
+    using A0 = decltype(a.c0); using NA = decltype(na1); using NC = decltype(nc0); using C1 = decltype(c.c1);
+    using B0 = decltype(b.c0); using D0 = decltype(d.c0);
+    constexpr uint64_t m1 = A0::LMAX > NA::LMAX ? A0::LMAX : NA::LMAX, m2 = NC::LMAX > C1::LMAX ? NC::LMAX : C1::LMAX, L1 = m1 > m2 ? m1 : m2;
+    constexpr int v1 = A0::VMAXB > NA::VMAXB ? A0::VMAXB : NA::VMAXB, v2 = NC::VMAXB > C1::VMAXB ? NC::VMAXB : C1::VMAXB, V1 = v1 > v2 ? v1 : v2;
+    constexpr uint64_t L2 = B0::LMAX > D0::LMAX ? B0::LMAX : D0::LMAX;
+    constexpr int V2 = B0::VMAXB > D0::VMAXB ? B0::VMAXB : D0::VMAXB;
+    using T1 = Fq<L1, V1>; using T2 = Fq<L2, V2>;
+    auto w1 = [](const auto& x) { return fq_widen<L1, V1>(x); };
+    auto w2 = [](const auto& x) { return fq_widen<L2, V2>(x); };
+    Fq2n r;
+    { const T1 aa[4] = {w1(a.c0), w1(na1), w1(nc0), w1(c.c1)}; const T2 bb[4] = {w2(b.c0), w2(b.c1), w2(d.c0), w2(d.c1)}; r.c0 = fq_dot<4>(aa, bb); } fq_pin(r.c0);
+    { const T1 aa[4] = {w1(a.c0), w1(a.c1), w1(nc0), w1(nc1)}; const T2 bb[4] = {w2(b.c1), w2(b.c0), w2(d.c1), w2(d.c0)}; r.c1 = fq_dot<4>(aa, bb); }
+    return r;
+}
+#endif
 template <class TX, class TY, class TZ> __device__ __forceinline__ void j2_set(JacQ2& a, const TX& x, const TY& y, const TZ& z) { a.x = f2_slot<Fq2X>(x); a.y = f2_slot<Fq2Y>(y); a.z = f2_slot<Fq2Z>(z); }
 __device__ __forceinline__ void j2_set_identity(JacQ2& a) { j2_set(a, Fq2n{fq_one(), fq_zero()}, Fq2n{fq_one(), fq_zero()}, Fq2n{fq_zero(), fq_zero()}); }
 // dbl-2009-l / madd-2007-bl in the low-liveness order of kernels.hpp (jdbl_lo / jmadd_lo), every product inlined and PINNED where it is written:
@@ -137,7 +157,6 @@ __device__ __forceinline__ bool jmadd2_q(JacQ2& p, LOADX loadx, LOADY loady, uin
     Fq2n J = f2_muld(H, I); f2_pin(J);
     Fq2n V = f2_muld(p.x, I); f2_pin(V);
     auto X3 = f2_lazy(f2_sub(f2_sub(f2_sub(f2_sqrd(r), J), V), V)); f2_pin(X3);
-    Fq2n t2;
     { uint4 q[7];
 #pragma unroll
       for (int k = 0; k < 7; ++k) q[k] = park[k * 64];
@@ -145,8 +164,13 @@ __device__ __forceinline__ bool jmadd2_q(JacQ2& p, LOADX loadx, LOADY loady, uin
       Fq2Y y1;
 #pragma unroll
       for (int k = 0; k < 14; ++k) { y1.c0.l[k] = w[k]; y1.c1.l[k] = w[14 + k]; }
-      t2 = f2_muld(J, y1); f2_pin(t2); }
-    p.y = f2_slot<Fq2Y>(f2_sub(f2_muld(r, f2_norm(f2_sub(V, X3))), f2_dbl(t2))); f2_pin(p.y);
+#if defined(RIPP_BLS12_377)
+      Fq2n t2 = f2_muld(J, y1); f2_pin(t2);
+      p.y = f2_slot<Fq2Y>(f2_sub(f2_muld(r, f2_norm(f2_sub(V, X3))), f2_dbl(t2))); f2_pin(p.y);
+#else
+      p.y = f2_slot<Fq2Y>(f2_muld_sub(r, f2_norm(f2_sub(V, X3)), f2_dbl(J), y1)); f2_pin(p.y);             // r (V - X3) - 2 J Y1: eight products, two reductions
+#endif
+    }
     p.x = f2_slot<Fq2X>(X3);
     return special;
 }

@@ -37,7 +37,7 @@ __device__ __forceinline__ bool jadd_q(JacQ& p, const JacT& q) {
     const auto rr = fq_norm(fq_dbl(fq_sub(S2, S1)));
     const Fqn V = fq_mul(U1, I); SBS();
     const auto X3 = fq_norm(fq_sub(fq_sub(fq_sub(fq_sqr(rr), J), V), V)); SBS();
-    p.y = fq_slot<JY>(fq_sub(fq_mul(rr, fq_norm(fq_sub(V, X3))), fq_dbl(fq_mul(S1, J))));
+    p.y = fq_slot<JY>(fq_mul_sub(rr, fq_norm(fq_sub(V, X3)), fq_dbl(S1), J));                            // r (V - X3) - 2 S1 J, one reduction
     p.x = fq_slot<JX>(X3);
     return special;
 }
