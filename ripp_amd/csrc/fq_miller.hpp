@@ -128,10 +128,25 @@ __device__ __forceinline__ void line_double_store_q(Fq2C& X, Fq2C& Y, Fq2C& Z, c
     Z = f2_to_coord(f2_muld(f2_dbl(b), f2_dbl(nh))); f2_pin(Z);                   // (2b)(2 nh) = -4 b h
     const auto f = f2_add(f2_add(e, e), e);                                       // 3e, lazy
     X = f2_to_coord(f2_muld(f2_dbl(a2), f2_norm(f2_sub(f, b)))); f2_pin(X);       // 2 a' (f - b) = -4 a (b - f)
+#if defined(RIPP_BLS12_377)
     Fq2n g2 = f2_sqrd(f2_norm(f2_add(b, f))); f2_pin(g2);                         // g'^2 = 4 g^2
     Fq2n e2 = f2_sqrd(e); f2_pin(e2);
     const auto e12 = f2_dbl(f2_dbl(f2_add(f2_add(e2, e2), e2)));                  // 12 e^2, lazy
     Y = f2_to_coord(f2_sub(e12, g2)); f2_pin(Y);                                  // 12 e^2 - g'^2 = -4 (g^2 - 3 e^2)
+#else
+    // Y3 = 12 e^2 - g'^2 (g' = b + 3e) as a difference of two SQUARES with one reduction per part (fq_curve.hpp fq_mul_sub):
+    //   re = 3 (e0 + e1) . 4 (e0 - e1) - (g0 + g1)(g0 - g1),   im = 8 e0 . 3 e1 - g0 . 2 g1
+    // four limb products + two reductions where the two squares took four + four and their difference two more quotient estimates; the result is a reduced value
+    {
+        const auto g = f2_norm(f2_add(b, f));
+        Fq2n y3;
+        { const auto se = fq_add(e.c0, e.c1); const auto a3 = fq_add(fq_dbl(se), se);
+          y3.c0 = fq_mul_sub(a3, fq_norm(fq_dbl(fq_dbl(fq_sub(e.c0, e.c1)))), fq_add(g.c0, g.c1), fq_norm(fq_sub(g.c0, g.c1))); } fq_pin(y3.c0);
+        { const auto e3 = fq_add(fq_dbl(e.c1), e.c1);
+          y3.c1 = fq_mul_sub(fq_norm(fq_dbl(fq_dbl(fq_dbl(e.c0)))), e3, g.c0, fq_dbl(g.c1)); }
+        Y = f2_to_coord(y3); f2_pin(Y);
+    }
+#endif
 }
 __device__ __forceinline__ Fq2n f2_load_conv(const Fp2* p) { const Fp2 v = *p; return f2_from(v); }
 // mixed addition step + its line (-j, theta xP, -lambda yP) = -1 x the textbook line
