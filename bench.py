@@ -34,7 +34,7 @@ HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 #   k_miller_lines_q   63 doubling steps x 9 800 (6 Fp2 squares of 784, 3 Fp2 products of 1 176, 2 Fp2 x Fp of 784) + 5 addition steps x 16 072 (fq_miller.hpp)
 #   k_line_products    68 x 3 x 8 064, k_miller_lines (63 x 25 + 5 x 41) Fp products x 288: the 12 x 32-bit forms (BLS12-377, RIPP_NO_FQ), every MAD followed by a carry capture
 #   k_line_products_k  68 lines x 6 lanes x 2 156 (per Fp2 output 9 products + 2 reductions: Karatsuba inside the lazily reduced sums, fq_line_products_k.hpp; build round 6, BLS12-381)
-MADS_PER_PAIR = {"k_line_products_q": 68 * 3 * 5488, "k_miller_lines_q": 63 * 9800 + 5 * 16072, "k_line_products_k": 68 * 6 * 2156,
+MADS_PER_PAIR = {"k_line_products_q": 68 * 3 * 5488, "k_miller_lines_q": 63 * 9408 + 5 * 16072, "k_line_products_k": 68 * 6 * 2156,
                  "k_line_products": 68 * 3 * 8064, "k_miller_lines": (63 * 25 + 5 * 41) * 288}
 MAD_ISSUE_PEAK_T = 34.72          # T lane-MAD/s, the hardware's measured v_mad_u64_u32 issue rate (profiles/r01_ubench_valu_rates.txt)
 # what an isolated multiplier chain reaches, in the same unit: carry-free 14 x 28-bit product 78.5 G/s x 392 MADs (profiles/r03_fqbench.txt);
