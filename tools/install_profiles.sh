@@ -7,6 +7,7 @@ cp $S/fpbench.txt profiles/${R}_fpbench_production.txt
 cp $S/fqbench.txt profiles/${R}_fqbench.txt
 cp $S/invbench.txt profiles/${R}_invbench.txt
 [ -s $S/lpbench.txt ] && cp $S/lpbench.txt profiles/${R}_lpbench.txt
+[ -s $S/fqgroup.txt ] && cp $S/fqgroup.txt profiles/${R}_fqgroup.txt
 cp $S/hbm_traffic.csv profiles/${R}_hbm_traffic_pmc.csv
 cp $S/traffic.json profiles/traffic_current.json
 cp $S/msm_sweep.txt profiles/${R}_msm_2p20.txt

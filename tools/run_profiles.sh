@@ -1,4 +1,5 @@
 # Collects every profile the bench line and DESIGN.md quote, on the CURRENT build.  Usage (GPU box): bash tools/run_profiles.sh <tag>
+# (the microbenchmarks are built here, before the box: make -C tools/ubench)
 set -x
 TAG=${1:-r06}
 OUT=gpurun_out/prof_$TAG
@@ -8,6 +9,8 @@ export TMPDIR=/tmp
 ./tools/ubench/build/fpbench > $OUT/fpbench.txt 2>&1
 ./tools/ubench/build/fqbench > $OUT/fqbench.txt 2>&1
 ./tools/ubench/build/invbench > $OUT/invbench.txt 2>&1
+# the group law in isolation at two waves per SIMD: products, G1 / G2 doublings and mixed additions, the cost of each piece of glue
+./tools/ubench/build/fqgroup 200 > $OUT/fqgroup.txt 2>&1
 # stage 2a of the pairing product in isolation: k_line_products_q (six-product sums) against k_line_products_k (Karatsuba), bit-compared
 ( ./tools/ubench/build/lpbench 17 2 5; ./tools/ubench/build/lpbench 17 6 3; ./tools/ubench/build/lpbench 15 2 3 ) > $OUT/lpbench.txt 2>&1
 timeout 900 python3 bench.py --steps 5 --warmup 1 > $OUT/bench_n1.json 2> $OUT/bench_n1.err        # incl. the CPU baseline at n = 2^20 (~100 s)
